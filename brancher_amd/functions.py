@@ -1,0 +1,62 @@
+"""
+Symbolic function namespace (``import brancher_amd.functions as BF``).
+
+The reference wraps *every* public function of ``torch.nn.functional`` and
+``torch._C._VariableFunctions`` into a ``BrancherFunction`` at import time
+(`brancher/functions.py:50-62`).  Here ``BF.<name>(...)`` builds a ``call`` node of the
+link expression DAG for any name (PEP 562 module ``__getattr__``); whether the fused
+kernel can execute it is decided by the lowering, which supports the closed set the
+reference's examples/tests actually use (SURVEY §2 census: matmul, exp, delta, sin, tanh,
+sum, softplus, sigmoid, sqrt, cos, abs, ...) and raises ``NotImplementedError`` with the
+offending name otherwise.
+"""
+from brancher_amd.variables import var2link, Variable, PartialLink
+from brancher_amd import symbolic as sym
+
+
+class BrancherFunction(object):
+    """Lifts a backend function (by name) or a user callable/module to symbolic links
+    (`brancher/functions.py:9-45`)."""
+
+    def __init__(self, fn, name="f_?"):
+        self.fn = fn
+        self.name = name if isinstance(fn, str) or name != "f_?" else getattr(fn, "__name__", name)
+        self.links = set()
+        if not isinstance(fn, str) and hasattr(fn, "parameters") and callable(getattr(fn, "parameters")):
+            # an optimizable module (`functions.py:15-20`)
+            self.links = {fn}
+
+    def _get_string(self, *args, **kwargs):
+        def s(a):
+            l = var2link(a)
+            return l.string if isinstance(l, PartialLink) else str(a)
+        return self.name + "(" + ", ".join([s(a) for a in list(args) + list(kwargs.values())]) + ")"
+
+    def __call__(self, *args, **kwargs):
+        link_args = [var2link(arg) for arg in args]
+        link_kwargs = {name: var2link(arg) for name, arg in kwargs.items()}
+        vars_ = set()
+        links = set(self.links)
+        for l in list(link_args) + list(link_kwargs.values()):
+            if isinstance(l, PartialLink):
+                vars_ |= l.vars
+                links |= l.links
+        e_args = [l.expr if isinstance(l, PartialLink) else l for l in link_args]
+        e_kwargs = {k: (l.expr if isinstance(l, PartialLink) else l) for k, l in link_kwargs.items()}
+        return PartialLink(vars_, sym.call(self.fn, e_args, e_kwargs), links,
+                           string=self._get_string(*args, **kwargs))
+
+
+# custom functions of the reference (`functions.py:65-66`, `utilities.py:341-358`)
+batch_meshgrid = BrancherFunction("batch_meshgrid", "batch_meshgrid")
+delta = BrancherFunction("delta", "delta")
+
+_cache = {}
+
+
+def __getattr__(name):
+    if name.startswith("_"):
+        raise AttributeError(name)
+    if name not in _cache:
+        _cache[name] = BrancherFunction(name, name)
+    return _cache[name]

@@ -1,0 +1,614 @@
+"""
+Lowering: (joint model, posterior model, estimator)  ->  immutable kernel program.
+
+What the reference does *per ELBO evaluation* in Python — the recursive sampling walk
+(`brancher/variables.py:527-570,732-742`), the name-based q->p re-mapping
+(`brancher/utilities.py:282-309`, rebuilt every call), the visit-once log-probability
+recursion (`variables.py:486-520,718-727`) and the entropy pass (`variables.py:744-749,
+156-162`) — is resolved here *once* into a flat program (include/bsvi.h):
+
+  uniform table   lane-uniform values U[k] = a + b*g(theta_i | const_i): every parameter
+                  transform of `geometric_ranges.py` is hoisted here, so the per-sample code
+                  never evaluates softplus/sigmoid of a parameter, and the gradient
+                  reduction over samples happens on U, not on theta
+  records         one per node evaluation, in dependency order: q nodes (SAMPLE +
+                  ENTROPY [+ LOGP for the score term]) then p nodes (LOGP)
+  micro-ops       the link expressions, register-allocated (SSA, <= BSVI_NUM_REGS)
+
+Reference semantics reproduced on purpose (all probed against the reference, see
+tests/golden and DESIGN.md §2):
+  * a p-variable (root, deterministic or random) takes the value of the q-variable with
+    the same *name* — including auto-created roots such as ``x3_scale``, so a prior's
+    numeric parameters are silently replaced by the posterior's learnable ones when both
+    use the same variable name (`utilities.py:282-309` + `variables.py:367-371,463-466`);
+  * observed values override that mapping (`variables.py:817`);
+  * ELBO = mean over the broadcast [N, B] of  log p + sum_v H_v  with analytic entropies
+    where ``has_analytic_entropy`` else ``-log q_v`` (`variables.py:851-855,156-162`);
+  * observed nodes are summed over the datapoint axis, others are not (`variables.py:513-514`).
+"""
+import warnings
+
+import numpy as np
+
+from brancher_amd import distributions as D
+from brancher_amd import symbolic as sym
+from brancher_amd.utilities import canonical_elem_shape, broadcast_shapes3, is_discrete
+from brancher_amd.variables import RootVariable, RandomVariable, ProbabilisticModel
+
+# ---- mirror of include/bsvi.h (tests/test_abi.py checks the two stay in sync) ------------
+NUM_REGS = 16
+OP = dict(NOP=0, LDI=1, LDU=2, LDZ=3, LDO=4, ADD=8, SUB=9, MUL=10, DIV=11, POW=12, POWI=13, DELTA=14,
+          NEG=16, EXP=17, LOG=18, SQRT=19, SIN=20, COS=21, TANH=22, ABS=23, SIGMOID=24, SOFTPLUS=25,
+          RELU=26, RECIP=27, LOG1P=28, EXPM1=29, SQUARE=30, P2L=31,
+          SAMPLE=40, LOGP=41, ENTROPY=42, STZ=43)
+UT = dict(identity=0, softplus=1, sigmoid=2, exp=3, log=4, tanh=5, sqrt=6, square=7)
+EST = dict(pathwise=0, blackbox=1)
+
+UNARY_CALLS = {"neg": "NEG", "exp": "EXP", "log": "LOG", "sqrt": "SQRT", "sin": "SIN", "cos": "COS",
+               "tanh": "TANH", "abs": "ABS", "sigmoid": "SIGMOID", "softplus": "SOFTPLUS", "relu": "RELU",
+               "reciprocal": "RECIP", "log1p": "LOG1P", "expm1": "EXPM1", "square": "SQUARE",
+               "p2l": "P2L"}
+BINARY_OPS = {"add": "ADD", "sub": "SUB", "mul": "MUL", "truediv": "DIV", "pow": "POW", "delta": "DELTA"}
+
+UNIFORM_DTYPE = np.dtype([("src", "<u4"), ("transform", "u1"), ("is_param", "u1"), ("reserved", "<u2"),
+                          ("a", "<f4"), ("b", "<f4")])
+RECORD_DTYPE = np.dtype([("code_begin", "<u4"), ("code_end", "<u4"), ("dims", "<u4", (3,)), ("flags", "<u4")])
+
+
+class LoweringError(NotImplementedError):
+    """The model uses something the fused kernel cannot execute (yet)."""
+
+
+def get_model_mapping(source_model, target_model):
+    """q-variable -> p-variable by name (`brancher/utilities.py:282-293`)."""
+    mapping = {}
+    table = {v.name: v for v in source_model._flatten()}
+    for p_var in target_model._flatten():
+        if p_var.name in table:
+            mapping[table[p_var.name]] = p_var
+    return mapping
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def _fbits(x):
+    return int(np.array([x], dtype=np.float32).view(np.uint32)[0])
+
+
+# ==========================================================================================
+#  intermediate representation of link expressions with the model context resolved
+# ==========================================================================================
+class IR:
+    __slots__ = ("op", "args", "attr", "shape", "key", "has_z")
+
+    def __init__(self, op, args, attr, shape, key, has_z):
+        self.op, self.args, self.attr, self.shape, self.key, self.has_z = op, args, attr, shape, key, has_z
+
+    def __repr__(self):
+        return "IR(%s%s)" % (self.op, "" if not self.args else "," + ",".join(a.op for a in self.args))
+
+
+def _elem_strides(leaf_shape, rec_shape):
+    """row-major strides of a leaf of `leaf_shape` walked by a loop over `rec_shape`."""
+    strides = []
+    nat = (leaf_shape[1] * leaf_shape[2], leaf_shape[2], 1)
+    for i in range(3):
+        if leaf_shape[i] == 1:
+            strides.append(0)
+        else:
+            if leaf_shape[i] != rec_shape[i]:
+                raise LoweringError("cannot walk a leaf of shape %r in a node of shape %r" % (leaf_shape, rec_shape))
+            strides.append(nat[i])
+    return strides
+
+
+class SlotInfo:
+    def __init__(self, var, base, shape, dist):
+        self.var, self.base, self.shape, self.dist = var, base, shape, dist
+        self.size = int(np.prod(shape))
+        self.name = var.name
+
+
+class Program:
+    """Everything the engine needs to run a compiled (joint, posterior) pair."""
+
+    def __init__(self):
+        self.estimator = "pathwise"
+        self.uniform = None
+        self.records = None
+        self.code = None
+        self.consts = None
+        self.obs = None
+        self.n_params = 0
+        self.n_slots = 0
+        self.n_noise = 0
+        self.n_uniform_grad = 0
+        self.param_uniform_ptr = None
+        self.param_uniform_idx = None
+        self.parameters = []        # [(Parameter, offset, size, group)]
+        self.param_active = None    # uint8 [n_params]: referenced by the program
+        self.param_group = None     # uint8 [n_params]: 0 posterior, 1 joint model
+        self.slots = {}             # q variable -> SlotInfo
+        self.slot_by_name = {}
+        self.bmax = 1
+        self.max_regs = 0
+        self.op_count = 0
+
+    def initial_params(self):
+        theta = np.zeros(self.n_params, dtype=np.float32)
+        for p, off, size, _ in self.parameters:
+            theta[off:off + size] = p.numpy().reshape(-1)
+        return theta
+
+    def noise_rows(self, name):
+        s = self.slot_by_name[name]
+        return s.base, s.size, s.shape
+
+    def summary(self):
+        return dict(n_params=self.n_params, n_slots=self.n_slots, n_uniform=len(self.uniform),
+                    n_uniform_grad=self.n_uniform_grad, n_records=len(self.records), n_code=len(self.code),
+                    max_regs=self.max_regs, bmax=self.bmax, estimator=self.estimator)
+
+
+class _Lowering:
+    def __init__(self, joint, posterior, estimator):
+        if estimator not in EST:
+            raise ValueError("unknown gradient estimator %r" % (estimator,))
+        self.joint, self.posterior, self.estimator = joint, posterior, estimator
+        self.ir_cache = {}
+        self.q_by_name = {}
+        self.slots = {}
+        self.n_slots = 0
+        self.param_index = {}      # id(Parameter) -> offset
+        self.parameters = []
+        self.n_params = 0
+        self.consts = []           # list of float arrays
+        self.n_consts = 0
+        self.const_index = {}      # key -> offset
+        self.obs = []
+        self.n_obs = 0
+        self.obs_index = {}        # id(var) -> (offset, shape)
+        self.uni_param = []        # provisional uniform entries (param-sourced)
+        self.uni_const = []
+        self.uni_index = {}        # (kind, id/ key, transform, a, b) -> (is_param, local k0)
+        self.code = []             # list of [w0,w1,w2,w3]
+        self.ldu_fixups = []       # (slot index, is_param)
+        self.records = []
+        self.max_regs = 0
+
+    # ---------------------------------------------------------------- IR construction
+    def mk(self, op, args=(), attr=None, shape=None):
+        if op in ("root", "z", "obs"):
+            key = (op, id(attr))
+        elif op == "imm":
+            key = (op, float(attr))
+        elif op == "carr":
+            key = (op, attr.shape, attr.tobytes())
+        else:
+            key = (op, attr if not isinstance(attr, np.ndarray) else None) + tuple(a.key for a in args)
+        hit = self.ir_cache.get(key)
+        if hit is not None:
+            return hit
+        if shape is None:
+            shape = broadcast_shapes3(*[a.shape for a in args]) if args else (1, 1, 1)
+        has_z = (op == "z") or any(a.has_z for a in args)
+        node = IR(op, tuple(args), attr, tuple(shape), key, has_z)
+        self.ir_cache[key] = node
+        return node
+
+    def root_shape(self, var):
+        v = var.value if not var.learnable else var.parameter.numpy()
+        if is_discrete(v):
+            raise LoweringError("discrete root value %r cannot enter the fused kernel" % (var.name,))
+        return canonical_elem_shape(v.shape[1:])
+
+    def from_expr(self, e, ctx):
+        """sym.Expr -> IR with variables replaced through ctx (a function Variable -> IR)."""
+        if e.op == "var":
+            return ctx(e.attr)
+        if e.op == "const":
+            v = e.attr
+            if isinstance(v, np.ndarray) and v.size > 1:
+                arr = np.ascontiguousarray(v, dtype=np.float32)
+                return self.mk("carr", (), arr, canonical_elem_shape((1,) + arr.shape))
+            return self.mk("imm", (), float(np.asarray(v).reshape(-1)[0]) if isinstance(v, np.ndarray) else float(v))
+        if e.op in sym.BINARY_OPS:
+            a, b = self.from_expr(e.args[0], ctx), self.from_expr(e.args[1], ctx)
+            return self.mk(e.op, (a, b))
+        if e.op == "call":
+            fn, kwargs = e.attr
+            if not isinstance(fn, str):
+                raise LoweringError("user callables / nn.Modules inside links are not lowered to the fused "
+                                    "kernel yet: %r" % (fn,))
+            if kwargs:
+                raise LoweringError("keyword arguments of BF.%s are not supported by the fused kernel" % fn)
+            args = [self.from_expr(a, ctx) if isinstance(a, sym.Expr) else self.mk("imm", (), float(a))
+                    for a in e.args]
+            if fn in UNARY_CALLS and len(args) == 1:
+                return self.mk("call:" + fn, (args[0],))
+            if fn in ("delta",) and len(args) == 2:
+                return self.mk("delta", tuple(args))
+            if fn in ("add", "sub", "mul", "div", "true_divide", "pow") and len(args) == 2:
+                return self.mk({"div": "truediv", "true_divide": "truediv"}.get(fn, fn), tuple(args))
+            raise LoweringError("BF.%s is not in the fused kernel's op set" % fn)
+        raise LoweringError("link expression node %r is not supported by the fused kernel" % (e.op,))
+
+    # ---------------------------------------------------------------- model contexts
+    def q_value(self, var):
+        if isinstance(var, RootVariable):
+            return self.mk("root", (), var, self.root_shape(var))
+        if getattr(var, "_type", None) == "Deterministic node":
+            return self.from_expr(var.link.expressions()["value"].expr, self.q_value)
+        if isinstance(var, RandomVariable):
+            if var not in self.slots:
+                raise LoweringError("posterior variable %r is used before it is sampled" % var.name)
+            return self.mk("z", (), var, self.slots[var].shape)
+        raise LoweringError("unsupported posterior variable %r" % (var,))
+
+    def p_value(self, var):
+        if isinstance(var, RandomVariable) and var.is_observed:
+            if not var.has_observed_value:
+                raise LoweringError("variable %r is observed through a random dataset (minibatch data path, "
+                                    "SURVEY §8f-1): not lowered yet" % var.name)
+            return self.mk("obs", (), var, canonical_elem_shape(var._observed_value.shape[1:]))
+        if var.name in self.q_by_name:
+            return self.q_value(self.q_by_name[var.name])
+        if isinstance(var, RootVariable):
+            return self.mk("root", (), var, self.root_shape(var))
+        if getattr(var, "_type", None) == "Deterministic node":
+            return self.from_expr(var.link.expressions()["value"].expr, self.p_value)
+        raise LoweringError("model variable %r is neither observed nor present in the posterior "
+                            "(the reference raises AttributeError here, variables.py:430)" % var.name)
+
+    # ---------------------------------------------------------------- tables
+    def param_offset(self, param, group):
+        off = self.param_index.get(id(param))
+        if off is None:
+            off = self.n_params
+            self.param_index[id(param)] = off
+            self.parameters.append((param, off, param.size, group))
+            self.n_params += param.size
+        return off
+
+    def const_offset(self, arr, key):
+        off = self.const_index.get(key)
+        if off is None:
+            off = self.n_consts
+            self.const_index[key] = off
+            flat = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+            self.consts.append(flat)
+            self.n_consts += flat.size
+        return off
+
+    def obs_offset(self, var):
+        hit = self.obs_index.get(id(var))
+        if hit is None:
+            flat = np.ascontiguousarray(var._observed_value, dtype=np.float32).reshape(-1)
+            hit = self.n_obs
+            self.obs_index[id(var)] = hit
+            self.obs.append(flat)
+            self.n_obs += flat.size
+        return hit
+
+    def uniform_entries(self, leaf, transform, a, b):
+        """allocate (or reuse) U entries a + b*g(leaf) for every element of a root/const leaf."""
+        ukey = (leaf.key, transform, float(a), float(b))
+        hit = self.uni_index.get(ukey)
+        if hit is not None:
+            return hit
+        size = int(np.prod(leaf.shape))
+        if leaf.op == "root" and leaf.attr.learnable:
+            src0 = self.param_offset(leaf.attr.parameter, self.group_of(leaf.attr))
+            table, is_param = self.uni_param, 1
+        elif leaf.op == "root":
+            src0 = self.const_offset(leaf.attr.value, ("root", id(leaf.attr)))
+            table, is_param = self.uni_const, 0
+        else:  # carr
+            src0 = self.const_offset(leaf.attr, leaf.key)
+            table, is_param = self.uni_const, 0
+        k0 = len(table)
+        for e in range(size):
+            table.append((src0 + e, UT[transform], is_param, a, b))
+        self.uni_index[ukey] = (is_param, k0)
+        return is_param, k0
+
+    def group_of(self, root):
+        return 0 if root in self.q_roots else 1
+
+    # ---------------------------------------------------------------- uniform pattern matcher
+    def match_uniform(self, node):
+        """node == a + b*g(leaf) with leaf a root/array constant?  -> (leaf, g, a, b) or None"""
+        if node.has_z:
+            return None
+        if node.op in ("root", "carr"):
+            return node, "identity", 0.0, 1.0
+        if node.op.startswith("call:"):
+            g = node.op[5:]
+            if g in UT and node.args[0].op in ("root", "carr"):
+                return node.args[0], g, 0.0, 1.0
+            return None
+        if node.op in ("add", "sub", "mul", "truediv"):
+            x, y = node.args
+            if x.op == "imm" and y.op != "imm":
+                m = self.match_uniform(y)
+                if m is None:
+                    return None
+                leaf, g, a, b = m
+                c = x.attr
+                if node.op == "add":
+                    return leaf, g, c + a, b
+                if node.op == "sub":
+                    return leaf, g, c - a, -b
+                if node.op == "mul":
+                    return leaf, g, c * a, c * b
+                return None
+            if y.op == "imm" and x.op != "imm":
+                m = self.match_uniform(x)
+                if m is None:
+                    return None
+                leaf, g, a, b = m
+                c = y.attr
+                if node.op == "add":
+                    return leaf, g, a + c, b
+                if node.op == "sub":
+                    return leaf, g, a - c, b
+                if node.op == "mul":
+                    return leaf, g, a * c, b * c
+                if node.op == "truediv":
+                    return leaf, g, a / c, b / c
+        return None
+
+    # ---------------------------------------------------------------- code generation
+    def begin_record(self, shape):
+        self.rec_shape = tuple(shape)
+        self.rec_begin = len(self.code)
+        self.rec_regs = {}
+        self.rec_nreg = 0
+
+    def end_record(self):
+        self.records.append((self.rec_begin, len(self.code), self.rec_shape))
+        self.max_regs = max(self.max_regs, self.rec_nreg)
+
+    def new_reg(self):
+        r = self.rec_nreg
+        if r >= NUM_REGS:
+            raise LoweringError("a node's link needs more than %d registers; split it with a "
+                                "DeterministicVariable" % NUM_REGS)
+        self.rec_nreg += 1
+        return r
+
+    def put(self, op, dst=0, a=0, b=0, w1=0, strides=(0, 0, 0), aux=0):
+        for s in strides:
+            if not 0 <= s < 65536:
+                raise LoweringError("element stride %d does not fit the 16-bit encoding" % s)
+        w0 = OP[op] | (dst << 8) | (a << 16) | (b << 24)
+        self.code.append([w0, int(w1) & 0xFFFFFFFF, strides[0] | (strides[1] << 16), strides[2] | (aux << 16)])
+        return len(self.code) - 1
+
+    def emit(self, node):
+        r = self.rec_regs.get(node.key)
+        if r is not None:
+            return r
+        m = self.match_uniform(node)
+        if m is not None:
+            leaf, g, a, b = m
+            is_param, k0 = self.uniform_entries(leaf, g, a, b)
+            r = self.new_reg()
+            idx = self.put("LDU", dst=r, w1=k0, strides=_elem_strides(leaf.shape, self.rec_shape))
+            self.ldu_fixups.append((idx, is_param))
+        elif node.op == "imm":
+            r = self.new_reg()
+            self.put("LDI", dst=r, w1=_fbits(node.attr))
+        elif node.op == "z":
+            slot = self.slots[node.attr]
+            r = self.new_reg()
+            self.put("LDZ", dst=r, w1=slot.base, strides=_elem_strides(slot.shape, self.rec_shape))
+        elif node.op == "obs":
+            off = self.obs_offset(node.attr)
+            r = self.new_reg()
+            self.put("LDO", dst=r, w1=off, strides=_elem_strides(node.shape, self.rec_shape))
+        elif node.op == "pow" and node.args[1].op == "imm":
+            ra = self.emit(node.args[0])
+            r = self.new_reg()
+            self.put("POWI", dst=r, a=ra, w1=_fbits(node.args[1].attr))
+        elif node.op in BINARY_OPS:
+            ra, rb = self.emit(node.args[0]), self.emit(node.args[1])
+            r = self.new_reg()
+            self.put(BINARY_OPS[node.op], dst=r, a=ra, b=rb)
+        elif node.op.startswith("call:"):
+            ra = self.emit(node.args[0])
+            r = self.new_reg()
+            self.put(UNARY_CALLS[node.op[5:]], dst=r, a=ra)
+        else:
+            raise LoweringError("cannot generate code for %r" % (node,))
+        self.rec_regs[node.key] = r
+        return r
+
+    def node_op(self, op, dist, dst=0, a=0, b=0, c=0, base=0, strides=(0, 0, 0), w=0.0, wf=0.0, noise=0):
+        self.put(op, dst=dst, a=a, b=b, w1=base, strides=strides, aux=dist)
+        self.code.append([_fbits(w), _fbits(wf), int(noise), int(c)])
+
+    # ---------------------------------------------------------------- node parameter IR
+    def node_params(self, var, ctx):
+        links = var.link.expressions()
+        var.distribution.check_parameters(**links)
+        out = []
+        for name, transform in var.distribution.resolve_kernel_parameters(links):
+            node = self.from_expr(links[name].expr, ctx)
+            if transform == "probs_to_logits":
+                node = self.mk("call:p2l", (node,))
+            out.append(node)
+        return out
+
+    # ---------------------------------------------------------------- driver
+    def run(self):
+        joint, posterior = self.joint, self.posterior
+        q_flat = posterior._flatten()
+        names = [v.name for v in q_flat]
+        if len(set(names)) != len(names):
+            warnings.warn("duplicate variable names in the posterior model; the last one in name order "
+                          "wins (reference behaviour, variables.py:79-81)")
+        self.q_by_name = {v.name: v for v in q_flat}
+        self.q_roots = {v for v in posterior.variables if isinstance(v, RootVariable)}
+        p_flat = joint._flatten()
+        pnames = [v.name for v in p_flat]
+        if len(set(pnames)) != len(pnames):
+            warnings.warn("duplicate variable names in the joint model (e.g. the README names y0 'x0'); "
+                          "name-based posterior mapping becomes order dependent (reference behaviour)")
+
+        supported = (D.DIST_NORMAL, D.DIST_LOGNORMAL, D.DIST_CAUCHY, D.DIST_LAPLACE, D.DIST_BETA,
+                     D.DIST_BINOMIAL, D.DIST_BERNOULLI)
+
+        # -- register learnable parameters in a stable order: posterior group first
+        for v in sorted(self.q_roots, key=lambda v: v.name):
+            if v.learnable:
+                self.param_offset(v.parameter, 0)
+        for v in sorted([v for v in joint.flatten() if isinstance(v, RootVariable)], key=lambda v: v.name):
+            if v.learnable:
+                self.param_offset(v.parameter, 1)
+
+        # -- q: topological order of the random (non-deterministic) variables
+        q_random = [v for v in q_flat if isinstance(v, RandomVariable)
+                    and getattr(v, "_type", None) != "Deterministic node"]
+        order, seen = [], set()
+
+        def visit(v):
+            if v in seen:
+                return
+            seen.add(v)
+            for parent in sorted(v.parents, key=lambda x: x.name):
+                if isinstance(parent, RandomVariable):
+                    visit(parent)
+            if isinstance(v, RandomVariable) and getattr(v, "_type", None) != "Deterministic node":
+                order.append(v)
+
+        for v in q_random:
+            visit(v)
+
+        # -- first pass over q: parameter IR and shapes (slots must exist before children)
+        q_nodes = []
+        for v in order:
+            if v.is_observed:
+                raise LoweringError("observed variables inside the posterior are not supported")
+            if v.distribution.kind not in supported:
+                raise LoweringError("distribution of %r is not supported by the fused kernel yet" % v.name)
+            params = self.node_params(v, self.q_value)
+            shape = broadcast_shapes3(*[p.shape for p in params])
+            self.slots[v] = SlotInfo(v, self.n_slots, shape, v.distribution.kind)
+            self.n_slots += self.slots[v].size
+            q_nodes.append((v, params, shape))
+
+        # -- p: every random variable of the joint model once (visit-once recursion)
+        p_nodes = []
+        for v in p_flat:
+            if not isinstance(v, RandomVariable) or getattr(v, "_type", None) == "Deterministic node":
+                continue
+            if v.distribution.kind not in supported:
+                raise LoweringError("distribution of %r is not supported by the fused kernel yet" % v.name)
+            value = self.p_value(v)
+            params = self.node_params(v, self.p_value)
+            shape = broadcast_shapes3(value.shape, *[p.shape for p in params])
+            p_nodes.append((v, value, params, shape))
+
+        # -- weights from the [N, B] mean rule
+        term_b = []
+        for v, params, shape in q_nodes:
+            term_b.append(shape[0])
+        for v, value, params, shape in p_nodes:
+            term_b.append(1 if v.is_observed else shape[0])
+        bmax = max(term_b) if term_b else 1
+        for b in term_b:
+            if b not in (1, bmax):
+                raise LoweringError("datapoint axes %r of the ELBO terms cannot be broadcast" % (sorted(set(term_b)),))
+        if self.estimator == "blackbox" and bmax != 1:
+            raise LoweringError("BlackBox estimator with a datapoint axis on latent terms is not lowered yet")
+
+        def weight(b_term):
+            return 1.0 if b_term == 1 else 1.0 / bmax
+
+        # -- emit q records
+        for v, params, shape in q_nodes:
+            dist = v.distribution
+            slot = self.slots[v]
+            self.begin_record(shape)
+            regs = [self.emit(p) for p in params]
+            ra = regs[0]
+            rb = regs[1] if len(regs) > 1 else 0
+            rz = self.new_reg()
+            self.node_op("SAMPLE", dist.kind, dst=rz, a=ra, b=rb, base=slot.base,
+                         strides=_elem_strides(shape, shape), noise=slot.base)
+            w = weight(shape[0])
+            wf = 1.0 if self.estimator == "blackbox" else 0.0
+            if dist.has_analytic_entropy:
+                self.node_op("ENTROPY", dist.kind, a=ra, b=rb, w=w)
+                if wf:
+                    self.node_op("LOGP", dist.kind, a=ra, b=rb, c=rz, w=0.0, wf=wf)
+            else:
+                self.node_op("LOGP", dist.kind, a=ra, b=rb, c=rz, w=-w, wf=wf)
+            self.end_record()
+
+        # -- emit p records
+        for v, value, params, shape in p_nodes:
+            self.begin_record(shape)
+            rv = self.emit(value)
+            regs = [self.emit(p) for p in params]
+            ra = regs[0]
+            rb = regs[1] if len(regs) > 1 else 0
+            w = 1.0 if v.is_observed else weight(shape[0])
+            self.node_op("LOGP", v.distribution.kind, a=ra, b=rb, c=rv, w=w, wf=0.0)
+            self.end_record()
+
+        return self.finish(bmax)
+
+    def finish(self, bmax):
+        prog = Program()
+        prog.estimator = self.estimator
+        n_up = len(self.uni_param)
+        uni = np.zeros(n_up + len(self.uni_const), dtype=UNIFORM_DTYPE)
+        for k, (src, tr, is_param, a, b) in enumerate(self.uni_param + self.uni_const):
+            uni[k] = (src, tr, is_param, 0, a, b)
+        code = np.array(self.code, dtype=np.uint32).reshape(-1, 4) if self.code else np.zeros((0, 4), np.uint32)
+        for idx, is_param in self.ldu_fixups:
+            if not is_param:
+                code[idx, 1] += n_up
+        recs = np.zeros(len(self.records), dtype=RECORD_DTYPE)
+        for i, (b, e, shape) in enumerate(self.records):
+            recs[i] = (b, e, shape, 0)
+        prog.uniform, prog.records, prog.code = uni, recs, code
+        prog.consts = np.concatenate(self.consts) if self.consts else np.zeros(0, np.float32)
+        prog.obs = np.concatenate(self.obs) if self.obs else np.zeros(0, np.float32)
+        prog.n_params, prog.n_slots, prog.n_noise = self.n_params, self.n_slots, self.n_slots
+        prog.n_uniform_grad = n_up
+        # CSR param -> uniform entries
+        ptr = np.zeros(self.n_params + 1, dtype=np.uint32)
+        src = uni["src"][:n_up].astype(np.int64)
+        np.add.at(ptr, src + 1, 1)
+        ptr = np.cumsum(ptr).astype(np.uint32)
+        prog.param_uniform_ptr = ptr
+        prog.param_uniform_idx = np.argsort(src, kind="stable").astype(np.uint32)
+        prog.parameters = list(self.parameters)
+        active = np.zeros(self.n_params, dtype=np.uint8)
+        active[src] = 1
+        prog.param_active = active
+        group = np.zeros(self.n_params, dtype=np.uint8)
+        for p, off, size, g in self.parameters:
+            group[off:off + size] = g
+        prog.param_group = group
+        prog.slots = dict(self.slots)
+        prog.slot_by_name = {s.name: s for s in self.slots.values()}
+        prog.bmax = bmax
+        prog.max_regs = self.max_regs
+        prog.op_count = len(code)
+        return prog
+
+
+def lower(joint_model, posterior_model=None, estimator="pathwise"):
+    """Compile a (joint, posterior) pair for the fused ELBO kernel."""
+    if posterior_model is None:
+        joint_model.check_posterior_model()
+        posterior_model = joint_model.posterior_model
+    if not isinstance(joint_model, ProbabilisticModel) or not isinstance(posterior_model, ProbabilisticModel):
+        raise ValueError("lower() expects probabilistic models")
+    return _Lowering(joint_model, posterior_model, estimator).run()

@@ -1,0 +1,278 @@
+"""
+Standard random variables (`brancher/standard_variables.py`).
+
+Same constructors and the same auto-parameterisation rule (`standard_variables.py:57-68`):
+every constructor argument given as a number/array becomes a ``RootVariable`` named
+``"<var>_<arg>"`` that stores the *unconstrained* value
+(``range.inverse_transform``), and the link uses ``range.forward_transform(root)``.
+
+``LogitNormalVariable`` is named by the README (`README.md:30,56`) but commented out in the
+reference snapshot (`standard_variables.py:201-213`, no ``LogitNormalDistribution``
+exists).  It is provided here as the reparameterisation SURVEY §8c defines: a Normal latent
+on the logit scale whose *use in links* is ``sigmoid(u)``.
+"""
+import numbers
+
+import numpy as np
+
+import brancher_amd.distributions as distributions
+import brancher_amd.functions as BF
+import brancher_amd.geometric_ranges as geometric_ranges
+from brancher_amd.variables import var2link, Variable, RootVariable, RandomVariable, PartialLink
+from brancher_amd.utilities import join_sets_list
+
+
+class LinkConstructor:
+    """Named parameter links of one variable (`standard_variables.py:14-29`)."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        self.modules = [link for partial_link in kwargs.values()
+                        for link in getattr(var2link(partial_link), "links", ())]
+
+    def expressions(self):
+        return {k: var2link(x) for k, x in self.kwargs.items()}
+
+    def parameters(self):
+        out = []
+        for m in self.modules:
+            out.extend(list(m.parameters()))
+        return out
+
+    def __iter__(self):
+        return iter(self.modules)
+
+
+class VariableConstructor(RandomVariable):
+    """`standard_variables.py:32-68`."""
+
+    def __init__(self, name, learnable, ranges, is_observed=False, **kwargs):
+        self.name = name
+        self._observed = is_observed
+        self._observed_value = None
+        self.construct_deterministic_parents(learnable, ranges, kwargs)
+        self.parents = join_sets_list([var2link(x).vars for x in kwargs.values()
+                                       if isinstance(var2link(x), PartialLink)])
+        self.ancestors = join_sets_list([self.parents] + [parent.ancestors for parent in self.parents])
+        self.link = LinkConstructor(**kwargs)
+        self.ranges = {}
+        self.dataset = None
+        self.has_random_dataset = False
+        self.has_observed_value = False
+        self.is_normalized = True
+        self.partial_links = {k: var2link(link) for k, link in kwargs.items()}
+
+    def construct_deterministic_parents(self, learnable, ranges, kwargs):
+        for parameter_name, value in list(kwargs.items()):
+            if not isinstance(value, (Variable, PartialLink)):
+                if isinstance(value, np.ndarray):
+                    dim = value.shape[0]
+                elif isinstance(value, numbers.Number):
+                    dim = 1
+                else:
+                    dim = []
+                deterministic_parent = RootVariable(ranges[parameter_name].inverse_transform(value, dim),
+                                                    self.name + "_" + parameter_name, learnable,
+                                                    is_observed=self._observed)
+                kwargs.update({parameter_name: ranges[parameter_name].forward_transform(deterministic_parent, dim)})
+
+
+class DeterministicVariable(VariableConstructor):
+    # `standard_variables.py:115-130`
+
+    def __init__(self, value, name, learnable=False, is_observed=False,
+                 variable_range=geometric_ranges.UnboundedRange()):
+        self._type = "Deterministic node"
+        ranges = {"value": variable_range}
+        super().__init__(name, value=value, learnable=learnable, ranges=ranges, is_observed=is_observed)
+        self.distribution = distributions.DeterministicDistribution()
+
+    @property
+    def value(self):
+        return self._get_sample(1)[self]
+
+
+def _loc_scale_ranges():
+    return {"loc": geometric_ranges.UnboundedRange(), "scale": geometric_ranges.RightHalfLine(0.)}
+
+
+class NormalVariable(VariableConstructor):
+    # `standard_variables.py:133-145`
+
+    def __init__(self, loc, scale, name, learnable=False, is_observed=False):
+        self._type = "Normal"
+        super().__init__(name, loc=loc, scale=scale, learnable=learnable, ranges=_loc_scale_ranges(),
+                         is_observed=is_observed)
+        self.distribution = distributions.NormalDistribution()
+
+
+class CauchyVariable(VariableConstructor):
+    # `standard_variables.py:156-168`
+
+    def __init__(self, loc, scale, name, learnable=False, is_observed=False):
+        self._type = "Cauchy"
+        super().__init__(name, loc=loc, scale=scale, learnable=learnable, ranges=_loc_scale_ranges(),
+                         is_observed=is_observed)
+        self.distribution = distributions.CauchyDistribution()
+
+
+class LaplaceVariable(VariableConstructor):
+    # `standard_variables.py:171-183`
+
+    def __init__(self, loc, scale, name, learnable=False, is_observed=False):
+        self._type = "Laplace"
+        super().__init__(name, loc=loc, scale=scale, learnable=learnable, ranges=_loc_scale_ranges(),
+                         is_observed=is_observed)
+        self.distribution = distributions.LaplaceDistribution()
+
+
+class LogNormalVariable(VariableConstructor):
+    # `standard_variables.py:186-198`
+
+    def __init__(self, loc, scale, name, learnable=False, is_observed=False):
+        self._type = "Log Normal"
+        super().__init__(name, loc=loc, scale=scale, learnable=learnable, ranges=_loc_scale_ranges(),
+                         is_observed=is_observed)
+        self.distribution = distributions.LogNormalDistribution()
+
+
+class LogitNormalVariable(NormalVariable):
+    """README `README.md:30,56`; SURVEY §8c definition.  The variable itself is the Normal
+    latent ``u`` on the logit scale; arithmetic on it (``b * x``) uses ``sigmoid(u)``.
+    With the semi-analytic ELBO of the reference (`variables.py:851-855`) this equals a
+    true logit-normal with ``-log q`` entropy in expectation (the Jacobians cancel)."""
+
+    def __init__(self, loc, scale, name, learnable=False, is_observed=False):
+        super().__init__(loc, scale, name, learnable=learnable, is_observed=is_observed)
+        self._type = "Logit Normal"
+
+    def _apply_operator(self, other, op):
+        return BF.sigmoid(self)._apply_operator(other, op)
+
+
+class BetaVariable(VariableConstructor):
+    # `standard_variables.py:216-231` (the reference labels the type "Logit Normal" by mistake)
+
+    def __init__(self, alpha, beta, name, learnable=False, is_observed=False):
+        self._type = "Beta"
+        ranges = {"concentration1": geometric_ranges.RightHalfLine(0.),
+                  "concentration0": geometric_ranges.RightHalfLine(0.)}
+        super().__init__(name, concentration1=alpha, concentration0=beta,
+                         learnable=learnable, ranges=ranges, is_observed=is_observed)
+        self.distribution = distributions.BetaDistribution()
+
+
+class BinomialVariable(VariableConstructor):
+    # `standard_variables.py:234-255`
+
+    def __init__(self, total_count, probs=None, logits=None, name="Binomial", learnable=False, is_observed=False):
+        self._type = "Binomial"
+        if probs is not None and logits is None:
+            ranges = {"total_count": geometric_ranges.UnboundedRange(),
+                      "probs": geometric_ranges.Interval(0., 1.)}
+            super().__init__(name, total_count=total_count, probs=probs, learnable=learnable, ranges=ranges,
+                             is_observed=is_observed)
+        elif logits is not None and probs is None:
+            ranges = {"total_count": geometric_ranges.UnboundedRange(),
+                      "logits": geometric_ranges.UnboundedRange()}
+            super().__init__(name, total_count=total_count, logits=logits, learnable=learnable, ranges=ranges)
+        else:
+            raise ValueError("Either probs or " + "logits needs to be provided as input")
+        self.distribution = distributions.BinomialDistribution()
+
+
+class BernulliVariable(VariableConstructor):
+    # `standard_variables.py:258-277` (spelling as in the reference)
+
+    def __init__(self, probs=None, logits=None, name="Bernulli", learnable=False, is_observed=False):
+        self._type = "Bernulli"
+        if probs is not None and logits is None:
+            ranges = {"probs": geometric_ranges.Interval(0., 1.)}
+            super().__init__(name, probs=probs, learnable=learnable, ranges=ranges, is_observed=is_observed)
+        elif logits is not None and probs is None:
+            ranges = {"logits": geometric_ranges.UnboundedRange()}
+            super().__init__(name, logits=logits, learnable=learnable, ranges=ranges)
+        else:
+            raise ValueError("Either probs or " + "logits needs to be provided as input")
+        self.distribution = distributions.BernulliDistribution()
+
+
+BernoulliVariable = BernulliVariable
+
+
+class CategoricalVariable(VariableConstructor):
+    # `standard_variables.py:280-299`
+
+    def __init__(self, probs=None, logits=None, name="Categorical", learnable=False, is_observed=False):
+        self._type = "Categorical"
+        if probs is not None and logits is None:
+            # the reference keys the range as "p" (`standard_variables.py:290`), so a constant
+            # `probs` raises KeyError there; a Variable/link works.  Same here.
+            ranges = {"p": geometric_ranges.Simplex()}
+            super().__init__(name, probs=probs, learnable=learnable, ranges=ranges, is_observed=is_observed)
+        elif logits is not None and probs is None:
+            ranges = {"logits": geometric_ranges.UnboundedRange()}
+            super().__init__(name, logits=logits, learnable=learnable, ranges=ranges, is_observed=is_observed)
+        else:
+            raise ValueError("Either probs or " + "logits needs to be provided as input")
+        self.distribution = distributions.CategoricalDistribution()
+
+
+class MultivariateNormalVariable(VariableConstructor):
+    # `standard_variables.py:317-347` — graph construction only; MVN kernels are a later row
+    # (SURVEY §8f-4).
+
+    def __init__(self, loc, covariance_matrix=None, precision_matrix=None,
+                 scale_tril=None, name="Multivariate Normal", learnable=False, is_observed=False):
+        self._type = "Multivariate Normal"
+        given = [x is not None for x in (scale_tril, covariance_matrix, precision_matrix)]
+        if sum(given) != 1:
+            raise ValueError("Either covariance_matrix or precision_matrix or" +
+                             "scale_tril needs to be provided as input")
+        if scale_tril is not None:
+            ranges = {"loc": geometric_ranges.UnboundedRange(), "scale_tril": geometric_ranges.UnboundedRange()}
+            super().__init__(name, loc=loc, scale_tril=scale_tril, learnable=learnable, ranges=ranges,
+                             is_observed=is_observed)
+        elif covariance_matrix is not None:
+            ranges = {"loc": geometric_ranges.UnboundedRange(),
+                      "covariance_matrix": geometric_ranges.PositiveDefiniteMatrix()}
+            super().__init__(name, loc=loc, covariance_matrix=covariance_matrix, learnable=learnable,
+                             ranges=ranges, is_observed=is_observed)
+        else:
+            ranges = {"loc": geometric_ranges.UnboundedRange(),
+                      "precision_matrix": geometric_ranges.UnboundedRange()}
+            super().__init__(name, loc=loc, precision_matrix=precision_matrix, learnable=learnable,
+                             ranges=ranges, is_observed=is_observed)
+        self.distribution = distributions.MultivariateNormalDistribution()
+
+
+class EmpiricalVariable(VariableConstructor):
+    # `standard_variables.py:71-96` — graph construction only (minibatch data path is the
+    # "next" row f-1 of SURVEY §8).
+
+    def __init__(self, dataset, name, learnable=False, is_observed=False, batch_size=None, indices=None,
+                 weights=None):
+        self._type = "Empirical"
+        input_parameters = {"dataset": dataset, "batch_size": batch_size, "indices": indices, "weights": weights}
+        ranges = {k: geometric_ranges.UnboundedRange() for k, v in input_parameters.items() if v is not None}
+        kwargs = {k: v for k, v in input_parameters.items() if v is not None}
+        super().__init__(name, **kwargs, learnable=learnable, ranges=ranges, is_observed=is_observed)
+        if not batch_size:
+            if indices:
+                batch_size = len(indices)
+            else:
+                raise ValueError("Either the indices or the batch size has to be given as input")
+        self.batch_size = batch_size
+        self.distribution = distributions.EmpiricalDistribution(batch_size=batch_size, is_observed=is_observed)
+
+
+class RandomIndices(EmpiricalVariable):
+    # `standard_variables.py:99-112`
+
+    def __init__(self, dataset_size, batch_size, name, is_observed=False):
+        self._type = "Random Index"
+        super().__init__(dataset=list(range(dataset_size)), batch_size=batch_size, is_observed=is_observed,
+                         name=name)
+
+    def __len__(self):
+        return self.batch_size

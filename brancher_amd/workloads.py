@@ -1,0 +1,133 @@
+"""
+Workload definitions (the reference's `examples/` and README models, BASELINE.json configs).
+
+Every builder takes an ``api`` namespace providing the Brancher constructor names
+(``NormalVariable``, ``ProbabilisticModel``, ``BF`` ...).  The same builder is therefore
+used three ways: with this package (tests, bench), with the oracle, and — inside this
+container only — with the real reference imported from /root/reference to generate the
+golden vectors (`oracle/gen_golden.py`).
+"""
+import types
+
+import numpy as np
+
+
+def native_api():
+    from brancher_amd import standard_variables as sv, variables as v, functions as BF
+    return types.SimpleNamespace(
+        NormalVariable=sv.NormalVariable, LogNormalVariable=sv.LogNormalVariable, BetaVariable=sv.BetaVariable,
+        BinomialVariable=sv.BinomialVariable, BernulliVariable=sv.BernulliVariable,
+        CauchyVariable=sv.CauchyVariable, LaplaceVariable=sv.LaplaceVariable,
+        DeterministicVariable=sv.DeterministicVariable, RootVariable=v.RootVariable,
+        ProbabilisticModel=v.ProbabilisticModel, BF=BF, name="brancher_amd")
+
+
+def ar_data(T, seed=0, b=0.8, driving_noise=1.0, measure_noise=0.3):
+    rng = np.random.RandomState(seed)
+    x = np.zeros(T)
+    x[0] = rng.normal(0., driving_noise)
+    for t in range(1, T):
+        x[t] = b * x[t - 1] + rng.normal(0., driving_noise)
+    return (x + rng.normal(0., measure_noise, size=T)).astype(np.float32)
+
+
+def build_readme_ar(api, T=20, data=None, driving_noise=1., measure_noise=0.3):
+    """BASELINE config 1/3: the README state-space AR model (`README.md:25-75`) with the
+    logit-Normal coefficient written as a Normal latent + sigmoid, distinct
+    variable names for x and y (the README's duplicate 'x0' is a typo)."""
+    BF = api.BF
+    if data is None:
+        data = ar_data(T, driving_noise=driving_noise, measure_noise=measure_noise)
+    x0 = api.NormalVariable(0., driving_noise, 'x0')
+    y0 = api.NormalVariable(x0, measure_noise, 'y0')
+    bl = api.NormalVariable(0.5, 1., 'b_logit')
+    x, y = [x0], [y0]
+    for t in range(1, T):
+        x.append(api.NormalVariable(BF.sigmoid(bl) * x[t - 1], driving_noise, "x{}".format(t)))
+        y.append(api.NormalVariable(x[t], measure_noise, "y{}".format(t)))
+    model = api.ProbabilisticModel(x + y)
+    for t, yt in enumerate(y):
+        yt.observe(np.array([[float(data[t])]], dtype=np.float32))
+
+    Qb = api.NormalVariable(0.5, 0.5, "b_logit", learnable=True)
+    logit_b_post = api.DeterministicVariable(0., 'logit_b_post', learnable=True)
+    Qx = [api.NormalVariable(0., 1., 'x0', learnable=True)]
+    Qx_mean = [api.DeterministicVariable(0., 'x0_mean', learnable=True)]
+    for t in range(1, T):
+        Qx_mean.append(api.DeterministicVariable(0., "x{}_mean".format(t), learnable=True))
+        Qx.append(api.NormalVariable(BF.sigmoid(logit_b_post) * Qx[t - 1] + Qx_mean[t], 1., "x{}".format(t),
+                                     learnable=True))
+    posterior = api.ProbabilisticModel([Qb] + Qx)
+    model.set_posterior_model(posterior)
+    return model
+
+
+def build_beta_ar(api, T=20, data=None, driving_noise=1., measure_noise=0.5):
+    """`tests/test_advanced_autoregressive.py:11-55` style: Beta coefficient, RootVariable
+    posterior means, structured Normal chain."""
+    if data is None:
+        data = ar_data(T, driving_noise=driving_noise, measure_noise=measure_noise)
+    x0 = api.NormalVariable(0., driving_noise, 'x0')
+    y0 = api.NormalVariable(x0, measure_noise, 'y0')
+    b = api.BetaVariable(1., 1., 'b')
+    x, y = [x0], [y0]
+    for t in range(1, T):
+        x.append(api.NormalVariable(b * x[t - 1], driving_noise, "x{}".format(t)))
+        y.append(api.NormalVariable(x[t], measure_noise, "y{}".format(t)))
+    model = api.ProbabilisticModel(x + y)
+    for t, yt in enumerate(y):
+        yt.observe(np.array([[float(data[t])]], dtype=np.float32))
+    Qb = api.BetaVariable(1., 1., "b", learnable=True)
+    coupling = api.RootVariable(0., 'logit_b_post', learnable=True)
+    Qx = [api.NormalVariable(0., 1., 'x0', learnable=True)]
+    Qx_mean = [api.RootVariable(0., 'x0_mean', learnable=True)]
+    for t in range(1, T):
+        Qx_mean.append(api.RootVariable(0., "x{}_mean".format(t), learnable=True))
+        Qx.append(api.NormalVariable(coupling * Qx[t - 1] + Qx_mean[t], 1., "x{}".format(t), learnable=True))
+    model.set_posterior_model(api.ProbabilisticModel([Qb] + Qx))
+    return model
+
+
+def build_beta_binomial(api, n_obs=30, p_real=0.8, seed=0, number_tosses=1):
+    """BASELINE config 2: `examples/beta_binomial.py:10-24`."""
+    rng = np.random.RandomState(seed)
+    k_data = rng.binomial(number_tosses, p_real, size=n_obs).astype(np.float32)
+    p = api.BetaVariable(1., 1., "p")
+    k = api.BinomialVariable(number_tosses, probs=p, name="k")
+    model = api.ProbabilisticModel([k, p])
+    k.observe(k_data)
+    Qp = api.BetaVariable(1., 1., "p", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qp]))
+    return model
+
+
+def build_lognormal_normal(api, n_obs=20, seed=0):
+    """`examples/logNormal_normal.py:12-31`: Normal likelihood with LogNormal scale."""
+    rng = np.random.RandomState(seed)
+    data = rng.normal(-2., 1., size=n_obs).astype(np.float32)
+    nu = api.LogNormalVariable(0., 1., "nu")
+    mu = api.NormalVariable(0., 10., "mu")
+    x = api.NormalVariable(mu, nu, "x")
+    model = api.ProbabilisticModel([x])
+    x.observe(data)
+    Qnu = api.LogNormalVariable(0., 1., "nu", learnable=True)
+    Qmu = api.NormalVariable(0., 1., "mu", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qmu, Qnu]))
+    return model
+
+
+def build_heavy_tails(api, n_obs=12, seed=1):
+    """Cauchy / Laplace coverage (`examples/logNormal_normal.py` imports both): a Laplace
+    location with Cauchy likelihood and an explicit nonlinear link."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    data = rng.standard_cauchy(size=n_obs).astype(np.float32) * 0.5 + 1.0
+    m = api.LaplaceVariable(0., 2., "m")
+    s = api.LogNormalVariable(0., 0.5, "s")
+    x = api.CauchyVariable(BF.tanh(m) * 2., s + 0.1, "x")
+    model = api.ProbabilisticModel([x])
+    x.observe(data)
+    Qm = api.LaplaceVariable(0.3, 1., "m", learnable=True)
+    Qs = api.LogNormalVariable(0.1, 0.4, "s", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qm, Qs]))
+    return model

@@ -1,0 +1,234 @@
+/*
+ * bsvi.h — C ABI of the MI355X-native stochastic-variational-inference engine.
+ *
+ * This is the drop-in boundary for Brancher's ELBO-gradient hot path.  The reference
+ * (LucaAmbrogioni/Brancher) is pure Python and has no FFI of its own; the seam this
+ * library plugs into is the `InferenceMethod` interface of `brancher/inference.py:114-126`
+ * (see INTEGRATION.md for the reference-side binding).  Each entry point below names the
+ * reference code it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every `*_dev` pointer is a HIP device pointer owned by the caller
+ *     (PyTorch-ROCm tensors in the Python host layer), `stream` is a hipStream_t passed as void*.
+ *   - all functions return 0 on success or a negative bsvi_status; bsvi_last_error() gives
+ *     a thread-local message.  Numerical failure (NaN/Inf loss) is NOT an error: it is
+ *     reported through the finite flag of the output block so that the host can reproduce
+ *     `inference.py:98,106-107` (warn and skip the optimizer step).
+ *   - no function here synchronises the stream or allocates device memory except
+ *     bsvi_program_create / bsvi_workspace_bytes users (allocation is the caller's job).
+ *   - re-entrant per (program, workspace, stream); no global mutable state.
+ *
+ * Device data layout: structure-of-arrays with the Monte-Carlo sample axis
+ * fastest — noise/eps, samples and per-sample outputs are [element][N] fp32, so the 64 lanes
+ * of a wavefront (one lane = one MC sample) read consecutive addresses.
+ */
+#ifndef BSVI_H
+#define BSVI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSVI_ABI_VERSION 1
+
+typedef enum bsvi_status {
+    BSVI_OK = 0,
+    BSVI_ERR_INVALID = -1,      /* malformed program / bad argument            */
+    BSVI_ERR_UNSUPPORTED = -2,  /* program needs a feature this build lacks    */
+    BSVI_ERR_HIP = -3,          /* a HIP runtime call failed                   */
+    BSVI_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                    */
+    BSVI_ERR_RESOURCE = -5      /* program does not fit LDS / register budget  */
+} bsvi_status;
+
+/* ---- distributions: torch.distributions classes reached through
+ *      brancher/distributions.py:476-592 (`self.torchdist`) ------------------------------ */
+typedef enum bsvi_dist {
+    BSVI_DIST_DETERMINISTIC = 0,
+    BSVI_DIST_NORMAL = 1,
+    BSVI_DIST_LOGNORMAL = 2,
+    BSVI_DIST_CAUCHY = 3,
+    BSVI_DIST_LAPLACE = 4,
+    BSVI_DIST_BETA = 5,
+    BSVI_DIST_BINOMIAL = 6,     /* p0 = total_count, p1 = logits */
+    BSVI_DIST_BERNOULLI = 7,    /* p0 = logits                   */
+    BSVI_DIST_CATEGORICAL = 8,
+    BSVI_DIST_COUNT = 9
+} bsvi_dist;
+
+/* ---- micro-ops of a link program.  One op = one 16-byte slot
+ *        w0 = opcode | dst<<8 | a<<16 | b<<24         (register numbers, 0..BSVI_NUM_REGS-1)
+ *        w1 = base index or immediate (float bits)
+ *        w2 = stride[0] | stride[1]<<16               (element strides along B, D1)
+ *        w3 = stride[2] | aux<<16                     (element stride along D2; aux = dist id)
+ *      node ops (SAMPLE / LOGP / ENTROPY) are followed by one payload slot:
+ *        p0 = weight (float)   p1 = weight_f (float)   p2 = noise index base   p3 = c register
+ *      They restate the closures built by brancher/variables.py:995-1002 and
+ *      brancher/functions.py:28-41, and the per-node calls of
+ *      brancher/distributions.py:63-96. --------------------------------------------------- */
+typedef enum bsvi_op {
+    BSVI_OP_NOP = 0,
+    /* leaves */
+    BSVI_OP_LDI = 1,      /* r[dst] = imm                                                    */
+    BSVI_OP_LDU = 2,      /* r[dst] = U[base + off]        lane-uniform table (params/consts) */
+    BSVI_OP_LDZ = 3,      /* r[dst] = Z[base + off][lane]  per-sample latent value            */
+    BSVI_OP_LDO = 4,      /* r[dst] = obs[base + off]      observed data                      */
+    /* binary arithmetic (operator.add/sub/mul/truediv/pow) */
+    BSVI_OP_ADD = 8, BSVI_OP_SUB = 9, BSVI_OP_MUL = 10, BSVI_OP_DIV = 11, BSVI_OP_POW = 12,
+    BSVI_OP_POWI = 13,    /* r[dst] = r[a] ** imm (constant exponent)                         */
+    BSVI_OP_DELTA = 14,   /* r[dst] = (r[a] == r[b]) ? 1 : 0   (brancher/utilities.py:357-358) */
+    /* unary functions (BF.<name>) */
+    BSVI_OP_NEG = 16, BSVI_OP_EXP = 17, BSVI_OP_LOG = 18, BSVI_OP_SQRT = 19, BSVI_OP_SIN = 20,
+    BSVI_OP_COS = 21, BSVI_OP_TANH = 22, BSVI_OP_ABS = 23, BSVI_OP_SIGMOID = 24,
+    BSVI_OP_SOFTPLUS = 25, BSVI_OP_RELU = 26, BSVI_OP_RECIP = 27, BSVI_OP_LOG1P = 28,
+    BSVI_OP_EXPM1 = 29, BSVI_OP_SQUARE = 30, BSVI_OP_P2L = 31 /* probs -> logits, torch clamp */,
+    /* node ops */
+    BSVI_OP_SAMPLE = 40,  /* draw z ~ dist(r[a], r[b]) from noise; r[dst] = z; Z[base+off] = z */
+    BSVI_OP_LOGP = 41,    /* f += w * log p(r[c] | r[a], r[b]);  lq += wf * (same)             */
+    BSVI_OP_ENTROPY = 42, /* f += w * H[dist(r[a], r[b])]                                      */
+    BSVI_OP_STZ = 43      /* Z[base+off] = r[a]   (deterministic node / spilled expression)    */
+} bsvi_op;
+
+#define BSVI_NUM_REGS 16
+
+/* uniform-table transforms: U[k] = a + b * g(src) (geometric_ranges.py forward transforms,
+ * hoisted out of the per-sample program because they do not depend on the sample) */
+typedef enum bsvi_utransform {
+    BSVI_UT_IDENTITY = 0, BSVI_UT_SOFTPLUS = 1, BSVI_UT_SIGMOID = 2, BSVI_UT_EXP = 3,
+    BSVI_UT_LOG = 4, BSVI_UT_TANH = 5, BSVI_UT_SQRT = 6, BSVI_UT_SQUARE = 7
+} bsvi_utransform;
+
+typedef struct bsvi_uniform_entry {
+    uint32_t src;        /* index into params (is_param=1) or consts (is_param=0) */
+    uint8_t  transform;  /* bsvi_utransform */
+    uint8_t  is_param;
+    uint16_t reserved;
+    float    a, b;
+} bsvi_uniform_entry;
+
+/* one record = one node evaluation: a micro-op span run once per element of the node */
+typedef struct bsvi_record {
+    uint32_t code_begin, code_end;  /* in 16-byte slots */
+    uint32_t dims[3];               /* element loop extents (B, D1, D2) */
+    uint32_t flags;                 /* reserved */
+} bsvi_record;
+
+typedef enum bsvi_estimator {
+    BSVI_EST_PATHWISE = 0,  /* gradient_estimators.py:39-44 */
+    BSVI_EST_BLACKBOX = 1   /* gradient_estimators.py:29-36 */
+} bsvi_estimator;
+
+typedef struct bsvi_program_desc {
+    uint32_t abi_version;
+    uint32_t n_params;        /* length of the flat parameter buffer                */
+    uint32_t n_consts;        /* length of the constant buffer                      */
+    uint32_t n_obs;           /* length of the observed-data buffer                 */
+    uint32_t n_slots;         /* per-sample latent elements (rows of Z / samples)   */
+    uint32_t n_noise;         /* rows of the noise input (one per drawn element)    */
+    uint32_t n_uniform;       /* entries of the uniform table                       */
+    uint32_t n_uniform_grad;  /* the first n_uniform_grad entries are param-sourced */
+    uint32_t n_records;
+    uint32_t n_code;          /* 16-byte slots                                      */
+    uint32_t estimator;       /* bsvi_estimator                                     */
+    uint32_t reserved;
+    const bsvi_uniform_entry* uniform;
+    const bsvi_record* records;
+    const uint32_t* code;     /* 4 * n_code words */
+    const float* consts;      /* host copy; uploaded by bsvi_program_create */
+    /* CSR map param -> uniform entries, for the deterministic chain rule U -> theta */
+    const uint32_t* param_uniform_ptr;   /* n_params + 1 */
+    const uint32_t* param_uniform_idx;   /* n_uniform_grad */
+} bsvi_program_desc;
+
+typedef struct bsvi_program bsvi_program;
+
+/* Validate + upload an immutable program (replaces the per-call recursive graph walk of
+ * brancher/variables.py:486-570,718-749 and the per-call name re-mapping of
+ * brancher/utilities.py:282-309). */
+int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program** out);
+void bsvi_program_destroy(bsvi_program* prog);
+
+/* Bytes of device workspace bsvi_elbo_fwd_bwd needs for n_samples_local samples. */
+size_t bsvi_workspace_bytes(const bsvi_program* prog, uint32_t n_samples_local);
+
+/* Output block layout (fp32, length 4 + n_params):
+ *   out[0] = sum over local samples of the per-sample estimator value (ELBO term, not yet /N)
+ *   out[1] = number of non-finite per-sample values seen locally
+ *   out[2] = loss = -out[0]/n_samples_global   (filled by bsvi_finalize)
+ *   out[3] = finite flag (1 = finite)          (filled by bsvi_finalize)
+ *   out[4..] = gradient sums d(sum f)/d theta  (bsvi_finalize scales them to d loss/d theta)
+ */
+#define BSVI_OUT_HEADER 4
+
+typedef struct bsvi_elbo_args {
+    const float* params_dev;      /* [n_params]                                             */
+    const float* obs_dev;         /* [n_obs]                                                */
+    const float* noise_dev;       /* [n_noise][n_samples_local] or NULL -> in-kernel Philox  */
+    uint64_t seed;                /* Philox key                                             */
+    uint64_t offset;              /* Philox counter offset (iteration number)               */
+    uint32_t n_samples_local;     /* samples evaluated by this call (this GPU's shard)      */
+    uint32_t n_samples_global;    /* N of the estimator (all shards)                        */
+    uint32_t sample_base;         /* global index of local sample 0 (Philox counter)        */
+    uint32_t reserved;
+    float* out_dev;               /* [BSVI_OUT_HEADER + n_params]                            */
+    float* samples_out_dev;       /* [n_slots][n_samples_local] or NULL                     */
+    float* noise_out_dev;         /* [n_noise][n_samples_local] or NULL (Philox draws used) */
+    float* fvalue_out_dev;        /* [2][n_samples_local] or NULL: per-sample f and log q   */
+    void* workspace_dev;          /* bsvi_workspace_bytes(...)                              */
+    void* stream;
+} bsvi_elbo_args;
+
+/* One ELBO forward+backward over this GPU's sample shard: q-sampling, p log-prob, q entropy
+ * and the reverse sweep, fused (replaces ProbabilisticModel.estimate_log_model_evidence
+ * brancher/variables.py:843-870, the estimators gradient_estimators.py:29-44 and
+ * loss.backward() inference.py:100).  Leaves *sums* in out_dev[0,1,4..]. */
+int bsvi_elbo_fwd_bwd(const bsvi_program* prog, const bsvi_elbo_args* args);
+
+/* Turn the (all-reduced) sums into loss, finite flag and d loss/d theta
+ * (the .mean() of gradient_estimators.py:36,44 and the sign of inference.py:141). */
+int bsvi_finalize(const bsvi_program* prog, float* out_dev, uint32_t n_samples_global, void* stream);
+
+/* ---- optimizer: torch.optim.{SGD,Adam} reached through brancher/optimizers.py:53-70 ---- */
+typedef enum bsvi_optimizer_kind { BSVI_OPT_SGD = 0, BSVI_OPT_ADAM = 1 } bsvi_optimizer_kind;
+
+typedef struct bsvi_opt_cfg {
+    uint32_t kind;            /* bsvi_optimizer_kind */
+    float lr;
+    float momentum, dampening, weight_decay;   /* SGD */
+    uint32_t nesterov;
+    float beta1, beta2, eps;                    /* Adam */
+    uint32_t amsgrad;
+    uint32_t maximize;
+} bsvi_opt_cfg;
+
+/* Apply one optimizer step to params[i] for every i with active_mask[i] != 0, unless
+ * out_dev[3] (finite flag) is 0 — `inference.py:98-107`.  `state_dev` is
+ * [3][n_params] floats (momentum / exp_avg, exp_avg_sq, max_exp_avg_sq) followed by one
+ * float step counter; zero-initialised by the caller. */
+int bsvi_optimizer_step(const bsvi_opt_cfg* cfg, float* params_dev, const float* out_dev,
+                        float* state_dev, const uint8_t* active_mask_dev, uint32_t n_params,
+                        void* stream);
+
+/* Run `n_iterations` complete SVI iterations (ELBO fwd+bwd, finalize, optimizer step, loss
+ * log) inside one kernel launch when the local sample count fits one workgroup; the whole
+ * loop of brancher/inference.py:95-108 without returning to the host.  loss_curve_dev gets
+ * one loss per iteration, finite_dev one flag per iteration. */
+int bsvi_train_persistent(const bsvi_program* prog, const bsvi_elbo_args* args,
+                          const bsvi_opt_cfg* cfg, float* params_dev, float* state_dev,
+                          const uint8_t* active_mask_dev, uint32_t n_iterations,
+                          float* loss_curve_dev, float* finite_dev);
+
+/* 1 if bsvi_train_persistent supports (prog, n_samples_local), else 0. */
+int bsvi_persistent_supported(const bsvi_program* prog, uint32_t n_samples_local);
+
+const char* bsvi_last_error(void);
+int bsvi_abi_version(void);
+/* number of gfx950 devices visible to the HIP runtime (0 if none) */
+int bsvi_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSVI_H */

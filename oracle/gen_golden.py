@@ -1,0 +1,251 @@
+"""
+ORACLE TOOLING — generates tests/golden/*.npz by running the REAL reference.
+
+Runs only in the build container: it imports LucaAmbrogioni/Brancher from /root/reference
+(read-only, never copied) on PyTorch-CPU, builds the workloads of brancher_amd/workloads.py
+through the reference's own constructors, and drives the reference's own
+`ReverseKL.compute_loss -> estimate_log_model_evidence -> GradientEstimator.__call__ ->
+loss.backward()` (`brancher/inference.py:140-144`, `variables.py:843-870`,
+`gradient_estimators.py:29-44`) and optimizer loop (`inference.py:95-108`, re-driven by the
+12-line harness of SURVEY Appendix B because `perform_inference` itself raises at
+`inference.py:109` under numpy >= 1.24).
+
+The only interception is *recording*: the raw random draws torch makes (`_standard_normal`,
+`Tensor.cauchy_`, `Tensor.uniform_`) and the dictionary returned by
+`posterior_model._get_sample` are captured so that the same noise can be fed to the HIP
+kernel and to oracle/svi_oracle.py.  Nothing in the reference's arithmetic is altered.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [case ...]
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CASES = {
+    # name: (builder, builder kwargs, N, seed, trajectory spec)
+    "readme_ar_T20_N300": ("build_readme_ar", dict(T=20), 300, 0, dict(iters=6, n=64, optimizer="SGD", lr=1e-3)),
+    "readme_ar_T5_N7": ("build_readme_ar", dict(T=5), 7, 1, dict(iters=5, n=7, optimizer="Adam", lr=5e-2)),
+    "readme_ar_T200_N32": ("build_readme_ar", dict(T=200), 32, 2, None),
+    "beta_ar_T20_N100": ("build_beta_ar", dict(T=20), 100, 3, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
+    "beta_binomial_N512": ("build_beta_binomial", dict(n_obs=30), 512, 4, dict(iters=6, n=128, optimizer="SGD", lr=0.1)),
+    "lognormal_normal_N100": ("build_lognormal_normal", dict(n_obs=20), 100, 5,
+                              dict(iters=5, n=50, optimizer="SGD", lr=1e-4)),
+    "heavy_tails_N64": ("build_heavy_tails", dict(n_obs=12), 64, 6, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
+}
+
+
+def reference_api():
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    warnings.filterwarnings("ignore")
+    from brancher import standard_variables as sv, variables as v, functions as BF
+    return types.SimpleNamespace(
+        NormalVariable=sv.NormalVariable, LogNormalVariable=sv.LogNormalVariable, BetaVariable=sv.BetaVariable,
+        BinomialVariable=sv.BinomialVariable, BernulliVariable=sv.BernulliVariable,
+        CauchyVariable=sv.CauchyVariable, LaplaceVariable=sv.LaplaceVariable,
+        DeterministicVariable=sv.DeterministicVariable, RootVariable=v.RootVariable,
+        ProbabilisticModel=v.ProbabilisticModel, BF=BF, name="reference")
+
+
+class DrawRecorder:
+    """Records every raw random draw torch makes while active."""
+
+    def __enter__(self):
+        import torch
+        import torch.distributions.normal as tn
+        self.torch, self.tn = torch, tn
+        self.draws = []
+        self._sn = tn._standard_normal
+        self._cauchy = torch.Tensor.cauchy_
+        self._uniform = torch.Tensor.uniform_
+        rec = self.draws
+
+        def standard_normal(shape, dtype, device):
+            out = self._sn(shape, dtype=dtype, device=device)
+            rec.append(("normal", out.clone()))
+            return out
+
+        def cauchy_(t, *a, **k):
+            out = self._cauchy(t, *a, **k)
+            rec.append(("cauchy", out.clone()))
+            return out
+
+        def uniform_(t, *a, **k):
+            out = self._uniform(t, *a, **k)
+            rec.append(("uniform", out.clone()))
+            return out
+
+        tn._standard_normal = standard_normal
+        torch.Tensor.cauchy_ = cauchy_
+        torch.Tensor.uniform_ = uniform_
+        return self
+
+    def __exit__(self, *exc):
+        self.tn._standard_normal = self._sn
+        self.torch.Tensor.cauchy_ = self._cauchy
+        self.torch.Tensor.uniform_ = self._uniform
+
+
+def match_noise(q, z, draws):
+    """For every random posterior variable find the raw draw that reproduces its sample
+    bit-for-bit through torch's own rsample formula; Beta/discrete draws are their own noise."""
+    import torch
+    from brancher import distributions as rd
+    noise = {}
+    for var, sample in z.items():
+        dist = getattr(var, "distribution", None)
+        if isinstance(dist, (rd.DeterministicDistribution,)) or dist is None:
+            continue
+        if type(var).__name__ == "RootVariable":
+            continue
+        params = var._get_parameters_from_input_values(z)
+        if isinstance(dist, (rd.NormalDistribution, rd.LogNormalDistribution, rd.CauchyDistribution,
+                             rd.LaplaceDistribution)):
+            loc, scale = params["loc"], params["scale"]
+            kind = {"NormalDistribution": "normal", "LogNormalDistribution": "normal",
+                    "CauchyDistribution": "cauchy", "LaplaceDistribution": "uniform"}[type(dist).__name__]
+            found = None
+            for k, d in draws:
+                if k != kind or d.numel() != sample.numel():
+                    continue
+                d4 = d.reshape(sample.shape)
+                if kind == "uniform":
+                    rec = loc - scale * d4.sign() * torch.log1p(-d4.abs())
+                else:
+                    rec = loc + d4 * scale
+                    if isinstance(dist, rd.LogNormalDistribution):
+                        rec = rec.exp()
+                if torch.equal(rec.detach(), sample.detach()):
+                    found = d4
+                    break
+            if found is None:
+                raise RuntimeError("could not match the noise of %s" % var.name)
+            noise[var.name] = found.detach().numpy().copy()
+        else:
+            noise[var.name] = sample.detach().numpy().copy()
+    return noise
+
+
+def named_parameters(model, q):
+    out = {}
+    for m in (q, model):
+        for v in m.flatten():
+            if type(v).__name__ == "RootVariable" and v.learnable:
+                out.setdefault(v.name, v)
+    return out
+
+
+def run_case(name, api):
+    import torch
+    from brancher import inference, gradient_estimators as ge
+    from brancher.optimizers import ProbabilisticOptimizer
+    import brancher_amd.workloads as W
+
+    builder, kwargs, N, seed, traj = CASES[name]
+    model = getattr(W, builder)(api, **kwargs)
+    model.update_observed_submodel()
+    q = model.posterior_model
+    roots = named_parameters(model, q)
+    out = {}
+    for pname, root in roots.items():
+        out["param/" + pname] = root.value.detach().numpy().copy()
+
+    captured = {}
+    orig = q._get_sample
+
+    def capture(*a, **k):
+        res = orig(*a, **k)
+        captured["z"] = dict(res)
+        return res
+
+    q._get_sample = capture
+
+    for est_name, est in (("pathwise", ge.PathwiseDerivativeEstimator), ("blackbox", ge.BlackBoxEstimator)):
+        for root in roots.values():
+            root.link.parameter.grad = None
+        torch.manual_seed(seed)
+        with DrawRecorder() as rec:
+            loss = inference.ReverseKL(gradient_estimator=est).compute_loss(model, q, None, N)
+        loss.backward()
+        z = captured["z"]
+        noise = match_noise(q, z, rec.draws)
+        if est_name == "pathwise":
+            for k, v in noise.items():
+                out["noise/" + k] = v
+            for var, s in z.items():
+                if type(var).__name__ != "RootVariable":
+                    out["z/" + var.name] = s.detach().numpy().copy()
+            emp = model.observed_submodel._get_sample(1, observed=True, differentiable=False)
+            zz = dict(z)
+            zz.update(emp)
+            lp = model.get_p_log_probabilities_from_q_samples(q_samples=zz, empirical_samples=emp,
+                                                              for_gradient=True, q_model=q)
+            H = q._get_entropy(zz, for_gradient=True)
+            lq = q.calculate_log_probability(zz)
+            out["lp"] = lp.detach().numpy().copy()
+            out["H"] = H.detach().numpy().copy()
+            out["lq"] = lq.detach().numpy().copy()
+        else:
+            for k, v in noise.items():
+                assert np.array_equal(out["noise/" + k], v), "estimators drew different noise"
+        out["loss_" + est_name] = np.float32(loss.detach().numpy())
+        for pname, root in roots.items():
+            g = root.link.parameter.grad
+            out["grad_%s/%s" % (est_name, pname)] = (np.zeros_like(out["param/" + pname]) if g is None
+                                                     else g.detach().numpy().copy())
+            out["gradnone_%s/%s" % (est_name, pname)] = np.array(g is None)
+
+    if traj is not None:
+        # the optimisation loop of inference.py:77-108 (harness; one loss per iteration)
+        method = inference.ReverseKL(gradient_estimator=ge.PathwiseDerivativeEstimator)
+        opt_kwargs = {k: v for k, v in traj.items() if k not in ("iters", "n", "optimizer")}
+        opts = []
+        for m in (q, model):
+            o = ProbabilisticOptimizer(m, traj["optimizer"], **opt_kwargs)
+            if o.optimizer:
+                opts.append(o)
+        torch.manual_seed(seed + 1000)
+        losses, noise_seq = [], {}
+        for it in range(traj["iters"]):
+            with DrawRecorder() as rec:
+                loss = method.compute_loss(model, q, None, traj["n"])
+            noise = match_noise(q, captured["z"], rec.draws)
+            for k, v in noise.items():
+                noise_seq.setdefault(k, []).append(v)
+            if torch.isfinite(loss.detach()).all().item():
+                [o.zero_grad() for o in opts]
+                loss.backward()
+                opts[0].update()
+                if it > 0:
+                    [o.update() for o in opts[1:]]
+            losses.append(float(loss.detach()))
+        out["traj/losses"] = np.array(losses, dtype=np.float32)
+        for k, v in noise_seq.items():
+            out["traj/noise/" + k] = np.stack(v)
+        for pname, root in roots.items():
+            out["traj/param_after/" + pname] = root.value.detach().numpy().copy()
+
+    meta = dict(case=name, builder=builder, kwargs=kwargs, N=N, seed=seed, trajectory=traj,
+                torch=torch.__version__, numpy=np.__version__,
+                reference="LucaAmbrogioni/Brancher @ /root/reference")
+    out["meta"] = np.array(json.dumps(meta))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%-28s loss_pathwise=%.6f loss_blackbox=%.6f  (%d arrays)" % (
+        name, out["loss_pathwise"], out["loss_blackbox"], len(out)))
+
+
+if __name__ == "__main__":
+    api = reference_api()
+    todo = sys.argv[1:] or list(CASES)
+    for case in todo:
+        run_case(case, api)

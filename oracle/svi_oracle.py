@@ -1,0 +1,417 @@
+"""
+ORACLE — test infrastructure, not product code.
+
+CPU restatement of the reference's ELBO-gradient path, used ONLY by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg as the checker / baseline.
+The product path (brancher_amd/) never imports this module.
+
+What is restated (reference file:line in every function): the recursive ancestral sampling
+of the posterior, the name-based q->p sample re-assignment, the visit-once log-probability
+recursion, the semi-analytic entropy, the Pathwise and BlackBox estimators and the
+optimisation loop of `brancher/inference.py`.  The arithmetic of the reference lives in an
+un-vendored dependency — ``torch.distributions`` / ATen (`requirements.txt:1` pins only
+``pytorch>=1.0.0``; this image has torch 2.10.0) — reached from `brancher/distributions.py:108,
+122,124,166,180`; the oracle calls the same ``torch.distributions`` classes on CPU tensors, so
+it shares the reference's numerics exactly.
+
+Pinning: the reference's own tests hold no assertions or golden values, so the
+oracle is pinned against outputs of the reference itself, generated in the build container by
+`oracle/gen_golden.py` (which imports /root/reference) and committed under tests/golden/.
+`tests/test_oracle_golden.py` checks this module against every one of them.
+
+It walks the graph objects of brancher_amd (which mirror the reference's classes) with
+per-call dictionaries, exactly like the reference, instead of using the compiled program —
+so it also checks the lowering.
+"""
+import math
+import operator
+
+import numpy as np
+import torch
+from torch import distributions as td
+
+from brancher_amd.variables import RootVariable, RandomVariable
+from brancher_amd import distributions as D
+from brancher_amd import symbolic as sym
+
+TORCHDIST = {
+    D.DIST_NORMAL: td.normal.Normal, D.DIST_LOGNORMAL: td.log_normal.LogNormal,
+    D.DIST_CAUCHY: td.cauchy.Cauchy, D.DIST_LAPLACE: td.laplace.Laplace, D.DIST_BETA: td.beta.Beta,
+    D.DIST_BINOMIAL: td.binomial.Binomial, D.DIST_BERNOULLI: td.bernoulli.Bernoulli,
+}
+BINOPS = {"add": operator.add, "sub": operator.sub, "mul": operator.mul, "truediv": operator.truediv,
+          "pow": operator.pow}
+
+
+# ---- brancher/utilities.py restated -------------------------------------------------------
+def sum_from_dim(t, dim_index):
+    # utilities.py:119-126
+    for dim in reversed(range(dim_index, t.dim())):
+        t = t.sum(dim=dim)
+    return t
+
+
+def partial_broadcast(*args):
+    # utilities.py:132-136
+    s0 = max(x.shape[0] for x in args)
+    s1 = max(x.shape[1] for x in args)
+    return [x.expand((s0, s1) + tuple(x.shape[2:])) for x in args]
+
+
+def broadcast_and_squeeze(*args):
+    # utilities.py:143-148 + uniform_shapes 274-279
+    if all(int(np.prod(v.shape[2:])) == 1 for v in args):
+        args = [v.contiguous().view(tuple(v.shape[:2]) + (1, 1)) for v in args]
+    max_len = max(len(a.shape) for a in args)
+    args = [a.unsqueeze(len(a.shape)) if len(a.shape) == max_len - 1 else a for a in args]
+    return torch.broadcast_tensors(*args)
+
+
+def number_samples_and_datapoints(values):
+    # utilities.py:189-207
+    n_list, m_list = [], []
+    for v in values.values():
+        if torch.is_tensor(v):
+            n_list.append(v.shape[0])
+            m_list.append(v.shape[1])
+    if not n_list:
+        return None, None
+    return max(n_list), max(m_list)
+
+
+def tile_parameter(t, n):
+    # utilities.py:257-266
+    if t.shape[0] == n:
+        return t
+    if t.shape[0] == 1:
+        return t.repeat(*([n] + [1] * (t.dim() - 1)))
+    raise ValueError("The parameter cannot be broadcasted to the required number of samples")
+
+
+def flatten_parent(v, n, m):
+    # utilities.py:138-186 (tile_batch_dimensions + reshape_parent_value)
+    v = v.expand((n, m) + tuple(v.shape[2:]))
+    return v.contiguous().view((n * m,) + tuple(v.shape[2:]))
+
+
+class _GivenBeta(torch.autograd.Function):
+    """A Beta draw whose value is supplied, with the implicit-reparameterisation gradient of
+    torch's `_Dirichlet` Function (torch/distributions/dirichlet.py:17-36, beta.py:85-86)."""
+
+    @staticmethod
+    def forward(ctx, concentration, x):
+        ctx.save_for_backward(x, concentration)
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, concentration = ctx.saved_tensors
+        total = concentration.sum(-1, True).expand_as(concentration)
+        grad = torch._dirichlet_grad(x, concentration, total)
+        return grad * (grad_output - (x * grad_output).sum(-1, True)), None
+
+
+def _call(name):
+    if name == "delta":
+        return lambda x, y: (x == y).float()          # utilities.py:357-358
+    if hasattr(torch, name):
+        return getattr(torch, name)
+    return getattr(torch.nn.functional, name)          # functions.py:50-62
+
+
+class Oracle:
+    def __init__(self, joint_model, posterior_model=None, dtype=torch.float32):
+        self.p = joint_model
+        self.q = posterior_model if posterior_model is not None else joint_model.posterior_model
+        self.dtype = dtype
+        self.params = {}     # id(Parameter) -> torch leaf
+        self.param_objs = {}
+        for model in (self.q, self.p):
+            for v in model.flatten():
+                if isinstance(v, RootVariable) and v.learnable:
+                    par = v.parameter
+                    if id(par) not in self.params:
+                        self.params[id(par)] = torch.tensor(par.numpy(), dtype=dtype, requires_grad=True)
+                        self.param_objs[id(par)] = (v.name, par)
+        # q->p mapping by name, built once here (reference: rebuilt per call, utilities.py:282-293)
+        table = {v.name: v for v in self.q._flatten()}
+        self.mapping = {}
+        for p_var in self.p._flatten():
+            if p_var.name in table:
+                self.mapping[table[p_var.name]] = p_var
+
+    # ------------------------------------------------------------------ parameters
+    def named_parameters(self):
+        return {name: self.params[i] for i, (name, _) in self.param_objs.items()}
+
+    def set_parameters(self, by_name):
+        with torch.no_grad():
+            for i, (name, _) in self.param_objs.items():
+                if name in by_name:
+                    self.params[i].copy_(torch.as_tensor(np.asarray(by_name[name]), dtype=self.dtype)
+                                         .reshape(self.params[i].shape))
+
+    def zero_grad(self):
+        for t in self.params.values():
+            t.grad = None
+
+    def root_value(self, root):
+        # variables.py:352-356
+        if root.learnable:
+            return self.params[id(root.parameter)]
+        return torch.as_tensor(root.value, dtype=self.dtype)
+
+    # ------------------------------------------------------------------ links
+    def eval_expr(self, e, values):
+        if e.op == "var":
+            return values[e.attr]
+        if e.op == "const":
+            return e.attr                                           # variables.py:914-916
+        if e.op in BINOPS:
+            a, b = self.eval_expr(e.args[0], values), self.eval_expr(e.args[1], values)
+            if isinstance(a, np.ndarray):
+                a = torch.as_tensor(a, dtype=self.dtype)
+            if isinstance(b, np.ndarray):
+                b = torch.as_tensor(b, dtype=self.dtype)
+            return BINOPS[e.op](a, b)                               # variables.py:995-1002
+        if e.op == "call":
+            fn, kwargs = e.attr
+            f = _call(fn) if isinstance(fn, str) else fn
+            args = [self.eval_expr(a, values) if isinstance(a, sym.Expr) else a for a in e.args]
+            kw = {k: (self.eval_expr(v, values) if isinstance(v, sym.Expr) else v) for k, v in kwargs.items()}
+            return f(*args, **kw)                                   # functions.py:34-38
+        if e.op == "getitem":
+            return self.eval_expr(e.args[0], values)[e.attr]
+        if e.op == "tuple":
+            return tuple(self.eval_expr(a, values) for a in e.args)
+        if e.op == "shape":
+            return self.eval_expr(e.args[0], values).shape
+        raise NotImplementedError(e.op)
+
+    def apply_link(self, var, parents_values):
+        # variables.py:436-449
+        n, m = number_samples_and_datapoints(parents_values)
+        reshaped = {k: flatten_parent(v, n, m) for k, v in parents_values.items()}
+        out = {k: self.eval_expr(link.expr, reshaped) for k, link in var.link.expressions().items()}
+        return {k: v.view((n, m) + tuple(v.shape[1:])) for k, v in out.items()}
+
+    def is_det_node(self, v):
+        return getattr(v, "_type", None) == "Deterministic node"
+
+    # ------------------------------------------------------------------ sampling
+    def sample_var(self, var, n, input_values, memo, noise, resample=False):
+        """RootVariable._get_sample (variables.py:367-375) / RandomVariable._get_sample
+        (variables.py:527-570).  `memo` plays the role of ``self.samples``."""
+        if isinstance(var, RootVariable):
+            value = input_values[var] if var in input_values else self.root_value(var)
+            return {var: tile_parameter(value, n)}
+        if var in memo and not resample:
+            return {var: memo[var]}
+        if var in input_values:
+            return {var: input_values[var]}
+        parents_samples = {}
+        for parent in var.parents:
+            parents_samples.update(self.sample_var(parent, n, input_values, memo, noise, resample))
+        params = self.apply_link(var, {p: parents_samples[p] for p in var.parents})
+        sample = self.dist_sample(var, params, noise)
+        memo[var] = sample
+        out = dict(parents_samples)
+        out[var] = sample
+        return out
+
+    def sample_posterior(self, n, noise=None):
+        # ProbabilisticModel._get_sample (variables.py:732-742) over PosteriorModel's variables
+        memo, joint = {}, {}
+        for var in self.q._input_variables:
+            joint.update(self.sample_var(var, n, {}, memo, noise, resample=False))
+        return joint
+
+    def dist_sample(self, var, params, noise):
+        # distributions.py:70-75,111-124 (+ Deterministic :348-357)
+        dist = var.distribution
+        if dist.kind == D.DIST_DETERMINISTIC:
+            return params["value"]
+        keys = list(params.keys())
+        vals = broadcast_and_squeeze(*[params[k] for k in keys])   # distributions.py:197-199
+        params = dict(zip(keys, vals))
+        tdist = TORCHDIST[dist.kind](**params)
+        given = None if noise is None else noise.get(var.name)
+        if given is None:
+            if dist.has_differentiable_samples:
+                return tdist.rsample()
+            return tdist.sample()
+        g = torch.as_tensor(np.asarray(given), dtype=self.dtype)
+        if dist.kind in (D.DIST_NORMAL, D.DIST_CAUCHY):
+            return params["loc"] + g * params["scale"]              # torch normal.py:83-86, cauchy.py:77-80
+        if dist.kind == D.DIST_LOGNORMAL:
+            return torch.exp(params["loc"] + g * params["scale"])  # torch log_normal.py / ExpTransform
+        if dist.kind == D.DIST_LAPLACE:
+            return params["loc"] - params["scale"] * g.sign() * torch.log1p(-g.abs())   # torch laplace.py:83-86
+        if dist.kind == D.DIST_BETA:
+            conc = torch.stack([params["concentration1"], params["concentration0"]], -1)
+            shape = torch.broadcast_shapes(conc.shape[:-1], g.shape)
+            conc = conc.expand(tuple(shape) + (2,))
+            g = g.expand(shape)
+            x = torch.stack([g, 1.0 - g], -1)
+            return _GivenBeta.apply(conc, x).select(-1, 0)          # torch beta.py:85-86
+        return g.expand(torch.broadcast_shapes(g.shape, vals[0].shape)).clone()   # .sample(): no gradient path
+
+    # ------------------------------------------------------------------ node statistics
+    def parameters_from_input_values(self, var, input_values):
+        # variables.py:451-468
+        n = number_samples_and_datapoints(input_values)[0] if input_values else 1
+        parents_values = {}
+        for parent in var.parents:
+            if parent in input_values:
+                parents_values[parent] = input_values[parent]
+        for parent in var.parents:
+            if isinstance(parent, RootVariable) or self.is_det_node(parent):
+                parents_values[parent] = self.sample_var(parent, n, input_values, {}, None, resample=True)[parent]
+        return self.apply_link(var, parents_values)
+
+    def dist_log_prob(self, var, x, params):
+        # distributions.py:63-68,170-181; Implicit (Deterministic) returns zeros (:226-227)
+        dist = var.distribution
+        if dist.kind == D.DIST_DETERMINISTIC:
+            return torch.zeros((1, 1), dtype=self.dtype)
+        keys = list(params.keys())
+        vals = broadcast_and_squeeze(x, *[params[k] for k in keys])         # distributions.py:201-203
+        x = vals[0]
+        params = dict(zip(keys, vals[1:]))
+        tdist = TORCHDIST[dist.kind](**params)
+        return sum_from_dim(tdist.log_prob(x), 2)                            # utilities.py:128-129
+
+    def dist_entropy(self, var, params):
+        # distributions.py:91-96,155-168; Deterministic :381-390
+        dist = var.distribution
+        if dist.kind == D.DIST_DETERMINISTIC:
+            return torch.zeros((1, 1, 1), dtype=self.dtype)
+        keys = list(params.keys())
+        vals = broadcast_and_squeeze(*[params[k] for k in keys])
+        return TORCHDIST[dist.kind](**dict(zip(keys, vals))).entropy()
+
+    def var_log_prob(self, var, input_values, evaluated, reevaluate=True, include_parents=True):
+        """RootVariable.calculate_log_probability (variables.py:333-350) /
+        RandomVariable.calculate_log_probability (variables.py:486-520)."""
+        if isinstance(var, RootVariable):
+            return torch.zeros((1, 1), dtype=self.dtype)
+        if var in evaluated and not reevaluate:
+            return 0.
+        if var in input_values:
+            value = input_values[var]
+        elif var.is_observed and var.has_observed_value:
+            value = torch.as_tensor(var._observed_value, dtype=self.dtype)
+        elif self.is_det_node(var):
+            value = None     # Implicit distribution ignores it
+        else:
+            raise AttributeError('RandomVariable has to be observed to receive value.')
+        evaluated.add(var)
+        params = self.parameters_from_input_values(var, input_values)
+        lp = self.dist_log_prob(var, value, params)
+        parents_lp = sum([self.var_log_prob(parent, input_values, evaluated, reevaluate) for parent in var.parents])
+        if var.is_observed:
+            lp = lp.sum(dim=1, keepdim=True)                                 # variables.py:513-514
+        if torch.is_tensor(lp) and torch.is_tensor(parents_lp):
+            lp, parents_lp = partial_broadcast(lp, parents_lp)
+        return lp + parents_lp if include_parents else lp
+
+    def model_log_prob(self, model, rv_values):
+        # ProbabilisticModel.calculate_log_probability (variables.py:718-727)
+        evaluated = set()
+        return sum([self.var_log_prob(v, rv_values, evaluated, reevaluate=False) for v in model._input_variables])
+
+    def var_entropy(self, var, input_values):
+        # Variable._get_entropy (variables.py:156-162)
+        if var.distribution.has_analytic_entropy:
+            if isinstance(var, RootVariable):
+                ent = torch.zeros((1, 1, 1), dtype=self.dtype)                # variables.py:362-365
+            else:
+                ent = self.dist_entropy(var, self.parameters_from_input_values(var, input_values))
+            return sum_from_dim(ent, 2)
+        return -self.var_log_prob(var, input_values, set(), reevaluate=True, include_parents=False)
+
+    def posterior_entropy(self, samples):
+        # ProbabilisticModel._get_entropy (variables.py:744-749)
+        ents = [self.var_entropy(v, samples) for v in self.q.variables]
+        return sum([sum_from_dim(e, 2) for e in ents])
+
+    def empirical_samples(self):
+        # observed_submodel._get_sample(1, observed=True) (variables.py:849, 555-557)
+        return {v: torch.as_tensor(v._observed_value, dtype=self.dtype)
+                for v in self.p._flatten() if isinstance(v, RandomVariable) and v.is_observed and v.has_observed_value}
+
+    def p_log_prob_from_q_samples(self, q_samples, empirical):
+        # get_p_log_probabilities_from_q_samples (variables.py:814-819) + reassign_samples (utilities.py:296-309)
+        p_samples = {self.mapping[k]: v for k, v in q_samples.items() if k in self.mapping}
+        p_samples.update(empirical)
+        return self.model_log_prob(self.p, p_samples)
+
+    # ------------------------------------------------------------------ estimators
+    def function(self, samples, empirical):
+        # the closure of estimate_log_model_evidence (variables.py:851-855)
+        return self.p_log_prob_from_q_samples(samples, empirical) + self.posterior_entropy(samples)
+
+    def elbo(self, n, estimator="pathwise", noise=None, return_parts=False):
+        """PathwiseDerivativeEstimator (gradient_estimators.py:39-44) /
+        BlackBoxEstimator (gradient_estimators.py:29-36).  Returns the estimator value
+        (loss = -value, inference.py:141)."""
+        empirical = self.empirical_samples()
+        samples = self.sample_posterior(n, noise)
+        samples.update(empirical)
+        if estimator == "pathwise":
+            f = self.function(samples, empirical)
+            value = f.mean()
+            lq = None
+        elif estimator == "blackbox":
+            lq = self.model_log_prob(self.q, samples)
+            f = self.function(samples, empirical)
+            value = (lq * f.detach() + self.function(samples, empirical)).mean()
+        else:
+            raise ValueError(estimator)
+        if return_parts:
+            named = {k.name: v for k, v in samples.items() if isinstance(k, RandomVariable)}
+            return value, f, lq, named
+        return value
+
+    def loss_and_grads(self, n, estimator="pathwise", noise=None):
+        self.zero_grad()
+        value, f, lq, samples = self.elbo(n, estimator, noise, return_parts=True)
+        loss = -value
+        loss.backward()
+        grads = {}
+        for i, (name, _) in self.param_objs.items():
+            g = self.params[i].grad
+            grads[name] = None if g is None else g.detach().numpy().copy()
+        return dict(loss=float(loss.detach()), f=f.detach().numpy().copy(),
+                    lq=None if lq is None else lq.detach().numpy().copy(), grads=grads,
+                    samples={k: v.detach().numpy().copy() for k, v in samples.items()})
+
+    # ------------------------------------------------------------------ the loop
+    def make_optimizers(self, optimizer="SGD", **opt_params):
+        """ProbabilisticOptimizer per model (optimizers.py:53-67, inference.py:79-89):
+        posterior first, then the joint model if it owns parameters."""
+        groups = [[], []]
+        q_roots = {v for v in self.q.variables if isinstance(v, RootVariable)}
+        for i, (name, par) in self.param_objs.items():
+            in_q = any(v.learnable and v.parameter is par for v in q_roots)
+            groups[0 if in_q else 1].append(self.params[i])
+        return [getattr(torch.optim, optimizer)(g, **opt_params) for g in groups if g]
+
+    def train(self, iterations, n, optimizer="SGD", estimator="pathwise", noise_seq=None,
+              pretraining_iterations=0, **opt_params):
+        """inference.py:95-108 (one loss entry per iteration; the reference appends twice)."""
+        opts = self.make_optimizers(optimizer, **opt_params)
+        losses = []
+        for it in range(iterations):
+            noise = None if noise_seq is None else noise_seq[it]
+            loss = -self.elbo(n, estimator, noise)
+            if torch.isfinite(loss.detach()).all().item():
+                for o in opts:
+                    o.zero_grad()
+                loss.backward()
+                opts[0].step()
+                if it > pretraining_iterations:
+                    for o in opts[1:]:
+                        o.step()
+            losses.append(float(loss.detach()))
+        return np.array(losses, dtype=np.float32)
