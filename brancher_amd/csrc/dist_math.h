@@ -1,0 +1,407 @@
+// dist_math.h — per-node distribution arithmetic of the fused ELBO kernel (device code).
+//
+// Each function restates, in closed form with its hand-derived reverse mode, what the
+// reference reaches through `self.torchdist(**parameters)` at brancher/distributions.py:108
+// (rsample :122, entropy :166, log_prob :180).  The formulas are torch.distributions' own
+// (torch 2.10: normal.py:83-116, log_normal.py:75-76, cauchy.py:77-100, laplace.py:74-105,
+// beta.py:85-95 + dirichlet.py:17-36,90-97,122-131, binomial.py:140-160, bernoulli.py:121-130);
+// special functions follow ATen/native/Math.h (digamma, trigamma) and
+// ATen/native/Distributions.h (dirichlet_grad_one) so that parity with the PyTorch-CPU
+// reference holds to 1e-5.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/bsvi.h"
+
+#define BSVI_DEV __device__ __forceinline__
+
+namespace bsvi {
+
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
+constexpr float kHalfLog2PiE = 1.41893853320467274178f;  // 0.5 + 0.5*log(2*pi)
+constexpr float kLogPi = 1.14472988584940017414f;
+constexpr float kLog4Pi = 2.53102424696929079309f;
+constexpr float kLog2 = 0.69314718055994530942f;
+constexpr float kFloatEps = 1.1920928955078125e-07f;
+
+BSVI_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// torch.nn.functional.softplus(beta=1, threshold=20)
+BSVI_DEV float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// ---- digamma / trigamma (ATen/native/Math.h calc_digamma / trigamma, float path) --------
+__device__ __noinline__ double digamma_d(double x) {
+    if (x == 0.0) return copysign(INFINITY, -x);
+    double add = 0.0;
+    if (x < 0.0) {
+        if (x == floor(x)) return NAN;
+        double q, r = modf(x, &q);
+        add = -M_PI / tan(M_PI * r);
+        x = 1.0 - x;
+    }
+    double result = 0.0;
+    while (x < 10.0) { result -= 1.0 / x; x += 1.0; }
+    if (x == 10.0) return result + 2.25175258906672110764 + add;
+    const double A[7] = {8.33333333333333333333E-2, -2.10927960927960927961E-2, 7.57575757575757575758E-3,
+                         -4.16666666666666666667E-3, 3.96825396825396825397E-3, -8.33333333333333333333E-3,
+                         8.33333333333333333333E-2};
+    double y = 0.0;
+    if (x < 1.0e17) {
+        double z = 1.0 / (x * x);
+        double p = A[0];
+        for (int i = 1; i < 7; ++i) p = p * z + A[i];
+        y = z * p;
+    }
+    return result + log(x) - 0.5 / x - y + add;
+}
+BSVI_DEV float digammaf_(float x) { return (float)digamma_d((double)x); }
+
+__device__ __noinline__ float trigammaf_(float xf) {
+    double x = xf, sign = 1.0, result = 0.0;
+    if (x < 0.5) {
+        sign = -1.0;
+        const double s = sin(M_PI * x);
+        result -= (M_PI * M_PI) / (s * s);
+        x = 1.0 - x;
+    }
+    for (int i = 0; i < 6; ++i) { result += 1.0 / (x * x); x += 1.0; }
+    const double ixx = 1.0 / (x * x);
+    result += (1.0 + 1.0 / (2.0 * x) + ixx * (1.0 / 6.0 - ixx * (1.0 / 30.0 - ixx * (1.0 / 42.0)))) / x;
+    return (float)(sign * result);
+}
+
+// ---- implicit reparameterisation gradient of a Beta draw --------------------------------
+// ATen/native/Distributions.h dirichlet_grad_one<float, double> (the CPU instantiation the
+// reference runs): -(d/dalpha cdf(x; alpha, beta)) / pdf(x; alpha, beta) / (1 - x).
+BSVI_DEV double beta_grad_alpha_small(double x, double alpha, double beta) {
+    const double factor = digamma_d(alpha) - digamma_d(alpha + beta) - log(x);
+    double numer = 1.0, series = numer / alpha * (factor + 1.0 / alpha);
+    for (int i = 1; i <= 10; ++i) {
+        numer *= (i - beta) * x / i;
+        const double denom = alpha + i;
+        series += numer / denom * (factor + 1.0 / denom);
+    }
+    const double result = x * pow(1.0 - x, -beta) * series;
+    return isnan(result) ? 0.0 : result;
+}
+BSVI_DEV double beta_grad_beta_small(double x, double alpha, double beta) {
+    const double factor = digamma_d(alpha + beta) - digamma_d(beta);
+    double numer = 1.0, betas = 1.0, dbetas = 0.0, series = factor / alpha;
+    for (int i = 1; i <= 8; ++i) {
+        numer *= -x / i;
+        dbetas = dbetas * (beta - i) + betas;
+        betas = betas * (beta - i);
+        series += numer / (alpha + i) * (dbetas + factor * betas);
+    }
+    const double result = -pow(1.0 - x, 1.0 - beta) * series;
+    return isnan(result) ? 0.0 : result;
+}
+BSVI_DEV double beta_grad_alpha_mid(double x, double alpha, double beta) {
+    const double total = alpha + beta, mean = alpha / total;
+    const double sd = sqrt(alpha * beta / (total + 1.0)) / total;
+    if (mean - 0.1 * sd <= x && x <= mean + 0.1 * sd) {
+        const double b2 = beta * beta;
+        const double poly = 47.0 * x * b2 * b2 + alpha * ((43.0 + 20.0 * (16.0 + 27.0 * beta) * x) * b2 * beta
+                          + alpha * (3.0 * (59.0 + 180.0 * beta - 90.0 * x) * b2
+                          + alpha * ((453.0 + 1620.0 * beta * (1.0 - x) - 455.0 * x) * beta
+                          + alpha * (8.0 * (1.0 - x) * (135.0 * beta - 11.0)))));
+        const double pn = (1.0 + 12.0 * alpha) * (1.0 + 12.0 * beta) / (total * total);
+        const double pd = 12960.0 * alpha * alpha * alpha * beta * beta * (1.0 + 12.0 * total);
+        return pn / (1.0 - x) * poly / pd;
+    }
+    const double prefactor = -x / sqrt(2.0 * alpha * beta / total);
+    const double stirling = (1.0 + 1.0 / (12.0 * alpha) + 1.0 / (288.0 * alpha * alpha))
+                          * (1.0 + 1.0 / (12.0 * beta) + 1.0 / (288.0 * beta * beta))
+                          / (1.0 + 1.0 / (12.0 * total) + 1.0 / (288.0 * total * total));
+    const double t1n = 2.0 * (alpha * alpha) * (x - 1.0) + alpha * beta * (x - 1.0) - x * (beta * beta);
+    const double axbx = alpha * (x - 1.0) + beta * x;
+    const double t1d = sqrt(2.0 * alpha / beta) * pow(total, 1.5) * axbx * axbx;
+    const double term1 = t1n / t1d;
+    const double term2 = 0.5 * log(alpha / (total * x));
+    const double term3 = sqrt(8.0 * alpha * beta / total) / (beta * x + alpha * (x - 1.0));
+    const double t4b = beta * log(beta / (total * (1.0 - x))) + alpha * log(alpha / (total * x));
+    const double term4 = pow(t4b, -1.5);
+    return stirling * prefactor * (term1 + term2 * (term3 + (x < mean ? term4 : -term4)));
+}
+__device__ __constant__ double kDirichletC[2][3][3][4] = {
+    {{{1.003668233, -0.01061107488, -0.0657888334, 0.01201642863},
+      {0.6336835991, -0.3557432599, 0.05486251648, -0.001465281033},
+      {-0.03276231906, 0.004474107445, 0.002429354597, -0.0001557569013}},
+     {{0.221950385, -0.3187676331, 0.01799915743, 0.01074823814},
+      {-0.2951249643, 0.06219954479, 0.01535556598, 0.001550077057},
+      {0.02155310298, 0.004170831599, 0.001292462449, 6.976601077e-05}},
+     {{-0.05980841433, 0.008441916499, 0.01085618172, 0.002319392565},
+      {0.02911413504, 0.01400243777, -0.002721828457, 0.000751041181},
+      {0.005900514878, -0.001936558688, -9.495446725e-06, 5.385558597e-05}}},
+    {{{1, -0.02924021934, -0.04438342661, 0.007285809825},
+      {0.6357567472, -0.3473456711, 0.05454656494, -0.002407477521},
+      {-0.03301322327, 0.004845219414, 0.00231480583, -0.0002307248149}},
+     {{0.5925320577, -0.1757678135, 0.01505928619, 0.000564515273},
+      {0.1014815858, -0.06589186703, 0.01272886114, -0.0007316646956},
+      {-0.007258481865, 0.001096195486, 0.0003934994223, -4.12701925e-05}},
+     {{0.06469649321, -0.0236701437, 0.002902096474, -5.896963079e-05},
+      {0.001925008108, -0.002869809258, 0.0008000589141, -6.063713228e-05},
+      {-0.0003477407336, 6.959756487e-05, 1.097287507e-05, -1.650964693e-06}}},
+};
+__device__ __noinline__ float dirichlet_grad_one(float xf, float alphaf, float totalf) {
+    const float betaf = totalf - alphaf;
+    const float boundary = totalf * xf * (1.0f - xf);
+    // the small-x / small-(1-x) branches run in scalar_t (=float) precision in ATen; double here
+    // only tightens them
+    if (xf <= 0.5f && boundary < 2.5f) return (float)beta_grad_alpha_small(xf, alphaf, betaf);
+    if (xf >= 0.5f && boundary < 0.75f) return (float)(-beta_grad_beta_small(1.0f - xf, betaf, alphaf));
+    const double x = xf, alpha = alphaf, total = totalf, beta = total - alpha;
+    if (alphaf > 6.0f && betaf > 6.0f) return (float)beta_grad_alpha_mid(x, alpha, beta);
+    const double u = log(x), a = log(alpha) - u, b = log(total) - a;
+    const double pow_u[3] = {1.0, u, u * u}, pow_a[3] = {1.0, a, a * a};
+    double p = 0.0, q = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double ua = pow_u[i] * pow_a[j];
+            const double* c0 = kDirichletC[0][i][j];
+            const double* c1 = kDirichletC[1][i][j];
+            p += ua * (c0[0] + b * (c0[1] + b * (c0[2] + b * c0[3])));
+            q += ua * (c1[0] + b * (c1[1] + b * (c1[2] + b * c1[3])));
+        }
+    const double approx = x * (digamma_d(total) - digamma_d(alpha)) / beta;
+    return (float)(p / q * approx);
+}
+
+// =========================================================================================
+//  node functions.  Conventions: x = value, (p0, p1) = parameters in the order of
+//  brancher_amd/distributions.py `kernel_parameters`; *_bwd ADD g * d(.)/d(arg) into the
+//  adjoints.
+// =========================================================================================
+
+// ---- log-probability -------------------------------------------------------------------
+__device__ __noinline__ float logp_generic(int dist, float x, float p0, float p1) {
+    switch (dist) {
+    case BSVI_DIST_NORMAL: {
+        const float d = x - p0;
+        return -(d * d) / (2.0f * (p1 * p1)) - logf(p1) - kLogSqrt2Pi;
+    }
+    case BSVI_DIST_LOGNORMAL: {
+        const float lx = logf(x), d = lx - p0;
+        return (-(d * d) / (2.0f * (p1 * p1)) - logf(p1) - kLogSqrt2Pi) - lx;
+    }
+    case BSVI_DIST_CAUCHY: {
+        const float u = (x - p0) / p1;
+        return -kLogPi - logf(p1) - log1pf(u * u);
+    }
+    case BSVI_DIST_LAPLACE:
+        return -logf(2.0f * p1) - fabsf(x - p0) / p1;
+    case BSVI_DIST_BETA: {
+        const float a1 = p0 - 1.0f, b1 = p1 - 1.0f;
+        const float t0 = (a1 == 0.0f) ? 0.0f : a1 * logf(x);            // torch.xlogy
+        const float t1 = (b1 == 0.0f) ? 0.0f : b1 * logf(1.0f - x);
+        return (t0 + t1) + lgammaf(p0 + p1) - (lgammaf(p0) + lgammaf(p1));
+    }
+    case BSVI_DIST_BINOMIAL: {   // p0 = total_count, p1 = logits
+        const float lfn = lgammaf(p0 + 1.0f), lfk = lgammaf(x + 1.0f), lfnmk = lgammaf(p0 - x + 1.0f);
+        const float norm = p0 * fmaxf(p1, 0.0f) + p0 * log1pf(expf(-fabsf(p1))) - lfn;
+        return x * p1 - lfk - lfnmk - norm;
+    }
+    case BSVI_DIST_BERNOULLI: {  // p0 = logits; -binary_cross_entropy_with_logits(l, x)
+        return -((1.0f - x) * p0 + (fmaxf(-p0, 0.0f) + log1pf(expf(-fabsf(p0)))));
+    }
+    default:
+        return 0.0f;
+    }
+}
+
+__device__ __noinline__ void logp_bwd_generic(int dist, float x, float p0, float p1, float g, float& gx, float& g0, float& g1) {
+    switch (dist) {
+    case BSVI_DIST_NORMAL: {
+        const float d = x - p0, iv = 1.0f / (p1 * p1), t = d * iv;
+        gx -= g * t;
+        g0 += g * t;
+        g1 += g * (d * t / p1 - 1.0f / p1);
+        break;
+    }
+    case BSVI_DIST_LOGNORMAL: {
+        const float lx = logf(x), d = lx - p0, iv = 1.0f / (p1 * p1), t = d * iv;
+        gx += g * ((-t - 1.0f) / x);
+        g0 += g * t;
+        g1 += g * (d * t / p1 - 1.0f / p1);
+        break;
+    }
+    case BSVI_DIST_CAUCHY: {
+        const float u = (x - p0) / p1, w = 2.0f * u / (p1 * (1.0f + u * u));
+        gx -= g * w;
+        g0 += g * w;
+        g1 += g * (-1.0f / p1 + u * w);
+        break;
+    }
+    case BSVI_DIST_LAPLACE: {
+        const float d = x - p0, s = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
+        gx -= g * s / p1;
+        g0 += g * s / p1;
+        g1 += g * (-1.0f / p1 + fabsf(d) / (p1 * p1));
+        break;
+    }
+    case BSVI_DIST_BETA: {
+        const float a1 = p0 - 1.0f, b1 = p1 - 1.0f, dg = digammaf_(p0 + p1);
+        gx += g * (a1 / x - b1 / (1.0f - x));
+        g0 += g * (logf(x) + dg - digammaf_(p0));          // d xlogy(a-1, x)/da = log x (unmasked in torch)
+        g1 += g * (logf(1.0f - x) + dg - digammaf_(p1));
+        break;
+    }
+    case BSVI_DIST_BINOMIAL:
+        g1 += g * (x - p0 * sigmoidf_(p1));
+        break;
+    case BSVI_DIST_BERNOULLI:
+        gx += g * p0;
+        g0 += g * (x - sigmoidf_(p0));
+        break;
+    default:
+        break;
+    }
+}
+
+// ---- analytic entropy ------------------------------------------------------------------
+__device__ __noinline__ float entropy_generic(int dist, float p0, float p1) {
+    switch (dist) {
+    case BSVI_DIST_NORMAL: return kHalfLog2PiE + logf(p1);
+    case BSVI_DIST_LOGNORMAL: return (kHalfLog2PiE + logf(p1)) + p0;
+    case BSVI_DIST_CAUCHY: return kLog4Pi + logf(p1);
+    case BSVI_DIST_LAPLACE: return 1.0f + logf(2.0f * p1);
+    case BSVI_DIST_BETA: {
+        const float a0 = p0 + p1;
+        return (lgammaf(p0) + lgammaf(p1)) - lgammaf(a0) - (2.0f - a0) * digammaf_(a0)
+               - ((p0 - 1.0f) * digammaf_(p0) + (p1 - 1.0f) * digammaf_(p1));
+    }
+    case BSVI_DIST_BERNOULLI: {  // binary_cross_entropy_with_logits(l, sigmoid(l))
+        const float p = sigmoidf_(p0);
+        return (1.0f - p) * p0 + (fmaxf(-p0, 0.0f) + log1pf(expf(-fabsf(p0))));
+    }
+    default: return 0.0f;
+    }
+}
+
+__device__ __noinline__ void entropy_bwd_generic(int dist, float p0, float p1, float g, float& g0, float& g1) {
+    switch (dist) {
+    case BSVI_DIST_NORMAL: g1 += g / p1; break;
+    case BSVI_DIST_LOGNORMAL: g0 += g; g1 += g / p1; break;
+    case BSVI_DIST_CAUCHY: g1 += g / p1; break;
+    case BSVI_DIST_LAPLACE: g1 += g / p1; break;
+    case BSVI_DIST_BETA: {
+        const float a0 = p0 + p1, t0 = (2.0f - a0) * trigammaf_(a0);
+        g0 += g * (-t0 - (p0 - 1.0f) * trigammaf_(p0));
+        g1 += g * (-t0 - (p1 - 1.0f) * trigammaf_(p1));
+        break;
+    }
+    case BSVI_DIST_BERNOULLI: {
+        const float p = sigmoidf_(p0);
+        g0 += g * (-p0 * p * (1.0f - p));
+        break;
+    }
+    default: break;
+    }
+}
+
+// ---- reparameterised draw from supplied noise ---------------------------------------------
+// noise meaning per distribution: brancher_amd/distributions.py NOISE_*.
+__device__ __noinline__ float sample_from_noise_generic(int dist, float p0, float p1, float e) {
+    switch (dist) {
+    case BSVI_DIST_NORMAL:
+    case BSVI_DIST_CAUCHY: return p0 + e * p1;
+    case BSVI_DIST_LOGNORMAL: return expf(p0 + e * p1);
+    case BSVI_DIST_LAPLACE: {
+        const float s = (e > 0.0f) ? 1.0f : ((e < 0.0f) ? -1.0f : 0.0f);
+        return p0 - p1 * s * log1pf(-fabsf(e));
+    }
+    case BSVI_DIST_DETERMINISTIC: return p0;
+    default: return e;   // Beta / discrete: the draw itself is the noise
+    }
+}
+
+// adjoint of the draw: zb = d loss / d z  ->  parameters (pathwise / implicit reparam.)
+__device__ __noinline__ void sample_bwd_generic(int dist, float z, float p0, float p1, float e, float zb, float& g0, float& g1) {
+    switch (dist) {
+    case BSVI_DIST_NORMAL:
+    case BSVI_DIST_CAUCHY: g0 += zb; g1 += zb * e; break;
+    case BSVI_DIST_LOGNORMAL: g0 += zb * z; g1 += zb * z * e; break;
+    case BSVI_DIST_LAPLACE: {
+        const float s = (e > 0.0f) ? 1.0f : ((e < 0.0f) ? -1.0f : 0.0f);
+        g0 += zb;
+        g1 += zb * (-s * log1pf(-fabsf(e)));
+        break;
+    }
+    case BSVI_DIST_BETA: {
+        // torch dirichlet.py:17-20 with grad_output = [zb, 0] on x = [z, 1-z]
+        const float total = p0 + p1;
+        g0 += dirichlet_grad_one(z, p0, total) * (zb * (1.0f - z));
+        g1 += dirichlet_grad_one(1.0f - z, p1, total) * (-(z * zb));
+        break;
+    }
+    case BSVI_DIST_DETERMINISTIC: g0 += zb; break;
+    default: break;   // .sample(): no gradient path (distributions.py:123-124)
+    }
+}
+
+// ---- inline fast path for Normal nodes (by far the most common), generic path out of line --
+BSVI_DEV float logp(int dist, float x, float p0, float p1) {
+    if (dist == BSVI_DIST_NORMAL) {
+        const float d = x - p0;
+        return -(d * d) / (2.0f * (p1 * p1)) - logf(p1) - kLogSqrt2Pi;
+    }
+    return logp_generic(dist, x, p0, p1);
+}
+BSVI_DEV void logp_bwd(int dist, float x, float p0, float p1, float g, float& gx, float& g0, float& g1) {
+    if (dist == BSVI_DIST_NORMAL) {
+        const float d = x - p0, iv = 1.0f / (p1 * p1), t = d * iv;
+        gx -= g * t;
+        g0 += g * t;
+        g1 += g * (d * t / p1 - 1.0f / p1);
+        return;
+    }
+    logp_bwd_generic(dist, x, p0, p1, g, gx, g0, g1);
+}
+BSVI_DEV float entropy(int dist, float p0, float p1) {
+    if (dist == BSVI_DIST_NORMAL) return kHalfLog2PiE + logf(p1);
+    return entropy_generic(dist, p0, p1);
+}
+BSVI_DEV void entropy_bwd(int dist, float p0, float p1, float g, float& g0, float& g1) {
+    if (dist == BSVI_DIST_NORMAL) { g1 += g / p1; return; }
+    entropy_bwd_generic(dist, p0, p1, g, g0, g1);
+}
+BSVI_DEV float sample_from_noise(int dist, float p0, float p1, float e) {
+    if (dist == BSVI_DIST_NORMAL) return p0 + e * p1;
+    return sample_from_noise_generic(dist, p0, p1, e);
+}
+BSVI_DEV void sample_bwd(int dist, float z, float p0, float p1, float e, float zb, float& g0, float& g1) {
+    if (dist == BSVI_DIST_NORMAL) { g0 += zb; g1 += zb * e; return; }
+    sample_bwd_generic(dist, z, p0, p1, e, zb, g0, g1);
+}
+
+// ---- rarely used unary link functions, out of line ------------------------------------------
+__device__ __noinline__ float rare_unary(int op, float x, float imm) {
+    switch (op) {
+    case BSVI_OP_POWI: return powf(x, imm);
+    case BSVI_OP_SIN: return sinf(x);
+    case BSVI_OP_COS: return cosf(x);
+    case BSVI_OP_TANH: return tanhf(x);
+    case BSVI_OP_LOG1P: return log1pf(x);
+    case BSVI_OP_EXPM1: return expm1f(x);
+    case BSVI_OP_P2L: {   // torch probs_to_logits(is_binary=True) with clamp_probs
+        const float p = fminf(fmaxf(x, kFloatEps), 1.0f - kFloatEps);
+        return logf(p) - log1pf(-p);
+    }
+    default: return x;
+    }
+}
+// derivative of the above at x (y = value)
+__device__ __noinline__ float rare_unary_grad(int op, float x, float y, float imm) {
+    switch (op) {
+    case BSVI_OP_POWI: return imm * powf(x, imm - 1.0f);
+    case BSVI_OP_SIN: return cosf(x);
+    case BSVI_OP_COS: return -sinf(x);
+    case BSVI_OP_TANH: return 1.0f - y * y;
+    case BSVI_OP_LOG1P: return 1.0f / (1.0f + x);
+    case BSVI_OP_EXPM1: return y + 1.0f;
+    case BSVI_OP_P2L: return (x >= kFloatEps && x <= 1.0f - kFloatEps) ? (1.0f / x + 1.0f / (1.0f - x)) : 0.0f;
+    default: return 1.0f;
+    }
+}
+__device__ __noinline__ float pow_ff(float x, float y) { return powf(x, y); }
+
+}  // namespace bsvi

@@ -1,0 +1,41 @@
+// philox.h — counter-based RNG for in-kernel reparameterisation noise (device code).
+//
+// The reference draws noise through torch's global generator once per node per iteration
+// (torch normal.py:83-86 `_standard_normal`, reached from brancher/distributions.py:122).
+// Here every draw is a pure function of (seed, global sample index, noise row, iteration,
+// attempt), so a Monte-Carlo shard on any GPU sees the same stream it would see on one GPU
+// and the kernel never reads noise from HBM.  Philox4x32-10 (Salmon et al., SC'11).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bsvi {
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// (0,1) open interval, 24 random bits
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    float s, c;
+    sincosf(6.28318530717958647692f * u01(b), &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+}  // namespace bsvi

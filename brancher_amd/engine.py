@@ -1,0 +1,372 @@
+"""
+Engine: owns the device buffers of a compiled (joint, posterior) pair and drives the C ABI.
+
+PyTorch-ROCm is used here for exactly three things: device memory (``torch.empty(...,
+device='cuda')``), the current HIP stream, and ``torch.distributed`` (RCCL) for the one
+all-reduce per step of the sample-sharded multi-GPU path.  All arithmetic of the hot path
+happens inside libbsvi.so.
+
+Multi-GPU: Monte-Carlo samples are i.i.d. given the parameters, so rank g
+evaluates samples [base_g, base_g + n_g) — Philox counters are global sample indices, so the
+union of the shards is bit-identical to a single-GPU run of the same seed — and the
+per-rank sums (loss sum, non-finite count, gradient sums; 4 + P floats) are combined by ONE
+``all_reduce(SUM)`` before the (replicated, identical) optimizer step.  No other collective
+exists on the path.
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+import torch
+
+from brancher_amd import config
+from brancher_amd import lowering
+from brancher_amd import native
+from brancher_amd.native import ElboArgs, OUT_HEADER
+
+
+def _device():
+    dev = config.get_device()
+    if dev.type != "cuda":
+        raise native.NativeError("brancher_amd evaluates models on an MI355X only (config.device is {!r}); "
+                                 "there is no CPU execution path".format(str(dev)))
+    return dev
+
+
+def dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard(n_global, rank, world):
+    """[base, base + n_local) of the global sample range owned by `rank`."""
+    q, r = divmod(n_global, world)
+    n_local = q + (1 if rank < r else 0)
+    base = rank * q + min(rank, r)
+    return base, n_local
+
+
+def estimator_name(gradient_estimator):
+    if gradient_estimator is None:
+        return "pathwise"
+    if isinstance(gradient_estimator, str):
+        return gradient_estimator
+    name = getattr(gradient_estimator, "kernel_name", None)
+    if name is None:
+        raise NotImplementedError("gradient estimator {!r} is not implemented by the fused kernel"
+                                  .format(gradient_estimator))
+    return name
+
+
+def noise_from_named(program, named, n):
+    """{variable name: array in the reference layout [N, B, d...]}  ->  [n_noise, N] fp32
+    (structure-of-arrays, sample axis fastest)."""
+    out = np.zeros((program.n_noise, n), dtype=np.float32)
+    for name, slot in program.slot_by_name.items():
+        if name not in named:
+            raise KeyError("no noise supplied for latent variable {!r}".format(name))
+        a = np.asarray(named[name], dtype=np.float32)
+        a = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(-1, 1)
+        if a.shape[0] == 1 and n > 1:
+            a = np.repeat(a, n, axis=0)
+        if a.shape[1] == 1 and slot.size > 1:
+            a = np.repeat(a, slot.size, axis=1)
+        if a.shape != (n, slot.size):
+            raise ValueError("noise for {!r} has shape {}, expected ({}, {})".format(name, a.shape, n, slot.size))
+        out[slot.base:slot.base + slot.size, :] = a.T
+    return out
+
+
+class FusedLoss:
+    """What ``InferenceMethod.compute_loss`` returns: the loss of one fused ELBO evaluation.
+    The gradients were produced by the same kernel launch, so ``backward()`` has nothing
+    left to do (`brancher/inference.py:96-100`)."""
+
+    def __init__(self, compiled, tensor):
+        self.compiled = compiled
+        self.tensor = tensor          # 0-d device tensor
+
+    def backward(self):
+        return None
+
+    def detach(self):
+        return self.tensor.detach()
+
+    def item(self):
+        return float(self.tensor.item())
+
+    def __float__(self):
+        return self.item()
+
+    def cpu(self):
+        return self.tensor.cpu()
+
+    def __neg__(self):
+        return -self.tensor
+
+
+class CompiledELBO:
+    def __init__(self, joint_model, posterior_model, estimator="pathwise", device=None):
+        self.device = device or _device()
+        self.program = lowering.lower(joint_model, posterior_model, estimator)
+        self.native = native.NativeProgram(self.program)
+        self.lib = self.native.lib
+        p = self.program
+        dev = self.device
+        self.n_params = p.n_params
+        self.params = torch.from_numpy(p.initial_params()).to(dev)
+        self.obs = torch.from_numpy(np.ascontiguousarray(p.obs)).to(dev) if p.obs.size else torch.zeros(1, device=dev)
+        self.out = torch.zeros(OUT_HEADER + max(p.n_params, 1), device=dev, dtype=torch.float32)
+        self.grads_valid = False
+        active = np.ascontiguousarray(p.param_active, dtype=np.uint8)
+        group = p.param_group
+        first_group = 0 if np.any(active[group == 0]) else 1
+        self.mask_all = torch.from_numpy(active.copy()).to(dev)
+        self.mask_first = torch.from_numpy((active * (group == first_group)).astype(np.uint8)).to(dev)
+        self._workspaces = {}
+        self._noise_cache = None
+        self.iteration = 0          # Philox counter offset: never reuse noise across calls
+        for par, off, size, _ in p.parameters:
+            par.bind(self, off)
+
+    # ---- ParameterStore protocol (modules.Parameter) -------------------------------------
+    def read_params(self, offset, size):
+        return self.params[offset:offset + size].detach().cpu().numpy()
+
+    def write_params(self, offset, values):
+        self.params[offset:offset + values.size] = torch.from_numpy(np.ascontiguousarray(values)).to(self.device)
+
+    def read_grads(self, offset, size):
+        if not self.grads_valid:
+            return None
+        o = OUT_HEADER + offset
+        return self.out[o:o + size].detach().cpu().numpy()
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def workspace(self, n_local):
+        ws = self._workspaces.get(n_local)
+        if ws is None:
+            nbytes = self.native.workspace_bytes(n_local)
+            if nbytes == 0:
+                raise native.NativeError("the model program does not fit the LDS budget for {} samples".format(n_local))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._workspaces[n_local] = ws
+        return ws
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _seed(self, seed):
+        return int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+
+    def _elbo_args(self, n_local, n_global, base, noise=None, seed=None, offset=0, samples_out=None,
+                   noise_out=None, fvalue_out=None):
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        return ElboArgs(params_dev=ptr(self.params), obs_dev=ptr(self.obs), noise_dev=ptr(noise),
+                        seed=self._seed(seed), offset=int(offset), n_samples_local=n_local,
+                        n_samples_global=n_global, sample_base=base, out_dev=ptr(self.out),
+                        samples_out_dev=ptr(samples_out), noise_out_dev=ptr(noise_out),
+                        fvalue_out_dev=ptr(fvalue_out), workspace_dev=ptr(self.workspace(n_local)),
+                        stream=self._stream())
+
+    def _noise_tensor(self, noise, n_global, base, n_local):
+        """named dict / [n_noise, N] array / device tensor -> device [n_noise, n_local] (this rank's columns)"""
+        if noise is None:
+            return None
+        if isinstance(noise, dict):
+            noise = noise_from_named(self.program, noise, n_global)
+        if isinstance(noise, np.ndarray):
+            noise = torch.from_numpy(np.ascontiguousarray(noise[:, base:base + n_local], dtype=np.float32))
+            return noise.to(self.device)
+        if noise.shape[1] != n_local:
+            noise = noise[:, base:base + n_local].contiguous()
+        return noise
+
+    # ---- one ELBO evaluation -------------------------------------------------------------------
+    def evaluate(self, number_samples, noise=None, seed=None, offset=None, want_samples=False,
+                 want_noise=False, want_fvalues=False):
+        """Loss and gradients of one ELBO estimate (`variables.py:843-870` with
+        for_gradient=True + `inference.py:100`).  Returns a dict of device tensors."""
+        rank, world = dist_info()
+        base, n_local = shard(number_samples, rank, world)
+        if n_local == 0:
+            raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
+        if offset is None:
+            offset = self.iteration
+            self.iteration += 1
+        dev = self.device
+        p = self.program
+        noise_t = self._noise_tensor(noise, number_samples, base, n_local)
+        samples = torch.empty((p.n_slots, n_local), device=dev) if want_samples else None
+        noise_o = torch.empty((p.n_noise, n_local), device=dev) if want_noise else None
+        fvals = torch.empty((2, n_local), device=dev) if want_fvalues else None
+        args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
+        native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.out, op=dist.ReduceOp.SUM)
+        native.check(self.lib.bsvi_finalize(self.native.handle, C.c_void_p(self.out.data_ptr()), number_samples,
+                                            self._stream()))
+        self.grads_valid = True
+        res = dict(loss=self.out[2], finite=self.out[3], nonfinite_count=self.out[1],
+                   grads=self.out[OUT_HEADER:OUT_HEADER + p.n_params], n_local=n_local, sample_base=base)
+        if want_samples:
+            res["samples"] = samples
+        if want_noise:
+            res["noise"] = noise_o
+        if want_fvalues:
+            res["f"], res["lq"] = fvals[0], fvals[1]
+        return res
+
+    def named_grads(self):
+        g = self.out[OUT_HEADER:].detach().cpu().numpy()
+        out = {}
+        for par, off, size, _ in self.program.parameters:
+            out[par.name] = g[off:off + size].reshape(par.shape).copy()
+        return out
+
+    def named_params(self):
+        t = self.params.detach().cpu().numpy()
+        return {par.name: t[off:off + size].reshape(par.shape).copy() for par, off, size, _ in self.program.parameters}
+
+    def samples_by_name(self, samples):
+        """device [n_slots, n] -> {name: numpy [n, B, D1, D2]} (reference layout at the API edge)"""
+        s = samples.detach().cpu().numpy()
+        out = {}
+        for name, slot in self.program.slot_by_name.items():
+            out[name] = s[slot.base:slot.base + slot.size, :].T.reshape((s.shape[1],) + tuple(slot.shape)).copy()
+        return out
+
+    # ---- the optimisation loop --------------------------------------------------------------------
+    def train(self, number_iterations, number_samples, optimizer="Adam", noise_seq=None, seed=None,
+              pretraining_iterations=0, allow_persistent=True, **opt_params):
+        """`brancher/inference.py:95-108` on the device.  Returns (loss_curve, finite_flags) as
+        device tensors of length number_iterations; nothing synchronises with the host."""
+        cfg = native.make_opt_cfg(optimizer, **opt_params)
+        rank, world = dist_info()
+        base, n_local = shard(number_samples, rank, world)
+        if n_local == 0:
+            raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
+        dev = self.device
+        p = self.program
+        K = int(number_iterations)
+        loss_curve = torch.zeros(max(K, 1), device=dev)
+        finite = torch.ones(max(K, 1), device=dev)
+        state = torch.zeros(4 * max(p.n_params, 1), device=dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        noise_t = None
+        if noise_seq is not None:
+            # [K][n_noise][n_local] contiguous
+            mats = [noise_from_named(p, nz, number_samples) if isinstance(nz, dict) else np.asarray(nz)
+                    for nz in noise_seq]
+            arr = np.ascontiguousarray(np.stack(mats)[:, :, base:base + n_local], dtype=np.float32)
+            noise_t = torch.from_numpy(arr).to(dev)
+        offset0 = self.iteration
+        self.iteration += K
+        self.grads_valid = True
+        if K == 0:
+            return loss_curve[:0], finite[:0]
+
+        persistent = (allow_persistent and world == 1 and self.native.persistent_supported(n_local))
+        if persistent:
+            args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset0)
+            native.check(self.lib.bsvi_train_persistent2(
+                self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(self.mask_all),
+                ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite)))
+            self.last_mode = "persistent"
+            return loss_curve, finite
+
+        import torch.distributed as dist
+        for it in range(K):
+            nz = None if noise_t is None else noise_t[it]
+            args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
+            mask = self.mask_all if it > pretraining_iterations else self.mask_first
+            if world == 1:
+                native.check(self.lib.bsvi_svi_step(
+                    self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(mask),
+                    C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it)))
+            else:
+                native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
+                dist.all_reduce(self.out, op=dist.ReduceOp.SUM)
+                native.check(self.lib.bsvi_finalize(self.native.handle, ptr(self.out), number_samples, self._stream()))
+                native.check(self.lib.bsvi_optimizer_step(C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state),
+                                                          ptr(mask), p.n_params, self._stream()))
+                loss_curve[it:it + 1].copy_(self.out[2:3])
+                finite[it:it + 1].copy_(self.out[3:4])
+        self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
+        return loss_curve, finite
+
+
+def compile_model(joint_model, posterior_model=None, gradient_estimator=None):
+    """Compile once per (posterior, estimator); cached on the joint model."""
+    if posterior_model is None:
+        joint_model.check_posterior_model()
+        posterior_model = joint_model.posterior_model
+    est = estimator_name(gradient_estimator)
+    key = (id(posterior_model), est)
+    compiled = joint_model._compiled.get(key)
+    if compiled is None:
+        # all programs of one (joint, posterior) pair share one parameter buffer
+        sibling = next((c for (pid, _), c in joint_model._compiled.items() if pid == id(posterior_model)), None)
+        compiled = CompiledELBO(joint_model, posterior_model, est)
+        if sibling is not None:
+            if sibling.n_params != compiled.n_params:
+                raise RuntimeError("parameter layouts of two estimators of the same model differ")
+            compiled.params = sibling.params
+            for par, off, size, _ in compiled.program.parameters:
+                par.bind(compiled, off)
+        joint_model._compiled[key] = compiled
+    return compiled
+
+
+def estimate_elbo(joint_model, posterior_model, number_samples, for_gradient=False, gradient_estimator=None):
+    compiled = compile_model(joint_model, posterior_model, gradient_estimator)
+    res = compiled.evaluate(number_samples)
+    if for_gradient:
+        return FusedLoss(compiled, -res["loss"])       # estimate_log_model_evidence returns +ELBO
+    return -res["loss"]
+
+
+# ---- sampling / evaluation API edge ("next" row) ---------------------------------
+def _not_yet(what):
+    raise NotImplementedError("{} is the posterior-predictive / evaluation path (SURVEY §8f-3), outside the "
+                              "ELBO-gradient hot path this build covers".format(what))
+
+
+def sample_model(model, number_samples, observed=False, input_values={}):
+    _not_yet("ProbabilisticModel._get_sample")
+
+
+def sample_variables(variables, number_samples, observed=False, input_values={}):
+    _not_yet("Variable._get_sample")
+
+
+def get_sample_frame(model, number_samples, input_values={}):
+    _not_yet("get_sample")
+
+
+def posterior_sample(model, number_samples, input_values={}):
+    """Posterior draws of the latent variables, keyed by the joint model's variables
+    (`variables.py:796-805` restricted to the latent variables of the posterior)."""
+    compiled = compile_model(model, model.posterior_model, None)
+    res = compiled.evaluate(number_samples, want_samples=True)
+    by_name = compiled.samples_by_name(res["samples"])
+    mapping = lowering.get_model_mapping(model.posterior_model, model)
+    out = {}
+    for q_var, p_var in mapping.items():
+        if q_var.name in by_name:
+            out[p_var] = torch.from_numpy(by_name[q_var.name])
+    return out
+
+
+def get_posterior_sample_frame(model, number_samples, input_values={}):
+    import pandas as pd
+    sample = posterior_sample(model, number_samples, input_values)
+    return pd.DataFrame({v.name: [x for x in t.numpy().reshape(t.shape[0], -1).squeeze(-1)]
+                         if t[0].numel() == 1 else list(t.numpy()) for v, t in sample.items()})
+
+
+def log_probability(variables, values, include_parents=True, model=None):
+    _not_yet("calculate_log_probability outside the ELBO")

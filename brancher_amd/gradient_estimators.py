@@ -1,0 +1,47 @@
+"""
+Gradient estimators (`brancher/gradient_estimators.py`).
+
+In the reference an estimator receives an opaque closure and a sampler and is evaluated in
+Python (`gradient_estimators.py:17-44`).  Here the classes are *selectors*: both land on the
+same fused kernel (include/bsvi.h `bsvi_estimator`), which evaluates
+
+  Pathwise :  mean_s f(z_s),                      z = reparameterised draw      (:39-44)
+  BlackBox :  mean_s [ log q(z_s) * stopgrad(f(z_s)) + f(z_s) ]                  (:29-36)
+
+BlackBox reproduces the reference exactly, including that its value is not the ELBO and that
+reparameterisable nodes still carry the pathwise term (the ``differentiable=False`` flag is
+dropped at `variables.py:567`).
+"""
+from abc import ABC, abstractmethod
+
+
+class GradientEstimator(ABC):
+    kernel_name = None
+
+    def __init__(self, function=None, sampler=None, empirical_samples={}):
+        self.function = function
+        self.sampler = sampler
+        self.empirical_samples = empirical_samples
+
+    @abstractmethod
+    def __call__(self, n_samples):
+        pass
+
+
+class _Fused(GradientEstimator):
+    def __call__(self, n_samples):
+        raise NotImplementedError("fused estimators are evaluated by the engine: use "
+                                  "ProbabilisticModel.estimate_log_model_evidence(..., gradient_estimator=cls)")
+
+
+class PathwiseDerivativeEstimator(_Fused):
+    kernel_name = "pathwise"
+
+
+class BlackBoxEstimator(_Fused):
+    kernel_name = "blackbox"
+
+
+class Taylor1Estimator(_Fused):
+    # `gradient_estimators.py:47-56` — "next" row f-2 of SURVEY §8; not lowered yet.
+    kernel_name = None

@@ -426,9 +426,17 @@ class _Lowering:
         self.rec_regs[node.key] = r
         return r
 
-    def node_op(self, op, dist, dst=0, a=0, b=0, c=0, base=0, strides=(0, 0, 0), w=0.0, wf=0.0, noise=0):
-        self.put(op, dst=dst, a=a, b=b, w1=base, strides=strides, aux=dist)
-        self.code.append([_fbits(w), _fbits(wf), int(noise), int(c)])
+    def node_op(self, op, dist, dst=0, a=0, b=0, c=0, base=0, strides=(0, 0, 0), w=0.0, wf=0.0):
+        """node ops fit one slot (include/bsvi.h): LOGP keeps the value register in the dst field
+        and its two weights in w1/w2; ENTROPY keeps its weight in w1; SAMPLE has base+strides."""
+        if op == "LOGP":
+            w0 = OP[op] | (c << 8) | (a << 16) | (b << 24)
+            self.code.append([w0, _fbits(w), _fbits(wf), dist << 16])
+        elif op == "ENTROPY":
+            w0 = OP[op] | (a << 16) | (b << 24)
+            self.code.append([w0, _fbits(w), 0, dist << 16])
+        else:
+            self.put(op, dst=dst, a=a, b=b, w1=base, strides=strides, aux=dist)
 
     # ---------------------------------------------------------------- node parameter IR
     def node_params(self, var, ctx):
@@ -538,7 +546,7 @@ class _Lowering:
             rb = regs[1] if len(regs) > 1 else 0
             rz = self.new_reg()
             self.node_op("SAMPLE", dist.kind, dst=rz, a=ra, b=rb, base=slot.base,
-                         strides=_elem_strides(shape, shape), noise=slot.base)
+                         strides=_elem_strides(shape, shape))
             w = weight(shape[0])
             wf = 1.0 if self.estimator == "blackbox" else 0.0
             if dist.has_analytic_entropy:

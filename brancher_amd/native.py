@@ -1,0 +1,186 @@
+"""
+ctypes binding of the C ABI (include/bsvi.h) — the only way the Python host layer reaches
+the HIP kernels.  There is deliberately no fallback: if ``libbsvi.so`` is missing or no
+MI355X is visible, evaluating a model raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsvi.so")
+ABI_VERSION = 1
+OUT_HEADER = 4
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class UniformEntry(C.Structure):
+    _fields_ = [("src", C.c_uint32), ("transform", C.c_uint8), ("is_param", C.c_uint8),
+                ("reserved", C.c_uint16), ("a", C.c_float), ("b", C.c_float)]
+
+
+class Record(C.Structure):
+    _fields_ = [("code_begin", C.c_uint32), ("code_end", C.c_uint32), ("dims", C.c_uint32 * 3),
+                ("flags", C.c_uint32)]
+
+
+class ProgramDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_params", C.c_uint32), ("n_consts", C.c_uint32),
+                ("n_obs", C.c_uint32), ("n_slots", C.c_uint32), ("n_noise", C.c_uint32),
+                ("n_uniform", C.c_uint32), ("n_uniform_grad", C.c_uint32), ("n_records", C.c_uint32),
+                ("n_code", C.c_uint32), ("estimator", C.c_uint32), ("reserved", C.c_uint32),
+                ("uniform", C.c_void_p), ("records", C.c_void_p), ("code", C.c_void_p), ("consts", C.c_void_p),
+                ("param_uniform_ptr", C.c_void_p), ("param_uniform_idx", C.c_void_p)]
+
+
+class ElboArgs(C.Structure):
+    _fields_ = [("params_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("noise_dev", C.c_void_p),
+                ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
+                ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
+                ("out_dev", C.c_void_p), ("samples_out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p),
+                ("fvalue_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class OptCfg(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("lr", C.c_float), ("momentum", C.c_float), ("dampening", C.c_float),
+                ("weight_decay", C.c_float), ("nesterov", C.c_uint32), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("amsgrad", C.c_uint32), ("maximize", C.c_uint32)]
+
+
+EXPORTS = {
+    "bsvi_program_create": (C.c_int, [C.POINTER(ProgramDesc), C.POINTER(C.c_void_p)]),
+    "bsvi_program_destroy": (None, [C.c_void_p]),
+    "bsvi_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "bsvi_elbo_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs)]),
+    "bsvi_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bsvi_optimizer_step": (C.c_int, [C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.c_void_p]),
+    "bsvi_svi_step": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsvi_train_persistent": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bsvi_train_persistent2": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bsvi_persistent_supported": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bsvi_query_geometry": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "bsvi_debug_math": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                  C.c_void_p]),
+    "bsvi_last_error": (C.c_char_p, []),
+    "bsvi_abi_version": (C.c_int, []),
+    "bsvi_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libbsvi.so (built by brancher_amd/csrc/Makefile / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (soname libamdhip64.so.7).  Import torch first so
+    # that libbsvi.so binds to that same runtime instance: two HIP runtimes in one process do
+    # not share devices, streams or allocations.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise NativeError("{} not found: build it with `make -C brancher_amd/csrc` (hipcc --offload-arch=gfx950). "
+                          "There is no CPU fallback.".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in EXPORTS.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.bsvi_abi_version() != ABI_VERSION:
+        raise NativeError("libbsvi.so ABI version {} != {}".format(lib.bsvi_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError("bsvi error {}: {}".format(rc, load().bsvi_last_error().decode()))
+
+
+def _ptr(arr):
+    return arr.ctypes.data_as(C.c_void_p) if arr is not None and arr.size else None
+
+
+class NativeProgram:
+    """Owns a ``bsvi_program*`` created from a lowered ``Program``."""
+
+    def __init__(self, program):
+        from brancher_amd.lowering import EST
+        lib = load()
+        if lib.bsvi_device_count() < 1:
+            raise NativeError("no MI355X / HIP device visible: the engine cannot run (no CPU fallback)")
+        self._keep = dict(
+            uniform=np.ascontiguousarray(program.uniform), records=np.ascontiguousarray(program.records),
+            code=np.ascontiguousarray(program.code, dtype=np.uint32),
+            consts=np.ascontiguousarray(program.consts, dtype=np.float32),
+            ptr=np.ascontiguousarray(program.param_uniform_ptr, dtype=np.uint32),
+            idx=np.ascontiguousarray(program.param_uniform_idx, dtype=np.uint32))
+        k = self._keep
+        assert k["uniform"].dtype.itemsize == C.sizeof(UniformEntry)
+        assert k["records"].dtype.itemsize == C.sizeof(Record)
+        d = ProgramDesc(abi_version=ABI_VERSION, n_params=program.n_params, n_consts=k["consts"].size,
+                        n_obs=program.obs.size, n_slots=program.n_slots, n_noise=program.n_noise,
+                        n_uniform=len(k["uniform"]), n_uniform_grad=program.n_uniform_grad,
+                        n_records=len(k["records"]), n_code=len(k["code"]), estimator=EST[program.estimator],
+                        uniform=_ptr(k["uniform"]), records=_ptr(k["records"]), code=_ptr(k["code"]),
+                        consts=_ptr(k["consts"]), param_uniform_ptr=_ptr(k["ptr"]), param_uniform_idx=_ptr(k["idx"]))
+        handle = C.c_void_p()
+        check(lib.bsvi_program_create(C.byref(d), C.byref(handle)))
+        self.handle = handle
+        self.lib = lib
+
+    def workspace_bytes(self, n_local):
+        return int(self.lib.bsvi_workspace_bytes(self.handle, n_local))
+
+    def geometry(self, n_local):
+        nb, nw, zg, lds = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(self.lib.bsvi_query_geometry(self.handle, n_local, C.byref(nb), C.byref(nw), C.byref(zg), C.byref(lds)))
+        return dict(n_blocks=nb.value, n_waves=nw.value, zglobal=bool(zg.value), lds_bytes=lds.value)
+
+    def persistent_supported(self, n_local):
+        return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.bsvi_program_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def make_opt_cfg(optimizer, **kw):
+    """torch.optim keyword arguments -> bsvi_opt_cfg (`brancher/optimizers.py:53-67` forwards
+    ``**opt_params`` verbatim to ``getattr(torch.optim, name)``)."""
+    name = optimizer if isinstance(optimizer, str) else getattr(optimizer, "__name__", str(optimizer))
+    if name == "SGD":
+        allowed = {"lr", "momentum", "dampening", "weight_decay", "nesterov", "maximize"}
+        extra = set(kw) - allowed
+        if extra:
+            raise NotImplementedError("SGD options {} are not supported by the fused optimizer".format(sorted(extra)))
+        if kw.get("nesterov") and (kw.get("momentum", 0) <= 0 or kw.get("dampening", 0) != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        return OptCfg(kind=0, lr=kw.get("lr", 1e-3), momentum=kw.get("momentum", 0.0),
+                      dampening=kw.get("dampening", 0.0), weight_decay=kw.get("weight_decay", 0.0),
+                      nesterov=int(bool(kw.get("nesterov", False))), maximize=int(bool(kw.get("maximize", False))))
+    if name == "Adam":
+        allowed = {"lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"}
+        extra = set(kw) - allowed
+        if extra:
+            raise NotImplementedError("Adam options {} are not supported by the fused optimizer".format(sorted(extra)))
+        b1, b2 = kw.get("betas", (0.9, 0.999))
+        return OptCfg(kind=1, lr=kw.get("lr", 1e-3), beta1=b1, beta2=b2, eps=kw.get("eps", 1e-8),
+                      weight_decay=kw.get("weight_decay", 0.0), amsgrad=int(bool(kw.get("amsgrad", False))),
+                      maximize=int(bool(kw.get("maximize", False))))
+    raise NotImplementedError("optimizer {!r}: the fused device optimizer implements torch.optim.SGD and "
+                              "torch.optim.Adam".format(name))

@@ -63,8 +63,12 @@ typedef enum bsvi_dist {
  *        w1 = base index or immediate (float bits)
  *        w2 = stride[0] | stride[1]<<16               (element strides along B, D1)
  *        w3 = stride[2] | aux<<16                     (element stride along D2; aux = dist id)
- *      node ops (SAMPLE / LOGP / ENTROPY) are followed by one payload slot:
- *        p0 = weight (float)   p1 = weight_f (float)   p2 = noise index base   p3 = c register
+ *      node ops reuse the fields they do not need, so every op is exactly one slot:
+ *        SAMPLE   dst = z register, a/b = parameter registers, w1 = slot base (= noise row
+ *                 base), strides, aux = distribution id
+ *        LOGP     dst field = VALUE register, a/b = parameter registers,
+ *                 w1 = weight (float bits), w2 = weight_f (float bits), aux = distribution id
+ *        ENTROPY  a/b = parameter registers, w1 = weight (float bits), aux = distribution id
  *      They restate the closures built by brancher/variables.py:995-1002 and
  *      brancher/functions.py:28-41, and the per-node calls of
  *      brancher/distributions.py:63-96. --------------------------------------------------- */
@@ -86,7 +90,7 @@ typedef enum bsvi_op {
     BSVI_OP_EXPM1 = 29, BSVI_OP_SQUARE = 30, BSVI_OP_P2L = 31 /* probs -> logits, torch clamp */,
     /* node ops */
     BSVI_OP_SAMPLE = 40,  /* draw z ~ dist(r[a], r[b]) from noise; r[dst] = z; Z[base+off] = z */
-    BSVI_OP_LOGP = 41,    /* f += w * log p(r[c] | r[a], r[b]);  lq += wf * (same)             */
+    BSVI_OP_LOGP = 41,    /* f += w * log p(r[dst] | r[a], r[b]);  lq += wf * (same)           */
     BSVI_OP_ENTROPY = 42, /* f += w * H[dist(r[a], r[b])]                                      */
     BSVI_OP_STZ = 43      /* Z[base+off] = r[a]   (deterministic node / spilled expression)    */
 } bsvi_op;
@@ -205,8 +209,8 @@ typedef struct bsvi_opt_cfg {
 
 /* Apply one optimizer step to params[i] for every i with active_mask[i] != 0, unless
  * out_dev[3] (finite flag) is 0 — `inference.py:98-107`.  `state_dev` is
- * [3][n_params] floats (momentum / exp_avg, exp_avg_sq, max_exp_avg_sq) followed by one
- * float step counter; zero-initialised by the caller. */
+ * [4][n_params] floats (momentum_buffer | exp_avg, exp_avg_sq, max_exp_avg_sq, step count —
+ * torch keeps one step counter per parameter); zero-initialised by the caller. */
 int bsvi_optimizer_step(const bsvi_opt_cfg* cfg, float* params_dev, const float* out_dev,
                         float* state_dev, const uint8_t* active_mask_dev, uint32_t n_params,
                         void* stream);
@@ -220,8 +224,36 @@ int bsvi_train_persistent(const bsvi_program* prog, const bsvi_elbo_args* args,
                           const uint8_t* active_mask_dev, uint32_t n_iterations,
                           float* loss_curve_dev, float* finite_dev);
 
+/* Same, with the reference's `pretraining_iterations` rule (inference.py:102-104): parameters
+ * selected by active_mask_first_dev are stepped on every iteration, the rest of active_mask_dev
+ * only when iteration > pretraining_iterations (the reference's second optimizer, built for the
+ * joint model, is skipped on iteration 0 even with the default pretraining_iterations=0). */
+int bsvi_train_persistent2(const bsvi_program* prog, const bsvi_elbo_args* args,
+                           const bsvi_opt_cfg* cfg, float* params_dev, float* state_dev,
+                           const uint8_t* active_mask_dev, const uint8_t* active_mask_first_dev,
+                           uint32_t pretraining_iterations, uint32_t n_iterations,
+                           float* loss_curve_dev, float* finite_dev);
+
 /* 1 if bsvi_train_persistent supports (prog, n_samples_local), else 0. */
 int bsvi_persistent_supported(const bsvi_program* prog, uint32_t n_samples_local);
+
+/* One complete single-GPU SVI iteration in two launches: ELBO fwd+bwd, then reduction fused
+ * with finalize and the optimizer step (inference.py:96-104).  Optionally logs the loss and the
+ * finite flag of the iteration to loss_slot_dev / finite_slot_dev (inference.py:105). */
+int bsvi_svi_step(const bsvi_program* prog, const bsvi_elbo_args* args, const bsvi_opt_cfg* cfg,
+                  float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
+                  float* loss_slot_dev, float* finite_slot_dev);
+
+/* Launch geometry the library uses for n_samples_local samples (for tests/bench/DESIGN.md). */
+int bsvi_query_geometry(const bsvi_program* prog, uint32_t n_samples_local, uint32_t* n_blocks,
+                        uint32_t* n_waves, uint32_t* zglobal, uint64_t* lds_bytes);
+
+/* Test hook, not used by the product path: evaluates one special function (fn 0 digamma,
+ * 1 trigamma, 2 dirichlet_grad_one(x, alpha=p0, total=p1), 6 lgamma) or one node function of
+ * distribution `dist` (fn 3 log-prob, 4 entropy, 5 reparameterised draw from noise x) elementwise;
+ * out_dev is [4][n] = value, d/dx, d/dp0, d/dp1. */
+int bsvi_debug_math(int fn, int dist, const float* x_dev, const float* p0_dev, const float* p1_dev,
+                    float* out_dev, uint32_t n, void* stream);
 
 const char* bsvi_last_error(void);
 int bsvi_abi_version(void);

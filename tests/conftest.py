@@ -1,0 +1,59 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+class Golden:
+    """One fixture generated from the real reference by oracle/gen_golden.py."""
+
+    def __init__(self, name):
+        self.name = name
+        self.data = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.meta = json.loads(str(self.data["meta"]))
+        self.N = self.meta["N"]
+
+    def group(self, prefix):
+        return {k[len(prefix):]: self.data[k] for k in self.data.files if k.startswith(prefix)}
+
+    @property
+    def noise(self):
+        return self.group("noise/")
+
+    def build(self, api=None):
+        from brancher_amd import workloads as W
+        return getattr(W, self.meta["builder"])(api or W.native_api(), **self.meta["kwargs"])
+
+    def trajectory_noise(self):
+        tr = self.meta["trajectory"]
+        seq = self.group("traj/noise/")
+        return [{k: v[i] for k, v in seq.items()} for i in range(tr["iters"])]
+
+    def opt_kwargs(self):
+        tr = self.meta["trajectory"]
+        return {k: v for k, v in tr.items() if k not in ("iters", "n", "optimizer")}
+
+
+@pytest.fixture(params=golden_cases())
+def golden(request):
+    return Golden(request.param)
+
+
+def rel_err(a, b, floor=1e-7):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + floor))

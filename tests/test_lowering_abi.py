@@ -1,0 +1,116 @@
+"""Host logic: lowering invariants, header/Python constant sync, and that the C-ABI library
+loads and exports every symbol include/bsvi.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, Golden
+from brancher_amd import lowering, native, workloads as W
+from brancher_amd import distributions as D
+
+HEADER = open(os.path.join(ROOT, "include", "bsvi.h")).read()
+
+
+def header_enum(prefix):
+    out = {}
+    for name, val in re.findall(r"(%s[A-Z0-9_]+)\s*=\s*(-?\d+)" % prefix, HEADER):
+        out[name[len(prefix):]] = int(val)
+    return out
+
+
+def test_opcodes_match_header():
+    ops = header_enum("BSVI_OP_")
+    for k, v in lowering.OP.items():
+        assert ops[k] == v, k
+    assert int(re.search(r"#define BSVI_NUM_REGS (\d+)", HEADER).group(1)) == lowering.NUM_REGS
+    ut = header_enum("BSVI_UT_")
+    for k, v in lowering.UT.items():
+        assert ut[k.upper()] == v
+    dist = header_enum("BSVI_DIST_")
+    for k in ("NORMAL", "LOGNORMAL", "CAUCHY", "LAPLACE", "BETA", "BINOMIAL", "BERNOULLI", "DETERMINISTIC"):
+        assert dist[k] == getattr(D, "DIST_" + k)
+    assert int(re.search(r"#define BSVI_OUT_HEADER (\d+)", HEADER).group(1)) == native.OUT_HEADER
+
+
+def test_struct_layouts():
+    assert ctypes.sizeof(native.UniformEntry) == 16 == lowering.UNIFORM_DTYPE.itemsize
+    assert ctypes.sizeof(native.Record) == 24 == lowering.RECORD_DTYPE.itemsize
+
+
+def test_library_exports_every_declared_symbol():
+    declared = set(re.findall(r"\b(bsvi_[a-z0-9_]+)\s*\(", HEADER))
+    declared -= {"bsvi_status", "bsvi_op"}
+    lib = native.load()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "libbsvi.so does not export %s" % sym
+        assert sym in native.EXPORTS, "native.py does not bind %s" % sym
+    assert lib.bsvi_abi_version() == native.ABI_VERSION
+
+
+def test_program_create_fails_loudly_without_gpu():
+    lib = native.load()
+    if lib.bsvi_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    prog = lowering.lower(W.build_readme_ar(W.native_api(), T=3))
+    with pytest.raises(native.NativeError):
+        native.NativeProgram(prog)
+
+
+def test_readme_ar_program_structure():
+    T = 20
+    model = W.build_readme_ar(W.native_api(), T=T)
+    prog = lowering.lower(model)
+    s = prog.summary()
+    assert s["n_params"] == 43                  # SURVEY §8d cfg 1: 43 parameters
+    assert s["n_slots"] == T + 1                # 21 latent scalars
+    assert s["n_records"] == (T + 1) + (2 * T + 1)   # 21 q nodes + 41 p nodes
+    assert prog.param_active.all()
+    # name-collision rule of the reference: the prior's x_t scale is the posterior's learnable root
+    names = {p.name for p, _, _, _ in prog.parameters}
+    assert "x3_scale" in names and "b_logit_loc" in names
+    # every uniform entry sourced from a parameter comes first
+    assert prog.uniform["is_param"][:prog.n_uniform_grad].all()
+    assert not prog.uniform["is_param"][prog.n_uniform_grad:].any()
+    # CSR covers the parameter-sourced entries exactly once
+    assert prog.param_uniform_ptr[-1] == prog.n_uniform_grad
+    assert sorted(prog.param_uniform_idx.tolist()) == list(range(prog.n_uniform_grad))
+
+
+def test_softplus_and_sigmoid_transforms_are_hoisted():
+    prog = lowering.lower(W.build_beta_binomial(W.native_api()))
+    tr = set(prog.uniform["transform"].tolist())
+    assert lowering.UT["softplus"] in tr
+    ops = prog.code[:, 0] & 0xFF
+    assert lowering.OP["SOFTPLUS"] not in ops    # never evaluated per sample
+
+
+def test_observed_nodes_sum_over_datapoints():
+    prog = lowering.lower(W.build_lognormal_normal(W.native_api(), n_obs=20))
+    dims = [tuple(r["dims"]) for r in prog.records]
+    assert (20, 1, 1) in dims
+    assert prog.obs.size == 20 and prog.bmax == 1
+
+
+def test_unsupported_function_raises():
+    api = W.native_api()
+    a = api.NormalVariable(0., 1., "a")
+    b = api.NormalVariable(api.BF.erfinv(a), 1., "b")
+    m = api.ProbabilisticModel([a, b])
+    b.observe(np.zeros((1, 1)))
+    m.set_posterior_model(api.ProbabilisticModel([api.NormalVariable(0., 1., "a", learnable=True)]))
+    with pytest.raises(lowering.LoweringError):
+        lowering.lower(m)
+
+
+def test_noise_packing_round_trip():
+    from brancher_amd.engine import noise_from_named
+    g = Golden("readme_ar_T5_N7")
+    prog = lowering.lower(g.build())
+    mat = noise_from_named(prog, g.noise, g.N)
+    assert mat.shape == (prog.n_noise, g.N)
+    for name, arr in g.noise.items():
+        base, size, _ = prog.noise_rows(name)
+        assert np.array_equal(mat[base], arr.reshape(g.N))
