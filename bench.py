@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""
+bench.py — ELBO iterations/sec of the fused SVI engine (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3] [--mode auto|persistent|stepwise]
+
+A "step" is one complete SVI iteration of `brancher/inference.py:95-108`: draw number_samples
+reparameterised posterior samples (in-kernel Philox), evaluate log p + entropy over the model
+graph, reverse sweep, (all-reduce over GPUs), finite check, optimizer step, loss log.
+Default workload = BASELINE config the metric is quoted on: the README T=20 autoregressive
+model at number_samples=300, SGD lr=1e-3 (`README.md:25-75`).
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): weak scaling over the
+Monte-Carlo sample axis — every GPU evaluates `number_samples` samples of the same
+iteration and ONE all-reduce (RCCL) of 4+P floats joins them.  `value` is whole-job
+throughput in 300-sample ELBO iterations per second:  (global samples per step / 300) * steps / s.
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (builder, kwargs, number_samples per GPU, optimizer, opt kwargs, description)
+    "cfg1": ("build_readme_ar", dict(T=20), 300, "SGD", dict(lr=1e-3),
+             "README AR state-space T=20, number_samples=300, SGD lr=1e-3 (BASELINE config 1)"),
+    "cfg2": ("build_beta_binomial", dict(n_obs=30), 4096, "SGD", dict(lr=0.1),
+             "beta_binomial.py Beta posterior, 30 observations, number_samples=4096, SGD lr=0.1 (BASELINE config 2)"),
+    "cfg3": ("build_readme_ar", dict(T=200), 1024, "SGD", dict(lr=1e-4),
+             "README AR state-space T=200, number_samples=8192 sharded as 1024 per GPU (BASELINE config 3)"),
+    "cfg1_big": ("build_readme_ar", dict(T=20), 262144, "SGD", dict(lr=1e-3),
+                 "README AR T=20 at number_samples=262144 (throughput regime of the same kernel)"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_iteration(program, n_local):
+    """N*L*4 noise bytes (the eps the estimator consumes; generated in registers here)
+    + parameters read + gradients written."""
+    return n_local * program.n_noise * 4 + 2 * program.n_params * 4
+
+
+def cpu_baseline(builder, kwargs, n_samples, optimizer, opt_kwargs, budget_s=12.0, max_iters=400):
+    """The oracle (PyTorch-CPU restatement of the reference loop, kind 'port') timed on the host."""
+    import torch
+    from brancher_amd import workloads as W
+    from oracle.svi_oracle import Oracle
+    torch.set_num_threads(1)    # the reference is dispatch-bound: more threads are slower
+    oracle = Oracle(getattr(W, builder)(W.native_api(), **kwargs))
+    torch.manual_seed(0)
+    oracle.train(2, n_samples, optimizer, "pathwise", None, **opt_kwargs)
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < max_iters:
+        oracle.train(5, n_samples, optimizer, "pathwise", None, **opt_kwargs)
+        iters += 5
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=iters / dt * (n_samples / 300.0), unit="it/s", cores=1, kind="port",
+                sample="%d iterations of the same workload (number_samples=%d) in %.1f s, oracle/svi_oracle.py "
+                       "on PyTorch-CPU, 1 thread" % (iters, n_samples, dt),
+                iters_per_sec=iters / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="auto", choices=["auto", "persistent", "stepwise"])
+    ap.add_argument("--samples", type=int, default=0, help="override number_samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from brancher_amd import config, engine, workloads as W
+    config.set_device("cuda:%d" % local_rank)
+    builder, kwargs, n_per_gpu, optimizer, opt_kwargs, desc = WORKLOADS[args.workload]
+    if args.samples:
+        n_per_gpu = args.samples
+    n_global = n_per_gpu * world
+    model = getattr(W, builder)(W.native_api(), **kwargs)
+    compiled = engine.compile_model(model, None, "pathwise")
+    program = compiled.program
+    allow_persistent = args.mode != "stepwise"
+    if args.mode == "persistent" and not (world == 1 and compiled.native.persistent_supported(n_per_gpu)):
+        raise SystemExit("persistent mode needs one GPU and a sample count that fits one workgroup")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (untimed): W steps through exactly the path that is timed
+    compiled.train(max(args.warmup, 1), n_global, optimizer, seed=0, allow_persistent=allow_persistent, **opt_kwargs)
+    barrier()
+
+    # ---- timed region: exactly K steps
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    losses, finite = compiled.train(args.steps, n_global, optimizer, seed=0, allow_persistent=allow_persistent,
+                                    **opt_kwargs)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    mode = compiled.last_mode
+
+    t = torch.tensor([dt, dev_ms], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, dev_ms = float(t[0]), float(t[1])
+    ok = bool(torch.isfinite(losses).all()) and bool(finite.all())
+
+    if rank == 0:
+        iters_per_sec = args.steps / dt
+        value = iters_per_sec * (n_global / 300.0)
+        geom = compiled.native.geometry(n_per_gpu)
+        # roofline of the dominant kernel (the fused ELBO kernel; in persistent mode one launch
+        # covers all K iterations).  Launch duration from HIP events on the launch stream.
+        alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu)
+        if mode == "persistent":
+            launch_ms, launches, units_per_launch = dev_ms, 1, args.steps
+            kernel = "bsvi::persistent_kernel<false>"
+        else:
+            launch_ms, launches, units_per_launch = dev_ms / args.steps, args.steps, 1
+            kernel = "bsvi::elbo_kernel<%s>" % ("true" if geom["zglobal"] else "false")
+        achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=None, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
+                        iterations_per_launch=units_per_launch, launch_ms=launch_ms,
+                        note="latency-bound workload (SURVEY §8d cfg 1): %.2f us per iteration; the per-iteration "
+                             "floor of a launch-per-step design is ~5-10 us of launch latency"
+                             % (dev_ms * 1e3 / args.steps))
+        line = dict(metric="ELBO iters/sec at num_samples=%d per GPU (300-sample-equivalent iterations, whole job)"
+                           % n_per_gpu,
+                    value=value, unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="f32", data="synthetic",
+                    config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
+                                optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
+                                estimator="pathwise", mode=mode, parallelism="sample-shard x%d" % world,
+                                grid=geom),
+                    iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
+                    device_ms_per_step=dev_ms / args.steps, all_finite=ok,
+                    final_loss=float(losses[-1].item()), roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(builder, kwargs, n_per_gpu, optimizer, opt_kwargs)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

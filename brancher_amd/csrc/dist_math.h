@@ -338,70 +338,6 @@ __device__ __noinline__ void sample_bwd_generic(int dist, float z, float p0, flo
     }
 }
 
-// ---- inline fast path for Normal nodes (by far the most common), generic path out of line --
-BSVI_DEV float logp(int dist, float x, float p0, float p1) {
-    if (dist == BSVI_DIST_NORMAL) {
-        const float d = x - p0;
-        return -(d * d) / (2.0f * (p1 * p1)) - logf(p1) - kLogSqrt2Pi;
-    }
-    return logp_generic(dist, x, p0, p1);
-}
-BSVI_DEV void logp_bwd(int dist, float x, float p0, float p1, float g, float& gx, float& g0, float& g1) {
-    if (dist == BSVI_DIST_NORMAL) {
-        const float d = x - p0, iv = 1.0f / (p1 * p1), t = d * iv;
-        gx -= g * t;
-        g0 += g * t;
-        g1 += g * (d * t / p1 - 1.0f / p1);
-        return;
-    }
-    logp_bwd_generic(dist, x, p0, p1, g, gx, g0, g1);
-}
-BSVI_DEV float entropy(int dist, float p0, float p1) {
-    if (dist == BSVI_DIST_NORMAL) return kHalfLog2PiE + logf(p1);
-    return entropy_generic(dist, p0, p1);
-}
-BSVI_DEV void entropy_bwd(int dist, float p0, float p1, float g, float& g0, float& g1) {
-    if (dist == BSVI_DIST_NORMAL) { g1 += g / p1; return; }
-    entropy_bwd_generic(dist, p0, p1, g, g0, g1);
-}
-BSVI_DEV float sample_from_noise(int dist, float p0, float p1, float e) {
-    if (dist == BSVI_DIST_NORMAL) return p0 + e * p1;
-    return sample_from_noise_generic(dist, p0, p1, e);
-}
-BSVI_DEV void sample_bwd(int dist, float z, float p0, float p1, float e, float zb, float& g0, float& g1) {
-    if (dist == BSVI_DIST_NORMAL) { g0 += zb; g1 += zb * e; return; }
-    sample_bwd_generic(dist, z, p0, p1, e, zb, g0, g1);
-}
-
-// ---- rarely used unary link functions, out of line ------------------------------------------
-__device__ __noinline__ float rare_unary(int op, float x, float imm) {
-    switch (op) {
-    case BSVI_OP_POWI: return powf(x, imm);
-    case BSVI_OP_SIN: return sinf(x);
-    case BSVI_OP_COS: return cosf(x);
-    case BSVI_OP_TANH: return tanhf(x);
-    case BSVI_OP_LOG1P: return log1pf(x);
-    case BSVI_OP_EXPM1: return expm1f(x);
-    case BSVI_OP_P2L: {   // torch probs_to_logits(is_binary=True) with clamp_probs
-        const float p = fminf(fmaxf(x, kFloatEps), 1.0f - kFloatEps);
-        return logf(p) - log1pf(-p);
-    }
-    default: return x;
-    }
-}
-// derivative of the above at x (y = value)
-__device__ __noinline__ float rare_unary_grad(int op, float x, float y, float imm) {
-    switch (op) {
-    case BSVI_OP_POWI: return imm * powf(x, imm - 1.0f);
-    case BSVI_OP_SIN: return cosf(x);
-    case BSVI_OP_COS: return -sinf(x);
-    case BSVI_OP_TANH: return 1.0f - y * y;
-    case BSVI_OP_LOG1P: return 1.0f / (1.0f + x);
-    case BSVI_OP_EXPM1: return y + 1.0f;
-    case BSVI_OP_P2L: return (x >= kFloatEps && x <= 1.0f - kFloatEps) ? (1.0f / x + 1.0f / (1.0f - x)) : 0.0f;
-    default: return 1.0f;
-    }
-}
 __device__ __noinline__ float pow_ff(float x, float y) { return powf(x, y); }
 
 }  // namespace bsvi

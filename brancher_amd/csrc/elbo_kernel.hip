@@ -34,15 +34,9 @@
 
 namespace bsvi {
 
-#define NUM_REGS BSVI_NUM_REGS
-// the register file of the link interpreter: one 16-wide vector value per lane, indexed with
-// wave-uniform indices (s_set_gpr_idx on gfx950) — a plain float[16] would live in scratch
-typedef float regfile __attribute__((ext_vector_type(16)));
-static_assert(NUM_REGS == 16, "regfile type must match BSVI_NUM_REGS");
 
 struct KParams {
     const uint4* code;
-    const bsvi_record* records;
     const bsvi_uniform_entry* uniform;
     const float* consts;
     const float* params;
@@ -53,7 +47,8 @@ struct KParams {
     float* fvalue_out;
     float* partials;   // [grid][2 + n_uniform_grad]
     float* zglobal;    // ZG variant: [2 * n_slots][n_pad]
-    uint32_t n_records, n_uniform, n_uniform_grad, n_slots, estimator;
+    unsigned long long* stamps;   // diagnostic build only: phase time stamps of block 0 (or NULL)
+    uint32_t n_code, n_uniform, n_uniform_grad, n_slots, n_noise, n_obs, estimator;
     uint32_t n_local, n_global, sample_base, n_pad;
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
 };
@@ -105,427 +100,654 @@ __device__ __forceinline__ float utransform_grad(int t, float x) {
 }
 
 // ---------------------------------------------------------------------------------------
-// per-lane interpreter state
+// dynamic LDS of every kernel in this file.  Declared at file scope and always indexed
+// directly, so that every access is a real ds_read/ds_write (a pointer that travels through
+// a struct degrades to flat loads, which cost a full memory round trip per operand).
+//   [0, n_uniform)                      U      lane-uniform table (params/consts, transformed)
+//   [n_uniform, +n_obs)                 OBS    observed data, staged once per launch
+//   uadj  [n_uniform_grad][n_waves]            per-wave partial sums of dU
+//   red   [4 * n_waves]
+//   rows  [nthreads][2 * n_slots + 1]          one row per sample: (value, adjoint) pairs of its
+//                                              slots.  The odd row length makes the 64 lanes
+//                                              of a wave hit distinct banks for any slot, and
+//                                              makes a slot's address lane_row + 8 * slot —
+//                                              independent of the launch geometry, so operands
+//                                              are resolved to byte offsets at lowering time.
+//                                              (ZG: slots live in a global [slot][n_pad] array)
 // ---------------------------------------------------------------------------------------
-struct NoiseGen {
-    uint32_t n_global_idx, seed_lo, seed_hi, off_lo, off_hi;
-    uint32_t cached_group;
-    float c0, c1, c2, c3;
+extern __shared__ __attribute__((aligned(16))) float g_lds[];
 
-    __device__ __forceinline__ void init(const KParams& K, uint32_t n) {
-        n_global_idx = K.sample_base + n;
-        seed_lo = K.seed_lo; seed_hi = K.seed_hi; off_lo = K.offset_lo; off_hi = K.offset_hi;
-        cached_group = 0xFFFFFFFFu;
-        c0 = c1 = c2 = c3 = 0.0f;
-    }
-    __device__ __forceinline__ u32x4 raw(uint32_t row, uint32_t attempt) const {
-        return philox4x32_10(n_global_idx, row, off_lo, off_hi ^ (attempt << 8), seed_lo, seed_hi);
-    }
-    // standard normal for noise row `row`: rows 4g..4g+3 share one Philox call
-    __device__ __forceinline__ float normal(uint32_t row) {
-        const uint32_t group = row >> 2;
-        if (group != cached_group) {
-            const u32x4 x = philox4x32_10(n_global_idx, group | 0x80000000u, off_lo, off_hi, seed_lo, seed_hi);
-            box_muller(x.x, x.y, c0, c1);
-            box_muller(x.z, x.w, c2, c3);
-            cached_group = group;
-        }
-        const uint32_t j = row & 3u;
-        return j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
-    }
-    __device__ __noinline__ float gamma(float alpha, uint32_t row, uint32_t stream) const {
-        // Marsaglia & Tsang (2000), as ATen/native/Distributions.h sample_gamma
-        float scale = 1.0f;
-        uint32_t attempt = stream << 12;
-        if (alpha < 1.0f) {
-            if (alpha == 0.0f) return 0.0f;
-            const u32x4 x = raw(row, attempt++);
-            scale *= powf(1.0f - u01(x.x), 1.0f / alpha);
-            alpha += 1.0f;
-        }
-        const float d = alpha - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
-        for (int it = 0; it < 64; ++it) {
-            const u32x4 x = raw(row, attempt++);
-            float n0, n1;
-            box_muller(x.x, x.y, n0, n1);
-            const float y = 1.0f + c * n0;
-            if (y <= 0.0f) continue;
-            const float v = y * y * y, u = 1.0f - u01(x.z), xx = n0 * n0;
-            if (u < 1.0f - 0.0331f * xx * xx) return scale * d * v;
-            if (logf(u) < 0.5f * xx + d * (1.0f - v + logf(v))) return scale * d * v;
-        }
-        return scale * d;
-    }
-    // a fresh draw for distributions whose "noise" is the value itself
-    __device__ __noinline__ float draw_value(int dist, float p0, float p1, uint32_t row) const {
-        if (dist == BSVI_DIST_BETA) {
-            const float ga = gamma(p0, row, 1), gb = gamma(p1, row, 2);
-            float x = ga / (ga + gb);
-            return fminf(fmaxf(x, 1.17549435e-38f), 1.0f - kFloatEps);
-        }
-        if (dist == BSVI_DIST_BERNOULLI) {
-            const u32x4 x = raw(row, 0);
-            return u01(x.x) < sigmoidf_(p0) ? 1.0f : 0.0f;
-        }
-        if (dist == BSVI_DIST_BINOMIAL) {
-            const float p = sigmoidf_(p1);
-            const int n = (int)p0;
-            float k = 0.0f;
-            for (int i = 0; i < n; i += 4) {
-                const u32x4 x = raw(row, (uint32_t)(i >> 2));
-                k += (u01(x.x) < p) ? 1.0f : 0.0f;
-                if (i + 1 < n) k += (u01(x.y) < p) ? 1.0f : 0.0f;
-                if (i + 2 < n) k += (u01(x.z) < p) ? 1.0f : 0.0f;
-                if (i + 3 < n) k += (u01(x.w) < p) ? 1.0f : 0.0f;
-            }
-            return k;
-        }
-        return 0.0f;
-    }
-    __device__ __forceinline__ float base_noise(int dist, uint32_t row) {
-        if (dist == BSVI_DIST_NORMAL || dist == BSVI_DIST_LOGNORMAL) return normal(row);
-        if (dist == BSVI_DIST_CAUCHY) {
-            const u32x4 x = raw(row, 0);
-            return tanf(3.14159265358979323846f * (u01(x.x) - 0.5f));
-        }
-        if (dist == BSVI_DIST_LAPLACE) {
-            const u32x4 x = raw(row, 0);
-            return (kFloatEps - 1.0f) + (2.0f - kFloatEps) * u01(x.x);   // torch laplace.py:83
-        }
-        return 0.0f;
-    }
+struct Lay {   // wave-uniform layout
+    uint32_t obs, uadj, red, rows;      // float offsets
+    uint32_t row_words;                 // 2 * n_slots + 1
+    uint32_t ugrad_bytes;               // uniform entries below this byte offset carry gradients
+    uint32_t nthreads, n_waves;
 };
 
-__device__ __forceinline__ bool noise_is_value(int dist) {
-    return dist == BSVI_DIST_BETA || dist == BSVI_DIST_BINOMIAL || dist == BSVI_DIST_BERNOULLI ||
-           dist == BSVI_DIST_CATEGORICAL;
+// per-lane state — lives in registers: never take its address across a call
+struct Lane {
+    float f, lq, fweight, mask;
+    uint32_t n, nc, tid, wave, lane;
+    uint32_t zrow;              // byte address of this sample's slot row in LDS
+    uint32_t nidx;              // global sample index (Philox counter)
+    uint32_t cached_group;      // wave-uniform
+    float c0, c1, c2, c3;       // cached normals of that group
+};
+
+struct PhiloxKey { uint32_t nidx, seed_lo, seed_hi, off_lo, off_hi; };
+
+__device__ __forceinline__ u32x4 philox_raw(const PhiloxKey& k, uint32_t row, uint32_t attempt) {
+    return philox4x32_10(k.nidx, row, k.off_lo, k.off_hi ^ (attempt << 8), k.seed_lo, k.seed_hi);
+}
+// Box-Muller on the hardware transcendental units: v_sin/v_cos take revolutions, so
+// sin(2*pi*u) is one instruction and needs no range reduction
+__device__ __forceinline__ void box_muller_fast(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    const float u = u01(b);
+    z0 = r * __builtin_amdgcn_cosf(u);
+    z1 = r * __builtin_amdgcn_sinf(u);
+}
+// standard normal for noise row `row`: rows 4g..4g+3 share one Philox call (the forward sweep
+// walks the rows upwards, the reverse sweep downwards: either way 1 call per 4 draws)
+__device__ __forceinline__ float philox_normal(const KParams& K, Lane& T, uint32_t row) {
+    const uint32_t group = row >> 2;
+    if (group != T.cached_group) {
+        const u32x4 x = philox4x32_10(T.nidx, group | 0x80000000u, K.offset_lo, K.offset_hi, K.seed_lo, K.seed_hi);
+        box_muller_fast(x.x, x.y, T.c0, T.c1);
+        box_muller_fast(x.z, x.w, T.c2, T.c3);
+        T.cached_group = group;
+    }
+    const uint32_t j = row & 3u;
+    return j == 0 ? T.c0 : (j == 1 ? T.c1 : (j == 2 ? T.c2 : T.c3));
 }
 
-// Z / Zb accessors: LDS [slot][thread] or global [slot][n_pad]
+__device__ __noinline__ float philox_gamma(PhiloxKey G, float alpha, uint32_t row, uint32_t stream) {
+    // Marsaglia & Tsang (2000), as ATen/native/Distributions.h sample_gamma
+    float scale = 1.0f;
+    uint32_t attempt = stream << 12;
+    if (alpha < 1.0f) {
+        if (alpha == 0.0f) return 0.0f;
+        const u32x4 x = philox_raw(G, row, attempt++);
+        scale *= powf(1.0f - u01(x.x), 1.0f / alpha);
+        alpha += 1.0f;
+    }
+    const float d = alpha - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+    for (int it = 0; it < 64; ++it) {
+        const u32x4 x = philox_raw(G, row, attempt++);
+        float n0, n1;
+        box_muller(x.x, x.y, n0, n1);
+        const float y = 1.0f + c * n0;
+        if (y <= 0.0f) continue;
+        const float v = y * y * y, u = 1.0f - u01(x.z), xx = n0 * n0;
+        if (u < 1.0f - 0.0331f * xx * xx) return scale * d * v;
+        if (logf(u) < 0.5f * xx + d * (1.0f - v + logf(v))) return scale * d * v;
+    }
+    return scale * d;
+}
+
+// a fresh draw for the non-Normal distributions (out of line: cold for the AR-type models);
+// returns the draw in .x and the base noise that produced it in .y
+__device__ __noinline__ float2 philox_draw(PhiloxKey G, int dist, float p0, float p1, uint32_t row) {
+    float noise = 0.0f, v = p0;
+    switch (dist) {
+    case BSVI_DIST_LOGNORMAL: {
+        const u32x4 x = philox_raw(G, row, 0);
+        float n1;
+        box_muller(x.x, x.y, noise, n1);
+        v = expf(p0 + noise * p1);
+        break;
+    }
+    case BSVI_DIST_CAUCHY: {
+        const u32x4 x = philox_raw(G, row, 0);
+        noise = tanf(3.14159265358979323846f * (u01(x.x) - 0.5f));
+        v = p0 + noise * p1;
+        break;
+    }
+    case BSVI_DIST_LAPLACE: {
+        const u32x4 x = philox_raw(G, row, 0);
+        noise = (kFloatEps - 1.0f) + (2.0f - kFloatEps) * u01(x.x);   // torch laplace.py:83
+        v = sample_from_noise_generic(dist, p0, p1, noise);
+        break;
+    }
+    case BSVI_DIST_BETA: {
+        const float ga = philox_gamma(G, p0, row, 1), gb = philox_gamma(G, p1, row, 2);
+        v = noise = fminf(fmaxf(ga / (ga + gb), 1.17549435e-38f), 1.0f - kFloatEps);
+        break;
+    }
+    case BSVI_DIST_BERNOULLI: {
+        const u32x4 x = philox_raw(G, row, 0);
+        v = noise = u01(x.x) < sigmoidf_(p0) ? 1.0f : 0.0f;
+        break;
+    }
+    case BSVI_DIST_BINOMIAL: {
+        const float p = sigmoidf_(p1);
+        const int n = (int)p0;
+        float k = 0.0f;
+        for (int i = 0; i < n; i += 4) {
+            const u32x4 x = philox_raw(G, row, (uint32_t)(i >> 2));
+            k += (u01(x.x) < p) ? 1.0f : 0.0f;
+            if (i + 1 < n) k += (u01(x.y) < p) ? 1.0f : 0.0f;
+            if (i + 2 < n) k += (u01(x.z) < p) ? 1.0f : 0.0f;
+            if (i + 3 < n) k += (u01(x.w) < p) ? 1.0f : 0.0f;
+        }
+        v = noise = k;
+        break;
+    }
+    default: break;
+    }
+    return make_float2(v, noise);
+}
+// the base noise again, for the reverse sweep of a reparameterised non-Normal draw
+__device__ __noinline__ float philox_noise_again(PhiloxKey G, int dist, uint32_t row) {
+    const u32x4 x = philox_raw(G, row, 0);
+    if (dist == BSVI_DIST_LOGNORMAL) { float n0, n1; box_muller(x.x, x.y, n0, n1); return n0; }
+    if (dist == BSVI_DIST_CAUCHY) return tanf(3.14159265358979323846f * (u01(x.x) - 0.5f));
+    if (dist == BSVI_DIST_LAPLACE) return (kFloatEps - 1.0f) + (2.0f - kFloatEps) * u01(x.x);
+    return 0.0f;
+}
+
+// Program tables are immutable for the lifetime of a launch and are addressed with
+// wave-uniform indices: read them through the constant address space so that hipcc emits
+// scalar loads (one s_load_dwordx8 per instruction through the scalar cache).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSVI_CONST_AS __attribute__((address_space(4)))
+#else
+#define BSVI_CONST_AS   /* host pass: never executed */
+#endif
+struct Insn { uint32_t w0, dst, a, b, c, s, imm0, imm1; };
+__device__ __forceinline__ Insn ld_insn(const uint4* code, uint32_t pc) {
+    return *((const BSVI_CONST_AS Insn*)(code) + pc);
+}
+__device__ __forceinline__ bsvi_record ld_record(const bsvi_record* recs, uint32_t i) {
+    return *((const BSVI_CONST_AS bsvi_record*)(recs) + i);
+}
+
+// ---- operand access.  An operand word is  byte_offset | walks<<30 | per_lane<<31  (resolved by
+// the lowering): uniform entries / observed data are read at byte_offset of the uniform region
+// (LDS offset 0), slots at lane_row + byte_offset, the adjoint of a slot 4 bytes further.
+// ONE ds_read per operand, no branches. ---------------------------------------------------------
+__device__ __forceinline__ float& lds_at(uint32_t byte_addr) {
+    return *reinterpret_cast<float*>(reinterpret_cast<char*>(g_lds) + byte_addr);
+}
+__device__ __forceinline__ uint32_t opnd_offset(uint32_t o, uint32_t e) {
+    const uint32_t per_lane = o >> 31;
+    const uint32_t step = ((o >> 30) & 1u) * (4u + 4u * per_lane);      // 8 bytes per slot, 4 per entry
+    return (o & 0x3FFFFFFFu) + e * step;
+}
 template <bool ZG>
-struct ZStore {
-    float* z;
-    float* zb;
-    uint32_t stride;   // elements between consecutive slots
-    uint32_t lane;     // this lane's column
-    __device__ __forceinline__ float ld(uint32_t s) const { return z[s * stride + lane]; }
-    __device__ __forceinline__ void st(uint32_t s, float v) const { z[s * stride + lane] = v; }
-    __device__ __forceinline__ float ldb(uint32_t s) const { return zb[s * stride + lane]; }
-    __device__ __forceinline__ void addb(uint32_t s, float v) const { zb[s * stride + lane] += v; }
-};
+__device__ __forceinline__ float ld_opnd(const KParams& K, const Lane& T, uint32_t o, uint32_t e) {
+    const uint32_t off = opnd_offset(o, e);
+    const uint32_t mask = (uint32_t)((int32_t)o >> 31);
+    if (ZG) {
+        if (mask) return K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n];
+        return lds_at(off);
+    }
+    return lds_at(off + (T.zrow & mask));
+}
+// slots addressed by a destination / slot operand
+template <bool ZG>
+__device__ __forceinline__ float ld_slot(const KParams& K, const Lane& T, uint32_t off) {
+    return ZG ? K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n] : lds_at(T.zrow + off);
+}
+template <bool ZG>
+__device__ __forceinline__ void st_slot(const KParams& K, const Lane& T, uint32_t off, float v) {
+    if (ZG) K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n] = v;
+    else lds_at(T.zrow + off) = v;
+}
+template <bool ZG>
+__device__ __forceinline__ float ld_adj(const KParams& K, const Lane& T, uint32_t off) {
+    return ZG ? K.zglobal[((size_t)K.n_slots + (off >> 3)) * K.n_pad + T.n] : lds_at(T.zrow + off + 4u);
+}
+template <bool ZG>
+__device__ __forceinline__ void st_adj(const KParams& K, const Lane& T, uint32_t off, float v) {
+    if (ZG) K.zglobal[((size_t)K.n_slots + (off >> 3)) * K.n_pad + T.n] = v;
+    else lds_at(T.zrow + off + 4u) = v;
+}
+// scatter an adjoint to an operand: slots accumulate per lane; lane-uniform values are summed
+// over the wave first (DPP) and accumulated per wave — no atomics, fixed order
+template <bool ZG>
+__device__ __forceinline__ void add_adj(const KParams& K, const Lay& L, const Lane& T, uint32_t o, uint32_t e, float g) {
+    const uint32_t off = opnd_offset(o, e);
+    if (o >> 31) {
+        st_adj<ZG>(K, T, off, ld_adj<ZG>(K, T, off) + g);
+    } else if (off < L.ugrad_bytes) {
+        const float tot = wave_sum(g);
+        if (T.lane == 0) g_lds[L.uadj + (off >> 2) * L.n_waves + T.wave] += tot;
+    }
+}
 
-enum { MODE_FWD = 0, MODE_RECOMP = 1 };
+__device__ __noinline__ float unop_rare(uint32_t sub, float x, float imm) {
+    switch (sub) {
+    case BSVI_U_SIN: return sinf(x);
+    case BSVI_U_COS: return cosf(x);
+    case BSVI_U_TANH: return tanhf(x);
+    case BSVI_U_LOG1P: return log1pf(x);
+    case BSVI_U_EXPM1: return expm1f(x);
+    case BSVI_U_P2L: { const float p = fminf(fmaxf(x, kFloatEps), 1.0f - kFloatEps); return logf(p) - log1pf(-p); }
+    case BSVI_U_POWI: return powf(x, imm);
+    default: return x;
+    }
+}
+__device__ __noinline__ float unop_rare_grad(uint32_t sub, float x, float y, float imm) {
+    switch (sub) {
+    case BSVI_U_SIN: return cosf(x);
+    case BSVI_U_COS: return -sinf(x);
+    case BSVI_U_TANH: return 1.0f - y * y;
+    case BSVI_U_LOG1P: return 1.0f / (1.0f + x);
+    case BSVI_U_EXPM1: return y + 1.0f;
+    case BSVI_U_P2L: return (x >= kFloatEps && x <= 1.0f - kFloatEps) ? (1.0f / x + 1.0f / (1.0f - x)) : 0.0f;
+    case BSVI_U_POWI: return imm * powf(x, imm - 1.0f);
+    default: return 1.0f;
+    }
+}
+template <bool GEN>
+__device__ __forceinline__ float unop(uint32_t sub, float x, float imm) {
+    switch (sub) {
+    case BSVI_U_COPY: return x;
+    case BSVI_U_NEG: return -x;
+    case BSVI_U_EXP: return expf(x);
+    case BSVI_U_LOG: return logf(x);
+    case BSVI_U_SQRT: return sqrtf(x);
+    case BSVI_U_ABS: return fabsf(x);
+    case BSVI_U_SIGMOID: return sigmoidf_(x);
+    case BSVI_U_SOFTPLUS: return softplusf_(x);
+    case BSVI_U_RELU: return fmaxf(x, 0.0f);
+    case BSVI_U_RECIP: return 1.0f / x;
+    case BSVI_U_SQUARE: return x * x;
+    case BSVI_U_POWI:
+        if (imm == 2.0f) return x * x;
+        if (imm == -1.0f) return 1.0f / x;
+        if (imm == 0.5f) return sqrtf(x);
+        return GEN ? unop_rare(sub, x, imm) : x;
+    default: return GEN ? unop_rare(sub, x, imm) : x;
+    }
+}
+template <bool GEN>
+__device__ __forceinline__ float unop_grad(uint32_t sub, float x, float y, float imm) {
+    switch (sub) {
+    case BSVI_U_COPY: return 1.0f;
+    case BSVI_U_NEG: return -1.0f;
+    case BSVI_U_EXP: return y;
+    case BSVI_U_LOG: return 1.0f / x;
+    case BSVI_U_SQRT: return 0.5f / y;
+    case BSVI_U_ABS: return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    case BSVI_U_SIGMOID: return y * (1.0f - y);
+    case BSVI_U_SOFTPLUS: return x > 20.0f ? 1.0f : sigmoidf_(x);
+    case BSVI_U_RELU: return (x > 0.0f) ? 1.0f : 0.0f;
+    case BSVI_U_RECIP: return -y * y;
+    case BSVI_U_SQUARE: return 2.0f * x;
+    case BSVI_U_POWI:
+        if (imm == 2.0f) return 2.0f * x;
+        if (imm == -1.0f) return -y * y;
+        if (imm == 0.5f) return 0.5f / y;
+        return GEN ? unop_rare_grad(sub, x, y, imm) : 1.0f;
+    default: return GEN ? unop_rare_grad(sub, x, y, imm) : 1.0f;
+    }
+}
 
-struct Ctx {
-    const KParams* K;
-    const float* U;       // LDS uniform table
-    float* Uadj;          // LDS [n_uniform_grad][n_waves]
-    uint32_t n_waves, wave, lane, n, nc;
-    float mask;           // 1 for a real sample, 0 for padding lanes
-    float f, lq;          // running per-sample sums
-    float fweight;        // backward: detached f for the score-function term
-    NoiseGen rng;
-};
+__device__ __forceinline__ PhiloxKey philox_key(const KParams& K, const Lane& T) {
+    return PhiloxKey{T.nidx, K.seed_lo, K.seed_hi, K.offset_lo, K.offset_hi};
+}
 
-__device__ __forceinline__ uint32_t rfl(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+// ---- forward of one instruction at element e -----------------------------------------------
+// NODES=false: only the arithmetic instructions (re-materialising temps for the reverse sweep)
+// OUT: the launch wants samples / noise written out (diagnostic and API-edge launches only)
+// GEN: the program contains instructions other than NAFF (launch-time property of the program);
+// with GEN=false every generic path — Beta/Binomial/... node math, unary functions — is compiled
+// out, which keeps the Normal-only interpreter small enough to live in registers
+template <bool ZG, bool GEN>
+__device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e);
 
-// ---- forward evaluation of one record element ------------------------------------------
-template <bool ZG, int MODE>
-__device__ __forceinline__ void run_forward(Ctx& C, const ZStore<ZG>& Z, regfile& r,
-                                            uint32_t pc0, uint32_t pc1, uint32_t eb, uint32_t ei, uint32_t ej) {
-    const KParams& K = *C.K;
-    for (uint32_t pc = pc0; pc < pc1; ++pc) {
-        const uint4 w = K.code[pc];
-        const uint32_t op = rfl(w.x & 0xFFu), dst = rfl((w.x >> 8) & 0xFFu);
-        const uint32_t a = rfl((w.x >> 16) & 0xFFu), b = rfl(w.x >> 24);
-        const uint32_t off = rfl(eb * (w.z & 0xFFFFu) + ei * (w.z >> 16) + ej * (w.w & 0xFFFFu));
-        const uint32_t aux = rfl(w.w >> 16);
-        switch (op) {
-        case BSVI_OP_LDI: r[dst] = __uint_as_float(w.y); break;
-        case BSVI_OP_LDU: r[dst] = C.U[w.y + off]; break;
-        case BSVI_OP_LDZ: r[dst] = Z.ld(w.y + off); break;
-        case BSVI_OP_LDO: r[dst] = K.obs[w.y + off]; break;
-        case BSVI_OP_ADD: r[dst] = r[a] + r[b]; break;
-        case BSVI_OP_SUB: r[dst] = r[a] - r[b]; break;
-        case BSVI_OP_MUL: r[dst] = r[a] * r[b]; break;
-        case BSVI_OP_DIV: r[dst] = r[a] / r[b]; break;
-        case BSVI_OP_POW: r[dst] = pow_ff(r[a], r[b]); break;
-        case BSVI_OP_POWI: {
-            const float e = __uint_as_float(w.y), x = r[a];
-            r[dst] = (e == 2.0f) ? x * x : ((e == -1.0f) ? 1.0f / x : ((e == 0.5f) ? sqrtf(x) : rare_unary(op, x, e)));
-            break;
+// A model log-probability term N(value | A*B + C, S) with a constant weight, finished in one visit:
+// operands are loaded once, the value goes to f and the adjoints straight to their operands.
+template <bool ZG>
+__device__ __forceinline__ void naff_sink(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e) {
+    const float A = ld_opnd<ZG>(K, T, I.a, e), B = ld_opnd<ZG>(K, T, I.b, e);
+    const float Cc = ld_opnd<ZG>(K, T, I.c, e), S = ld_opnd<ZG>(K, T, I.s, e);
+    const float v = ld_opnd<ZG>(K, T, I.dst, e);
+    const float w = __uint_as_float(I.imm0);
+    const float rS = __builtin_amdgcn_rcpf(S), logS = __logf(S);
+    const float loc = A * B + Cc;
+    const float u = (v - loc) * rS;
+    T.f += w * (-0.5f * (u * u) - logS - kLogSqrt2Pi);
+    const float gw = w * T.mask;
+    const float gloc = gw * u * rS;                 // d lp / d loc = (v - loc) / S^2
+    add_adj<ZG>(K, L, T, I.dst, e, -gloc);
+    add_adj<ZG>(K, L, T, I.a, e, gloc * B);
+    add_adj<ZG>(K, L, T, I.b, e, gloc * A);
+    add_adj<ZG>(K, L, T, I.c, e, gloc);
+    add_adj<ZG>(K, L, T, I.s, e, gw * (u * u - 1.0f) * rS);
+}
+
+template <bool ZG, bool OUT, bool NODES, bool GEN>
+__device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e) {
+    const uint32_t op = I.w0 & 0xFFu, flags = (I.w0 >> 8) & 0xFFu;
+    if (op == BSVI_OP_NAFF) {
+        if (!NODES) return;
+        const float A = ld_opnd<ZG>(K, T, I.a, e), B = ld_opnd<ZG>(K, T, I.b, e);
+        const float Cc = ld_opnd<ZG>(K, T, I.c, e), S = ld_opnd<ZG>(K, T, I.s, e);
+        const float loc = A * B + Cc;
+        float v;
+        if (flags & BSVI_F_SAMPLE) {
+            const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
+            const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+            v = loc + eps * S;
+            st_slot<ZG>(K, T, doff, v);
+            if (OUT && T.mask != 0.0f) {
+                if (K.samples_out) K.samples_out[(size_t)row * K.n_local + T.n] = v;
+                if (K.noise_out) K.noise_out[(size_t)row * K.n_local + T.n] = eps;
+            }
+        } else {
+            v = ld_opnd<ZG>(K, T, I.dst, e);
         }
-        case BSVI_OP_DELTA: r[dst] = (r[a] == r[b]) ? 1.0f : 0.0f; break;
-        case BSVI_OP_NEG: r[dst] = -r[a]; break;
-        case BSVI_OP_EXP: r[dst] = expf(r[a]); break;
-        case BSVI_OP_LOG: r[dst] = logf(r[a]); break;
-        case BSVI_OP_SQRT: r[dst] = sqrtf(r[a]); break;
-        case BSVI_OP_ABS: r[dst] = fabsf(r[a]); break;
-        case BSVI_OP_SIGMOID: r[dst] = sigmoidf_(r[a]); break;
-        case BSVI_OP_SOFTPLUS: r[dst] = softplusf_(r[a]); break;
-        case BSVI_OP_RELU: r[dst] = fmaxf(r[a], 0.0f); break;
-        case BSVI_OP_RECIP: r[dst] = 1.0f / r[a]; break;
-        case BSVI_OP_SQUARE: r[dst] = r[a] * r[a]; break;
-        case BSVI_OP_SIN: case BSVI_OP_COS: case BSVI_OP_TANH: case BSVI_OP_LOG1P: case BSVI_OP_EXPM1:
-        case BSVI_OP_P2L:
-            r[dst] = rare_unary(op, r[a], 0.0f);
-            break;
-        case BSVI_OP_SAMPLE: {
-            const uint32_t row = w.y + off;
-            if (MODE == MODE_FWD) {
-                const int dist = (int)aux;
-                float e, z;
-                if (K.noise) {
-                    e = K.noise[(size_t)row * K.n_local + C.nc];
-                    z = sample_from_noise(dist, r[a], r[b], e);
-                } else if (noise_is_value(dist)) {
-                    z = C.rng.draw_value(dist, r[a], r[b], row);
-                    e = z;
-                } else {
-                    e = C.rng.base_noise(dist, row);
-                    z = sample_from_noise(dist, r[a], r[b], e);
-                }
-                r[dst] = z;
-                Z.st(row, z);
-                if (C.mask != 0.0f) {
-                    if (K.samples_out) K.samples_out[(size_t)row * K.n_local + C.n] = z;
-                    if (K.noise_out) K.noise_out[(size_t)row * K.n_local + C.n] = e;
-                }
+        // hardware log / reciprocal (1 ulp): the per-sample chain is issue-bound, not throughput-bound
+        const float logS = __logf(S);
+        if (flags & BSVI_F_ENT) T.f += __uint_as_float(I.imm1) * (kHalfLog2PiE + logS);
+        if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+            const float u = (v - loc) * __builtin_amdgcn_rcpf(S);
+            const float lp = -0.5f * (u * u) - logS - kLogSqrt2Pi;
+            T.f += __uint_as_float(I.imm0) * lp;
+            if (flags & BSVI_F_WF) T.lq += lp;
+        }
+    } else if (op == BSVI_OP_BIN) {
+        const float a = ld_opnd<ZG>(K, T, I.a, e), b = ld_opnd<ZG>(K, T, I.b, e);
+        float y;
+        switch (flags) {
+        case BSVI_B_ADD: y = a + b; break;
+        case BSVI_B_SUB: y = a - b; break;
+        case BSVI_B_MUL: y = a * b; break;
+        case BSVI_B_DIV: y = a / b; break;
+        case BSVI_B_POW: y = GEN ? pow_ff(a, b) : a; break;
+        default: y = (a == b) ? 1.0f : 0.0f; break;
+        }
+        st_slot<ZG>(K, T, opnd_offset(I.dst, e), y);
+    } else if (op == BSVI_OP_UN) {
+        const float a = ld_opnd<ZG>(K, T, I.a, e);
+        st_slot<ZG>(K, T, opnd_offset(I.dst, e), unop<GEN>(flags, a, __uint_as_float(I.imm0)));
+    } else if (GEN && op == BSVI_OP_NODE) {
+        if (!NODES) return;
+        const int dist = (int)((I.w0 >> 16) & 0xFFu);
+        const float p0 = ld_opnd<ZG>(K, T, I.a, e), p1 = ld_opnd<ZG>(K, T, I.b, e);
+        float v;
+        if (flags & BSVI_F_SAMPLE) {
+            const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
+            float noise;
+            if (K.noise) {
+                noise = K.noise[(size_t)row * K.n_local + T.nc];
+                v = sample_from_noise_generic(dist, p0, p1, noise);
             } else {
-                r[dst] = Z.ld(row);
+                const float2 d = philox_draw(philox_key(K, T), dist, p0, p1, row);
+                v = d.x;
+                noise = d.y;
             }
-            break;
+            st_slot<ZG>(K, T, doff, v);
+            if (OUT && T.mask != 0.0f) {
+                if (K.samples_out) K.samples_out[(size_t)row * K.n_local + T.n] = v;
+                if (K.noise_out) K.noise_out[(size_t)row * K.n_local + T.n] = noise;
+            }
+        } else {
+            v = ld_opnd<ZG>(K, T, I.dst, e);
         }
-        case BSVI_OP_STZ:
-            if (MODE == MODE_FWD) Z.st(w.y + off, r[a]);
-            break;
-        case BSVI_OP_LOGP:
-            if (MODE == MODE_FWD) {
-                const float lp = logp((int)aux, r[dst], r[a], r[b]);
-                C.f += __uint_as_float(w.y) * lp;
-                C.lq += __uint_as_float(w.z) * lp;
-            }
-            break;
-        case BSVI_OP_ENTROPY:
-            if (MODE == MODE_FWD) C.f += __uint_as_float(w.y) * entropy((int)aux, r[a], r[b]);
+        if (flags & BSVI_F_ENT) T.f += __uint_as_float(I.imm1) * entropy_generic(dist, p0, p1);
+        if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+            const float lp = logp_generic(dist, v, p0, p1);
+            T.f += __uint_as_float(I.imm0) * lp;
+            if (flags & BSVI_F_WF) T.lq += lp;
+        }
+    }
+}
+
+// ---- reverse of one instruction at element e -------------------------------------------------
+template <bool ZG, bool GEN>
+__device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e) {
+    const uint32_t op = I.w0 & 0xFFu, flags = (I.w0 >> 8) & 0xFFu;
+    if (op == BSVI_OP_NAFF) {
+        const float A = ld_opnd<ZG>(K, T, I.a, e), B = ld_opnd<ZG>(K, T, I.b, e);
+        const float Cc = ld_opnd<ZG>(K, T, I.c, e), S = ld_opnd<ZG>(K, T, I.s, e);
+        const float v = ld_opnd<ZG>(K, T, I.dst, e);     // SAMPLE: DST is the latent's own slot
+        const float loc = A * B + Cc;
+        const float rS = __builtin_amdgcn_rcpf(S);
+        float gloc = 0.0f, gS = 0.0f, gv = 0.0f;
+        if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+            const float gw = (__uint_as_float(I.imm0) + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
+            const float d = v - loc, t = d * (rS * rS);
+            gv = -gw * t;
+            gloc = gw * t;
+            gS = gw * (d * t * rS - rS);
+        }
+        if (flags & BSVI_F_ENT) gS += __uint_as_float(I.imm1) * T.mask * rS;
+        if (flags & BSVI_F_SAMPLE) {
+            const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
+            const float zb = ld_adj<ZG>(K, T, doff) + gv;
+            const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+            gloc += zb;
+            gS += zb * eps;
+        } else {
+            add_adj<ZG>(K, L, T, I.dst, e, gv);
+        }
+        add_adj<ZG>(K, L, T, I.a, e, gloc * B);
+        add_adj<ZG>(K, L, T, I.b, e, gloc * A);
+        add_adj<ZG>(K, L, T, I.c, e, gloc);
+        add_adj<ZG>(K, L, T, I.s, e, gS);
+    } else if (op == BSVI_OP_BIN) {
+        const float a = ld_opnd<ZG>(K, T, I.a, e), b = ld_opnd<ZG>(K, T, I.b, e);
+        const uint32_t d = opnd_offset(I.dst, e);
+        const float g = ld_adj<ZG>(K, T, d);
+        float ga = 0.0f, gb = 0.0f;
+        switch (flags) {
+        case BSVI_B_ADD: ga = g; gb = g; break;
+        case BSVI_B_SUB: ga = g; gb = -g; break;
+        case BSVI_B_MUL: ga = g * b; gb = g * a; break;
+        case BSVI_B_DIV: ga = g / b; gb = -ga * ld_slot<ZG>(K, T, d); break;
+        case BSVI_B_POW:
+            if (GEN) { ga = g * b * pow_ff(a, b - 1.0f); gb = (g == 0.0f) ? 0.0f : g * ld_slot<ZG>(K, T, d) * logf(a); }
             break;
         default: break;
         }
-    }
-}
-
-// ---- reverse sweep over one record element (registers r hold the recomputed forward) -----
-template <bool ZG>
-__device__ __forceinline__ void run_backward(Ctx& C, const ZStore<ZG>& Z, regfile& r, regfile& g,
-                                             uint32_t pc0, uint32_t pc1, uint32_t eb, uint32_t ei, uint32_t ej) {
-    const KParams& K = *C.K;
-    for (uint32_t pc = pc1; pc-- > pc0;) {
-        const uint4 w = K.code[pc];
-        const uint32_t op = rfl(w.x & 0xFFu), dst = rfl((w.x >> 8) & 0xFFu);
-        const uint32_t a = rfl((w.x >> 16) & 0xFFu), b = rfl(w.x >> 24);
-        const uint32_t off = rfl(eb * (w.z & 0xFFFFu) + ei * (w.z >> 16) + ej * (w.w & 0xFFFFu));
-        const uint32_t aux = rfl(w.w >> 16);
-        switch (op) {
-        case BSVI_OP_LDU: {
-            const uint32_t k = w.y + off;
-            if (k < K.n_uniform_grad) {
-                const float tot = wave_sum(g[dst]);
-                if (C.lane == 0) C.Uadj[k * C.n_waves + C.wave] += tot;
-            }
-            break;
+        add_adj<ZG>(K, L, T, I.a, e, ga);
+        add_adj<ZG>(K, L, T, I.b, e, gb);
+    } else if (op == BSVI_OP_UN) {
+        const float a = ld_opnd<ZG>(K, T, I.a, e);
+        const uint32_t d = opnd_offset(I.dst, e);
+        const float g = ld_adj<ZG>(K, T, d);
+        add_adj<ZG>(K, L, T, I.a, e, g * unop_grad<GEN>(flags, a, ld_slot<ZG>(K, T, d), __uint_as_float(I.imm0)));
+    } else if (GEN && op == BSVI_OP_NODE) {
+        const int dist = (int)((I.w0 >> 16) & 0xFFu);
+        const float p0 = ld_opnd<ZG>(K, T, I.a, e), p1 = ld_opnd<ZG>(K, T, I.b, e);
+        const float v = ld_opnd<ZG>(K, T, I.dst, e);
+        float gv = 0.0f, g0 = 0.0f, g1 = 0.0f;
+        if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+            const float gw = (__uint_as_float(I.imm0) + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
+            logp_bwd_generic(dist, v, p0, p1, gw, gv, g0, g1);
         }
-        case BSVI_OP_LDZ: Z.addb(w.y + off, g[dst]); break;
-        case BSVI_OP_ADD: g[a] += g[dst]; g[b] += g[dst]; break;
-        case BSVI_OP_SUB: g[a] += g[dst]; g[b] -= g[dst]; break;
-        case BSVI_OP_MUL: { const float t = g[dst]; g[a] += t * r[b]; g[b] += t * r[a]; break; }
-        case BSVI_OP_DIV: {
-            const float t = g[dst] / r[b];
-            g[a] += t;
-            g[b] -= t * r[dst];
-            break;
+        if (flags & BSVI_F_ENT) entropy_bwd_generic(dist, p0, p1, __uint_as_float(I.imm1) * T.mask, g0, g1);
+        if (flags & BSVI_F_SAMPLE) {
+            const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
+            const float zb = ld_adj<ZG>(K, T, doff) + gv;
+            float noise = v;
+            if (dist == BSVI_DIST_LOGNORMAL || dist == BSVI_DIST_CAUCHY || dist == BSVI_DIST_LAPLACE)
+                noise = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_noise_again(philox_key(K, T), dist, row);
+            sample_bwd_generic(dist, v, p0, p1, noise, zb, g0, g1);
+        } else {
+            add_adj<ZG>(K, L, T, I.dst, e, gv);
         }
-        case BSVI_OP_POW: {
-            const float t = g[dst], x = r[a], y = r[b];
-            g[a] += t * y * pow_ff(x, y - 1.0f);
-            g[b] += (t == 0.0f) ? 0.0f : t * r[dst] * logf(x);
-            break;
-        }
-        case BSVI_OP_POWI: {
-            const float e = __uint_as_float(w.y), x = r[a];
-            g[a] += g[dst] * ((e == 2.0f) ? 2.0f * x : rare_unary_grad(op, x, r[dst], e));
-            break;
-        }
-        case BSVI_OP_NEG: g[a] -= g[dst]; break;
-        case BSVI_OP_EXP: g[a] += g[dst] * r[dst]; break;
-        case BSVI_OP_LOG: g[a] += g[dst] / r[a]; break;
-        case BSVI_OP_SQRT: g[a] += g[dst] * 0.5f / r[dst]; break;
-        case BSVI_OP_ABS: g[a] += g[dst] * ((r[a] > 0.0f) ? 1.0f : ((r[a] < 0.0f) ? -1.0f : 0.0f)); break;
-        case BSVI_OP_SIGMOID: g[a] += g[dst] * r[dst] * (1.0f - r[dst]); break;
-        case BSVI_OP_SOFTPLUS: g[a] += g[dst] * (r[a] > 20.0f ? 1.0f : sigmoidf_(r[a])); break;
-        case BSVI_OP_RELU: g[a] += (r[a] > 0.0f) ? g[dst] : 0.0f; break;
-        case BSVI_OP_RECIP: g[a] -= g[dst] * r[dst] * r[dst]; break;
-        case BSVI_OP_SQUARE: g[a] += g[dst] * 2.0f * r[a]; break;
-        case BSVI_OP_SIN: case BSVI_OP_COS: case BSVI_OP_TANH: case BSVI_OP_LOG1P: case BSVI_OP_EXPM1:
-        case BSVI_OP_P2L:
-            g[a] += g[dst] * rare_unary_grad(op, r[a], r[dst], 0.0f);
-            break;
-        case BSVI_OP_SAMPLE: {
-            const uint32_t row = w.y + off;
-            const int dist = (int)aux;
-            const float zb = g[dst] + Z.ldb(row);
-            float e = 0.0f;
-            if (!noise_is_value(dist)) {
-                e = K.noise ? K.noise[(size_t)row * K.n_local + C.nc] : C.rng.base_noise(dist, row);
-            }
-            float ga = 0.0f, gb = 0.0f;
-            sample_bwd(dist, r[dst], r[a], r[b], e, zb, ga, gb);
-            g[a] += ga;
-            g[b] += gb;
-            break;
-        }
-        case BSVI_OP_STZ: g[a] += Z.ldb(w.y + off); break;
-        case BSVI_OP_LOGP: {
-            const float gw = (__uint_as_float(w.y) + __uint_as_float(w.z) * C.fweight) * C.mask;
-            float gx = 0.0f, ga = 0.0f, gb = 0.0f;
-            logp_bwd((int)aux, r[dst], r[a], r[b], gw, gx, ga, gb);
-            g[dst] += gx;
-            g[a] += ga;
-            g[b] += gb;
-            break;
-        }
-        case BSVI_OP_ENTROPY: {
-            float ga = 0.0f, gb = 0.0f;
-            entropy_bwd((int)aux, r[a], r[b], __uint_as_float(w.y) * C.mask, ga, gb);
-            g[a] += ga;
-            g[b] += gb;
-            break;
-        }
-        default: break;   // LDI, LDO, DELTA: no adjoint
-        }
+        add_adj<ZG>(K, L, T, I.a, e, g0);
+        add_adj<ZG>(K, L, T, I.b, e, g1);
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // The workgroup body.  On exit (after the trailing barrier):
-//   Uadj[k * n_waves]  = workgroup sum of d(sum_s v_s)/dU[k]     (k < n_uniform_grad)
-//   red[0] = workgroup sum of the per-sample estimator value v_s, red[1] = #non-finite v_s
+//   g_lds[uadj + k * n_waves] = workgroup sum of d(sum_s v_s)/dU[k]     (k < n_uniform_grad)
+//   g_lds[red + 0] = workgroup sum of the per-sample estimator value, [red + 1] = #non-finite
 // ---------------------------------------------------------------------------------------
-template <bool ZG>
-__device__ __forceinline__ void elbo_block(const KParams& K, float* lds, uint32_t block_first_sample,
-                                           uint32_t n_waves, float*& red_out, float*& usum_out) {
-    const uint32_t tid = threadIdx.x, nthreads = n_waves * 64;
-    float* U = lds;
-    float* Uadj = U + K.n_uniform;
-    float* red = Uadj + K.n_uniform_grad * n_waves;
-    float* zbase = red + 4 * n_waves;
+__device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
+    Lay L;
+    L.n_waves = n_waves;
+    L.nthreads = n_waves * 64;
+    L.ugrad_bytes = K.n_uniform_grad * 4;
+    L.obs = K.n_uniform;
+    L.uadj = K.n_uniform + K.n_obs;
+    L.red = L.uadj + K.n_uniform_grad * n_waves;
+    L.rows = L.red + 4 * n_waves;
+    L.row_words = 2 * K.n_slots + 1;
+    return L;
+}
 
+template <bool ZG, bool OUT, bool GEN>
+__device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint32_t block_first_sample) {
+    const uint32_t tid = threadIdx.x, nthreads = L.nthreads;
+#define BSVI_STAMP(i)                                                                      \
+    if (OUT && K.stamps && blockIdx.x == 0 && tid == 0) {                                    \
+        K.stamps[2 * (i)] = __builtin_amdgcn_s_memtime();                                    \
+        K.stamps[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                            \
+    }
+    BSVI_STAMP(0)
     for (uint32_t k = tid; k < K.n_uniform; k += nthreads) {
         const bsvi_uniform_entry e = K.uniform[k];
         // agent-scope load: the persistent trainer rewrites params between iterations, so the
         // read must not be served from a stale L1 line
         const float x = e.is_param ? __hip_atomic_load(&K.params[e.src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                    : K.consts[e.src];
-        U[k] = e.a + e.b * utransform(e.transform, x);
+        g_lds[k] = e.a + e.b * utransform(e.transform, x);
     }
-    for (uint32_t i = tid; i < K.n_uniform_grad * n_waves; i += nthreads) Uadj[i] = 0.0f;
+    for (uint32_t i = tid; i < K.n_obs; i += nthreads) g_lds[L.obs + i] = K.obs[i];
+    for (uint32_t i = tid; i < K.n_uniform_grad * L.n_waves; i += nthreads) g_lds[L.uadj + i] = 0.0f;
 
-    Ctx C;
-    C.K = &K;
-    C.U = U;
-    C.Uadj = Uadj;
-    C.n_waves = n_waves;
-    C.wave = tid >> 6;
-    C.lane = tid & 63u;
-    C.n = block_first_sample + tid;
-    const bool active = C.n < K.n_local;
-    C.nc = active ? C.n : (K.n_local - 1);
-    C.mask = active ? 1.0f : 0.0f;
-    C.f = 0.0f;
-    C.lq = 0.0f;
-    C.fweight = 0.0f;
-    C.rng.init(K, C.nc);
+    Lane T;
+    T.tid = tid;
+    T.wave = tid >> 6;
+    T.lane = tid & 63u;
+    T.n = block_first_sample + tid;
+    const bool active = T.n < K.n_local;
+    T.nc = active ? T.n : (K.n_local - 1);
+    T.mask = active ? 1.0f : 0.0f;
+    T.f = 0.0f;
+    T.lq = 0.0f;
+    T.fweight = 0.0f;
+    T.nidx = K.sample_base + T.nc;
+    T.cached_group = 0xFFFFFFFFu;
+    T.c0 = T.c1 = T.c2 = T.c3 = 0.0f;
+    T.zrow = (L.rows + tid * L.row_words) * 4u;
 
-    ZStore<ZG> Z;
-    if (ZG) {
-        Z.z = K.zglobal;
-        Z.zb = K.zglobal + (size_t)K.n_slots * K.n_pad;
-        Z.stride = K.n_pad;
-        Z.lane = block_first_sample + tid;
-    } else {
-        Z.z = zbase;
-        Z.zb = zbase + K.n_slots * nthreads;
-        Z.stride = nthreads;
-        Z.lane = tid;
-    }
-    for (uint32_t s = 0; s < K.n_slots; ++s) Z.zb[s * Z.stride + Z.lane] = 0.0f;
+    for (uint32_t s = 0; s < K.n_slots; ++s) st_adj<ZG>(K, T, s * 8u, 0.0f);
     __syncthreads();
+    BSVI_STAMP(1)
 
-    regfile r = 0.0f, g = 0.0f;
-
-    // ---------------- forward
-    for (uint32_t rec = 0; rec < K.n_records; ++rec) {
-        const bsvi_record R = K.records[rec];
-        const uint32_t pc0 = rfl(R.code_begin), pc1 = rfl(R.code_end);
-        const uint32_t d0 = rfl(R.dims[0]), d1 = rfl(R.dims[1]), d2 = rfl(R.dims[2]);
-        for (uint32_t eb = 0; eb < d0; ++eb)
-            for (uint32_t ei = 0; ei < d1; ++ei)
-                for (uint32_t ej = 0; ej < d2; ++ej)
-                    run_forward<ZG, MODE_FWD>(C, Z, r, pc0, pc1, eb, ei, ej);
-    }
-    const float value = (K.estimator == BSVI_EST_BLACKBOX) ? (C.lq * C.f + C.f) : C.f;
-    C.fweight = C.f;
-    if (K.fvalue_out && active) {
-        K.fvalue_out[C.n] = C.f;
-        K.fvalue_out[(size_t)K.n_local + C.n] = C.lq;
-    }
-
-    // ---------------- backward
-    for (uint32_t rec = K.n_records; rec-- > 0;) {
-        const bsvi_record R = K.records[rec];
-        const uint32_t pc0 = rfl(R.code_begin), pc1 = rfl(R.code_end);
-        const uint32_t d0 = rfl(R.dims[0]), d1 = rfl(R.dims[1]), d2 = rfl(R.dims[2]);
-        for (uint32_t eb = d0; eb-- > 0;)
-            for (uint32_t ei = d1; ei-- > 0;)
-                for (uint32_t ej = d2; ej-- > 0;) {
-                    g = 0.0f;
-                    run_forward<ZG, MODE_RECOMP>(C, Z, r, pc0, pc1, eb, ei, ej);
-                    run_backward<ZG>(C, Z, r, g, pc0, pc1, eb, ei, ej);
+    // ---------------- forward sweep (sink records: value AND adjoints, see BSVI_R_SINK)
+    {
+        uint32_t pc = 0;
+        Insn I = ld_insn(K.code, 0);
+        while (pc < K.n_code) {
+            const uint32_t op = I.w0 & 0xFFu;
+            const bool sink = (I.w0 >> 24) & BSVI_R_SINK;
+            if (op == BSVI_OP_REC_BEGIN) {
+                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                for (uint32_t e = 0; e < n_elems; ++e) {
+                    for (uint32_t j = 1; j <= n; ++j) {
+                        const Insn J = ld_insn(K.code, pc + j);
+                        exec_forward<ZG, OUT, true, GEN>(K, L, T, J, e);
+                    }
+                    if (sink) {
+                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<ZG>(K, T, (temp_base + t) * 8u, 0.0f);
+                        for (uint32_t j = n; j >= 1; --j) {
+                            const Insn J = ld_insn(K.code, pc + j);
+                            exec_backward<ZG, GEN>(K, L, T, J, e);
+                        }
+                    }
                 }
+                pc += n + 2;
+                I = ld_insn(K.code, pc < K.n_code ? pc : 0);
+            } else {
+                // fetch the next instruction while this one executes
+                const uint32_t npc = pc + 1;
+                const Insn nxt = ld_insn(K.code, npc < K.n_code ? npc : 0);
+                if (sink && op == BSVI_OP_NAFF) {
+                    naff_sink<ZG>(K, L, T, I, 0);
+                } else {
+                    exec_forward<ZG, OUT, true, GEN>(K, L, T, I, 0);
+                    if (sink) exec_backward<ZG, GEN>(K, L, T, I, 0);
+                }
+                I = nxt;
+                pc = npc;
+            }
+        }
     }
+    BSVI_STAMP(2)
+    const float value = (K.estimator == BSVI_EST_BLACKBOX) ? (T.lq * T.f + T.f) : T.f;
+    T.fweight = T.f;
+    if (OUT && K.fvalue_out && active) {
+        K.fvalue_out[T.n] = T.f;
+        K.fvalue_out[(size_t)K.n_local + T.n] = T.lq;
+    }
+
+    // ---------------- reverse sweep: the posterior's sampling chain and the derived values
+    {
+        uint32_t pc = K.n_code;
+        Insn I = ld_insn(K.code, pc - 1);
+        while (pc > 0) {
+            const uint32_t op = I.w0 & 0xFFu;
+            const bool sink = (I.w0 >> 24) & BSVI_R_SINK;
+            if (op == BSVI_OP_REC_END) {
+                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                const uint32_t first = pc - 1 - n;          // index of the first body instruction
+                if (!sink) {
+                    for (uint32_t e = n_elems; e-- > 0;) {
+                        // temps are shared by all records: re-materialise this record's, clear their adjoints
+                        for (uint32_t j = 0; j < n; ++j) {
+                            const Insn J = ld_insn(K.code, first + j);
+                            exec_forward<ZG, false, false, GEN>(K, L, T, J, e);
+                        }
+                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<ZG>(K, T, (temp_base + t) * 8u, 0.0f);
+                        for (uint32_t j = n; j-- > 0;) {
+                            const Insn J = ld_insn(K.code, first + j);
+                            exec_backward<ZG, GEN>(K, L, T, J, e);
+                        }
+                    }
+                }
+                pc = first - 1;                              // skip the REC_BEGIN bracket too
+                I = ld_insn(K.code, pc > 0 ? pc - 1 : 0);
+            } else {
+                const uint32_t npc = pc - 1;
+                const Insn nxt = ld_insn(K.code, npc > 0 ? npc - 1 : 0);
+                if (!sink) exec_backward<ZG, GEN>(K, L, T, I, 0);
+                I = nxt;
+                pc = npc;
+            }
+        }
+    }
+    BSVI_STAMP(3)
 
     // ---------------- workgroup reduction (fixed order)
     const float vsum = wave_sum(active ? value : 0.0f);
     const float nonfinite = wave_sum((active && !isfinite(value)) ? 1.0f : 0.0f);
-    if (C.lane == 0) {
-        red[2 + 2 * C.wave] = vsum;
-        red[3 + 2 * C.wave] = nonfinite;
+    if (T.lane == 0) {
+        g_lds[L.red + 2 + 2 * T.wave] = vsum;
+        g_lds[L.red + 3 + 2 * T.wave] = nonfinite;
     }
     __syncthreads();
     for (uint32_t k = tid; k < K.n_uniform_grad; k += nthreads) {
         float s = 0.0f;
-        for (uint32_t wv = 0; wv < n_waves; ++wv) s += Uadj[k * n_waves + wv];
-        Uadj[k * n_waves] = s;
+        for (uint32_t wv = 0; wv < L.n_waves; ++wv) s += g_lds[L.uadj + k * L.n_waves + wv];
+        g_lds[L.uadj + k * L.n_waves] = s;
     }
     if (tid == 0) {
         float s = 0.0f, c = 0.0f;
-        for (uint32_t wv = 0; wv < n_waves; ++wv) { s += red[2 + 2 * wv]; c += red[3 + 2 * wv]; }
-        red[0] = s;
-        red[1] = c;
+        for (uint32_t wv = 0; wv < L.n_waves; ++wv) { s += g_lds[L.red + 2 + 2 * wv]; c += g_lds[L.red + 3 + 2 * wv]; }
+        g_lds[L.red] = s;
+        g_lds[L.red + 1] = c;
     }
     __syncthreads();
-    red_out = red;
-    usum_out = Uadj;
+    BSVI_STAMP(4)
 }
 
-template <bool ZG>
-__global__ void elbo_kernel(const KParams K) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const uint32_t n_waves = blockDim.x >> 6;
-    float *red, *usum;
-    elbo_block<ZG>(K, lds, blockIdx.x * blockDim.x, n_waves, red, usum);
+template <bool ZG, bool OUT, bool GEN>
+__global__ void __launch_bounds__(1024) elbo_kernel(const KParams K) {
+    const Lay L = make_layout(K, blockDim.x >> 6);
+    elbo_block<ZG, OUT, GEN>(K, L, blockIdx.x * blockDim.x);
     float* part = K.partials + (size_t)blockIdx.x * (2 + K.n_uniform_grad);
-    if (threadIdx.x == 0) { part[0] = red[0]; part[1] = red[1]; }
-    for (uint32_t k = threadIdx.x; k < K.n_uniform_grad; k += blockDim.x) part[2 + k] = usum[k * n_waves];
+    if (threadIdx.x == 0) { part[0] = g_lds[L.red]; part[1] = g_lds[L.red + 1]; }
+    for (uint32_t k = threadIdx.x; k < K.n_uniform_grad; k += blockDim.x) part[2 + k] = g_lds[L.uadj + k * L.n_waves];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -589,8 +811,7 @@ struct RParams {
 
 // One workgroup: partial sums -> gradient sums (-> loss / grads -> optimizer step).
 __global__ void reduce_kernel(const RParams R) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* usum = lds;                       // [n_uniform_grad]
+    float* usum = g_lds;                     // [n_uniform_grad]
     __shared__ float hdr[4];
     const uint32_t stride = 2 + R.n_uniform_grad;
     for (uint32_t k = threadIdx.x; k < R.n_uniform_grad; k += blockDim.x) {
@@ -662,22 +883,22 @@ struct PParams {
     uint32_t pretraining_iterations;
 };
 
-template <bool ZG>
-__global__ void persistent_kernel(const PParams P) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <bool ZG, bool GEN>
+__global__ void __launch_bounds__(1024) persistent_kernel(const PParams P) {
     __shared__ float hdr[2];
     const uint32_t n_waves = blockDim.x >> 6;
     KParams K = P.K;
+    const Lay L = make_layout(K, n_waves);
     for (uint32_t it = 0; it < P.n_iterations; ++it) {
-        float *red, *usum;
-        elbo_block<ZG>(K, lds, 0, n_waves, red, usum);
+        elbo_block<ZG, false, GEN>(K, L, 0);
         if (threadIdx.x == 0) {
-            const float loss = -red[0] / (float)K.n_global;
+            const float vsum = g_lds[L.red], bad = g_lds[L.red + 1];
+            const float loss = -vsum / (float)K.n_global;
             const float finite = isfinite(loss) ? 1.0f : 0.0f;
             hdr[0] = loss; hdr[1] = finite;
             P.loss_curve[it] = loss;
             P.finite_curve[it] = finite;
-            P.R.out[0] = red[0]; P.R.out[1] = red[1]; P.R.out[2] = loss; P.R.out[3] = finite;
+            P.R.out[0] = vsum; P.R.out[1] = bad; P.R.out[2] = loss; P.R.out[3] = finite;
         }
         __syncthreads();
         const float scale = -1.0f / (float)K.n_global;
@@ -688,22 +909,20 @@ __global__ void persistent_kernel(const PParams P) {
             for (uint32_t j = P.R.pu_ptr[i]; j < P.R.pu_ptr[i + 1]; ++j) {
                 const uint32_t k = P.R.pu_idx[j];
                 const bsvi_uniform_entry e = P.R.uniform[k];
-                gsum += usum[k * n_waves] * (e.b * utransform_grad(e.transform, theta));
+                gsum += g_lds[L.uadj + k * n_waves] * (e.b * utransform_grad(e.transform, theta));
             }
             const float grad = gsum * scale;
             P.R.out[BSVI_OUT_HEADER + i] = grad;
             if (hdr[1] != 0.0f && mask[i]) optimizer_update(P.R.cfg, P.R.params, P.R.state, P.R.n_params, i, grad);
         }
-        // parameters were written with plain stores by this workgroup and are re-read by this
-        // workgroup only: a workgroup barrier + vmcnt drain orders them (same CU, same L1 policy:
-        // stores are write-through to L2, loads below must not hit stale L1 lines -> glc loads
-        // are unnecessary because the L1 line is updated/invalidated by the CU's own store).
-        __threadfence_block();
+        // The parameters are written and re-read by this one workgroup only: the stores are
+        // drained by the barrier below (s_waitcnt vmcnt(0) + s_barrier) and the next prologue
+        // re-reads them with agent-scope loads that bypass the L1.
         __syncthreads();
         // advance the Philox counter: one iteration = one offset
         K.offset_lo += 1u;
         if (K.offset_lo == 0u) K.offset_hi += 1u;
-        if (K.noise) K.noise += (size_t)K.n_slots * K.n_local;   // given-noise sequence [it][row][N]
+        if (K.noise) K.noise += (size_t)K.n_noise * K.n_local;   // given-noise sequence [it][row][N]
     }
 }
 
@@ -720,9 +939,9 @@ __global__ void debug_math_kernel(int fn, int dist, const float* x, const float*
     case 0: r0 = digammaf_(xv); break;
     case 1: r0 = trigammaf_(xv); break;
     case 2: r0 = dirichlet_grad_one(xv, a, b); break;
-    case 3: r0 = logp(dist, xv, a, b); logp_bwd(dist, xv, a, b, 1.0f, r1, r2, r3); break;
-    case 4: r0 = entropy(dist, a, b); entropy_bwd(dist, a, b, 1.0f, r2, r3); break;
-    case 5: r0 = sample_from_noise(dist, a, b, xv); sample_bwd(dist, r0, a, b, xv, 1.0f, r2, r3); break;
+    case 3: r0 = logp_generic(dist, xv, a, b); logp_bwd_generic(dist, xv, a, b, 1.0f, r1, r2, r3); break;
+    case 4: r0 = entropy_generic(dist, a, b); entropy_bwd_generic(dist, a, b, 1.0f, r2, r3); break;
+    case 5: r0 = sample_from_noise_generic(dist, a, b, xv); sample_bwd_generic(dist, r0, a, b, xv, 1.0f, r2, r3); break;
     case 6: r0 = lgammaf(xv); break;
     default: break;
     }
@@ -759,6 +978,7 @@ struct bsvi_program {
     const uint32_t* pu_ptr = nullptr;
     const uint32_t* pu_idx = nullptr;
     int max_lds = 0;
+    bool generic = false;   // contains instructions other than NAFF
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -788,29 +1008,62 @@ static int validate(const bsvi_program_desc* d) {
     for (uint32_t r = 0; r < d->n_records; ++r) {
         const bsvi_record& R = d->records[r];
         if (R.code_begin > R.code_end || R.code_end > d->n_code) return fail(BSVI_ERR_INVALID, "record code span out of range");
-        if (!R.dims[0] || !R.dims[1] || !R.dims[2]) return fail(BSVI_ERR_INVALID, "empty record");
-        const uint32_t ext[3] = {R.dims[0] - 1, R.dims[1] - 1, R.dims[2] - 1};
+        if (!R.n_elems) return fail(BSVI_ERR_INVALID, "empty record");
+        if ((uint64_t)R.temp_base + R.n_temps > d->n_slots) return fail(BSVI_ERR_INVALID, "temp slots out of range");
+        const uint64_t ext = R.n_elems - 1;
         for (uint32_t pc = R.code_begin; pc < R.code_end; ++pc) {
-            const uint32_t* w = d->code + 4 * (size_t)pc;
-            const uint32_t op = w[0] & 0xFF, dst = (w[0] >> 8) & 0xFF, a = (w[0] >> 16) & 0xFF, b = w[0] >> 24;
-            if (dst >= BSVI_NUM_REGS || a >= BSVI_NUM_REGS || b >= BSVI_NUM_REGS)
-                return fail(BSVI_ERR_INVALID, "register index out of range");
-            const uint64_t span = (uint64_t)ext[0] * (w[2] & 0xFFFF) + (uint64_t)ext[1] * (w[2] >> 16) + (uint64_t)ext[2] * (w[3] & 0xFFFF);
-            uint64_t limit = 0;
-            bool mem = true;
-            switch (op) {
-            case BSVI_OP_LDU: limit = d->n_uniform; break;
-            case BSVI_OP_LDO: limit = d->n_obs; break;
-            case BSVI_OP_LDZ: case BSVI_OP_SAMPLE: case BSVI_OP_STZ: limit = d->n_slots; break;
-            default: mem = false; break;
+            const uint32_t* w = d->code + 8 * (size_t)pc;
+            const uint32_t op = w[0] & 0xFF, flags = (w[0] >> 8) & 0xFF, dist = (w[0] >> 16) & 0xFF;
+            if (op < BSVI_OP_NAFF || op > BSVI_OP_UN) return fail(BSVI_ERR_INVALID, "unknown opcode inside a record");
+            if (op == BSVI_OP_BIN && flags > BSVI_B_DELTA) return fail(BSVI_ERR_INVALID, "unknown binary operator");
+            if (op == BSVI_OP_UN && flags > BSVI_U_POWI) return fail(BSVI_ERR_INVALID, "unknown unary function");
+            if ((op == BSVI_OP_NAFF || op == BSVI_OP_NODE) && dist >= BSVI_DIST_COUNT) return fail(BSVI_ERR_INVALID, "bad distribution id");
+            if (op == BSVI_OP_NAFF && dist != BSVI_DIST_NORMAL) return fail(BSVI_ERR_INVALID, "NAFF is a Normal node");
+            const int n_opnd = (op == BSVI_OP_NAFF) ? 5 : ((op == BSVI_OP_UN) ? 2 : 3);
+            for (int j = 1; j <= n_opnd; ++j) {
+                const uint32_t o = w[j], per_lane = o >> 31, walks = (o >> 30) & 1;
+                const uint64_t last = (uint64_t)(o & 0x3FFFFFFFu) + walks * ext * (per_lane ? 8 : 4);
+                const uint64_t limit = per_lane ? (uint64_t)d->n_slots * 8 : ((uint64_t)d->n_uniform + d->n_obs) * 4;
+                if ((o & 3u) || (per_lane && (o & 7u))) return fail(BSVI_ERR_INVALID, "misaligned operand");
+                if (last >= limit) return fail(BSVI_ERR_INVALID, "operand address out of range");
             }
-            if (mem && (uint64_t)w[1] + span >= limit) return fail(BSVI_ERR_INVALID, "operand address out of range");
-            if ((op == BSVI_OP_SAMPLE || op == BSVI_OP_LOGP || op == BSVI_OP_ENTROPY) && (w[3] >> 16) >= BSVI_DIST_COUNT)
-                return fail(BSVI_ERR_INVALID, "bad distribution id");
-            const bool known = (op <= BSVI_OP_LDO) || (op >= BSVI_OP_ADD && op <= BSVI_OP_DELTA) ||
-                               (op >= BSVI_OP_NEG && op <= BSVI_OP_P2L) || (op >= BSVI_OP_SAMPLE && op <= BSVI_OP_STZ);
-            if (!known) return fail(BSVI_ERR_INVALID, "unknown opcode");
+            const bool writes = (op == BSVI_OP_BIN || op == BSVI_OP_UN) || (flags & BSVI_F_SAMPLE);
+            if (writes && !(w[1] >> 31)) return fail(BSVI_ERR_INVALID, "destination must be a slot");
+            if ((op == BSVI_OP_NAFF || op == BSVI_OP_NODE) && (flags & BSVI_F_SAMPLE) &&
+                (uint64_t)((w[1] & 0x3FFFFFFFu) >> 3) + ((w[1] >> 30) & 1) * ext >= d->n_noise)
+                return fail(BSVI_ERR_INVALID, "sampled slot is not a latent row");
         }
+    }
+    // the stream outside record bodies: plain single-element instructions and matching brackets
+    {
+        std::vector<uint8_t> in_body(d->n_code, 0);
+        for (uint32_t r = 0; r < d->n_records; ++r)
+            for (uint32_t pc = d->records[r].code_begin; pc < d->records[r].code_end; ++pc) in_body[pc] = 1;
+        uint32_t r = 0;
+        for (uint32_t pc = 0; pc < d->n_code;) {
+            const uint32_t* w = d->code + 8 * (size_t)pc;
+            const uint32_t op = w[0] & 0xFF;
+            if (r >= d->n_records) return fail(BSVI_ERR_INVALID, "instructions outside any record");
+            const bsvi_record& R = d->records[r];
+            if (op == BSVI_OP_REC_BEGIN) {
+                const uint32_t n = w[1];
+                if (R.code_begin != pc + 1 || R.code_end != pc + 1 + n || pc + n + 1 >= d->n_code)
+                    return fail(BSVI_ERR_INVALID, "record bracket does not match the record table");
+                const uint32_t* we = d->code + 8 * (size_t)(pc + n + 1);
+                if ((we[0] & 0xFF) != BSVI_OP_REC_END || memcmp(w + 1, we + 1, 16) != 0 || (w[0] >> 24) != (we[0] >> 24))
+                    return fail(BSVI_ERR_INVALID, "unbalanced record brackets");
+                if (w[2] != R.n_elems || w[3] != R.temp_base || w[4] != R.n_temps || ((w[0] >> 24) & 1) != (R.flags & 1))
+                    return fail(BSVI_ERR_INVALID, "record bracket fields do not match the record table");
+                pc += n + 2;
+            } else {
+                if (!in_body[pc] || R.code_begin != pc || R.code_end != pc + 1 || R.n_elems != 1 ||
+                    ((w[0] >> 24) & 1) != (R.flags & 1))
+                    return fail(BSVI_ERR_INVALID, "bare instruction is not a single-element record");
+                pc += 1;
+            }
+            ++r;
+        }
+        if (r != d->n_records) return fail(BSVI_ERR_INVALID, "record table longer than the stream");
     }
     if (d->n_params) {
         if (!d->param_uniform_ptr || (d->n_uniform_grad && !d->param_uniform_idx)) return fail(BSVI_ERR_INVALID, "missing CSR map");
@@ -828,7 +1081,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(BSVI_ERR_NO_DEVICE, "no HIP device visible");
     bsvi_program* p = new bsvi_program();
     p->d = *desc;
-    const size_t b_code = align_up((size_t)desc->n_code * 16, 256);
+    const size_t b_code = align_up((size_t)desc->n_code * 32, 256);
     const size_t b_rec = align_up((size_t)desc->n_records * sizeof(bsvi_record), 256);
     const size_t b_uni = align_up((size_t)desc->n_uniform * sizeof(bsvi_uniform_entry), 256);
     const size_t b_con = align_up((size_t)desc->n_consts * 4, 256);
@@ -837,7 +1090,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
     const size_t total = b_code + b_rec + b_uni + b_con + b_ptr + b_idx + 256;
     std::vector<char> host(total, 0);
     size_t o = 0;
-    const size_t o_code = o; if (desc->n_code) memcpy(&host[o], desc->code, (size_t)desc->n_code * 16); o += b_code;
+    const size_t o_code = o; if (desc->n_code) memcpy(&host[o], desc->code, (size_t)desc->n_code * 32); o += b_code;
     const size_t o_rec = o; if (desc->n_records) memcpy(&host[o], desc->records, (size_t)desc->n_records * sizeof(bsvi_record)); o += b_rec;
     const size_t o_uni = o; if (desc->n_uniform) memcpy(&host[o], desc->uniform, (size_t)desc->n_uniform * sizeof(bsvi_uniform_entry)); o += b_uni;
     const size_t o_con = o; if (desc->n_consts) memcpy(&host[o], desc->consts, (size_t)desc->n_consts * 4); o += b_con;
@@ -857,20 +1110,42 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
     // host pointers of the descriptor are not kept
     p->d.code = nullptr; p->d.records = nullptr; p->d.uniform = nullptr; p->d.consts = nullptr;
     p->d.param_uniform_ptr = nullptr; p->d.param_uniform_idx = nullptr;
+    // "generic" programs need the out-of-line paths: non-Normal nodes, pow and the rare functions
+    for (uint32_t i = 0; i < desc->n_code; ++i) {
+        const uint32_t* w = desc->code + 8 * (size_t)i;
+        const uint32_t op = w[0] & 0xFF, sub = (w[0] >> 8) & 0xFF;
+        float imm;
+        memcpy(&imm, &w[6], 4);
+        if (op == BSVI_OP_NODE) p->generic = true;
+        if (op == BSVI_OP_BIN && sub == BSVI_B_POW) p->generic = true;
+        if (op == BSVI_OP_UN) {
+            const bool common = sub == BSVI_U_COPY || sub == BSVI_U_NEG || sub == BSVI_U_EXP || sub == BSVI_U_LOG ||
+                                sub == BSVI_U_SQRT || sub == BSVI_U_ABS || sub == BSVI_U_SIGMOID || sub == BSVI_U_SOFTPLUS ||
+                                sub == BSVI_U_RELU || sub == BSVI_U_RECIP || sub == BSVI_U_SQUARE ||
+                                (sub == BSVI_U_POWI && (imm == 2.0f || imm == -1.0f || imm == 0.5f));
+            if (!common) p->generic = true;
+        }
+    }
     int dev = 0;
     (void)hipGetDevice(&dev);
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) lds = 65536;
+    if (lds < 163840) lds = 163840;   // gfx950 has 160 KiB per CU; older runtimes under-report the opt-in limit
     // opt in to the full 160 KiB of gfx950 where the runtime allows it; never leave a sticky
     // error behind (PyTorch checks hipGetLastError after its own launches)
-    const void* kernels[] = {(const void*)elbo_kernel<false>, (const void*)elbo_kernel<true>,
-                             (const void*)persistent_kernel<false>, (const void*)persistent_kernel<true>,
-                             (const void*)reduce_kernel};
+    const void* kernels[] = {
+        (const void*)elbo_kernel<false, false, false>, (const void*)elbo_kernel<true, false, false>,
+        (const void*)elbo_kernel<false, true, false>, (const void*)elbo_kernel<true, true, false>,
+        (const void*)elbo_kernel<false, false, true>, (const void*)elbo_kernel<true, false, true>,
+        (const void*)elbo_kernel<false, true, true>, (const void*)elbo_kernel<true, true, true>,
+        (const void*)persistent_kernel<false, false>, (const void*)persistent_kernel<true, false>,
+        (const void*)persistent_kernel<false, true>, (const void*)persistent_kernel<true, true>,
+        (const void*)reduce_kernel};
     int granted = lds;
     for (const void* k : kernels) {
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             (void)hipGetLastError();
-            granted = granted < 65536 ? granted : 65536;
+            granted = 65536;
         }
     }
     p->max_lds = granted;
@@ -894,8 +1169,8 @@ struct Geometry {
 };
 
 static size_t lds_need(const bsvi_program* p, uint32_t n_waves, bool zglobal) {
-    size_t floats = (size_t)p->d.n_uniform + (size_t)p->d.n_uniform_grad * n_waves + 4 * (size_t)n_waves;
-    if (!zglobal) floats += 2 * (size_t)p->d.n_slots * n_waves * 64;
+    size_t floats = (size_t)p->d.n_uniform + (size_t)p->d.n_obs + (size_t)p->d.n_uniform_grad * n_waves + 4 * (size_t)n_waves;
+    if (!zglobal) floats += (2 * (size_t)p->d.n_slots + 1) * n_waves * 64;
     return floats * 4 + 64;
 }
 
@@ -948,18 +1223,24 @@ extern "C" size_t bsvi_workspace_bytes(const bsvi_program* p, uint32_t n_local) 
     return a > b ? a : b;
 }
 
+static unsigned long long* g_debug_stamps = nullptr;
+// diagnostic hook: device buffer of 10 uint64 receiving (s_memtime, s_memrealtime) at 5 phase
+// boundaries of workgroup 0; pass NULL to switch off.  Not part of the product path.
+extern "C" void bsvi_debug_set_stamps(unsigned long long* dev) { g_debug_stamps = dev; }
+
 static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Geometry& g, KParams& K) {
     if (!a->params_dev && p->d.n_params) return fail(BSVI_ERR_INVALID, "params_dev is null");
     if (!a->obs_dev && p->d.n_obs) return fail(BSVI_ERR_INVALID, "obs_dev is null");
     if (!a->workspace_dev) return fail(BSVI_ERR_INVALID, "workspace_dev is null");
     if (!a->n_samples_local || !a->n_samples_global) return fail(BSVI_ERR_INVALID, "zero samples");
-    K.code = p->code; K.records = p->records; K.uniform = p->uniform; K.consts = p->consts;
+    K.code = p->code; K.uniform = p->uniform; K.consts = p->consts;
     K.params = a->params_dev; K.obs = a->obs_dev; K.noise = a->noise_dev;
     K.samples_out = a->samples_out_dev; K.noise_out = a->noise_out_dev; K.fvalue_out = a->fvalue_out_dev;
     K.partials = (float*)a->workspace_dev;
     K.zglobal = (float*)((char*)a->workspace_dev + partial_bytes(p, g));
-    K.n_records = p->d.n_records; K.n_uniform = p->d.n_uniform; K.n_uniform_grad = p->d.n_uniform_grad;
-    K.n_slots = p->d.n_slots; K.estimator = p->d.estimator;
+    K.stamps = g_debug_stamps;
+    K.n_code = p->d.n_code; K.n_uniform = p->d.n_uniform; K.n_uniform_grad = p->d.n_uniform_grad;
+    K.n_slots = p->d.n_slots; K.n_noise = p->d.n_noise; K.n_obs = p->d.n_obs; K.estimator = p->d.estimator;
     K.n_local = a->n_samples_local; K.n_global = a->n_samples_global; K.sample_base = a->sample_base;
     K.n_pad = g.n_pad;
     K.seed_lo = (uint32_t)a->seed; K.seed_hi = (uint32_t)(a->seed >> 32);
@@ -978,8 +1259,16 @@ static void fill_rparams(const bsvi_program* p, const Geometry& g, const KParams
 
 static int launch_elbo(const bsvi_program* p, const Geometry& g, const KParams& K, hipStream_t s) {
     dim3 grid(g.n_blocks), block(g.n_waves * 64);
-    if (g.zglobal) hipLaunchKernelGGL(elbo_kernel<true>, grid, block, g.lds_bytes, s, K);
-    else hipLaunchKernelGGL(elbo_kernel<false>, grid, block, g.lds_bytes, s, K);
+    const bool out = K.samples_out || K.noise_out || K.fvalue_out || K.stamps;
+#define BSVI_LAUNCH_ELBO(ZG_, OUT_, GEN_) hipLaunchKernelGGL((elbo_kernel<ZG_, OUT_, GEN_>), grid, block, g.lds_bytes, s, K)
+    if (p->generic) {
+        if (g.zglobal) { if (out) BSVI_LAUNCH_ELBO(true, true, true); else BSVI_LAUNCH_ELBO(true, false, true); }
+        else { if (out) BSVI_LAUNCH_ELBO(false, true, true); else BSVI_LAUNCH_ELBO(false, false, true); }
+    } else {
+        if (g.zglobal) { if (out) BSVI_LAUNCH_ELBO(true, true, false); else BSVI_LAUNCH_ELBO(true, false, false); }
+        else { if (out) BSVI_LAUNCH_ELBO(false, true, false); else BSVI_LAUNCH_ELBO(false, false, false); }
+    }
+#undef BSVI_LAUNCH_ELBO
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }
@@ -1094,8 +1383,14 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
     P.n_iterations = n_iterations; P.loss_curve = loss_curve_dev; P.finite_curve = finite_dev;
     P.active_mask_first = active_mask_first_dev; P.pretraining_iterations = pretraining_iterations;
     dim3 grid(1), block(g.n_waves * 64);
-    if (g.zglobal) hipLaunchKernelGGL(persistent_kernel<true>, grid, block, g.lds_bytes, (hipStream_t)a->stream, P);
-    else hipLaunchKernelGGL(persistent_kernel<false>, grid, block, g.lds_bytes, (hipStream_t)a->stream, P);
+    hipStream_t st = (hipStream_t)a->stream;
+    if (p->generic) {
+        if (g.zglobal) hipLaunchKernelGGL((persistent_kernel<true, true>), grid, block, g.lds_bytes, st, P);
+        else hipLaunchKernelGGL((persistent_kernel<false, true>), grid, block, g.lds_bytes, st, P);
+    } else {
+        if (g.zglobal) hipLaunchKernelGGL((persistent_kernel<true, false>), grid, block, g.lds_bytes, st, P);
+        else hipLaunchKernelGGL((persistent_kernel<false, false>), grid, block, g.lds_bytes, st, P);
+    }
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }

@@ -199,7 +199,7 @@ class CompiledELBO:
         dev = self.device
         p = self.program
         noise_t = self._noise_tensor(noise, number_samples, base, n_local)
-        samples = torch.empty((p.n_slots, n_local), device=dev) if want_samples else None
+        samples = torch.empty((p.n_noise, n_local), device=dev) if want_samples else None
         noise_o = torch.empty((p.n_noise, n_local), device=dev) if want_noise else None
         fvals = torch.empty((2, n_local), device=dev) if want_fvalues else None
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
@@ -258,7 +258,7 @@ class CompiledELBO:
         ptr = lambda t: C.c_void_p(t.data_ptr())
         noise_t = None
         if noise_seq is not None:
-            # [K][n_noise][n_local] contiguous
+            # [K][n_noise][n_local] contiguous (the persistent trainer advances by n_noise*n_local per iteration)
             mats = [noise_from_named(p, nz, number_samples) if isinstance(nz, dict) else np.asarray(nz)
                     for nz in noise_seq]
             arr = np.ascontiguousarray(np.stack(mats)[:, :, base:base + n_local], dtype=np.float32)

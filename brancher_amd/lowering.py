@@ -35,24 +35,51 @@ from brancher_amd import symbolic as sym
 from brancher_amd.utilities import canonical_elem_shape, broadcast_shapes3, is_discrete
 from brancher_amd.variables import RootVariable, RandomVariable, ProbabilisticModel
 
-# ---- mirror of include/bsvi.h (tests/test_abi.py checks the two stay in sync) ------------
-NUM_REGS = 16
-OP = dict(NOP=0, LDI=1, LDU=2, LDZ=3, LDO=4, ADD=8, SUB=9, MUL=10, DIV=11, POW=12, POWI=13, DELTA=14,
-          NEG=16, EXP=17, LOG=18, SQRT=19, SIN=20, COS=21, TANH=22, ABS=23, SIGMOID=24, SOFTPLUS=25,
-          RELU=26, RECIP=27, LOG1P=28, EXPM1=29, SQUARE=30, P2L=31,
-          SAMPLE=40, LOGP=41, ENTROPY=42, STZ=43)
+# ---- mirror of include/bsvi.h (tests/test_lowering_abi.py checks the two stay in sync) -----
+OP = dict(NOP=0, NAFF=1, NODE=2, BIN=3, UN=4, REC_BEGIN=5, REC_END=6)
+R_SINK = 1     # record flag: complete (forward and reverse) in the forward sweep
+F_SAMPLE, F_ENT, F_LOGP, F_WF = 1, 2, 4, 8
+K_NONE, K_U, K_Z, K_OBS = 0, 1, 2, 3
+BINOP = dict(add=0, sub=1, mul=2, truediv=3, pow=4, delta=5)
+UNOP = dict(copy=0, neg=1, exp=2, log=3, sqrt=4, sin=5, cos=6, tanh=7, abs=8, sigmoid=9, softplus=10,
+            relu=11, reciprocal=12, log1p=13, expm1=14, square=15, p2l=16, powi=17)
 UT = dict(identity=0, softplus=1, sigmoid=2, exp=3, log=4, tanh=5, sqrt=6, square=7)
 EST = dict(pathwise=0, blackbox=1)
 
-UNARY_CALLS = {"neg": "NEG", "exp": "EXP", "log": "LOG", "sqrt": "SQRT", "sin": "SIN", "cos": "COS",
-               "tanh": "TANH", "abs": "ABS", "sigmoid": "SIGMOID", "softplus": "SOFTPLUS", "relu": "RELU",
-               "reciprocal": "RECIP", "log1p": "LOG1P", "expm1": "EXPM1", "square": "SQUARE",
-               "p2l": "P2L"}
-BINARY_OPS = {"add": "ADD", "sub": "SUB", "mul": "MUL", "truediv": "DIV", "pow": "POW", "delta": "DELTA"}
+UNARY_CALLS = set(UNOP) - {"copy", "powi"}
 
 UNIFORM_DTYPE = np.dtype([("src", "<u4"), ("transform", "u1"), ("is_param", "u1"), ("reserved", "<u2"),
                           ("a", "<f4"), ("b", "<f4")])
-RECORD_DTYPE = np.dtype([("code_begin", "<u4"), ("code_end", "<u4"), ("dims", "<u4", (3,)), ("flags", "<u4")])
+RECORD_DTYPE = np.dtype([("code_begin", "<u4"), ("code_end", "<u4"), ("n_elems", "<u4"), ("temp_base", "<u4"),
+                         ("n_temps", "<u4"), ("flags", "<u4")])
+
+
+K_UCONST = 4   # lowering-internal: a uniform entry sourced from the constant buffer
+
+
+def operand(kind, index=0, stride=0):
+    """symbolic operand; encoded by _Lowering.finish() once the table sizes are known"""
+    return (kind, int(index), int(stride))
+
+
+def encode_operand(opnd, n_uniform_param, n_uniform):
+    """include/bsvi.h operand word: byte offset | walks<<30 | per_lane<<31.
+    U / OBS operands address the uniform region of LDS (4 bytes per entry, observed data behind
+    the uniform table); Z operands address the lane's own slot row, where value and adjoint
+    of a slot are interleaved (8 bytes per slot)."""
+    kind, index, stride = opnd
+    if kind == K_NONE:
+        return 0
+    if kind == K_U:
+        off, per_lane = index * 4, 0
+    elif kind == K_UCONST:
+        off, per_lane = (n_uniform_param + index) * 4, 0
+    elif kind == K_OBS:
+        off, per_lane = (n_uniform + index) * 4, 0
+    else:
+        off, per_lane = index * 8, 1
+    assert off < (1 << 30)
+    return off | (stride << 30) | (per_lane << 31)
 
 
 class LoweringError(NotImplementedError):
@@ -90,18 +117,15 @@ class IR:
         return "IR(%s%s)" % (self.op, "" if not self.args else "," + ",".join(a.op for a in self.args))
 
 
-def _elem_strides(leaf_shape, rec_shape):
-    """row-major strides of a leaf of `leaf_shape` walked by a loop over `rec_shape`."""
-    strides = []
-    nat = (leaf_shape[1] * leaf_shape[2], leaf_shape[2], 1)
-    for i in range(3):
-        if leaf_shape[i] == 1:
-            strides.append(0)
-        else:
-            if leaf_shape[i] != rec_shape[i]:
-                raise LoweringError("cannot walk a leaf of shape %r in a node of shape %r" % (leaf_shape, rec_shape))
-            strides.append(nat[i])
-    return strides
+def _stride_flag(leaf_shape, rec_shape):
+    """0 = broadcast (scalar leaf), 1 = walks the record's flattened element loop."""
+    size = int(np.prod(leaf_shape))
+    if size == 1:
+        return 0
+    if tuple(leaf_shape) != tuple(rec_shape):
+        raise LoweringError("partial broadcasting of a %r operand inside a %r node is not supported by the "
+                            "fused kernel" % (tuple(leaf_shape), tuple(rec_shape)))
+    return 1
 
 
 class SlotInfo:
@@ -133,7 +157,8 @@ class Program:
         self.slots = {}             # q variable -> SlotInfo
         self.slot_by_name = {}
         self.bmax = 1
-        self.max_regs = 0
+        self.n_derived = 0
+        self.n_temps = 0
         self.op_count = 0
 
     def initial_params(self):
@@ -149,7 +174,8 @@ class Program:
     def summary(self):
         return dict(n_params=self.n_params, n_slots=self.n_slots, n_uniform=len(self.uniform),
                     n_uniform_grad=self.n_uniform_grad, n_records=len(self.records), n_code=len(self.code),
-                    max_regs=self.max_regs, bmax=self.bmax, estimator=self.estimator)
+                    n_latent=self.n_noise, n_derived=self.n_derived, n_temps=self.n_temps, bmax=self.bmax,
+                    estimator=self.estimator)
 
 
 class _Lowering:
@@ -173,10 +199,14 @@ class _Lowering:
         self.uni_param = []        # provisional uniform entries (param-sourced)
         self.uni_const = []
         self.uni_index = {}        # (kind, id/ key, transform, a, b) -> (is_param, local k0)
-        self.code = []             # list of [w0,w1,w2,w3]
-        self.ldu_fixups = []       # (slot index, is_param)
+        self.code = []             # list of instructions with symbolic operands
         self.records = []
-        self.max_regs = 0
+        self.derived = {}          # IR key -> derived slot base
+        self.use_count = {}
+        self.n_latent = 0
+        self.n_derived = 0
+        self.temp_base = 0
+        self.max_temps = 0
 
     # ---------------------------------------------------------------- IR construction
     def mk(self, op, args=(), attr=None, shape=None):
@@ -361,82 +391,153 @@ class _Lowering:
         return None
 
     # ---------------------------------------------------------------- code generation
-    def begin_record(self, shape):
+    def is_leaf_operand(self, node):
+        return node.op in ("z", "obs", "imm") or self.match_uniform(node) is not None
+
+    def count_uses(self, roots):
+        """per record: every computed (non-leaf, sample-dependent) sub-expression counts once"""
+        seen = set()
+        stack = list(roots)
+        while stack:
+            n = stack.pop()
+            if n.key in seen or self.is_leaf_operand(n):
+                continue
+            seen.add(n.key)
+            stack.extend(n.args)
+        for k in seen:
+            self.use_count[k] = self.use_count.get(k, 0) + 1
+
+    def begin_record(self, shape, sink=False):
+        self.rec_sink = sink
         self.rec_shape = tuple(shape)
         self.rec_begin = len(self.code)
-        self.rec_regs = {}
-        self.rec_nreg = 0
+        self.rec_operands = {}
+        self.rec_ntemp = 0
 
     def end_record(self):
-        self.records.append((self.rec_begin, len(self.code), self.rec_shape))
-        self.max_regs = max(self.max_regs, self.rec_nreg)
+        self.records.append((self.rec_begin, len(self.code), int(np.prod(self.rec_shape)), self.rec_ntemp, self.rec_sink))
+        self.max_temps = max(self.max_temps, self.rec_ntemp)
 
-    def new_reg(self):
-        r = self.rec_nreg
-        if r >= NUM_REGS:
-            raise LoweringError("a node's link needs more than %d registers; split it with a "
-                                "DeterministicVariable" % NUM_REGS)
-        self.rec_nreg += 1
-        return r
+    def put(self, op, flags=0, dist=0, dst=None, a=None, b=None, c=None, s=None, imm0=0.0, imm1=0.0):
+        w0 = OP[op] | (flags << 8) | (dist << 16)
+        none = operand(K_NONE)
+        self.code.append([w0, dst or none, a or none, b or none, c or none, s or none, _fbits(imm0), _fbits(imm1)])
 
-    def put(self, op, dst=0, a=0, b=0, w1=0, strides=(0, 0, 0), aux=0):
-        for s in strides:
-            if not 0 <= s < 65536:
-                raise LoweringError("element stride %d does not fit the 16-bit encoding" % s)
-        w0 = OP[op] | (dst << 8) | (a << 16) | (b << 24)
-        self.code.append([w0, int(w1) & 0xFFFFFFFF, strides[0] | (strides[1] << 16), strides[2] | (aux << 16)])
-        return len(self.code) - 1
+    def const_operand(self, value):
+        """a literal constant lives in the constant buffer and is read through the uniform table"""
+        key = ("imm", float(np.float32(value)))
+        off = self.const_offset(np.array([value], dtype=np.float32), key)
+        ukey = (key, "identity", 0.0, 1.0)
+        hit = self.uni_index.get(ukey)
+        if hit is None:
+            self.uni_const.append((off, UT["identity"], 0, 0.0, 1.0))
+            hit = (0, len(self.uni_const) - 1)
+            self.uni_index[ukey] = hit
+        return hit
 
-    def emit(self, node):
-        r = self.rec_regs.get(node.key)
-        if r is not None:
-            return r
+    def operand_of(self, node):
+        """operand for an IR node; computed sub-expressions are materialised into a temp (or a
+        shared derived slot) by instructions emitted in front of the consumer"""
+        hit = self.rec_operands.get(node.key)
+        if hit is not None:
+            return hit
         m = self.match_uniform(node)
         if m is not None:
             leaf, g, a, b = m
             is_param, k0 = self.uniform_entries(leaf, g, a, b)
-            r = self.new_reg()
-            idx = self.put("LDU", dst=r, w1=k0, strides=_elem_strides(leaf.shape, self.rec_shape))
-            self.ldu_fixups.append((idx, is_param))
+            res = operand(K_U if is_param else K_UCONST, k0, _stride_flag(leaf.shape, self.rec_shape))
         elif node.op == "imm":
-            r = self.new_reg()
-            self.put("LDI", dst=r, w1=_fbits(node.attr))
+            _, k0 = self.const_operand(node.attr)
+            res = operand(K_UCONST, k0, 0)
         elif node.op == "z":
             slot = self.slots[node.attr]
-            r = self.new_reg()
-            self.put("LDZ", dst=r, w1=slot.base, strides=_elem_strides(slot.shape, self.rec_shape))
+            res = operand(K_Z, slot.base, _stride_flag(slot.shape, self.rec_shape))
         elif node.op == "obs":
-            off = self.obs_offset(node.attr)
-            r = self.new_reg()
-            self.put("LDO", dst=r, w1=off, strides=_elem_strides(node.shape, self.rec_shape))
-        elif node.op == "pow" and node.args[1].op == "imm":
-            ra = self.emit(node.args[0])
-            r = self.new_reg()
-            self.put("POWI", dst=r, a=ra, w1=_fbits(node.args[1].attr))
-        elif node.op in BINARY_OPS:
-            ra, rb = self.emit(node.args[0]), self.emit(node.args[1])
-            r = self.new_reg()
-            self.put(BINARY_OPS[node.op], dst=r, a=ra, b=rb)
+            res = operand(K_OBS, self.obs_offset(node.attr), _stride_flag(node.shape, self.rec_shape))
+        elif node.key in self.derived:
+            res = operand(K_Z, self.derived[node.key], _stride_flag(node.shape, self.rec_shape))
+        else:
+            t = self.rec_ntemp
+            self.rec_ntemp += 1
+            res = operand(K_Z, self.temp_base + t, 0)
+            self.emit_compute(node, res)
+        self.rec_operands[node.key] = res
+        return res
+
+    def emit_compute(self, node, dst):
+        if node.op == "pow" and node.args[1].op == "imm":
+            self.put("UN", flags=UNOP["powi"], dst=dst, a=self.operand_of(node.args[0]), imm0=node.args[1].attr)
+        elif node.op in BINOP:
+            a, b = self.operand_of(node.args[0]), self.operand_of(node.args[1])
+            self.put("BIN", flags=BINOP[node.op], dst=dst, a=a, b=b)
         elif node.op.startswith("call:"):
-            ra = self.emit(node.args[0])
-            r = self.new_reg()
-            self.put(UNARY_CALLS[node.op[5:]], dst=r, a=ra)
+            self.put("UN", flags=UNOP[node.op[5:]], dst=dst, a=self.operand_of(node.args[0]))
         else:
             raise LoweringError("cannot generate code for %r" % (node,))
-        self.rec_regs[node.key] = r
-        return r
 
-    def node_op(self, op, dist, dst=0, a=0, b=0, c=0, base=0, strides=(0, 0, 0), w=0.0, wf=0.0):
-        """node ops fit one slot (include/bsvi.h): LOGP keeps the value register in the dst field
-        and its two weights in w1/w2; ENTROPY keeps its weight in w1; SAMPLE has base+strides."""
-        if op == "LOGP":
-            w0 = OP[op] | (c << 8) | (a << 16) | (b << 24)
-            self.code.append([w0, _fbits(w), _fbits(wf), dist << 16])
-        elif op == "ENTROPY":
-            w0 = OP[op] | (a << 16) | (b << 24)
-            self.code.append([w0, _fbits(w), 0, dist << 16])
+    def ensure_derived(self, roots):
+        """emit the defining records of shared sub-expressions these roots need (before their first use)"""
+        order = []
+        seen = set()
+
+        def visit(n):
+            if n.key in seen or self.is_leaf_operand(n):
+                return
+            seen.add(n.key)
+            for a in n.args:
+                visit(a)
+            if n.key in self.derived_nodes and n.key not in self.derived:
+                order.append(n)
+
+        for r in roots:
+            visit(r)
+        for n in order:
+            base = self.n_latent + self.n_derived
+            size = int(np.prod(n.shape))
+            self.n_derived += size
+            self.begin_record(n.shape)
+            self.emit_compute(n, operand(K_Z, base, 1 if size > 1 else 0))
+            self.end_record()
+            self.derived[n.key] = base
+
+    @staticmethod
+    def affine_parts(loc, is_leaf):
+        """loc == A*B + C with A, B, C arbitrary sub-expressions (None = neutral element)"""
+        if is_leaf(loc):
+            return loc, None, None
+        if loc.op == "add":
+            x, y = loc.args
+            if x.op == "mul" and not is_leaf(x):
+                return x.args[0], x.args[1], y
+            if y.op == "mul" and not is_leaf(y):
+                return y.args[0], y.args[1], x
+            return x, None, y
+        if loc.op == "mul":
+            return loc.args[0], loc.args[1], None
+        return loc, None, None
+
+    def emit_node(self, dist, flags, params, value=None, slot=None, w_lp=0.0, w_ent=0.0):
+        """one node instruction (NAFF for Normal, NODE otherwise) plus whatever temps its operands need"""
+
+        def opnd(node, neutral=0.0):
+            # an absent factor/addend reads the constant 1.0 / 0.0 from the uniform table, so the
+            # kernel loads every operand with the same branch-free ds_read
+            if node is None:
+                return operand(K_UCONST, self.const_operand(neutral)[1], 0)
+            return self.operand_of(node)
+
+        if flags & F_SAMPLE:
+            dst = operand(K_Z, slot.base, 1 if slot.size > 1 else 0)
         else:
-            self.put(op, dst=dst, a=a, b=b, w1=base, strides=strides, aux=dist)
+            dst = opnd(value)
+        if dist == D.DIST_NORMAL:
+            A, B, C = self.affine_parts(params[0], self.is_leaf_operand)
+            a, b, c, s = opnd(A, 1.0), opnd(B, 1.0), opnd(C, 0.0), opnd(params[1], 1.0)
+            self.put("NAFF", flags=flags, dist=dist, dst=dst, a=a, b=b, c=c, s=s, imm0=w_lp, imm1=w_ent)
+        else:
+            a = opnd(params[0])
+            b = opnd(params[1]) if len(params) > 1 else opnd(None, 0.0)
+            self.put("NODE", flags=flags, dist=dist, dst=dst, a=a, b=b, imm0=w_lp, imm1=w_ent)
 
     # ---------------------------------------------------------------- node parameter IR
     def node_params(self, var, ctx):
@@ -536,36 +637,45 @@ class _Lowering:
         def weight(b_term):
             return 1.0 if b_term == 1 else 1.0 / bmax
 
+        # -- shared sample-dependent sub-expressions become derived slots (computed once per sample)
+        for v, params, shape in q_nodes:
+            self.count_uses(params)
+        for v, value, params, shape in p_nodes:
+            self.count_uses([value] + params)
+        self.derived_nodes = {k for k, c in self.use_count.items() if c >= 2}
+        self.n_latent = self.n_slots
+        n_derived_upper = 0
+        for k in self.derived_nodes:
+            n_derived_upper += int(np.prod(self.ir_cache[k].shape))
+        self.temp_base = self.n_latent + n_derived_upper
+
         # -- emit q records
         for v, params, shape in q_nodes:
             dist = v.distribution
             slot = self.slots[v]
+            self.ensure_derived(params)
             self.begin_record(shape)
-            regs = [self.emit(p) for p in params]
-            ra = regs[0]
-            rb = regs[1] if len(regs) > 1 else 0
-            rz = self.new_reg()
-            self.node_op("SAMPLE", dist.kind, dst=rz, a=ra, b=rb, base=slot.base,
-                         strides=_elem_strides(shape, shape))
             w = weight(shape[0])
-            wf = 1.0 if self.estimator == "blackbox" else 0.0
+            flags = F_SAMPLE
+            w_lp = 0.0
             if dist.has_analytic_entropy:
-                self.node_op("ENTROPY", dist.kind, a=ra, b=rb, w=w)
-                if wf:
-                    self.node_op("LOGP", dist.kind, a=ra, b=rb, c=rz, w=0.0, wf=wf)
+                flags |= F_ENT
             else:
-                self.node_op("LOGP", dist.kind, a=ra, b=rb, c=rz, w=-w, wf=wf)
+                flags |= F_LOGP
+                w_lp = -w                      # entropy fallback -log q (variables.py:161-162)
+            if self.estimator == "blackbox":
+                flags |= F_WF
+            self.emit_node(dist.kind, flags, params, slot=slot, w_lp=w_lp, w_ent=w)
             self.end_record()
 
         # -- emit p records
         for v, value, params, shape in p_nodes:
-            self.begin_record(shape)
-            rv = self.emit(value)
-            regs = [self.emit(p) for p in params]
-            ra = regs[0]
-            rb = regs[1] if len(regs) > 1 else 0
+            self.ensure_derived([value] + params)
+            # a model log-prob term has a constant weight and nothing depends on its value: the
+            # kernel finishes it (value and adjoints) in the forward sweep
+            self.begin_record(shape, sink=True)
             w = 1.0 if v.is_observed else weight(shape[0])
-            self.node_op("LOGP", v.distribution.kind, a=ra, b=rb, c=rv, w=w, wf=0.0)
+            self.emit_node(v.distribution.kind, F_LOGP, params, value=value, w_lp=w)
             self.end_record()
 
         return self.finish(bmax)
@@ -577,17 +687,38 @@ class _Lowering:
         uni = np.zeros(n_up + len(self.uni_const), dtype=UNIFORM_DTYPE)
         for k, (src, tr, is_param, a, b) in enumerate(self.uni_param + self.uni_const):
             uni[k] = (src, tr, is_param, 0, a, b)
-        code = np.array(self.code, dtype=np.uint32).reshape(-1, 4) if self.code else np.zeros((0, 4), np.uint32)
-        for idx, is_param in self.ldu_fixups:
-            if not is_param:
-                code[idx, 1] += n_up
-        recs = np.zeros(len(self.records), dtype=RECORD_DTYPE)
-        for i, (b, e, shape) in enumerate(self.records):
-            recs[i] = (b, e, shape, 0)
+        n_uni = len(uni)
+        # flatten the records into ONE instruction stream.  A record that is a single instruction
+        # over a single element (the overwhelmingly common case) is that instruction; anything
+        # else is bracketed by REC_BEGIN / REC_END pseudo-instructions that carry the loop
+        # extent and the temp range, so that both sweeps find record boundaries in the stream.
+        words, recs_out = [], []
+        for (b, e, n_elems, n_temps, sink) in self.records:
+            body = [[ins[0]] + [encode_operand(o, n_up, n_uni) for o in ins[1:6]] + [ins[6], ins[7]]
+                    for ins in self.code[b:e]]
+            rflag = (R_SINK if sink else 0) << 24
+            if len(body) == 1 and n_elems == 1:
+                body[0][0] |= rflag
+                recs_out.append((len(words), len(words) + 1, n_elems, self.temp_base, n_temps, int(sink)))
+                words.extend(body)
+            else:
+                bracket = [len(body), n_elems, self.temp_base, n_temps, 0, 0, 0]
+                words.append([OP["REC_BEGIN"] | rflag] + bracket)
+                recs_out.append((len(words), len(words) + len(body), n_elems, self.temp_base, n_temps, int(sink)))
+                words.extend(body)
+                words.append([OP["REC_END"] | rflag] + bracket)
+        code = np.array(words, dtype=np.uint32).reshape(-1, 8) if words else np.zeros((0, 8), np.uint32)
+        recs = np.zeros(len(recs_out), dtype=RECORD_DTYPE)
+        for i, r in enumerate(recs_out):
+            recs[i] = r
         prog.uniform, prog.records, prog.code = uni, recs, code
         prog.consts = np.concatenate(self.consts) if self.consts else np.zeros(0, np.float32)
         prog.obs = np.concatenate(self.obs) if self.obs else np.zeros(0, np.float32)
-        prog.n_params, prog.n_slots, prog.n_noise = self.n_params, self.n_slots, self.n_slots
+        prog.n_params = self.n_params
+        prog.n_noise = self.n_latent
+        prog.n_derived = self.temp_base - self.n_latent
+        prog.n_temps = self.max_temps
+        prog.n_slots = self.temp_base + self.max_temps
         prog.n_uniform_grad = n_up
         # CSR param -> uniform entries
         ptr = np.zeros(self.n_params + 1, dtype=np.uint32)
@@ -607,7 +738,6 @@ class _Lowering:
         prog.slots = dict(self.slots)
         prog.slot_by_name = {s.name: s for s in self.slots.values()}
         prog.bmax = bmax
-        prog.max_regs = self.max_regs
         prog.op_count = len(code)
         return prog
 

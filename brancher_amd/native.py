@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 1
+ABI_VERSION = 3
 OUT_HEADER = 4
 
 
@@ -24,8 +24,8 @@ class UniformEntry(C.Structure):
 
 
 class Record(C.Structure):
-    _fields_ = [("code_begin", C.c_uint32), ("code_end", C.c_uint32), ("dims", C.c_uint32 * 3),
-                ("flags", C.c_uint32)]
+    _fields_ = [("code_begin", C.c_uint32), ("code_end", C.c_uint32), ("n_elems", C.c_uint32),
+                ("temp_base", C.c_uint32), ("n_temps", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class ProgramDesc(C.Structure):
@@ -71,6 +71,7 @@ EXPORTS = {
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "bsvi_debug_math": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                   C.c_void_p]),
+    "bsvi_debug_set_stamps": (None, [C.c_void_p]),
     "bsvi_last_error": (C.c_char_p, []),
     "bsvi_abi_version": (C.c_int, []),
     "bsvi_device_count": (C.c_int, []),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 1
+#define BSVI_ABI_VERSION 3
 
 typedef enum bsvi_status {
     BSVI_OK = 0,
@@ -58,44 +58,69 @@ typedef enum bsvi_dist {
     BSVI_DIST_COUNT = 9
 } bsvi_dist;
 
-/* ---- micro-ops of a link program.  One op = one 16-byte slot
- *        w0 = opcode | dst<<8 | a<<16 | b<<24         (register numbers, 0..BSVI_NUM_REGS-1)
- *        w1 = base index or immediate (float bits)
- *        w2 = stride[0] | stride[1]<<16               (element strides along B, D1)
- *        w3 = stride[2] | aux<<16                     (element stride along D2; aux = dist id)
- *      node ops reuse the fields they do not need, so every op is exactly one slot:
- *        SAMPLE   dst = z register, a/b = parameter registers, w1 = slot base (= noise row
- *                 base), strides, aux = distribution id
- *        LOGP     dst field = VALUE register, a/b = parameter registers,
- *                 w1 = weight (float bits), w2 = weight_f (float bits), aux = distribution id
- *        ENTROPY  a/b = parameter registers, w1 = weight (float bits), aux = distribution id
- *      They restate the closures built by brancher/variables.py:995-1002 and
- *      brancher/functions.py:28-41, and the per-node calls of
- *      brancher/distributions.py:63-96. --------------------------------------------------- */
+/* ---- the model program: a memory-to-memory instruction set over per-sample slots.
+ *
+ *  Every operand of every instruction is a memory operand, so the interpreter needs no
+ *  register file (dynamic VGPR indexing spills on gfx950) and an instruction is fully
+ *  described by one 32-byte slot fetched with a single scalar load:
+ *
+ *      w0 = opcode | flags<<8 | dist<<16 | rflags<<24     (rflags bit 0 = BSVI_R_SINK)
+ *      w1 = DST operand      (SAMPLE: the latent slot to write; LOGP: the VALUE operand)
+ *      w2 = A operand   w3 = B operand   w4 = C operand   w5 = S operand
+ *      w6 = imm0 (float bits)            w7 = imm1 (float bits)
+ *
+ *  operand word = byte_offset | walks<<30 | per_lane<<31      (resolved by the lowering)
+ *      per_lane = 0  lane-uniform value in the uniform region of LDS: the uniform table U
+ *                    (params / constants, transformed; entry k at byte 4k) followed by the
+ *                    observed data (element i at byte 4*(n_uniform + i))
+ *      per_lane = 1  a slot of this sample (latents, derived values, temps): slot s at byte 8s of
+ *                    the sample's row — value at +0, adjoint at +4
+ *      walks = 1     the operand advances with the element index e of the record's loop
+ *                    (by 4 bytes for uniform entries / observed data, 8 bytes for slots)
+ *      An absent factor / addend is encoded as the constant 1.0 / 0.0 of the uniform table.
+ *
+ *  BSVI_OP_NAFF   fused Normal node with affine location — the whole of
+ *                 NormalVariable(loc = A*B + C, scale = S) in ONE instruction:
+ *                 flags SAMPLE: z = loc + S*eps, DST slot <- z          (variables.py:527-570)
+ *                       ENT:    f += imm1 * H[Normal(loc, S)]           (variables.py:156-162)
+ *                       LOGP:   f += imm0 * log N(value | loc, S)       (variables.py:486-520)
+ *                       WF:     lq += log N(value | loc, S)  (score term, gradient_estimators.py:33)
+ *  BSVI_OP_NODE   the same for any other distribution `dist`, parameters p0 = A, p1 = B
+ *  BSVI_OP_BIN    DST <- A (flags: add sub mul div pow delta) B         (variables.py:995-1002)
+ *  BSVI_OP_UN     DST <- flags(A)  [imm0 = exponent of POWI]            (functions.py:28-41)
+ *
+ *  The program is ONE instruction stream.  A record (= one node evaluation) that is a single
+ *  instruction over a single element is just that instruction; any other record is bracketed:
+ *  BSVI_OP_REC_BEGIN / BSVI_OP_REC_END   w1 = body length, w2 = element-loop extent,
+ *                 w3 = first temp slot, w4 = number of temp slots (their adjoints are re-zeroed
+ *                 per element).  Both brackets carry the same words so that the reverse sweep
+ *                 finds the record start from its end.
+ *  BSVI_R_SINK    (rflags) the record is a model log-probability term: its weight is a constant
+ *                 and nothing reads its value, so the kernel runs its forward AND reverse step
+ *                 in the forward sweep (one visit, operands loaded once); the reverse sweep only
+ *                 walks the posterior's sampling chain and the derived values.
+ * --------------------------------------------------------------------------------------- */
 typedef enum bsvi_op {
-    BSVI_OP_NOP = 0,
-    /* leaves */
-    BSVI_OP_LDI = 1,      /* r[dst] = imm                                                    */
-    BSVI_OP_LDU = 2,      /* r[dst] = U[base + off]        lane-uniform table (params/consts) */
-    BSVI_OP_LDZ = 3,      /* r[dst] = Z[base + off][lane]  per-sample latent value            */
-    BSVI_OP_LDO = 4,      /* r[dst] = obs[base + off]      observed data                      */
-    /* binary arithmetic (operator.add/sub/mul/truediv/pow) */
-    BSVI_OP_ADD = 8, BSVI_OP_SUB = 9, BSVI_OP_MUL = 10, BSVI_OP_DIV = 11, BSVI_OP_POW = 12,
-    BSVI_OP_POWI = 13,    /* r[dst] = r[a] ** imm (constant exponent)                         */
-    BSVI_OP_DELTA = 14,   /* r[dst] = (r[a] == r[b]) ? 1 : 0   (brancher/utilities.py:357-358) */
-    /* unary functions (BF.<name>) */
-    BSVI_OP_NEG = 16, BSVI_OP_EXP = 17, BSVI_OP_LOG = 18, BSVI_OP_SQRT = 19, BSVI_OP_SIN = 20,
-    BSVI_OP_COS = 21, BSVI_OP_TANH = 22, BSVI_OP_ABS = 23, BSVI_OP_SIGMOID = 24,
-    BSVI_OP_SOFTPLUS = 25, BSVI_OP_RELU = 26, BSVI_OP_RECIP = 27, BSVI_OP_LOG1P = 28,
-    BSVI_OP_EXPM1 = 29, BSVI_OP_SQUARE = 30, BSVI_OP_P2L = 31 /* probs -> logits, torch clamp */,
-    /* node ops */
-    BSVI_OP_SAMPLE = 40,  /* draw z ~ dist(r[a], r[b]) from noise; r[dst] = z; Z[base+off] = z */
-    BSVI_OP_LOGP = 41,    /* f += w * log p(r[dst] | r[a], r[b]);  lq += wf * (same)           */
-    BSVI_OP_ENTROPY = 42, /* f += w * H[dist(r[a], r[b])]                                      */
-    BSVI_OP_STZ = 43      /* Z[base+off] = r[a]   (deterministic node / spilled expression)    */
+    BSVI_OP_NOP = 0, BSVI_OP_NAFF = 1, BSVI_OP_NODE = 2, BSVI_OP_BIN = 3, BSVI_OP_UN = 4,
+    BSVI_OP_REC_BEGIN = 5, BSVI_OP_REC_END = 6
 } bsvi_op;
 
-#define BSVI_NUM_REGS 16
+#define BSVI_R_SINK 1u
+
+typedef enum bsvi_node_flags { BSVI_F_SAMPLE = 1, BSVI_F_ENT = 2, BSVI_F_LOGP = 4, BSVI_F_WF = 8 } bsvi_node_flags;
+
+typedef enum bsvi_binop {
+    BSVI_B_ADD = 0, BSVI_B_SUB = 1, BSVI_B_MUL = 2, BSVI_B_DIV = 3, BSVI_B_POW = 4,
+    BSVI_B_DELTA = 5   /* (a == b) ? 1 : 0, brancher/utilities.py:357-358 */
+} bsvi_binop;
+
+typedef enum bsvi_unop {
+    BSVI_U_COPY = 0, BSVI_U_NEG = 1, BSVI_U_EXP = 2, BSVI_U_LOG = 3, BSVI_U_SQRT = 4, BSVI_U_SIN = 5,
+    BSVI_U_COS = 6, BSVI_U_TANH = 7, BSVI_U_ABS = 8, BSVI_U_SIGMOID = 9, BSVI_U_SOFTPLUS = 10,
+    BSVI_U_RELU = 11, BSVI_U_RECIP = 12, BSVI_U_LOG1P = 13, BSVI_U_EXPM1 = 14, BSVI_U_SQUARE = 15,
+    BSVI_U_P2L = 16,   /* probs -> logits with torch's clamp (torch/distributions/utils.py:127-137) */
+    BSVI_U_POWI = 17   /* a ** imm0 */
+} bsvi_unop;
 
 /* uniform-table transforms: U[k] = a + b * g(src) (geometric_ranges.py forward transforms,
  * hoisted out of the per-sample program because they do not depend on the sample) */
@@ -112,11 +137,14 @@ typedef struct bsvi_uniform_entry {
     float    a, b;
 } bsvi_uniform_entry;
 
-/* one record = one node evaluation: a micro-op span run once per element of the node */
+/* one record = one node evaluation: the body span inside the instruction stream (the kernel
+ * itself reads record boundaries from the stream; this table is what bsvi_program_create
+ * validates the stream against) */
 typedef struct bsvi_record {
-    uint32_t code_begin, code_end;  /* in 16-byte slots */
-    uint32_t dims[3];               /* element loop extents (B, D1, D2) */
-    uint32_t flags;                 /* reserved */
+    uint32_t code_begin, code_end;  /* body, in 32-byte instructions (brackets excluded) */
+    uint32_t n_elems;               /* element loop extent (flattened B*D1*D2) */
+    uint32_t temp_base, n_temps;    /* scratch slots this record writes (adjoints re-zeroed per element) */
+    uint32_t flags;                 /* bit 0: BSVI_R_SINK */
 } bsvi_record;
 
 typedef enum bsvi_estimator {
@@ -129,17 +157,17 @@ typedef struct bsvi_program_desc {
     uint32_t n_params;        /* length of the flat parameter buffer                */
     uint32_t n_consts;        /* length of the constant buffer                      */
     uint32_t n_obs;           /* length of the observed-data buffer                 */
-    uint32_t n_slots;         /* per-sample latent elements (rows of Z / samples)   */
-    uint32_t n_noise;         /* rows of the noise input (one per drawn element)    */
+    uint32_t n_slots;         /* per-sample slots: latents, then derived, then temps */
+    uint32_t n_noise;         /* latent rows = rows of the noise input / samples out */
     uint32_t n_uniform;       /* entries of the uniform table                       */
     uint32_t n_uniform_grad;  /* the first n_uniform_grad entries are param-sourced */
     uint32_t n_records;
-    uint32_t n_code;          /* 16-byte slots                                      */
+    uint32_t n_code;          /* 32-byte instructions                               */
     uint32_t estimator;       /* bsvi_estimator                                     */
     uint32_t reserved;
     const bsvi_uniform_entry* uniform;
     const bsvi_record* records;
-    const uint32_t* code;     /* 4 * n_code words */
+    const uint32_t* code;     /* 8 * n_code words */
     const float* consts;      /* host copy; uploaded by bsvi_program_create */
     /* CSR map param -> uniform entries, for the deterministic chain rule U -> theta */
     const uint32_t* param_uniform_ptr;   /* n_params + 1 */
@@ -177,7 +205,7 @@ typedef struct bsvi_elbo_args {
     uint32_t sample_base;         /* global index of local sample 0 (Philox counter)        */
     uint32_t reserved;
     float* out_dev;               /* [BSVI_OUT_HEADER + n_params]                            */
-    float* samples_out_dev;       /* [n_slots][n_samples_local] or NULL                     */
+    float* samples_out_dev;       /* [n_noise][n_samples_local] or NULL                     */
     float* noise_out_dev;         /* [n_noise][n_samples_local] or NULL (Philox draws used) */
     float* fvalue_out_dev;        /* [2][n_samples_local] or NULL: per-sample f and log q   */
     void* workspace_dev;          /* bsvi_workspace_bytes(...)                              */
@@ -254,6 +282,10 @@ int bsvi_query_geometry(const bsvi_program* prog, uint32_t n_samples_local, uint
  * out_dev is [4][n] = value, d/dx, d/dp0, d/dp1. */
 int bsvi_debug_math(int fn, int dist, const float* x_dev, const float* p0_dev, const float* p1_dev,
                     float* out_dev, uint32_t n, void* stream);
+
+/* Diagnostic hook (tools/phase_stamps.py): 10 uint64 = (s_memtime, s_memrealtime) at the phase
+ * boundaries prologue / forward / backward / reduction of workgroup 0; NULL switches it off. */
+void bsvi_debug_set_stamps(unsigned long long* stamps_dev);
 
 const char* bsvi_last_error(void);
 int bsvi_abi_version(void);

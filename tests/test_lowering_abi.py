@@ -25,7 +25,15 @@ def test_opcodes_match_header():
     ops = header_enum("BSVI_OP_")
     for k, v in lowering.OP.items():
         assert ops[k] == v, k
-    assert int(re.search(r"#define BSVI_NUM_REGS (\d+)", HEADER).group(1)) == lowering.NUM_REGS
+    binops = header_enum("BSVI_B_")
+    for k, v in lowering.BINOP.items():
+        assert binops[{"truediv": "DIV"}.get(k, k.upper())] == v, k
+    unops = header_enum("BSVI_U_")
+    for k, v in lowering.UNOP.items():
+        assert unops[{"reciprocal": "RECIP"}.get(k, k.upper())] == v, k
+    flags = header_enum("BSVI_F_")
+    assert (flags["SAMPLE"], flags["ENT"], flags["LOGP"], flags["WF"]) == (
+        lowering.F_SAMPLE, lowering.F_ENT, lowering.F_LOGP, lowering.F_WF)
     ut = header_enum("BSVI_UT_")
     for k, v in lowering.UT.items():
         assert ut[k.upper()] == v
@@ -33,6 +41,7 @@ def test_opcodes_match_header():
     for k in ("NORMAL", "LOGNORMAL", "CAUCHY", "LAPLACE", "BETA", "BINOMIAL", "BERNOULLI", "DETERMINISTIC"):
         assert dist[k] == getattr(D, "DIST_" + k)
     assert int(re.search(r"#define BSVI_OUT_HEADER (\d+)", HEADER).group(1)) == native.OUT_HEADER
+    assert int(re.search(r"#define BSVI_ABI_VERSION (\d+)", HEADER).group(1)) == native.ABI_VERSION
 
 
 def test_struct_layouts():
@@ -65,8 +74,12 @@ def test_readme_ar_program_structure():
     prog = lowering.lower(model)
     s = prog.summary()
     assert s["n_params"] == 43                  # SURVEY §8d cfg 1: 43 parameters
-    assert s["n_slots"] == T + 1                # 21 latent scalars
-    assert s["n_records"] == (T + 1) + (2 * T + 1)   # 21 q nodes + 41 p nodes
+    assert s["n_latent"] == T + 1               # 21 latent scalars
+    # 21 q nodes + 41 p nodes, each ONE fused instruction, + sigmoid(b_logit) shared by the 19
+    # transition priors, computed once per sample into a derived slot
+    assert s["n_records"] == (T + 1) + (2 * T + 1) + 1 == s["n_code"]
+    assert s["n_derived"] == 1 and s["n_temps"] == 0
+    assert ((prog.code[:, 0] & 0xFF) == lowering.OP["NAFF"]).sum() == 62
     assert prog.param_active.all()
     # name-collision rule of the reference: the prior's x_t scale is the posterior's learnable root
     names = {p.name for p, _, _, _ in prog.parameters}
@@ -83,14 +96,13 @@ def test_softplus_and_sigmoid_transforms_are_hoisted():
     prog = lowering.lower(W.build_beta_binomial(W.native_api()))
     tr = set(prog.uniform["transform"].tolist())
     assert lowering.UT["softplus"] in tr
-    ops = prog.code[:, 0] & 0xFF
-    assert lowering.OP["SOFTPLUS"] not in ops    # never evaluated per sample
+    un = prog.code[(prog.code[:, 0] & 0xFF) == lowering.OP["UN"]]
+    assert lowering.UNOP["softplus"] not in ((un[:, 0] >> 8) & 0xFF)    # never evaluated per sample
 
 
 def test_observed_nodes_sum_over_datapoints():
     prog = lowering.lower(W.build_lognormal_normal(W.native_api(), n_obs=20))
-    dims = [tuple(r["dims"]) for r in prog.records]
-    assert (20, 1, 1) in dims
+    assert 20 in [int(r["n_elems"]) for r in prog.records]
     assert prog.obs.size == 20 and prog.bmax == 1
 
 
