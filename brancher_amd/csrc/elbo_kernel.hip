@@ -119,7 +119,9 @@ extern __shared__ __attribute__((aligned(16))) float g_lds[];
 
 struct Lay {   // wave-uniform layout
     uint32_t obs, uadj, red, rows;      // float offsets
-    uint32_t row_words;                 // 2 * n_slots + 1
+    uint32_t row_words;                 // 2 * n_slots + 1 (+ lane accumulators), odd
+    uint32_t uacc, dummy;               // SM_LACC: byte offsets inside a row of the per-lane
+                                        // dU accumulators and of the write-only dummy cell
     uint32_t ugrad_bytes;               // uniform entries below this byte offset carry gradients
     uint32_t nthreads, n_waves;
 };
@@ -262,6 +264,8 @@ __device__ __forceinline__ bsvi_record ld_record(const bsvi_record* recs, uint32
     return *((const BSVI_CONST_AS bsvi_record*)(recs) + i);
 }
 
+enum { SM_WSUM = 0, SM_LACC = 1, SM_ZG = 2 };
+#define ZG (SM == SM_ZG)
 // ---- operand access.  An operand word is  byte_offset | walks<<30 | per_lane<<31  (resolved by
 // the lowering): uniform entries / observed data are read at byte_offset of the uniform region
 // (LDS offset 0), slots at lane_row + byte_offset, the adjoint of a slot 4 bytes further.
@@ -274,7 +278,7 @@ __device__ __forceinline__ uint32_t opnd_offset(uint32_t o, uint32_t e) {
     const uint32_t step = ((o >> 30) & 1u) * (4u + 4u * per_lane);      // 8 bytes per slot, 4 per entry
     return (o & 0x3FFFFFFFu) + e * step;
 }
-template <bool ZG>
+template <int SM>
 __device__ __forceinline__ float ld_opnd(const KParams& K, const Lane& T, uint32_t o, uint32_t e) {
     const uint32_t off = opnd_offset(o, e);
     const uint32_t mask = (uint32_t)((int32_t)o >> 31);
@@ -285,31 +289,39 @@ __device__ __forceinline__ float ld_opnd(const KParams& K, const Lane& T, uint32
     return lds_at(off + (T.zrow & mask));
 }
 // slots addressed by a destination / slot operand
-template <bool ZG>
+template <int SM>
 __device__ __forceinline__ float ld_slot(const KParams& K, const Lane& T, uint32_t off) {
     return ZG ? K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n] : lds_at(T.zrow + off);
 }
-template <bool ZG>
+template <int SM>
 __device__ __forceinline__ void st_slot(const KParams& K, const Lane& T, uint32_t off, float v) {
     if (ZG) K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n] = v;
     else lds_at(T.zrow + off) = v;
 }
-template <bool ZG>
+template <int SM>
 __device__ __forceinline__ float ld_adj(const KParams& K, const Lane& T, uint32_t off) {
     return ZG ? K.zglobal[((size_t)K.n_slots + (off >> 3)) * K.n_pad + T.n] : lds_at(T.zrow + off + 4u);
 }
-template <bool ZG>
+template <int SM>
 __device__ __forceinline__ void st_adj(const KParams& K, const Lane& T, uint32_t off, float v) {
     if (ZG) K.zglobal[((size_t)K.n_slots + (off >> 3)) * K.n_pad + T.n] = v;
     else lds_at(T.zrow + off + 4u) = v;
 }
 // scatter an adjoint to an operand: slots accumulate per lane; lane-uniform values are summed
 // over the wave first (DPP) and accumulated per wave — no atomics, fixed order
-template <bool ZG>
+template <int SM>
 __device__ __forceinline__ void add_adj(const KParams& K, const Lay& L, const Lane& T, uint32_t o, uint32_t e, float g) {
     const uint32_t off = opnd_offset(o, e);
+    if (SM == SM_LACC) {
+        // every operand has a per-lane adjoint cell: its slot's, its uniform entry's accumulator,
+        // or (constants, observed data) a write-only dummy — one branch-free read-modify-write,
+        // no cross-lane traffic; the accumulators are summed over lanes once per launch
+        const uint32_t cell = (o >> 31) ? off + 4u : ((off < L.ugrad_bytes) ? L.uacc + off : L.dummy);
+        lds_at(T.zrow + cell) += g;
+        return;
+    }
     if (o >> 31) {
-        st_adj<ZG>(K, T, off, ld_adj<ZG>(K, T, off) + g);
+        st_adj<SM>(K, T, off, ld_adj<SM>(K, T, off) + g);
     } else if (off < L.ugrad_bytes) {
         const float tot = wave_sum(g);
         if (T.lane == 0) g_lds[L.uadj + (off >> 2) * L.n_waves + T.wave] += tot;
@@ -395,16 +407,16 @@ __device__ __forceinline__ PhiloxKey philox_key(const KParams& K, const Lane& T)
 // GEN: the program contains instructions other than NAFF (launch-time property of the program);
 // with GEN=false every generic path — Beta/Binomial/... node math, unary functions — is compiled
 // out, which keeps the Normal-only interpreter small enough to live in registers
-template <bool ZG, bool GEN>
+template <int SM, bool GEN>
 __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e);
 
 // A model log-probability term N(value | A*B + C, S) with a constant weight, finished in one visit:
 // operands are loaded once, the value goes to f and the adjoints straight to their operands.
-template <bool ZG>
+template <int SM>
 __device__ __forceinline__ void naff_sink(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e) {
-    const float A = ld_opnd<ZG>(K, T, I.a, e), B = ld_opnd<ZG>(K, T, I.b, e);
-    const float Cc = ld_opnd<ZG>(K, T, I.c, e), S = ld_opnd<ZG>(K, T, I.s, e);
-    const float v = ld_opnd<ZG>(K, T, I.dst, e);
+    const float A = ld_opnd<SM>(K, T, I.a, e), B = ld_opnd<SM>(K, T, I.b, e);
+    const float Cc = ld_opnd<SM>(K, T, I.c, e), S = ld_opnd<SM>(K, T, I.s, e);
+    const float v = ld_opnd<SM>(K, T, I.dst, e);
     const float w = __uint_as_float(I.imm0);
     const float rS = __builtin_amdgcn_rcpf(S), logS = __logf(S);
     const float loc = A * B + Cc;
@@ -412,33 +424,33 @@ __device__ __forceinline__ void naff_sink(const KParams& K, const Lay& L, Lane& 
     T.f += w * (-0.5f * (u * u) - logS - kLogSqrt2Pi);
     const float gw = w * T.mask;
     const float gloc = gw * u * rS;                 // d lp / d loc = (v - loc) / S^2
-    add_adj<ZG>(K, L, T, I.dst, e, -gloc);
-    add_adj<ZG>(K, L, T, I.a, e, gloc * B);
-    add_adj<ZG>(K, L, T, I.b, e, gloc * A);
-    add_adj<ZG>(K, L, T, I.c, e, gloc);
-    add_adj<ZG>(K, L, T, I.s, e, gw * (u * u - 1.0f) * rS);
+    add_adj<SM>(K, L, T, I.dst, e, -gloc);
+    add_adj<SM>(K, L, T, I.a, e, gloc * B);
+    add_adj<SM>(K, L, T, I.b, e, gloc * A);
+    add_adj<SM>(K, L, T, I.c, e, gloc);
+    add_adj<SM>(K, L, T, I.s, e, gw * (u * u - 1.0f) * rS);
 }
 
-template <bool ZG, bool OUT, bool NODES, bool GEN>
+template <int SM, bool OUT, bool NODES, bool GEN>
 __device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e) {
     const uint32_t op = I.w0 & 0xFFu, flags = (I.w0 >> 8) & 0xFFu;
     if (op == BSVI_OP_NAFF) {
         if (!NODES) return;
-        const float A = ld_opnd<ZG>(K, T, I.a, e), B = ld_opnd<ZG>(K, T, I.b, e);
-        const float Cc = ld_opnd<ZG>(K, T, I.c, e), S = ld_opnd<ZG>(K, T, I.s, e);
+        const float A = ld_opnd<SM>(K, T, I.a, e), B = ld_opnd<SM>(K, T, I.b, e);
+        const float Cc = ld_opnd<SM>(K, T, I.c, e), S = ld_opnd<SM>(K, T, I.s, e);
         const float loc = A * B + Cc;
         float v;
         if (flags & BSVI_F_SAMPLE) {
             const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
             const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
             v = loc + eps * S;
-            st_slot<ZG>(K, T, doff, v);
+            st_slot<SM>(K, T, doff, v);
             if (OUT && T.mask != 0.0f) {
                 if (K.samples_out) K.samples_out[(size_t)row * K.n_local + T.n] = v;
                 if (K.noise_out) K.noise_out[(size_t)row * K.n_local + T.n] = eps;
             }
         } else {
-            v = ld_opnd<ZG>(K, T, I.dst, e);
+            v = ld_opnd<SM>(K, T, I.dst, e);
         }
         // hardware log / reciprocal (1 ulp): the per-sample chain is issue-bound, not throughput-bound
         const float logS = __logf(S);
@@ -450,7 +462,7 @@ __device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lan
             if (flags & BSVI_F_WF) T.lq += lp;
         }
     } else if (op == BSVI_OP_BIN) {
-        const float a = ld_opnd<ZG>(K, T, I.a, e), b = ld_opnd<ZG>(K, T, I.b, e);
+        const float a = ld_opnd<SM>(K, T, I.a, e), b = ld_opnd<SM>(K, T, I.b, e);
         float y;
         switch (flags) {
         case BSVI_B_ADD: y = a + b; break;
@@ -460,14 +472,14 @@ __device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lan
         case BSVI_B_POW: y = GEN ? pow_ff(a, b) : a; break;
         default: y = (a == b) ? 1.0f : 0.0f; break;
         }
-        st_slot<ZG>(K, T, opnd_offset(I.dst, e), y);
+        st_slot<SM>(K, T, opnd_offset(I.dst, e), y);
     } else if (op == BSVI_OP_UN) {
-        const float a = ld_opnd<ZG>(K, T, I.a, e);
-        st_slot<ZG>(K, T, opnd_offset(I.dst, e), unop<GEN>(flags, a, __uint_as_float(I.imm0)));
+        const float a = ld_opnd<SM>(K, T, I.a, e);
+        st_slot<SM>(K, T, opnd_offset(I.dst, e), unop<GEN>(flags, a, __uint_as_float(I.imm0)));
     } else if (GEN && op == BSVI_OP_NODE) {
         if (!NODES) return;
         const int dist = (int)((I.w0 >> 16) & 0xFFu);
-        const float p0 = ld_opnd<ZG>(K, T, I.a, e), p1 = ld_opnd<ZG>(K, T, I.b, e);
+        const float p0 = ld_opnd<SM>(K, T, I.a, e), p1 = ld_opnd<SM>(K, T, I.b, e);
         float v;
         if (flags & BSVI_F_SAMPLE) {
             const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
@@ -480,13 +492,13 @@ __device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lan
                 v = d.x;
                 noise = d.y;
             }
-            st_slot<ZG>(K, T, doff, v);
+            st_slot<SM>(K, T, doff, v);
             if (OUT && T.mask != 0.0f) {
                 if (K.samples_out) K.samples_out[(size_t)row * K.n_local + T.n] = v;
                 if (K.noise_out) K.noise_out[(size_t)row * K.n_local + T.n] = noise;
             }
         } else {
-            v = ld_opnd<ZG>(K, T, I.dst, e);
+            v = ld_opnd<SM>(K, T, I.dst, e);
         }
         if (flags & BSVI_F_ENT) T.f += __uint_as_float(I.imm1) * entropy_generic(dist, p0, p1);
         if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
@@ -498,13 +510,13 @@ __device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lan
 }
 
 // ---- reverse of one instruction at element e -------------------------------------------------
-template <bool ZG, bool GEN>
+template <int SM, bool GEN>
 __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, Lane& T, const Insn& I, uint32_t e) {
     const uint32_t op = I.w0 & 0xFFu, flags = (I.w0 >> 8) & 0xFFu;
     if (op == BSVI_OP_NAFF) {
-        const float A = ld_opnd<ZG>(K, T, I.a, e), B = ld_opnd<ZG>(K, T, I.b, e);
-        const float Cc = ld_opnd<ZG>(K, T, I.c, e), S = ld_opnd<ZG>(K, T, I.s, e);
-        const float v = ld_opnd<ZG>(K, T, I.dst, e);     // SAMPLE: DST is the latent's own slot
+        const float A = ld_opnd<SM>(K, T, I.a, e), B = ld_opnd<SM>(K, T, I.b, e);
+        const float Cc = ld_opnd<SM>(K, T, I.c, e), S = ld_opnd<SM>(K, T, I.s, e);
+        const float v = ld_opnd<SM>(K, T, I.dst, e);     // SAMPLE: DST is the latent's own slot
         const float loc = A * B + Cc;
         const float rS = __builtin_amdgcn_rcpf(S);
         float gloc = 0.0f, gS = 0.0f, gv = 0.0f;
@@ -518,43 +530,43 @@ __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, La
         if (flags & BSVI_F_ENT) gS += __uint_as_float(I.imm1) * T.mask * rS;
         if (flags & BSVI_F_SAMPLE) {
             const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
-            const float zb = ld_adj<ZG>(K, T, doff) + gv;
+            const float zb = ld_adj<SM>(K, T, doff) + gv;
             const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
             gloc += zb;
             gS += zb * eps;
         } else {
-            add_adj<ZG>(K, L, T, I.dst, e, gv);
+            add_adj<SM>(K, L, T, I.dst, e, gv);
         }
-        add_adj<ZG>(K, L, T, I.a, e, gloc * B);
-        add_adj<ZG>(K, L, T, I.b, e, gloc * A);
-        add_adj<ZG>(K, L, T, I.c, e, gloc);
-        add_adj<ZG>(K, L, T, I.s, e, gS);
+        add_adj<SM>(K, L, T, I.a, e, gloc * B);
+        add_adj<SM>(K, L, T, I.b, e, gloc * A);
+        add_adj<SM>(K, L, T, I.c, e, gloc);
+        add_adj<SM>(K, L, T, I.s, e, gS);
     } else if (op == BSVI_OP_BIN) {
-        const float a = ld_opnd<ZG>(K, T, I.a, e), b = ld_opnd<ZG>(K, T, I.b, e);
+        const float a = ld_opnd<SM>(K, T, I.a, e), b = ld_opnd<SM>(K, T, I.b, e);
         const uint32_t d = opnd_offset(I.dst, e);
-        const float g = ld_adj<ZG>(K, T, d);
+        const float g = ld_adj<SM>(K, T, d);
         float ga = 0.0f, gb = 0.0f;
         switch (flags) {
         case BSVI_B_ADD: ga = g; gb = g; break;
         case BSVI_B_SUB: ga = g; gb = -g; break;
         case BSVI_B_MUL: ga = g * b; gb = g * a; break;
-        case BSVI_B_DIV: ga = g / b; gb = -ga * ld_slot<ZG>(K, T, d); break;
+        case BSVI_B_DIV: ga = g / b; gb = -ga * ld_slot<SM>(K, T, d); break;
         case BSVI_B_POW:
-            if (GEN) { ga = g * b * pow_ff(a, b - 1.0f); gb = (g == 0.0f) ? 0.0f : g * ld_slot<ZG>(K, T, d) * logf(a); }
+            if (GEN) { ga = g * b * pow_ff(a, b - 1.0f); gb = (g == 0.0f) ? 0.0f : g * ld_slot<SM>(K, T, d) * logf(a); }
             break;
         default: break;
         }
-        add_adj<ZG>(K, L, T, I.a, e, ga);
-        add_adj<ZG>(K, L, T, I.b, e, gb);
+        add_adj<SM>(K, L, T, I.a, e, ga);
+        add_adj<SM>(K, L, T, I.b, e, gb);
     } else if (op == BSVI_OP_UN) {
-        const float a = ld_opnd<ZG>(K, T, I.a, e);
+        const float a = ld_opnd<SM>(K, T, I.a, e);
         const uint32_t d = opnd_offset(I.dst, e);
-        const float g = ld_adj<ZG>(K, T, d);
-        add_adj<ZG>(K, L, T, I.a, e, g * unop_grad<GEN>(flags, a, ld_slot<ZG>(K, T, d), __uint_as_float(I.imm0)));
+        const float g = ld_adj<SM>(K, T, d);
+        add_adj<SM>(K, L, T, I.a, e, g * unop_grad<GEN>(flags, a, ld_slot<SM>(K, T, d), __uint_as_float(I.imm0)));
     } else if (GEN && op == BSVI_OP_NODE) {
         const int dist = (int)((I.w0 >> 16) & 0xFFu);
-        const float p0 = ld_opnd<ZG>(K, T, I.a, e), p1 = ld_opnd<ZG>(K, T, I.b, e);
-        const float v = ld_opnd<ZG>(K, T, I.dst, e);
+        const float p0 = ld_opnd<SM>(K, T, I.a, e), p1 = ld_opnd<SM>(K, T, I.b, e);
+        const float v = ld_opnd<SM>(K, T, I.dst, e);
         float gv = 0.0f, g0 = 0.0f, g1 = 0.0f;
         if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
             const float gw = (__uint_as_float(I.imm0) + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
@@ -563,16 +575,16 @@ __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, La
         if (flags & BSVI_F_ENT) entropy_bwd_generic(dist, p0, p1, __uint_as_float(I.imm1) * T.mask, g0, g1);
         if (flags & BSVI_F_SAMPLE) {
             const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
-            const float zb = ld_adj<ZG>(K, T, doff) + gv;
+            const float zb = ld_adj<SM>(K, T, doff) + gv;
             float noise = v;
             if (dist == BSVI_DIST_LOGNORMAL || dist == BSVI_DIST_CAUCHY || dist == BSVI_DIST_LAPLACE)
                 noise = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_noise_again(philox_key(K, T), dist, row);
             sample_bwd_generic(dist, v, p0, p1, noise, zb, g0, g1);
         } else {
-            add_adj<ZG>(K, L, T, I.dst, e, gv);
+            add_adj<SM>(K, L, T, I.dst, e, gv);
         }
-        add_adj<ZG>(K, L, T, I.a, e, g0);
-        add_adj<ZG>(K, L, T, I.b, e, g1);
+        add_adj<SM>(K, L, T, I.a, e, g0);
+        add_adj<SM>(K, L, T, I.b, e, g1);
     }
 }
 
@@ -581,6 +593,7 @@ __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, La
 //   g_lds[uadj + k * n_waves] = workgroup sum of d(sum_s v_s)/dU[k]     (k < n_uniform_grad)
 //   g_lds[red + 0] = workgroup sum of the per-sample estimator value, [red + 1] = #non-finite
 // ---------------------------------------------------------------------------------------
+template <int SM>
 __device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
     Lay L;
     L.n_waves = n_waves;
@@ -590,11 +603,13 @@ __device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
     L.uadj = K.n_uniform + K.n_obs;
     L.red = L.uadj + K.n_uniform_grad * n_waves;
     L.rows = L.red + 4 * n_waves;
-    L.row_words = 2 * K.n_slots + 1;
+    L.uacc = 2 * K.n_slots * 4;
+    L.dummy = L.uacc + L.ugrad_bytes;
+    L.row_words = (SM == SM_LACC) ? ((2 * K.n_slots + K.n_uniform_grad + 1) | 1u) : (2 * K.n_slots + 1);
     return L;
 }
 
-template <bool ZG, bool OUT, bool GEN>
+template <int SM, bool OUT, bool GEN>
 __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint32_t block_first_sample) {
     const uint32_t tid = threadIdx.x, nthreads = L.nthreads;
 #define BSVI_STAMP(i)                                                                      \
@@ -612,7 +627,8 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         g_lds[k] = e.a + e.b * utransform(e.transform, x);
     }
     for (uint32_t i = tid; i < K.n_obs; i += nthreads) g_lds[L.obs + i] = K.obs[i];
-    for (uint32_t i = tid; i < K.n_uniform_grad * L.n_waves; i += nthreads) g_lds[L.uadj + i] = 0.0f;
+    if (SM != SM_LACC)
+        for (uint32_t i = tid; i < K.n_uniform_grad * L.n_waves; i += nthreads) g_lds[L.uadj + i] = 0.0f;
 
     Lane T;
     T.tid = tid;
@@ -630,7 +646,9 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     T.c0 = T.c1 = T.c2 = T.c3 = 0.0f;
     T.zrow = (L.rows + tid * L.row_words) * 4u;
 
-    for (uint32_t s = 0; s < K.n_slots; ++s) st_adj<ZG>(K, T, s * 8u, 0.0f);
+    for (uint32_t s = 0; s < K.n_slots; ++s) st_adj<SM>(K, T, s * 8u, 0.0f);
+    if (SM == SM_LACC)
+        for (uint32_t k = 0; k <= K.n_uniform_grad; ++k) lds_at(T.zrow + L.uacc + 4u * k) = 0.0f;   // + dummy
     __syncthreads();
     BSVI_STAMP(1)
 
@@ -646,13 +664,13 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                 for (uint32_t e = 0; e < n_elems; ++e) {
                     for (uint32_t j = 1; j <= n; ++j) {
                         const Insn J = ld_insn(K.code, pc + j);
-                        exec_forward<ZG, OUT, true, GEN>(K, L, T, J, e);
+                        exec_forward<SM, OUT, true, GEN>(K, L, T, J, e);
                     }
                     if (sink) {
-                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<ZG>(K, T, (temp_base + t) * 8u, 0.0f);
+                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
                         for (uint32_t j = n; j >= 1; --j) {
                             const Insn J = ld_insn(K.code, pc + j);
-                            exec_backward<ZG, GEN>(K, L, T, J, e);
+                            exec_backward<SM, GEN>(K, L, T, J, e);
                         }
                     }
                 }
@@ -663,10 +681,10 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                 const uint32_t npc = pc + 1;
                 const Insn nxt = ld_insn(K.code, npc < K.n_code ? npc : 0);
                 if (sink && op == BSVI_OP_NAFF) {
-                    naff_sink<ZG>(K, L, T, I, 0);
+                    naff_sink<SM>(K, L, T, I, 0);
                 } else {
-                    exec_forward<ZG, OUT, true, GEN>(K, L, T, I, 0);
-                    if (sink) exec_backward<ZG, GEN>(K, L, T, I, 0);
+                    exec_forward<SM, OUT, true, GEN>(K, L, T, I, 0);
+                    if (sink) exec_backward<SM, GEN>(K, L, T, I, 0);
                 }
                 I = nxt;
                 pc = npc;
@@ -696,12 +714,12 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                         // temps are shared by all records: re-materialise this record's, clear their adjoints
                         for (uint32_t j = 0; j < n; ++j) {
                             const Insn J = ld_insn(K.code, first + j);
-                            exec_forward<ZG, false, false, GEN>(K, L, T, J, e);
+                            exec_forward<SM, false, false, GEN>(K, L, T, J, e);
                         }
-                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<ZG>(K, T, (temp_base + t) * 8u, 0.0f);
+                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
                         for (uint32_t j = n; j-- > 0;) {
                             const Insn J = ld_insn(K.code, first + j);
-                            exec_backward<ZG, GEN>(K, L, T, J, e);
+                            exec_backward<SM, GEN>(K, L, T, J, e);
                         }
                     }
                 }
@@ -710,7 +728,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
             } else {
                 const uint32_t npc = pc - 1;
                 const Insn nxt = ld_insn(K.code, npc > 0 ? npc - 1 : 0);
-                if (!sink) exec_backward<ZG, GEN>(K, L, T, I, 0);
+                if (!sink) exec_backward<SM, GEN>(K, L, T, I, 0);
                 I = nxt;
                 pc = npc;
             }
@@ -726,6 +744,18 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         g_lds[L.red + 3 + 2 * T.wave] = nonfinite;
     }
     __syncthreads();
+    if (SM == SM_LACC) {
+        // sum the per-lane accumulators of every entry over the workgroup's samples, in two
+        // fixed-order stages: n_waves partial sums per entry (one per 64-lane group), then their sum
+        const uint32_t row_bytes = L.row_words * 4u, cell0 = L.rows * 4u + L.uacc;
+        for (uint32_t i = tid; i < K.n_uniform_grad * L.n_waves; i += nthreads) {
+            const uint32_t k = i / L.n_waves, wv = i - k * L.n_waves;
+            float s = 0.0f;
+            for (uint32_t l = wv * 64u; l < wv * 64u + 64u; ++l) s += lds_at(cell0 + 4u * k + l * row_bytes);
+            g_lds[L.uadj + i] = s;
+        }
+        __syncthreads();
+    }
     for (uint32_t k = tid; k < K.n_uniform_grad; k += nthreads) {
         float s = 0.0f;
         for (uint32_t wv = 0; wv < L.n_waves; ++wv) s += g_lds[L.uadj + k * L.n_waves + wv];
@@ -741,10 +771,10 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     BSVI_STAMP(4)
 }
 
-template <bool ZG, bool OUT, bool GEN>
+template <int SM, bool OUT, bool GEN>
 __global__ void __launch_bounds__(1024) elbo_kernel(const KParams K) {
-    const Lay L = make_layout(K, blockDim.x >> 6);
-    elbo_block<ZG, OUT, GEN>(K, L, blockIdx.x * blockDim.x);
+    const Lay L = make_layout<SM>(K, blockDim.x >> 6);
+    elbo_block<SM, OUT, GEN>(K, L, blockIdx.x * blockDim.x);
     float* part = K.partials + (size_t)blockIdx.x * (2 + K.n_uniform_grad);
     if (threadIdx.x == 0) { part[0] = g_lds[L.red]; part[1] = g_lds[L.red + 1]; }
     for (uint32_t k = threadIdx.x; k < K.n_uniform_grad; k += blockDim.x) part[2 + k] = g_lds[L.uadj + k * L.n_waves];
@@ -883,19 +913,18 @@ struct PParams {
     uint32_t pretraining_iterations;
 };
 
-template <bool ZG, bool GEN>
+template <int SM, bool GEN>
 __global__ void __launch_bounds__(1024) persistent_kernel(const PParams P) {
-    __shared__ float hdr[2];
     const uint32_t n_waves = blockDim.x >> 6;
     KParams K = P.K;
-    const Lay L = make_layout(K, n_waves);
+    const Lay L = make_layout<SM>(K, n_waves);
     for (uint32_t it = 0; it < P.n_iterations; ++it) {
-        elbo_block<ZG, false, GEN>(K, L, 0);
+        elbo_block<SM, false, GEN>(K, L, 0);
         if (threadIdx.x == 0) {
             const float vsum = g_lds[L.red], bad = g_lds[L.red + 1];
             const float loss = -vsum / (float)K.n_global;
             const float finite = isfinite(loss) ? 1.0f : 0.0f;
-            hdr[0] = loss; hdr[1] = finite;
+            g_lds[L.red + 2] = finite;     // red[2..] is free once elbo_block has returned
             P.loss_curve[it] = loss;
             P.finite_curve[it] = finite;
             P.R.out[0] = vsum; P.R.out[1] = bad; P.R.out[2] = loss; P.R.out[3] = finite;
@@ -913,7 +942,7 @@ __global__ void __launch_bounds__(1024) persistent_kernel(const PParams P) {
             }
             const float grad = gsum * scale;
             P.R.out[BSVI_OUT_HEADER + i] = grad;
-            if (hdr[1] != 0.0f && mask[i]) optimizer_update(P.R.cfg, P.R.params, P.R.state, P.R.n_params, i, grad);
+            if (g_lds[L.red + 2] != 0.0f && mask[i]) optimizer_update(P.R.cfg, P.R.params, P.R.state, P.R.n_params, i, grad);
         }
         // The parameters are written and re-read by this one workgroup only: the stores are
         // drained by the barrier below (s_waitcnt vmcnt(0) + s_barrier) and the next prologue
@@ -950,6 +979,7 @@ __global__ void debug_math_kernel(int fn, int dist, const float* x, const float*
 
 }  // namespace bsvi
 
+#undef ZG
 // =========================================================================================
 //  C ABI
 // =========================================================================================
@@ -1134,18 +1164,28 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
     // opt in to the full 160 KiB of gfx950 where the runtime allows it; never leave a sticky
     // error behind (PyTorch checks hipGetLastError after its own launches)
     const void* kernels[] = {
-        (const void*)elbo_kernel<false, false, false>, (const void*)elbo_kernel<true, false, false>,
-        (const void*)elbo_kernel<false, true, false>, (const void*)elbo_kernel<true, true, false>,
-        (const void*)elbo_kernel<false, false, true>, (const void*)elbo_kernel<true, false, true>,
-        (const void*)elbo_kernel<false, true, true>, (const void*)elbo_kernel<true, true, true>,
-        (const void*)persistent_kernel<false, false>, (const void*)persistent_kernel<true, false>,
-        (const void*)persistent_kernel<false, true>, (const void*)persistent_kernel<true, true>,
+#define BSVI_K3(OUT_, GEN_) (const void*)elbo_kernel<SM_WSUM, OUT_, GEN_>, (const void*)elbo_kernel<SM_LACC, OUT_, GEN_>, \
+                            (const void*)elbo_kernel<SM_ZG, OUT_, GEN_>
+        BSVI_K3(false, false), BSVI_K3(true, false), BSVI_K3(false, true), BSVI_K3(true, true),
+#undef BSVI_K3
+        (const void*)persistent_kernel<SM_WSUM, false>, (const void*)persistent_kernel<SM_LACC, false>,
+        (const void*)persistent_kernel<SM_ZG, false>, (const void*)persistent_kernel<SM_WSUM, true>,
+        (const void*)persistent_kernel<SM_LACC, true>, (const void*)persistent_kernel<SM_ZG, true>,
         (const void*)reduce_kernel};
+    // a kernel with static LDS cannot opt in to the full 160 KiB: leave 256 B of head-room there
     int granted = lds;
     for (const void* k : kernels) {
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
             (void)hipGetLastError();
-            granted = 65536;
+            e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds - 256);
+            if (e == hipSuccess) {
+                granted = granted < lds - 256 ? granted : lds - 256;
+            } else {
+                (void)hipGetLastError();
+                if (getenv("BSVI_DEBUG")) fprintf(stderr, "bsvi: hipFuncSetAttribute(%d) failed: %s\n", lds, hipGetErrorString(e));
+                granted = 65536;
+            }
         }
     }
     p->max_lds = granted;
@@ -1163,45 +1203,51 @@ extern "C" void bsvi_program_destroy(bsvi_program* p) {
 struct Geometry {
     uint32_t n_waves = 0;   // per workgroup
     uint32_t n_blocks = 0;
+    int mode = SM_WSUM;     // where slots and dU accumulators live
     bool zglobal = false;
     size_t lds_bytes = 0;
     uint32_t n_pad = 0;
 };
 
-static size_t lds_need(const bsvi_program* p, uint32_t n_waves, bool zglobal) {
+static size_t lds_need(const bsvi_program* p, uint32_t n_waves, int mode) {
     size_t floats = (size_t)p->d.n_uniform + (size_t)p->d.n_obs + (size_t)p->d.n_uniform_grad * n_waves + 4 * (size_t)n_waves;
-    if (!zglobal) floats += (2 * (size_t)p->d.n_slots + 1) * n_waves * 64;
+    if (mode == SM_WSUM) floats += (2 * (size_t)p->d.n_slots + 1) * n_waves * 64;
+    if (mode == SM_LACC) floats += ((2 * (size_t)p->d.n_slots + p->d.n_uniform_grad + 1) | 1) * n_waves * 64;
     return floats * 4 + 64;
 }
 
-// Policy: keep samples in LDS whenever they fit.  A shard that fits one workgroup (<= 1024
-// lanes) runs as one workgroup (needed by the persistent trainer, and the cheapest reduction);
-// otherwise 4-wave workgroups, shrinking while the LDS image does not fit; if not even one wave
-// fits, samples spill to a global [slot][N] workspace (still coalesced along N).
+// Policy: keep samples in LDS whenever they fit, with per-lane dU accumulators when those fit too
+// (no cross-lane traffic inside the sweeps).  A shard that fits one workgroup (<= 1024 lanes) runs
+// as one workgroup (needed by the persistent trainer, and the cheapest reduction); otherwise
+// 4-wave workgroups, shrinking while the LDS image does not fit; if not even one wave fits,
+// samples spill to a global [slot][N] workspace (still coalesced along N).
 static Geometry choose_geometry(const bsvi_program* p, uint32_t n_local, bool single_block_only) {
     Geometry g;
     const uint32_t waves_total = (n_local + 63) / 64;
     const size_t budget = (size_t)p->max_lds;
-    if (waves_total <= 16 && lds_need(p, waves_total, false) <= budget) {
-        g.n_waves = waves_total; g.n_blocks = 1; g.zglobal = false;
+    auto fits = [&](uint32_t w, int mode) { return lds_need(p, w, mode) <= budget; };
+    auto best_lds_mode = [&](uint32_t w) { return fits(w, SM_LACC) ? SM_LACC : (fits(w, SM_WSUM) ? SM_WSUM : -1); };
+    if (waves_total <= 16 && best_lds_mode(waves_total) >= 0) {
+        g.n_waves = waves_total; g.n_blocks = 1; g.mode = best_lds_mode(waves_total);
     } else if (single_block_only) {
-        if (waves_total <= 16 && lds_need(p, waves_total, true) <= budget) {
-            g.n_waves = waves_total; g.n_blocks = 1; g.zglobal = true;
+        if (waves_total <= 16 && fits(waves_total, SM_ZG)) {
+            g.n_waves = waves_total; g.n_blocks = 1; g.mode = SM_ZG;
         } else {
             return g;
         }
     } else {
         uint32_t w = 4;
-        while (w > 1 && lds_need(p, w, false) > budget) w >>= 1;
-        if (lds_need(p, w, false) <= budget) {
-            g.n_waves = w; g.zglobal = false;
+        while (w > 1 && best_lds_mode(w) < 0) w >>= 1;
+        if (best_lds_mode(w) >= 0) {
+            g.n_waves = w; g.mode = best_lds_mode(w);
         } else {
-            g.n_waves = 4; g.zglobal = true;
-            if (lds_need(p, 4, true) > budget) return Geometry();
+            g.n_waves = 4; g.mode = SM_ZG;
+            if (!fits(4, SM_ZG)) return Geometry();
         }
         g.n_blocks = (waves_total + g.n_waves - 1) / g.n_waves;
     }
-    g.lds_bytes = lds_need(p, g.n_waves, g.zglobal);
+    g.zglobal = g.mode == SM_ZG;
+    g.lds_bytes = lds_need(p, g.n_waves, g.mode);
     g.n_pad = g.n_blocks * g.n_waves * 64;
     return g;
 }
@@ -1260,14 +1306,16 @@ static void fill_rparams(const bsvi_program* p, const Geometry& g, const KParams
 static int launch_elbo(const bsvi_program* p, const Geometry& g, const KParams& K, hipStream_t s) {
     dim3 grid(g.n_blocks), block(g.n_waves * 64);
     const bool out = K.samples_out || K.noise_out || K.fvalue_out || K.stamps;
-#define BSVI_LAUNCH_ELBO(ZG_, OUT_, GEN_) hipLaunchKernelGGL((elbo_kernel<ZG_, OUT_, GEN_>), grid, block, g.lds_bytes, s, K)
-    if (p->generic) {
-        if (g.zglobal) { if (out) BSVI_LAUNCH_ELBO(true, true, true); else BSVI_LAUNCH_ELBO(true, false, true); }
-        else { if (out) BSVI_LAUNCH_ELBO(false, true, true); else BSVI_LAUNCH_ELBO(false, false, true); }
-    } else {
-        if (g.zglobal) { if (out) BSVI_LAUNCH_ELBO(true, true, false); else BSVI_LAUNCH_ELBO(true, false, false); }
-        else { if (out) BSVI_LAUNCH_ELBO(false, true, false); else BSVI_LAUNCH_ELBO(false, false, false); }
-    }
+#define BSVI_LAUNCH_ELBO(SM_, OUT_, GEN_) hipLaunchKernelGGL((elbo_kernel<SM_, OUT_, GEN_>), grid, block, g.lds_bytes, s, K)
+#define BSVI_LAUNCH_SM(OUT_, GEN_)                                       \
+    do {                                                                 \
+        if (g.mode == SM_LACC) BSVI_LAUNCH_ELBO(SM_LACC, OUT_, GEN_);    \
+        else if (g.mode == SM_ZG) BSVI_LAUNCH_ELBO(SM_ZG, OUT_, GEN_);   \
+        else BSVI_LAUNCH_ELBO(SM_WSUM, OUT_, GEN_);                      \
+    } while (0)
+    if (p->generic) { if (out) BSVI_LAUNCH_SM(true, true); else BSVI_LAUNCH_SM(false, true); }
+    else { if (out) BSVI_LAUNCH_SM(true, false); else BSVI_LAUNCH_SM(false, false); }
+#undef BSVI_LAUNCH_SM
 #undef BSVI_LAUNCH_ELBO
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
@@ -1350,7 +1398,7 @@ extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, con
 extern "C" int bsvi_persistent_supported(const bsvi_program* p, uint32_t n_local) {
     if (!p || !n_local) return 0;
     Geometry g = choose_geometry(p, n_local, true);
-    return g.n_blocks == 1 ? 1 : 0;
+    return (g.n_blocks == 1 && g.mode != SM_ZG) ? 1 : 0;   // a spilled (global-slot) workgroup is slower than many LDS ones
 }
 
 extern "C" int bsvi_train_persistent(const bsvi_program* p, const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
@@ -1384,16 +1432,18 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
     P.active_mask_first = active_mask_first_dev; P.pretraining_iterations = pretraining_iterations;
     dim3 grid(1), block(g.n_waves * 64);
     hipStream_t st = (hipStream_t)a->stream;
+#define BSVI_LAUNCH_P(SM_, GEN_) hipLaunchKernelGGL((persistent_kernel<SM_, GEN_>), grid, block, g.lds_bytes, st, P)
     if (p->generic) {
-        if (g.zglobal) hipLaunchKernelGGL((persistent_kernel<true, true>), grid, block, g.lds_bytes, st, P);
-        else hipLaunchKernelGGL((persistent_kernel<false, true>), grid, block, g.lds_bytes, st, P);
+        if (g.mode == SM_LACC) BSVI_LAUNCH_P(SM_LACC, true); else if (g.mode == SM_ZG) BSVI_LAUNCH_P(SM_ZG, true); else BSVI_LAUNCH_P(SM_WSUM, true);
     } else {
-        if (g.zglobal) hipLaunchKernelGGL((persistent_kernel<true, false>), grid, block, g.lds_bytes, st, P);
-        else hipLaunchKernelGGL((persistent_kernel<false, false>), grid, block, g.lds_bytes, st, P);
+        if (g.mode == SM_LACC) BSVI_LAUNCH_P(SM_LACC, false); else if (g.mode == SM_ZG) BSVI_LAUNCH_P(SM_ZG, false); else BSVI_LAUNCH_P(SM_WSUM, false);
     }
+#undef BSVI_LAUNCH_P
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }
+
+extern "C" int bsvi_max_lds_bytes(const bsvi_program* p) { return p ? p->max_lds : 0; }
 
 // launch geometry the library would use — exported for tests, bench and DESIGN.md tables
 extern "C" int bsvi_query_geometry(const bsvi_program* p, uint32_t n_local, uint32_t* n_blocks, uint32_t* n_waves,
@@ -1403,7 +1453,7 @@ extern "C" int bsvi_query_geometry(const bsvi_program* p, uint32_t n_local, uint
     if (!g.n_blocks) return fail(BSVI_ERR_RESOURCE, "program does not fit the LDS budget");
     if (n_blocks) *n_blocks = g.n_blocks;
     if (n_waves) *n_waves = g.n_waves;
-    if (zglobal) *zglobal = g.zglobal ? 1 : 0;
+    if (zglobal) *zglobal = (uint32_t)g.mode;   // 0 LDS rows + wave sums, 1 LDS rows + lane accumulators, 2 global slots
     if (lds_bytes) *lds_bytes = g.lds_bytes;
     return BSVI_OK;
 }

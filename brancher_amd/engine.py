@@ -48,6 +48,16 @@ def shard(n_global, rank, world):
     return base, n_local
 
 
+def allreduce_sums(out):
+    """The ONE collective of the multi-GPU path: sum the per-rank output blocks
+    [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.  RCCL over xGMI
+    when `out` is a device tensor (backend "nccl"), gloo in the CPU tests."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out
+
+
 def estimator_name(gradient_estimator):
     if gradient_estimator is None:
         return "pathwise"
@@ -204,9 +214,7 @@ class CompiledELBO:
         fvals = torch.empty((2, n_local), device=dev) if want_fvalues else None
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.out, op=dist.ReduceOp.SUM)
+        allreduce_sums(self.out)
         native.check(self.lib.bsvi_finalize(self.native.handle, C.c_void_p(self.out.data_ptr()), number_samples,
                                             self._stream()))
         self.grads_valid = True
@@ -278,7 +286,6 @@ class CompiledELBO:
             self.last_mode = "persistent"
             return loss_curve, finite
 
-        import torch.distributed as dist
         for it in range(K):
             nz = None if noise_t is None else noise_t[it]
             args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
@@ -289,7 +296,7 @@ class CompiledELBO:
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it)))
             else:
                 native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
-                dist.all_reduce(self.out, op=dist.ReduceOp.SUM)
+                allreduce_sums(self.out)
                 native.check(self.lib.bsvi_finalize(self.native.handle, ptr(self.out), number_samples, self._stream()))
                 native.check(self.lib.bsvi_optimizer_step(C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state),
                                                           ptr(mask), p.n_params, self._stream()))

@@ -67,6 +67,7 @@ EXPORTS = {
     "bsvi_train_persistent2": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bsvi_persistent_supported": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bsvi_max_lds_bytes": (C.c_int, [C.c_void_p]),
     "bsvi_query_geometry": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "bsvi_debug_math": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
@@ -146,7 +147,8 @@ class NativeProgram:
     def geometry(self, n_local):
         nb, nw, zg, lds = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
         check(self.lib.bsvi_query_geometry(self.handle, n_local, C.byref(nb), C.byref(nw), C.byref(zg), C.byref(lds)))
-        return dict(n_blocks=nb.value, n_waves=nw.value, zglobal=bool(zg.value), lds_bytes=lds.value)
+        return dict(n_blocks=nb.value, n_waves=nw.value, zglobal=zg.value == 2,
+                    storage=("lds+wave_sum", "lds+lane_acc", "global")[zg.value], lds_bytes=lds.value)
 
     def persistent_supported(self, n_local):
         return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))

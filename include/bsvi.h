@@ -272,6 +272,9 @@ int bsvi_svi_step(const bsvi_program* prog, const bsvi_elbo_args* args, const bs
                   float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                   float* loss_slot_dev, float* finite_slot_dev);
 
+/* LDS bytes per workgroup the runtime granted to this program's kernels (160 KiB on gfx950). */
+int bsvi_max_lds_bytes(const bsvi_program* prog);
+
 /* Launch geometry the library uses for n_samples_local samples (for tests/bench/DESIGN.md). */
 int bsvi_query_geometry(const bsvi_program* prog, uint32_t n_samples_local, uint32_t* n_blocks,
                         uint32_t* n_waves, uint32_t* zglobal, uint64_t* lds_bytes);

@@ -1,0 +1,102 @@
+"""N>1 path on CPU (gloo, world_size 2): the sample-shard partition and the one all-reduce of
+un-normalised sums.  The per-rank sums the HIP kernel would produce are computed here by the
+oracle on each rank's shard; the host logic under test is engine.shard / engine.allreduce_sums
+and the out-block layout (include/bsvi.h BSVI_OUT_HEADER)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, Golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, case, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brancher_amd import engine, lowering
+    from brancher_amd.native import OUT_HEADER
+    from oracle.svi_oracle import Oracle
+    g = Golden(case)
+    model = g.build()
+    prog = lowering.lower(model)
+    oracle = Oracle(model)
+    N = g.N
+    base, n_local = engine.shard(N, rank, world)
+    noise = {k: v[base:base + n_local] for k, v in g.noise.items()}
+    # what bsvi_elbo_fwd_bwd leaves in out_dev for this shard: sums, not means
+    oracle.zero_grad()
+    value = oracle.elbo(n_local, "pathwise", noise)            # mean over the shard
+    (value * n_local).backward()                               # -> d(sum_s f_s)/d theta
+    out = torch.zeros(OUT_HEADER + prog.n_params)
+    out[0] = float(value.detach()) * n_local
+    for par, off, size, _ in prog.parameters:
+        grad = oracle.named_parameters()[par.name].grad
+        if grad is not None:
+            out[OUT_HEADER + off:OUT_HEADER + off + size] = grad.reshape(-1)
+    engine.allreduce_sums(out)
+    loss = -out[0] / N                                         # bsvi_finalize
+    grads = -out[OUT_HEADER:] / N
+    if rank == 0:
+        named = {par.name: grads[off:off + size].numpy().copy() for par, off, size, _ in prog.parameters}
+        out_q.put((float(loss), named, (base, n_local)))
+    else:
+        out_q.put((None, None, (base, n_local)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["readme_ar_T20_N300", "lognormal_normal_N100"])
+def test_two_rank_sample_shards_reproduce_the_reference(case):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = Golden(case)
+    shards = sorted(r[2] for r in results)
+    assert shards[0][0] == 0 and shards[0][0] + shards[0][1] == shards[1][0] and sum(s[1] for s in shards) == g.N
+    loss, grads, _ = next(r for r in results if r[0] is not None)
+    ref = float(g.data["loss_pathwise"])
+    assert abs(loss - ref) <= 1e-5 * abs(ref)
+    ref_grads = g.group("grad_pathwise/")
+    scale = max(np.abs(v).max() for v in ref_grads.values())
+    for name, gr in ref_grads.items():
+        assert np.abs(grads[name].reshape(gr.shape) - gr).max() <= 1e-5 * scale, name
+
+
+def test_shard_partition_is_exact():
+    from brancher_amd import engine
+    for n in (1, 7, 300, 8192, 1000003):
+        for world in (1, 2, 3, 8):
+            if n < world:
+                continue
+            spans = [engine.shard(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0
+            for (b0, n0), (b1, _) in zip(spans, spans[1:]):
+                assert b0 + n0 == b1
+            assert spans[-1][0] + spans[-1][1] == n
+            sizes = [s[1] for s in spans]
+            assert max(sizes) - min(sizes) <= 1
