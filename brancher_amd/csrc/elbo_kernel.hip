@@ -270,9 +270,11 @@ enum { SM_WSUM = 0, SM_LACC = 1, SM_ZG = 2 };
 // the lowering): uniform entries / observed data are read at byte_offset of the uniform region
 // (LDS offset 0), slots at lane_row + byte_offset, the adjoint of a slot 4 bytes further.
 // ONE ds_read per operand, no branches. ---------------------------------------------------------
-__device__ __forceinline__ float& lds_at(uint32_t byte_addr) {
-    return *reinterpret_cast<float*>(reinterpret_cast<char*>(g_lds) + byte_addr);
+__device__ __forceinline__ float* lds_ptr(uint32_t byte_addr) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(g_lds) + byte_addr);
 }
+__device__ __forceinline__ float lds_ld(uint32_t byte_addr) { return *lds_ptr(byte_addr); }
+__device__ __forceinline__ void lds_st(uint32_t byte_addr, float v) { *lds_ptr(byte_addr) = v; }
 __device__ __forceinline__ uint32_t opnd_offset(uint32_t o, uint32_t e) {
     const uint32_t per_lane = o >> 31;
     const uint32_t step = ((o >> 30) & 1u) * (4u + 4u * per_lane);      // 8 bytes per slot, 4 per entry
@@ -284,28 +286,28 @@ __device__ __forceinline__ float ld_opnd(const KParams& K, const Lane& T, uint32
     const uint32_t mask = (uint32_t)((int32_t)o >> 31);
     if (ZG) {
         if (mask) return K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n];
-        return lds_at(off);
+        return lds_ld(off);
     }
-    return lds_at(off + (T.zrow & mask));
+    return lds_ld(off + (T.zrow & mask));
 }
 // slots addressed by a destination / slot operand
 template <int SM>
 __device__ __forceinline__ float ld_slot(const KParams& K, const Lane& T, uint32_t off) {
-    return ZG ? K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n] : lds_at(T.zrow + off);
+    return ZG ? K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n] : lds_ld(T.zrow + off);
 }
 template <int SM>
 __device__ __forceinline__ void st_slot(const KParams& K, const Lane& T, uint32_t off, float v) {
     if (ZG) K.zglobal[(size_t)(off >> 3) * K.n_pad + T.n] = v;
-    else lds_at(T.zrow + off) = v;
+    else lds_st(T.zrow + off, v);
 }
 template <int SM>
 __device__ __forceinline__ float ld_adj(const KParams& K, const Lane& T, uint32_t off) {
-    return ZG ? K.zglobal[((size_t)K.n_slots + (off >> 3)) * K.n_pad + T.n] : lds_at(T.zrow + off + 4u);
+    return ZG ? K.zglobal[((size_t)K.n_slots + (off >> 3)) * K.n_pad + T.n] : lds_ld(T.zrow + off + 4u);
 }
 template <int SM>
 __device__ __forceinline__ void st_adj(const KParams& K, const Lane& T, uint32_t off, float v) {
     if (ZG) K.zglobal[((size_t)K.n_slots + (off >> 3)) * K.n_pad + T.n] = v;
-    else lds_at(T.zrow + off + 4u) = v;
+    else lds_st(T.zrow + off + 4u, v);
 }
 // scatter an adjoint to an operand: slots accumulate per lane; lane-uniform values are summed
 // over the wave first (DPP) and accumulated per wave — no atomics, fixed order
@@ -317,7 +319,7 @@ __device__ __forceinline__ void add_adj(const KParams& K, const Lay& L, const La
         // or (constants, observed data) a write-only dummy — one branch-free read-modify-write,
         // no cross-lane traffic; the accumulators are summed over lanes once per launch
         const uint32_t cell = (o >> 31) ? off + 4u : ((off < L.ugrad_bytes) ? L.uacc + off : L.dummy);
-        lds_at(T.zrow + cell) += g;
+        lds_st(T.zrow + cell, lds_ld(T.zrow + cell) + g);
         return;
     }
     if (o >> 31) {
@@ -326,6 +328,25 @@ __device__ __forceinline__ void add_adj(const KParams& K, const Lay& L, const La
         const float tot = wave_sum(g);
         if (T.lane == 0) g_lds[L.uadj + (off >> 2) * L.n_waves + T.wave] += tot;
     }
+}
+
+// SM_LACC with BSVI_R_NOALIAS: the five adjoint cells of a NAFF instruction are distinct, so the
+// read-modify-writes can be issued as 5 reads, ONE wait, 5 writes instead of 5 dependent round trips
+__device__ __forceinline__ uint32_t adj_cell(const Lay& L, uint32_t o, uint32_t e) {
+    const uint32_t off = opnd_offset(o, e);
+    return (o >> 31) ? off + 4u : ((off < L.ugrad_bytes) ? L.uacc + off : L.dummy);
+}
+__device__ __forceinline__ void add_adj5(const Lay& L, const Lane& T, uint32_t od_, uint32_t oa_, uint32_t ob_, uint32_t oc_,
+                                         uint32_t os_, uint32_t e, float gd, float ga, float gb, float gc, float gs) {
+    const uint32_t cd = T.zrow + adj_cell(L, od_, e), ca = T.zrow + adj_cell(L, oa_, e);
+    const uint32_t cb = T.zrow + adj_cell(L, ob_, e), cc = T.zrow + adj_cell(L, oc_, e);
+    const uint32_t cs = T.zrow + adj_cell(L, os_, e);
+    const float od = lds_ld(cd), oa = lds_ld(ca), ob = lds_ld(cb), oc = lds_ld(cc), os = lds_ld(cs);
+    lds_st(cd, od + gd);
+    lds_st(ca, oa + ga);
+    lds_st(cb, ob + gb);
+    lds_st(cc, oc + gc);
+    lds_st(cs, os + gs);
 }
 
 __device__ __noinline__ float unop_rare(uint32_t sub, float x, float imm) {
@@ -424,11 +445,16 @@ __device__ __forceinline__ void naff_sink(const KParams& K, const Lay& L, Lane& 
     T.f += w * (-0.5f * (u * u) - logS - kLogSqrt2Pi);
     const float gw = w * T.mask;
     const float gloc = gw * u * rS;                 // d lp / d loc = (v - loc) / S^2
-    add_adj<SM>(K, L, T, I.dst, e, -gloc);
-    add_adj<SM>(K, L, T, I.a, e, gloc * B);
-    add_adj<SM>(K, L, T, I.b, e, gloc * A);
-    add_adj<SM>(K, L, T, I.c, e, gloc);
-    add_adj<SM>(K, L, T, I.s, e, gw * (u * u - 1.0f) * rS);
+    const float gS = gw * (u * u - 1.0f) * rS;
+    if (SM == SM_LACC && ((I.w0 >> 24) & BSVI_R_NOALIAS)) {
+        add_adj5(L, T, I.dst, I.a, I.b, I.c, I.s, e, -gloc, gloc * B, gloc * A, gloc, gS);
+    } else {
+        add_adj<SM>(K, L, T, I.dst, e, -gloc);
+        add_adj<SM>(K, L, T, I.a, e, gloc * B);
+        add_adj<SM>(K, L, T, I.b, e, gloc * A);
+        add_adj<SM>(K, L, T, I.c, e, gloc);
+        add_adj<SM>(K, L, T, I.s, e, gS);
+    }
 }
 
 template <int SM, bool OUT, bool NODES, bool GEN>
@@ -528,19 +554,43 @@ __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, La
             gS = gw * (d * t * rS - rS);
         }
         if (flags & BSVI_F_ENT) gS += __uint_as_float(I.imm1) * T.mask * rS;
-        if (flags & BSVI_F_SAMPLE) {
-            const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
-            const float zb = ld_adj<SM>(K, T, doff) + gv;
-            const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
-            gloc += zb;
-            gS += zb * eps;
+        const bool sampled = (flags & BSVI_F_SAMPLE) != 0;
+        if (SM == SM_LACC && ((I.w0 >> 24) & BSVI_R_NOALIAS)) {
+            // batched: the five adjoint cells are read together (one wait); a sampled latent's own
+            // cell is read for its incoming adjoint and written back unchanged
+            const uint32_t cd = T.zrow + adj_cell(L, I.dst, e), ca = T.zrow + adj_cell(L, I.a, e);
+            const uint32_t cb = T.zrow + adj_cell(L, I.b, e), cc = T.zrow + adj_cell(L, I.c, e);
+            const uint32_t cs = T.zrow + adj_cell(L, I.s, e);
+            const float od = lds_ld(cd), oa = lds_ld(ca), ob = lds_ld(cb), oc = lds_ld(cc), os = lds_ld(cs);
+            float gdst = gv;
+            if (sampled) {
+                const uint32_t row = opnd_offset(I.dst, e) >> 3;
+                const float zb = od + gv;
+                const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+                gloc += zb;
+                gS += zb * eps;
+                gdst = 0.0f;
+            }
+            lds_st(cd, od + gdst);
+            lds_st(ca, oa + gloc * B);
+            lds_st(cb, ob + gloc * A);
+            lds_st(cc, oc + gloc);
+            lds_st(cs, os + gS);
         } else {
-            add_adj<SM>(K, L, T, I.dst, e, gv);
+            if (sampled) {
+                const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
+                const float zb = ld_adj<SM>(K, T, doff) + gv;
+                const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+                gloc += zb;
+                gS += zb * eps;
+            } else {
+                add_adj<SM>(K, L, T, I.dst, e, gv);
+            }
+            add_adj<SM>(K, L, T, I.a, e, gloc * B);
+            add_adj<SM>(K, L, T, I.b, e, gloc * A);
+            add_adj<SM>(K, L, T, I.c, e, gloc);
+            add_adj<SM>(K, L, T, I.s, e, gS);
         }
-        add_adj<SM>(K, L, T, I.a, e, gloc * B);
-        add_adj<SM>(K, L, T, I.b, e, gloc * A);
-        add_adj<SM>(K, L, T, I.c, e, gloc);
-        add_adj<SM>(K, L, T, I.s, e, gS);
     } else if (op == BSVI_OP_BIN) {
         const float a = ld_opnd<SM>(K, T, I.a, e), b = ld_opnd<SM>(K, T, I.b, e);
         const uint32_t d = opnd_offset(I.dst, e);
@@ -648,7 +698,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
 
     for (uint32_t s = 0; s < K.n_slots; ++s) st_adj<SM>(K, T, s * 8u, 0.0f);
     if (SM == SM_LACC)
-        for (uint32_t k = 0; k <= K.n_uniform_grad; ++k) lds_at(T.zrow + L.uacc + 4u * k) = 0.0f;   // + dummy
+        for (uint32_t k = 0; k <= K.n_uniform_grad; ++k) lds_st(T.zrow + L.uacc + 4u * k, 0.0f);   // + dummy
     __syncthreads();
     BSVI_STAMP(1)
 
@@ -751,7 +801,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         for (uint32_t i = tid; i < K.n_uniform_grad * L.n_waves; i += nthreads) {
             const uint32_t k = i / L.n_waves, wv = i - k * L.n_waves;
             float s = 0.0f;
-            for (uint32_t l = wv * 64u; l < wv * 64u + 64u; ++l) s += lds_at(cell0 + 4u * k + l * row_bytes);
+            for (uint32_t l = wv * 64u; l < wv * 64u + 64u; ++l) s += lds_ld(cell0 + 4u * k + l * row_bytes);
             g_lds[L.uadj + i] = s;
         }
         __syncthreads();

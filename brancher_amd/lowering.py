@@ -38,6 +38,7 @@ from brancher_amd.variables import RootVariable, RandomVariable, ProbabilisticMo
 # ---- mirror of include/bsvi.h (tests/test_lowering_abi.py checks the two stay in sync) -----
 OP = dict(NOP=0, NAFF=1, NODE=2, BIN=3, UN=4, REC_BEGIN=5, REC_END=6)
 R_SINK = 1     # record flag: complete (forward and reverse) in the forward sweep
+R_NOALIAS = 2  # instruction flag: no two operands share an adjoint cell (adjoint updates may be batched)
 F_SAMPLE, F_ENT, F_LOGP, F_WF = 1, 2, 4, 8
 K_NONE, K_U, K_Z, K_OBS = 0, 1, 2, 3
 BINOP = dict(add=0, sub=1, mul=2, truediv=3, pow=4, delta=5)
@@ -693,8 +694,24 @@ class _Lowering:
         # else is bracketed by REC_BEGIN / REC_END pseudo-instructions that carry the loop
         # extent and the temp range, so that both sweeps find record boundaries in the stream.
         words, recs_out = [], []
+
+        def no_alias(ins, n_elems):
+            """True when the adjoint cells of the instruction's operands are pairwise distinct for
+            every element of the record's loop (constants / observed data have no adjoint)."""
+            spans = []
+            for kind, index, stride in ins[1:6]:
+                if kind == K_Z or kind == K_U:
+                    spans.append((kind, index, index + stride * (n_elems - 1)))
+            for i in range(len(spans)):
+                for j in range(i + 1, len(spans)):
+                    (k0, a0, b0), (k1, a1, b1) = spans[i], spans[j]
+                    if k0 == k1 and a0 <= b1 and a1 <= b0:
+                        return False
+            return True
+
         for (b, e, n_elems, n_temps, sink) in self.records:
-            body = [[ins[0]] + [encode_operand(o, n_up, n_uni) for o in ins[1:6]] + [ins[6], ins[7]]
+            body = [[ins[0] | ((R_NOALIAS << 24) if no_alias(ins, n_elems) else 0)]
+                    + [encode_operand(o, n_up, n_uni) for o in ins[1:6]] + [ins[6], ins[7]]
                     for ins in self.code[b:e]]
             rflag = (R_SINK if sink else 0) << 24
             if len(body) == 1 and n_elems == 1:

@@ -64,7 +64,7 @@ typedef enum bsvi_dist {
  *  register file (dynamic VGPR indexing spills on gfx950) and an instruction is fully
  *  described by one 32-byte slot fetched with a single scalar load:
  *
- *      w0 = opcode | flags<<8 | dist<<16 | rflags<<24     (rflags bit 0 = BSVI_R_SINK)
+ *      w0 = opcode | flags<<8 | dist<<16 | rflags<<24     (rflags: BSVI_R_SINK | BSVI_R_NOALIAS)
  *      w1 = DST operand      (SAMPLE: the latent slot to write; LOGP: the VALUE operand)
  *      w2 = A operand   w3 = B operand   w4 = C operand   w5 = S operand
  *      w6 = imm0 (float bits)            w7 = imm1 (float bits)
@@ -106,6 +106,7 @@ typedef enum bsvi_op {
 } bsvi_op;
 
 #define BSVI_R_SINK 1u
+#define BSVI_R_NOALIAS 2u   /* no two operands of the instruction share an adjoint cell */
 
 typedef enum bsvi_node_flags { BSVI_F_SAMPLE = 1, BSVI_F_ENT = 2, BSVI_F_LOGP = 4, BSVI_F_WF = 8 } bsvi_node_flags;
 
