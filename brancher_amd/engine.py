@@ -118,9 +118,10 @@ class FusedLoss:
 
 
 class CompiledELBO:
-    def __init__(self, joint_model, posterior_model, estimator="pathwise", device=None):
+    def __init__(self, joint_model, posterior_model, estimator="pathwise", device=None, program=None,
+                 bind_parameters=True):
         self.device = device or _device()
-        self.program = lowering.lower(joint_model, posterior_model, estimator)
+        self.program = program if program is not None else lowering.lower(joint_model, posterior_model, estimator)
         self.native = native.NativeProgram(self.program)
         self.lib = self.native.lib
         p = self.program
@@ -138,8 +139,9 @@ class CompiledELBO:
         self._workspaces = {}
         self._noise_cache = None
         self.iteration = 0          # Philox counter offset: never reuse noise across calls
-        for par, off, size, _ in p.parameters:
-            par.bind(self, off)
+        if bind_parameters:
+            for par, off, size, _ in p.parameters:
+                par.bind(self, off)
 
     # ---- ParameterStore protocol (modules.Parameter) -------------------------------------
     def read_params(self, offset, size):
@@ -336,44 +338,88 @@ def estimate_elbo(joint_model, posterior_model, number_samples, for_gradient=Fal
     return -res["loss"]
 
 
-# ---- sampling / evaluation API edge ("next" row) ---------------------------------
-def _not_yet(what):
-    raise NotImplementedError("{} is the posterior-predictive / evaluation path (SURVEY §8f-3), outside the "
-                              "ELBO-gradient hot path this build covers".format(what))
+# ---- sampling / evaluation API edge ------------------------------------------------
+_sample_tick = [0]
 
 
-def sample_model(model, number_samples, observed=False, input_values={}):
-    _not_yet("ProbabilisticModel._get_sample")
-
-
-def sample_variables(variables, number_samples, observed=False, input_values={}):
-    _not_yet("Variable._get_sample")
-
-
-def get_sample_frame(model, number_samples, input_values={}):
-    _not_yet("get_sample")
-
-
-def posterior_sample(model, number_samples, input_values={}):
-    """Posterior draws of the latent variables, keyed by the joint model's variables
-    (`variables.py:796-805` restricted to the latent variables of the posterior)."""
-    compiled = compile_model(model, model.posterior_model, None)
-    res = compiled.evaluate(number_samples, want_samples=True)
-    by_name = compiled.samples_by_name(res["samples"])
-    mapping = lowering.get_model_mapping(model.posterior_model, model)
+def _run_sampler(model, posterior_model, number_samples, input_values):
+    """Ancestral sampling through the same fused kernel (a SAMPLE-only program).  Returns
+    {variable: device tensor in the reference layout [N, B, d1, d2]} for every variable sampled,
+    plus tiled roots (`RootVariable._get_sample`, variables.py:367-375)."""
+    from brancher_amd.variables import RootVariable
+    program = lowering.lower_sampler(model, posterior_model, input_values)
+    run = CompiledELBO(model, posterior_model, program=program, bind_parameters=False)
+    _sample_tick[0] += 1
+    res = run.evaluate(number_samples, want_samples=True, offset=(1 << 40) + _sample_tick[0])
+    samples = res["samples"]
     out = {}
-    for q_var, p_var in mapping.items():
-        if q_var.name in by_name:
-            out[p_var] = torch.from_numpy(by_name[q_var.name])
+    for var, slot in program.outputs:
+        rows = samples[slot.base:slot.base + slot.size]
+        out[var] = rows.t().reshape((number_samples,) + tuple(slot.shape)).contiguous()
+    models = [model] + ([posterior_model] if posterior_model is not None else [])
+    for m in models:
+        for var in m.flatten():
+            if isinstance(var, RootVariable) and var not in out:
+                value = var.value
+                if not isinstance(value, np.ndarray):
+                    continue
+                t = torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32)).to(run.device)
+                out[var] = t.expand((number_samples,) + tuple(t.shape[1:])).contiguous() if t.shape[0] == 1 else t
+    for var, value in (input_values or {}).items():
+        out[var] = value if torch.is_tensor(value) else torch.as_tensor(np.asarray(value, dtype=np.float32))
     return out
 
 
-def get_posterior_sample_frame(model, number_samples, input_values={}):
+def sample_model(model, number_samples, observed=False, input_values={}):
+    """`ProbabilisticModel._get_sample` (variables.py:732-742)."""
+    if observed:
+        from brancher_amd.variables import RandomVariable
+        return {v: torch.from_numpy(v._observed_value) for v in model._flatten()
+                if isinstance(v, RandomVariable) and v.is_observed and v.has_observed_value}
+    return _run_sampler(model, None, number_samples, input_values)
+
+
+def sample_variables(variables, number_samples, observed=False, input_values={}):
+    """`Variable._get_sample` (variables.py:367-375, 527-570): the variable and its ancestors."""
+    from brancher_amd.variables import ProbabilisticModel
+    return sample_model(ProbabilisticModel(list(variables)), number_samples, observed, input_values)
+
+
+def posterior_sample(model, number_samples, input_values={}):
+    """`ProbabilisticModel._get_posterior_sample` (variables.py:796-805): posterior draws re-keyed to the
+    joint model's variables by name, then the remaining variables of the joint model (posterior predictive)."""
+    raw = _run_sampler(model, model.posterior_model, number_samples, input_values)
+    mapping = lowering.get_model_mapping(model.posterior_model, model)
+    out = {}
+    for var, value in raw.items():
+        out[mapping.get(var, var)] = value
+    return out
+
+
+def _frame(sample):
     import pandas as pd
-    sample = posterior_sample(model, number_samples, input_values)
-    return pd.DataFrame({v.name: [x for x in t.numpy().reshape(t.shape[0], -1).squeeze(-1)]
-                         if t[0].numel() == 1 else list(t.numpy()) for v, t in sample.items()})
+    from brancher_amd.variables import RootVariable
+    cols = {}
+    for var, t in sample.items():
+        if isinstance(var, RootVariable):
+            continue
+        a = t.detach().cpu().numpy()
+        cols[var.name] = [float(x) for x in a.reshape(a.shape[0], -1)[:, 0]] if a[0].size == 1 else list(a)
+    return pd.DataFrame(cols)
+
+
+def get_sample_frame(model, number_samples, input_values={}):
+    """`get_sample` (variables.py:164-173, 751-757): a DataFrame, one row per sample."""
+    from brancher_amd.variables import Variable
+    if isinstance(model, Variable):
+        return _frame({model: sample_variables([model], number_samples, input_values=input_values)[model]})
+    return _frame(sample_model(model, number_samples, input_values=input_values))
+
+
+def get_posterior_sample_frame(model, number_samples, input_values={}):
+    return _frame(posterior_sample(model, number_samples, input_values))
 
 
 def log_probability(variables, values, include_parents=True, model=None):
-    _not_yet("calculate_log_probability outside the ELBO")
+    raise NotImplementedError("calculate_log_probability on arbitrary supplied values is outside the ELBO-gradient hot "
+                              "path this build covers (SURVEY §8f-3); the ELBO path evaluates log-probabilities in-kernel")

@@ -681,6 +681,93 @@ class _Lowering:
 
         return self.finish(bmax)
 
+    # ---------------------------------------------------------------- sampling programs
+    def run_sampler(self, input_values):
+        """Ancestral sampling program: the posterior's variables first (if a posterior
+        is attached: `ProbabilisticModel._get_posterior_sample`, variables.py:796-805, 903-907), then
+        every variable of the model that did not receive a value from the posterior by name —
+        `ProbabilisticModel._get_sample(observed=False)`, variables.py:732-742, 527-570.
+        Deterministic nodes get a slot too so that their values are part of the result."""
+        joint, posterior = self.joint, self.posterior
+        self.q_by_name, self.q_roots = {}, set()
+        if posterior is not None:
+            self.q_by_name = {v.name: v for v in posterior._flatten()}
+            self.q_roots = {v for v in posterior.variables if isinstance(v, RootVariable)}
+        given = {}
+        for var, value in (input_values or {}).items():
+            arr = np.asarray(value, dtype=np.float32) if not hasattr(value, "detach") else value.detach().cpu().numpy()
+            if arr.ndim >= 1 and arr.shape[0] > 1:
+                raise LoweringError("per-sample input_values are not supported by sampling programs yet")
+            given[var] = np.ascontiguousarray(arr.reshape(arr.shape[1:]) if arr.ndim > 1 else arr.reshape(1))
+        self.outputs = []          # (variable, slot) in sampling order
+
+        def topo(variables):
+            order, seen = [], set()
+
+            def visit(v):
+                if v in seen or not isinstance(v, RandomVariable):
+                    return
+                seen.add(v)
+                for parent in sorted(v.parents, key=lambda x: x.name):
+                    visit(parent)
+                order.append(v)
+
+            for v in sorted(variables, key=lambda x: x.name):
+                visit(v)
+            return order
+
+        def const_leaf(var):
+            arr = given[var]
+            if arr.size == 1:
+                return self.mk("imm", (), float(arr.reshape(-1)[0]))
+            return self.mk("carr", (), arr, canonical_elem_shape((1,) + arr.shape) if arr.ndim < 3 else canonical_elem_shape(arr.shape))
+
+        def q_ctx(var):
+            if var in given:
+                return const_leaf(var)
+            if var in self.slots:
+                return self.mk("z", (), var, self.slots[var].shape)
+            return self.q_value(var)
+
+        def p_ctx(var):
+            if var in given:
+                return const_leaf(var)
+            if var in self.slots:
+                return self.mk("z", (), var, self.slots[var].shape)
+            if var.name in self.q_by_name:
+                return q_ctx(self.q_by_name[var.name])
+            if isinstance(var, RootVariable):
+                return self.mk("root", (), var, self.root_shape(var))
+            raise LoweringError("variable %r is used before it is sampled" % var.name)
+
+        supported = (D.DIST_NORMAL, D.DIST_LOGNORMAL, D.DIST_CAUCHY, D.DIST_LAPLACE, D.DIST_BETA,
+                     D.DIST_BINOMIAL, D.DIST_BERNOULLI, D.DIST_DETERMINISTIC)
+        plan = []
+        if posterior is not None:
+            plan += [(v, q_ctx) for v in topo(posterior._flatten()) if v not in given]
+        mapped = set(self.q_by_name)
+        plan += [(v, p_ctx) for v in topo(joint._flatten()) if v not in given and v.name not in mapped]
+        for v, ctx in plan:
+            if v.distribution.kind not in supported:
+                raise LoweringError("distribution of %r is not supported by the fused kernel yet" % v.name)
+            params = self.node_params(v, ctx)
+            shape = broadcast_shapes3(*[p.shape for p in params])
+            slot = SlotInfo(v, self.n_slots, shape, v.distribution.kind)
+            self.n_slots += slot.size
+            self.n_latent = self.n_slots
+            plan_item = (v, params, shape, slot)
+            self.slots[v] = slot
+            self.outputs.append(plan_item)
+        self.temp_base = self.n_slots          # no derived slots in sampling programs
+        self.derived_nodes = set()
+        for v, params, shape, slot in self.outputs:
+            self.begin_record(shape)
+            self.emit_node(v.distribution.kind, F_SAMPLE, params, slot=slot)
+            self.end_record()
+        prog = self.finish(1)
+        prog.outputs = [(v, slot) for v, _, _, slot in self.outputs]
+        return prog
+
     def finish(self, bmax):
         prog = Program()
         prog.estimator = self.estimator
@@ -757,6 +844,11 @@ class _Lowering:
         prog.bmax = bmax
         prog.op_count = len(code)
         return prog
+
+
+def lower_sampler(model, posterior_model=None, input_values=None):
+    """Compile an ancestral-sampling program for `model` (optionally conditioned on its posterior)."""
+    return _Lowering(model, posterior_model, "pathwise").run_sampler(input_values)
 
 
 def lower(joint_model, posterior_model=None, estimator="pathwise"):

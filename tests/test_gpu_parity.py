@@ -160,3 +160,35 @@ def test_perform_inference_api_runs_and_improves_elbo():
     curve = model.diagnostics["loss curve"]
     assert curve.shape == (400,) and np.isfinite(curve).all()
     assert curve[-50:].mean() < curve[:50].mean()
+
+
+def test_prior_and_posterior_predictive_sampling_match_oracle_statistics():
+    """`_get_sample` / `_get_posterior_sample` through the same kernel.  The Philox stream
+    differs from torch's generator, so the check is distributional: moments of every variable against
+    the oracle's ancestral sampler on 60k draws."""
+    from oracle.svi_oracle import Oracle
+    api = W.native_api()
+    model = W.build_readme_ar(api, T=6)
+    n = 60000
+    torch.manual_seed(0)
+    prior = model._get_sample(n)
+    by_name = {v.name: t.cpu().numpy().reshape(n) for v, t in prior.items() if t.shape[0] == n and t[0].numel() == 1}
+    oracle = Oracle(W.build_readme_ar(api, T=6))
+    memo, ref = {}, {}
+    for v in oracle.p._flatten():
+        ref.update(oracle.sample_var(v, n, {}, memo, None, resample=False))
+    for v, t in ref.items():
+        if v.name in by_name and not v.name.endswith(("_loc", "_scale")):
+            a, b = by_name[v.name], t.detach().numpy().reshape(-1)
+            se = b.std() / np.sqrt(n)
+            assert abs(a.mean() - b.mean()) < 6 * se + 1e-3, v.name
+            assert abs(a.std() - b.std()) < 0.03 * b.std() + 1e-3, v.name
+    post = model._get_posterior_sample(n)
+    names = {v.name for v in post}
+    assert {"x0", "x5", "y0", "y5", "b_logit"} <= names
+    x5 = [t for v, t in post.items() if v.name == "x5"][0].cpu().numpy().reshape(n)
+    y5 = [t for v, t in post.items() if v.name == "y5"][0].cpu().numpy().reshape(n)
+    # posterior predictive: y5 | x5 ~ N(x5, 0.3)
+    assert abs((y5 - x5).std() - 0.3) < 0.01 and abs((y5 - x5).mean()) < 0.01
+    frame = model.get_posterior_sample(100)
+    assert len(frame) == 100 and "x3" in frame.columns
