@@ -1517,3 +1517,5 @@ extern "C" int bsvi_debug_math(int fn, int dist, const float* x_dev, const float
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }
+
+#include "dense_kernel.inc"

@@ -198,7 +198,7 @@ class CompiledELBO:
 
     # ---- one ELBO evaluation -------------------------------------------------------------------
     def evaluate(self, number_samples, noise=None, seed=None, offset=None, want_samples=False,
-                 want_noise=False, want_fvalues=False):
+                 want_noise=False, want_fvalues=False, minibatch=None):
         """Loss and gradients of one ELBO estimate (`variables.py:843-870` with
         for_gradient=True + `inference.py:100`).  Returns a dict of device tensors."""
         rank, world = dist_info()
@@ -251,7 +251,7 @@ class CompiledELBO:
 
     # ---- the optimisation loop --------------------------------------------------------------------
     def train(self, number_iterations, number_samples, optimizer="Adam", noise_seq=None, seed=None,
-              pretraining_iterations=0, allow_persistent=True, **opt_params):
+              pretraining_iterations=0, allow_persistent=True, minibatch_seq=None, **opt_params):
         """`brancher/inference.py:95-108` on the device.  Returns (loss_curve, finite_flags) as
         device tensors of length number_iterations; nothing synchronises with the host."""
         cfg = native.make_opt_cfg(optimizer, **opt_params)
@@ -319,7 +319,15 @@ def compile_model(joint_model, posterior_model=None, gradient_estimator=None):
     if compiled is None:
         # all programs of one (joint, posterior) pair share one parameter buffer
         sibling = next((c for (pid, _), c in joint_model._compiled.items() if pid == id(posterior_model)), None)
-        compiled = CompiledELBO(joint_model, posterior_model, est)
+        try:
+            compiled = CompiledELBO(joint_model, posterior_model, est)
+        except lowering.LoweringError as scalar_error:
+            # graphs with a dense matmul link go to the MFMA path (dense.py); anything else is an error
+            from brancher_amd import dense
+            try:
+                compiled = dense.CompiledDense(joint_model, posterior_model, est)
+            except lowering.LoweringError as dense_error:
+                raise lowering.LoweringError("{}; dense path: {}".format(scalar_error, dense_error)) from None
         if sibling is not None:
             if sibling.n_params != compiled.n_params:
                 raise RuntimeError("parameter layouts of two estimators of the same model differ")

@@ -768,6 +768,32 @@ class _Lowering:
         prog.outputs = [(v, slot) for v, _, _, slot in self.outputs]
         return prog
 
+    def fill_parameter_tables(self, prog, uni, n_up):
+        """CSR map parameter -> uniform entries, activity mask and optimizer groups"""
+        prog.n_params = self.n_params
+        prog.n_uniform_grad = n_up
+        ptr = np.zeros(self.n_params + 1, dtype=np.uint32)
+        src = uni["src"][:n_up].astype(np.int64)
+        np.add.at(ptr, src + 1, 1)
+        ptr = np.cumsum(ptr).astype(np.uint32)
+        prog.param_uniform_ptr = ptr
+        prog.param_uniform_idx = np.argsort(src, kind="stable").astype(np.uint32)
+        prog.parameters = list(self.parameters)
+        active = np.zeros(self.n_params, dtype=np.uint8)
+        active[src] = 1
+        prog.param_active = active
+        group = np.zeros(self.n_params, dtype=np.uint8)
+        for p, off, size, g in self.parameters:
+            group[off:off + size] = g
+        prog.param_group = group
+
+    def uniform_table(self):
+        n_up = len(self.uni_param)
+        uni = np.zeros(n_up + len(self.uni_const), dtype=UNIFORM_DTYPE)
+        for k, (src, tr, is_param, a, b) in enumerate(self.uni_param + self.uni_const):
+            uni[k] = (src, tr, is_param, 0, a, b)
+        return uni, n_up
+
     def finish(self, bmax):
         prog = Program()
         prog.estimator = self.estimator
@@ -818,27 +844,11 @@ class _Lowering:
         prog.uniform, prog.records, prog.code = uni, recs, code
         prog.consts = np.concatenate(self.consts) if self.consts else np.zeros(0, np.float32)
         prog.obs = np.concatenate(self.obs) if self.obs else np.zeros(0, np.float32)
-        prog.n_params = self.n_params
         prog.n_noise = self.n_latent
         prog.n_derived = self.temp_base - self.n_latent
         prog.n_temps = self.max_temps
         prog.n_slots = self.temp_base + self.max_temps
-        prog.n_uniform_grad = n_up
-        # CSR param -> uniform entries
-        ptr = np.zeros(self.n_params + 1, dtype=np.uint32)
-        src = uni["src"][:n_up].astype(np.int64)
-        np.add.at(ptr, src + 1, 1)
-        ptr = np.cumsum(ptr).astype(np.uint32)
-        prog.param_uniform_ptr = ptr
-        prog.param_uniform_idx = np.argsort(src, kind="stable").astype(np.uint32)
-        prog.parameters = list(self.parameters)
-        active = np.zeros(self.n_params, dtype=np.uint8)
-        active[src] = 1
-        prog.param_active = active
-        group = np.zeros(self.n_params, dtype=np.uint8)
-        for p, off, size, g in self.parameters:
-            group[off:off + size] = g
-        prog.param_group = group
+        self.fill_parameter_tables(prog, uni, n_up)
         prog.slots = dict(self.slots)
         prog.slot_by_name = {s.name: s for s in self.slots.values()}
         prog.bmax = bmax

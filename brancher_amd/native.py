@@ -52,6 +52,41 @@ class OptCfg(C.Structure):
                 ("eps", C.c_float), ("amsgrad", C.c_uint32), ("maximize", C.c_uint32)]
 
 
+class DenseDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_params", C.c_uint32), ("n_consts", C.c_uint32),
+                ("n_uniform", C.c_uint32), ("n_uniform_grad", C.c_uint32),
+                ("n_classes", C.c_uint32), ("n_features", C.c_uint32), ("dataset_size", C.c_uint32),
+                ("batch_size", C.c_uint32), ("likelihood", C.c_uint32),
+                ("q_loc_u", C.c_uint32), ("q_scale_u", C.c_uint32), ("prior_loc_u", C.c_uint32),
+                ("prior_scale_u", C.c_uint32), ("q_loc_stride", C.c_uint32), ("q_scale_stride", C.c_uint32),
+                ("prior_loc_stride", C.c_uint32), ("prior_scale_stride", C.c_uint32),
+                ("lik_weight", C.c_float), ("prior_weight", C.c_float), ("entropy_weight", C.c_float),
+                ("reserved", C.c_uint32),
+                ("uniform", C.c_void_p), ("consts", C.c_void_p), ("param_uniform_ptr", C.c_void_p),
+                ("param_uniform_idx", C.c_void_p), ("dataset", C.c_void_p), ("labels", C.c_void_p)]
+
+
+class DenseArgs(C.Structure):
+    _fields_ = [("params_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("indices_dev", C.c_void_p),
+                ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
+                ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
+                ("out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p), ("indices_out_dev", C.c_void_p),
+                ("fvalue_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p)]
+
+
+DENSE_EXPORTS = {
+    "bsvi_dense_create": (C.c_int, [C.POINTER(DenseDesc), C.POINTER(C.c_void_p)]),
+    "bsvi_dense_destroy": (None, [C.c_void_p]),
+    "bsvi_dense_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "bsvi_dense_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(DenseArgs)]),
+    "bsvi_dense_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bsvi_dense_step": (C.c_int, [C.c_void_p, C.POINTER(DenseArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+
 EXPORTS = {
     "bsvi_program_create": (C.c_int, [C.POINTER(ProgramDesc), C.POINTER(C.c_void_p)]),
     "bsvi_program_destroy": (None, [C.c_void_p]),
@@ -77,6 +112,7 @@ EXPORTS = {
     "bsvi_abi_version": (C.c_int, []),
     "bsvi_device_count": (C.c_int, []),
 }
+EXPORTS.update(DENSE_EXPORTS)
 
 _lib = None
 

@@ -19,6 +19,8 @@ def native_api():
         BinomialVariable=sv.BinomialVariable, BernulliVariable=sv.BernulliVariable,
         CauchyVariable=sv.CauchyVariable, LaplaceVariable=sv.LaplaceVariable,
         DeterministicVariable=sv.DeterministicVariable, RootVariable=v.RootVariable,
+        CategoricalVariable=sv.CategoricalVariable, EmpiricalVariable=sv.EmpiricalVariable,
+        RandomIndices=sv.RandomIndices,
         ProbabilisticModel=v.ProbabilisticModel, BF=BF, name="brancher_amd")
 
 
@@ -130,4 +132,34 @@ def build_heavy_tails(api, n_obs=12, seed=1):
     Qm = api.LaplaceVariable(0.3, 1., "m", learnable=True)
     Qs = api.LogNormalVariable(0.1, 0.4, "s", learnable=True)
     model.set_posterior_model(api.ProbabilisticModel([Qm, Qs]))
+    return model
+
+
+def logreg_data(dataset_size, n_features, n_classes, seed=0):
+    """Synthetic stand-in for MNIST (not available offline; SURVEY §8d cfg 4): pixel-like features in
+    [0, 1] and uniformly random labels."""
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(0., 1., size=(dataset_size, n_features, 1)).astype(np.float32)
+    labels = rng.randint(0, n_classes, size=dataset_size)
+    return X, labels
+
+
+def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=784, n_classes=10, seed=0,
+                              prior_scale=10., q_scale=0.1):
+    """BASELINE config 4: Bayesian multinomial logistic regression with a dense `matmul` link and a
+    random minibatch per iteration (`examples/MNIST_logistic_regression.py:15-54`)."""
+    BF = api.BF
+    X, labels = logreg_data(dataset_size, n_features, n_classes, seed)
+    minibatch_indices = api.RandomIndices(dataset_size=dataset_size, batch_size=batch_size, name="indices",
+                                          is_observed=True)
+    x = api.EmpiricalVariable(X, indices=minibatch_indices, name="x", is_observed=True)
+    y = api.EmpiricalVariable(labels, indices=minibatch_indices, name="labels", is_observed=True)
+    weights = api.NormalVariable(np.zeros((n_classes, n_features)), prior_scale * np.ones((n_classes, n_features)),
+                                 "weights")
+    k = api.CategoricalVariable(logits=BF.matmul(weights, x), name="k")
+    model = api.ProbabilisticModel([k])
+    k.observe(y)
+    Qweights = api.NormalVariable(np.zeros((n_classes, n_features)), q_scale * np.ones((n_classes, n_features)),
+                                  "weights", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qweights]))
     return model

@@ -280,6 +280,69 @@ int bsvi_max_lds_bytes(const bsvi_program* prog);
 int bsvi_query_geometry(const bsvi_program* prog, uint32_t n_samples_local, uint32_t* n_blocks,
                         uint32_t* n_waves, uint32_t* zglobal, uint64_t* lds_bytes);
 
+/* =========================================================================================
+ *  Dense-link path (BASELINE config 4): a mean-field Normal weight matrix W[C][P] whose use is
+ *  the dense link  activations[n][b][c] = sum_p W[n][c][p] * x[b][p]  (`BF.matmul(weights, x)`,
+ *  examples/MNIST_logistic_regression.py:33; brancher/functions.py:28-41) feeding an observed
+ *  likelihood, with the minibatch x drawn per iteration by RandomIndices / EmpiricalVariable
+ *  (standard_variables.py:71-112, distributions.py:410-462).  The per-sample weights
+ *  W = loc + scale * eps are never materialised: the forward GEMM [N*C x P] x [P x B] builds its
+ *  A operand from eps on the fly and runs on the f32 matrix cores (v_mfma_f32_16x16x4_f32), the
+ *  likelihood (log-softmax cross-entropy / Bernoulli logits) is its epilogue, and the backward
+ *  is a second MFMA GEMM  T_c = eps_c^T x dlogits_c  reduced against x.
+ * ========================================================================================= */
+typedef enum bsvi_dense_likelihood {
+    BSVI_LIK_CATEGORICAL = 0,   /* CategoricalVariable(logits=...)            distributions.py:294-311 */
+    BSVI_LIK_BERNOULLI = 1      /* Binomial(1, logits=...) / Bernulli(logits) distributions.py:561-592 */
+} bsvi_dense_likelihood;
+
+typedef struct bsvi_dense_desc {
+    uint32_t abi_version;
+    uint32_t n_params, n_consts, n_uniform, n_uniform_grad;
+    uint32_t n_classes, n_features, dataset_size, batch_size;
+    uint32_t likelihood;                       /* bsvi_dense_likelihood */
+    /* rows r = c * n_features + p of the weight matrix read their parameters from the uniform
+     * table at  base + r * stride  (stride 0 = one scalar for all rows) */
+    uint32_t q_loc_u, q_scale_u, prior_loc_u, prior_scale_u;
+    uint32_t q_loc_stride, q_scale_stride, prior_loc_stride, prior_scale_stride;
+    float lik_weight, prior_weight, entropy_weight;
+    uint32_t reserved;
+    const bsvi_uniform_entry* uniform;
+    const float* consts;
+    const uint32_t* param_uniform_ptr;
+    const uint32_t* param_uniform_idx;
+    const float* dataset;                      /* [dataset_size][n_features] host copy */
+    const float* labels;                       /* [dataset_size] host copy            */
+} bsvi_dense_desc;
+
+typedef struct bsvi_dense bsvi_dense;
+
+typedef struct bsvi_dense_args {
+    const float* params_dev;     /* [n_params]                                                   */
+    const float* noise_dev;      /* eps [C*P][n_samples_local] or NULL -> Philox                  */
+    const int32_t* indices_dev;  /* minibatch rows [batch_size] or NULL -> drawn on the device    */
+    uint64_t seed, offset;
+    uint32_t n_samples_local, n_samples_global, sample_base, reserved;
+    float* out_dev;              /* [BSVI_OUT_HEADER + n_params], same layout as bsvi_elbo_fwd_bwd */
+    float* noise_out_dev;        /* eps used [C*P][n_samples_local] or NULL                       */
+    int32_t* indices_out_dev;    /* minibatch used [batch_size] or NULL                           */
+    float* fvalue_out_dev;       /* per-sample f [n_samples_local] or NULL                        */
+    void* workspace_dev;
+    void* stream;
+} bsvi_dense_args;
+
+int bsvi_dense_create(const bsvi_dense_desc* desc, bsvi_dense** out);
+void bsvi_dense_destroy(bsvi_dense* d);
+size_t bsvi_dense_workspace_bytes(const bsvi_dense* d, uint32_t n_samples_local);
+/* ELBO forward+backward of the dense model over this GPU's sample shard; leaves sums in out_dev
+ * (then bsvi_finalize / all-reduce / bsvi_optimizer_step as for bsvi_elbo_fwd_bwd). */
+int bsvi_dense_fwd_bwd(const bsvi_dense* d, const bsvi_dense_args* args);
+int bsvi_dense_finalize(const bsvi_dense* d, float* out_dev, uint32_t n_samples_global, void* stream);
+/* single-GPU iteration with the reduction fused with finalize + optimizer step */
+int bsvi_dense_step(const bsvi_dense* d, const bsvi_dense_args* args, const bsvi_opt_cfg* cfg,
+                    float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
+                    float* loss_slot_dev, float* finite_slot_dev);
+
 /* Test hook, not used by the product path: evaluates one special function (fn 0 digamma,
  * 1 trigamma, 2 dirichlet_grad_one(x, alpha=p0, total=p1), 6 lgamma) or one node function of
  * distribution `dist` (fn 3 log-prob, 4 entropy, 5 reparameterised draw from noise x) elementwise;

@@ -40,6 +40,12 @@ CASES = {
     "lognormal_normal_N100": ("build_lognormal_normal", dict(n_obs=20), 100, 5,
                               dict(iters=5, n=50, optimizer="SGD", lr=1e-4)),
     "heavy_tails_N64": ("build_heavy_tails", dict(n_obs=12), 64, 6, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
+    # dense matmul link + Categorical likelihood + random minibatch (BASELINE config 4, reduced sizes)
+    "logreg_C3_P6_DS20_B12_N5": ("build_logistic_regression",
+                                 dict(dataset_size=20, batch_size=12, n_features=6, n_classes=3), 5, 7,
+                                 dict(iters=5, n=6, optimizer="Adam", lr=5e-3)),
+    "logreg_C10_P784_DS24_B16_N4": ("build_logistic_regression",
+                                    dict(dataset_size=24, batch_size=16, n_features=784, n_classes=10), 4, 8, None),
 }
 
 
@@ -53,6 +59,8 @@ def reference_api():
         BinomialVariable=sv.BinomialVariable, BernulliVariable=sv.BernulliVariable,
         CauchyVariable=sv.CauchyVariable, LaplaceVariable=sv.LaplaceVariable,
         DeterministicVariable=sv.DeterministicVariable, RootVariable=v.RootVariable,
+        CategoricalVariable=sv.CategoricalVariable, EmpiricalVariable=sv.EmpiricalVariable,
+        RandomIndices=sv.RandomIndices,
         ProbabilisticModel=v.ProbabilisticModel, BF=BF, name="reference")
 
 
@@ -169,13 +177,30 @@ def run_case(name, api):
 
     q._get_sample = capture
 
+    # minibatch indices drawn by RandomIndices variables (numpy RNG) are recorded the same way
+    obs_model = model.observed_submodel
+    orig_obs = obs_model._get_sample
+
+    def capture_obs(*a, **k):
+        res = orig_obs(*a, **k)
+        captured["minibatch"] = {var.name: np.array([int(i) for i in val], dtype=np.int64)
+                                 for var, val in res.items() if type(var).__name__ == "RandomIndices"}
+        return res
+
+    obs_model._get_sample = capture_obs
+
     for est_name, est in (("pathwise", ge.PathwiseDerivativeEstimator), ("blackbox", ge.BlackBoxEstimator)):
         for root in roots.values():
             root.link.parameter.grad = None
         torch.manual_seed(seed)
+        np.random.seed(seed)
         with DrawRecorder() as rec:
             loss = inference.ReverseKL(gradient_estimator=est).compute_loss(model, q, None, N)
         loss.backward()
+        for k, v in captured.get("minibatch", {}).items():
+            if "minibatch/" + k in out:
+                assert np.array_equal(out["minibatch/" + k], v), "estimators drew different minibatches"
+            out["minibatch/" + k] = v
         z = captured["z"]
         noise = match_noise(q, z, rec.draws)
         if est_name == "pathwise":
@@ -184,6 +209,7 @@ def run_case(name, api):
             for var, s in z.items():
                 if type(var).__name__ != "RootVariable":
                     out["z/" + var.name] = s.detach().numpy().copy()
+            np.random.seed(seed)
             emp = model.observed_submodel._get_sample(1, observed=True, differentiable=False)
             zz = dict(z)
             zz.update(emp)
@@ -214,13 +240,16 @@ def run_case(name, api):
             if o.optimizer:
                 opts.append(o)
         torch.manual_seed(seed + 1000)
-        losses, noise_seq = [], {}
+        np.random.seed(seed + 1000)
+        losses, noise_seq, mb_seq = [], {}, {}
         for it in range(traj["iters"]):
             with DrawRecorder() as rec:
                 loss = method.compute_loss(model, q, None, traj["n"])
             noise = match_noise(q, captured["z"], rec.draws)
             for k, v in noise.items():
                 noise_seq.setdefault(k, []).append(v)
+            for k, v in captured.get("minibatch", {}).items():
+                mb_seq.setdefault(k, []).append(v)
             if torch.isfinite(loss.detach()).all().item():
                 [o.zero_grad() for o in opts]
                 loss.backward()
@@ -231,6 +260,8 @@ def run_case(name, api):
         out["traj/losses"] = np.array(losses, dtype=np.float32)
         for k, v in noise_seq.items():
             out["traj/noise/" + k] = np.stack(v)
+        for k, v in mb_seq.items():
+            out["traj/minibatch/" + k] = np.stack(v)
         for pname, root in roots.items():
             out["traj/param_after/" + pname] = root.value.detach().numpy().copy()
 

@@ -67,6 +67,11 @@ def broadcast_and_squeeze(*args):
     return torch.broadcast_tensors(*args)
 
 
+def is_discrete(data):
+    # utilities.py:31-32
+    return type(data) in [list, set, tuple, dict, str]
+
+
 def number_samples_and_datapoints(values):
     # utilities.py:189-207
     n_list, m_list = [], []
@@ -124,6 +129,7 @@ class Oracle:
         self.p = joint_model
         self.q = posterior_model if posterior_model is not None else joint_model.posterior_model
         self.dtype = dtype
+        self.minibatch = None  # {RandomIndices name: indices} for parity runs
         self.params = {}     # id(Parameter) -> torch leaf
         self.param_objs = {}
         for model in (self.q, self.p):
@@ -159,6 +165,8 @@ class Oracle:
         # variables.py:352-356
         if root.learnable:
             return self.params[id(root.parameter)]
+        if is_discrete(root.value):
+            return root.value
         return torch.as_tensor(root.value, dtype=self.dtype)
 
     # ------------------------------------------------------------------ links
@@ -189,11 +197,11 @@ class Oracle:
         raise NotImplementedError(e.op)
 
     def apply_link(self, var, parents_values):
-        # variables.py:436-449
+        # variables.py:436-449 (discrete values — lists of indices — bypass the reshaping)
         n, m = number_samples_and_datapoints(parents_values)
-        reshaped = {k: flatten_parent(v, n, m) for k, v in parents_values.items()}
+        reshaped = {k: (v if is_discrete(v) else flatten_parent(v, n, m)) for k, v in parents_values.items()}
         out = {k: self.eval_expr(link.expr, reshaped) for k, link in var.link.expressions().items()}
-        return {k: v.view((n, m) + tuple(v.shape[1:])) for k, v in out.items()}
+        return {k: (v.view((n, m) + tuple(v.shape[1:])) if torch.is_tensor(v) else v) for k, v in out.items()}
 
     def is_det_node(self, v):
         return getattr(v, "_type", None) == "Deterministic node"
@@ -204,6 +212,8 @@ class Oracle:
         (variables.py:527-570).  `memo` plays the role of ``self.samples``."""
         if isinstance(var, RootVariable):
             value = input_values[var] if var in input_values else self.root_value(var)
+            if is_discrete(value):
+                return {var: value}                                       # variables.py:372-375
             return {var: tile_parameter(value, n)}
         if var in memo and not resample:
             return {var: memo[var]}
@@ -240,7 +250,7 @@ class Oracle:
             if dist.has_differentiable_samples:
                 return tdist.rsample()
             return tdist.sample()
-        g = torch.as_tensor(np.asarray(given), dtype=self.dtype)
+        g = torch.as_tensor(np.asarray(given)).to(self.dtype)
         if dist.kind in (D.DIST_NORMAL, D.DIST_CAUCHY):
             return params["loc"] + g * params["scale"]              # torch normal.py:83-86, cauchy.py:77-80
         if dist.kind == D.DIST_LOGNORMAL:
@@ -269,11 +279,58 @@ class Oracle:
                 parents_values[parent] = self.sample_var(parent, n, input_values, {}, None, resample=True)[parent]
         return self.apply_link(var, parents_values)
 
+    def empirical_draw(self, var, params):
+        """EmpiricalDistribution._get_sample (distributions.py:410-462): minibatch without replacement;
+        indices come from `self.minibatch[var.name]` when supplied (parity runs), else numpy's RNG."""
+        dataset = params["dataset"]
+        batch_size = var.distribution.batch_size
+        if "indices" in params:
+            indices = params["indices"]
+        else:
+            size = dataset.shape[1] if torch.is_tensor(dataset) else len(dataset)
+            if self.minibatch is not None and var.name in self.minibatch:
+                indices = [np.int64(i) for i in self.minibatch[var.name]]
+            else:
+                indices = list(np.random.choice(range(size), size=batch_size, replace=False))
+        if torch.is_tensor(dataset):
+            return dataset[:, [int(i) for i in indices], :]                 # is_observed branch (:455)
+        return list(np.array(dataset)[[int(i) for i in indices]])
+
+    def sample_observed(self, var, memo):
+        """RandomVariable._get_sample(observed=True) (variables.py:548-570)."""
+        if isinstance(var, RootVariable):
+            value = self.root_value(var)
+            return value if is_discrete(value) else tile_parameter(value, 1)
+        if var in memo:
+            return memo[var]
+        if var.has_observed_value:
+            memo[var] = torch.as_tensor(var._observed_value, dtype=self.dtype)
+            return memo[var]
+        target = var.dataset if var.has_random_dataset else var
+        parents = {p: self.sample_observed(p, memo) for p in target.parents}
+        params = self.apply_link(target, parents)
+        if target.distribution.kind == D.DIST_EMPIRICAL:
+            sample = self.empirical_draw(target, params)
+        else:
+            sample = self.dist_sample(target, params, None)
+        memo[var] = sample
+        return sample
+
     def dist_log_prob(self, var, x, params):
-        # distributions.py:63-68,170-181; Implicit (Deterministic) returns zeros (:226-227)
+        # distributions.py:63-68,170-181; Implicit (Deterministic, Empirical) returns zeros (:226-227)
         dist = var.distribution
-        if dist.kind == D.DIST_DETERMINISTIC:
+        if dist.kind in (D.DIST_DETERMINISTIC, D.DIST_EMPIRICAL):
             return torch.zeros((1, 1), dtype=self.dtype)
+        if dist.kind == D.DIST_CATEGORICAL:
+            # VectorDistribution preprocessing (distributions.py:257-266) + Categorical (:294-311)
+            both = dict(params)
+            both["x_data"] = x
+            n, m = number_samples_and_datapoints(both)
+            flat = {k: flatten_parent(v, n, m) for k, v in both.items()}
+            flat = {k: v.contiguous().view(v.shape[0], int(np.prod(v.shape[1:]))) for k, v in flat.items()}
+            xv = flat.pop("x_data")
+            lp = td.categorical.Categorical(**flat).log_prob(xv[:, 0])
+            return lp.contiguous().view(n, m)
         keys = list(params.keys())
         vals = broadcast_and_squeeze(x, *[params[k] for k in keys])         # distributions.py:201-203
         x = vals[0]
@@ -336,9 +393,14 @@ class Oracle:
         return sum([sum_from_dim(e, 2) for e in ents])
 
     def empirical_samples(self):
-        # observed_submodel._get_sample(1, observed=True) (variables.py:849, 555-557)
-        return {v: torch.as_tensor(v._observed_value, dtype=self.dtype)
-                for v in self.p._flatten() if isinstance(v, RandomVariable) and v.is_observed and v.has_observed_value}
+        # observed_submodel._get_sample(1, observed=True) (variables.py:849, 548-570): every observed
+        # variable of the joint model, one shared memo so that minibatch indices are drawn once
+        memo = {}
+        out = {}
+        for v in self.p._flatten():
+            if isinstance(v, RandomVariable) and v.is_observed:
+                out[v] = self.sample_observed(v, memo)
+        return out
 
     def p_log_prob_from_q_samples(self, q_samples, empirical):
         # get_p_log_probabilities_from_q_samples (variables.py:814-819) + reassign_samples (utilities.py:296-309)
@@ -369,11 +431,12 @@ class Oracle:
         else:
             raise ValueError(estimator)
         if return_parts:
-            named = {k.name: v for k, v in samples.items() if isinstance(k, RandomVariable)}
+            named = {k.name: v for k, v in samples.items() if isinstance(k, RandomVariable) and torch.is_tensor(v)}
             return value, f, lq, named
         return value
 
-    def loss_and_grads(self, n, estimator="pathwise", noise=None):
+    def loss_and_grads(self, n, estimator="pathwise", noise=None, minibatch=None):
+        self.minibatch = minibatch
         self.zero_grad()
         value, f, lq, samples = self.elbo(n, estimator, noise, return_parts=True)
         loss = -value
@@ -384,7 +447,7 @@ class Oracle:
             grads[name] = None if g is None else g.detach().numpy().copy()
         return dict(loss=float(loss.detach()), f=f.detach().numpy().copy(),
                     lq=None if lq is None else lq.detach().numpy().copy(), grads=grads,
-                    samples={k: v.detach().numpy().copy() for k, v in samples.items()})
+                    samples={k: v.detach().numpy().copy() for k, v in samples.items() if torch.is_tensor(v)})
 
     # ------------------------------------------------------------------ the loop
     def make_optimizers(self, optimizer="SGD", **opt_params):
@@ -398,12 +461,13 @@ class Oracle:
         return [getattr(torch.optim, optimizer)(g, **opt_params) for g in groups if g]
 
     def train(self, iterations, n, optimizer="SGD", estimator="pathwise", noise_seq=None,
-              pretraining_iterations=0, **opt_params):
+              pretraining_iterations=0, minibatch_seq=None, **opt_params):
         """inference.py:95-108 (one loss entry per iteration; the reference appends twice)."""
         opts = self.make_optimizers(optimizer, **opt_params)
         losses = []
         for it in range(iterations):
             noise = None if noise_seq is None else noise_seq[it]
+            self.minibatch = None if minibatch_seq is None else minibatch_seq[it]
             loss = -self.elbo(n, estimator, noise)
             if torch.isfinite(loss.detach()).all().item():
                 for o in opts:

@@ -39,6 +39,17 @@ class Golden:
         from brancher_amd import workloads as W
         return getattr(W, self.meta["builder"])(api or W.native_api(), **self.meta["kwargs"])
 
+    @property
+    def minibatch(self):
+        mb = {k: [int(i) for i in v] for k, v in self.group("minibatch/").items()}
+        return mb or None
+
+    def trajectory_minibatch(self):
+        seq = self.group("traj/minibatch/")
+        if not seq:
+            return None
+        return [{k: [int(i) for i in v[it]] for k, v in seq.items()} for it in range(self.meta["trajectory"]["iters"])]
+
     def trajectory_noise(self):
         tr = self.meta["trajectory"]
         seq = self.group("traj/noise/")
