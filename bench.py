@@ -34,10 +34,21 @@ WORKLOADS = {
              "beta_binomial.py Beta posterior, 30 observations, number_samples=4096, SGD lr=0.1 (BASELINE config 2)"),
     "cfg3": ("build_readme_ar", dict(T=200), 1024, "SGD", dict(lr=1e-4),
              "README AR state-space T=200, number_samples=8192 sharded as 1024 per GPU (BASELINE config 3)"),
+    "cfg4": ("build_logistic_regression", dict(dataset_size=60000, batch_size=512, n_features=784, n_classes=10),
+             1024, "Adam", dict(lr=5e-3),
+             "Bayesian multinomial logistic regression, dense matmul link 10x784, minibatch 512 of 60000 synthetic "
+             "rows, number_samples=1024, Adam lr=5e-3 (BASELINE config 4)"),
     "cfg1_big": ("build_readme_ar", dict(T=20), 262144, "SGD", dict(lr=1e-3),
                  "README AR T=20 at number_samples=262144 (throughput regime of the same kernel)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak
+
+
+def dense_flops_per_iteration(program, n_local):
+    """SURVEY §8d cfg 4: forward 2*N*C*P*B for the logits GEMM and the same again for the
+    weight-gradient GEMM."""
+    return 2 * 2.0 * n_local * program.n_classes * program.n_features * program.batch_size
 
 
 def algorithmic_bytes_per_iteration(program, n_local):
@@ -75,6 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
+    ap.add_argument("--dataset-size", type=int, default=0, help="cfg4: override the synthetic dataset size")
     ap.add_argument("--mode", default="auto", choices=["auto", "persistent", "stepwise"])
     ap.add_argument("--samples", type=int, default=0, help="override number_samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,12 +110,14 @@ def main():
     builder, kwargs, n_per_gpu, optimizer, opt_kwargs, desc = WORKLOADS[args.workload]
     if args.samples:
         n_per_gpu = args.samples
+    if args.dataset_size and "dataset_size" in kwargs:
+        kwargs = dict(kwargs, dataset_size=args.dataset_size)
     n_global = n_per_gpu * world
     model = getattr(W, builder)(W.native_api(), **kwargs)
     compiled = engine.compile_model(model, None, "pathwise")
     program = compiled.program
     allow_persistent = args.mode != "stepwise"
-    if args.mode == "persistent" and not (world == 1 and compiled.native.persistent_supported(n_per_gpu)):
+    if args.mode == "persistent" and not (world == 1 and hasattr(compiled, "native") and compiled.native.persistent_supported(n_per_gpu)):
         raise SystemExit("persistent mode needs one GPU and a sample count that fits one workgroup")
 
     def barrier():
@@ -137,16 +151,17 @@ def main():
     if rank == 0:
         iters_per_sec = args.steps / dt
         value = iters_per_sec * (n_global / 300.0)
-        geom = compiled.native.geometry(n_per_gpu)
+        dense = hasattr(program, "n_classes")
+        geom = dict(kind="dense") if dense else compiled.native.geometry(n_per_gpu)
         # roofline of the dominant kernel (the fused ELBO kernel; in persistent mode one launch
         # covers all K iterations).  Launch duration from HIP events on the launch stream.
         alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu)
         if mode == "persistent":
             launch_ms, launches, units_per_launch = dev_ms, 1, args.steps
-            kernel = "bsvi::persistent_kernel<false>"
+            kernel = "bsvi::persistent_kernel<%s>" % geom.get("storage", "")
         else:
             launch_ms, launches, units_per_launch = dev_ms / args.steps, args.steps, 1
-            kernel = "bsvi::elbo_kernel<%s>" % ("true" if geom["zglobal"] else "false")
+            kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
         achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=None, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
@@ -154,6 +169,16 @@ def main():
                         note="latency-bound workload (SURVEY §8d cfg 1): %.2f us per iteration; the per-iteration "
                              "floor of a launch-per-step design is ~5-10 us of launch latency"
                              % (dev_ms * 1e3 / args.steps))
+        if dense:
+            # the whole iteration (8 launches) is timed; the two MFMA GEMMs are >90 % of it (profiles/)
+            flops = dense_flops_per_iteration(program, n_per_gpu)
+            tf = flops / (dev_ms * 1e-3 / args.steps) / 1e12
+            roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                            kernel="bsvi::dense_forward<10> + bsvi::dense_backward",
+                            algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / args.steps,
+                            note="f32-input MFMA (v_mfma_f32_16x16x4_f32); achieved = GEMM flops of one iteration / "
+                                 "duration of the whole iteration")
         line = dict(metric="ELBO iters/sec at num_samples=%d per GPU (300-sample-equivalent iterations, whole job)"
                            % n_per_gpu,
                     value=value, unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
