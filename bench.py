@@ -57,26 +57,30 @@ def algorithmic_bytes_per_iteration(program, n_local):
     return n_local * program.n_noise * 4 + 2 * program.n_params * 4
 
 
-def cpu_baseline(builder, kwargs, n_samples, optimizer, opt_kwargs, budget_s=12.0, max_iters=400):
-    """The oracle (PyTorch-CPU restatement of the reference loop, kind 'port') timed on the host."""
+def cpu_baseline(builder, kwargs, n_samples, optimizer, opt_kwargs, dense=False, budget_s=12.0, max_iters=400):
+    """The oracle (PyTorch-CPU restatement of the reference loop, kind 'port') timed on the host.
+    Scalar graphs are dispatch-bound (more threads are slower): 1 thread, batches of 5
+    iterations.  The dense-link workload is GEMM-bound on the CPU: all host cores, single iterations."""
     import torch
     from brancher_amd import workloads as W
     from oracle.svi_oracle import Oracle
-    torch.set_num_threads(1)    # the reference is dispatch-bound: more threads are slower (BASELINE.md §2)
+    cores = (os.cpu_count() or 1) if dense else 1
+    torch.set_num_threads(cores)
+    batch = 1 if dense else 5
     oracle = Oracle(getattr(W, builder)(W.native_api(), **kwargs))
     torch.manual_seed(0)
-    oracle.train(2, n_samples, optimizer, "pathwise", None, **opt_kwargs)
+    oracle.train(1 if dense else 2, n_samples, optimizer, "pathwise", None, **opt_kwargs)
     t0 = time.perf_counter()
     iters = 0
     while iters < max_iters:
-        oracle.train(5, n_samples, optimizer, "pathwise", None, **opt_kwargs)
-        iters += 5
+        oracle.train(batch, n_samples, optimizer, "pathwise", None, **opt_kwargs)
+        iters += batch
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return dict(value=iters / dt * (n_samples / 300.0), unit="it/s", cores=1, kind="port",
+    return dict(value=iters / dt * (n_samples / 300.0), unit="it/s", cores=cores, kind="port",
                 sample="%d iterations of the same workload (number_samples=%d) in %.1f s, oracle/svi_oracle.py "
-                       "on PyTorch-CPU, 1 thread" % (iters, n_samples, dt),
+                       "on PyTorch-CPU, %d thread(s)" % (iters, n_samples, dt, cores),
                 iters_per_sec=iters / dt)
 
 
@@ -192,7 +196,7 @@ def main():
                     device_ms_per_step=dev_ms / args.steps, all_finite=ok,
                     final_loss=float(losses[-1].item()), roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(builder, kwargs, n_per_gpu, optimizer, opt_kwargs)
+            line["cpu_baseline"] = cpu_baseline(builder, kwargs, n_per_gpu, optimizer, opt_kwargs, dense=dense)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
