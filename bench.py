@@ -42,6 +42,26 @@ WORKLOADS = {
                  "README AR T=20 at number_samples=262144 (throughput regime of the same kernel)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r1")
+
+
+def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False):
+    """HBM bytes per launch of the named kernel(s) from the committed rocprofv3 PMC summary (FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc passes by tools/pmc_hbm.sh, KB per dispatch).  double_fetch applies
+    the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies the 128-B requests of 16-B-per-lane
+    streaming reads at 64 B).  None when the summary is not there."""
+    import csv
+    path = os.path.join(PROFILE_DIR, csv_name)
+    if not os.path.exists(path):
+        return None
+    total = 0.0
+    hit = False
+    for row in csv.DictReader(open(path)):
+        if any(k in row["kernel"] for k in kernel_substrings):
+            kb = float(row["mean_KB_per_dispatch"])
+            total += kb * 1024.0 * (2.0 if double_fetch and row["counter"] == "FETCH_SIZE" else 1.0)
+            hit = True
+    return total if hit else None
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak
 
 
@@ -167,8 +187,16 @@ def main():
             launch_ms, launches, units_per_launch = dev_ms / args.steps, args.steps, 1
             kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
         achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
+        if mode == "persistent":
+            # measured for the default launch (2100 iterations in one launch); a launch's HBM traffic is its
+            # parameter/observation reads and loss-curve writes, so it is reported as measured, not rescaled
+            traffic = pmc_traffic_bytes("cfg1_persistent_pmc_hbm_traffic.csv", ["persistent_kernel"]) \
+                if args.workload == "cfg1" and not args.samples else None
+        else:
+            traffic = pmc_traffic_bytes("pmc_hbm_traffic.csv", ["elbo_kernel"]) \
+                if args.workload == "cfg1" and not args.samples else None
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=None, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
+                        traffic=traffic, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
                         iterations_per_launch=units_per_launch, launch_ms=launch_ms,
                         note="latency-bound workload (SURVEY §8d cfg 1): %.2f us per iteration; the per-iteration "
                              "floor of a launch-per-step design is ~5-10 us of launch latency"
@@ -177,8 +205,10 @@ def main():
             # the whole iteration (8 launches) is timed; the two MFMA GEMMs are >90 % of it (profiles/)
             flops = dense_flops_per_iteration(program, n_per_gpu)
             tf = flops / (dev_ms * 1e-3 / args.steps) / 1e12
+            traffic = pmc_traffic_bytes("cfg4_pmc_hbm_traffic.csv", ["dense_forward", "dense_backward"],
+                                        double_fetch=True) if args.workload == "cfg4" and not args.samples else None
             roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
                             kernel="bsvi::dense_forward<10> + bsvi::dense_backward",
                             algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / args.steps,
                             note="f32-input MFMA (v_mfma_f32_16x16x4_f32); achieved = GEMM flops of one iteration / "
