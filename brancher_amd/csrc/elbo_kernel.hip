@@ -37,6 +37,7 @@ namespace bsvi {
 
 struct KParams {
     const uint4* code;
+    const uint4* aux;       // [n_code][4]: pre-resolved addresses of the instructions marked kFastFlag (library-internal)
     const bsvi_uniform_entry* uniform;
     const float* consts;
     const float* params;
@@ -155,12 +156,18 @@ __device__ __forceinline__ float philox_normal(const KParams& K, Lane& T, uint32
     const uint32_t group = row >> 2;
     if (group != T.cached_group) {
         const u32x4 x = philox4x32_10(T.nidx, group | 0x80000000u, K.offset_lo, K.offset_hi, K.seed_lo, K.seed_hi);
-        box_muller_fast(x.x, x.y, T.c0, T.c1);
-        box_muller_fast(x.z, x.w, T.c2, T.c3);
+        float z0, z1, z2, z3;
+        box_muller_fast(x.x, x.y, z0, z1);
+        box_muller_fast(x.z, x.w, z2, z3);
+        T.c0 = z0; T.c1 = z1; T.c2 = z2; T.c3 = z3;
         T.cached_group = group;
     }
+    // select on VALUES: a conditional over the struct fields themselves is an lvalue (a select of
+    // addresses), which pins the four cached normals in scratch memory — one flat load per draw
     const uint32_t j = row & 3u;
-    return j == 0 ? T.c0 : (j == 1 ? T.c1 : (j == 2 ? T.c2 : T.c3));
+    const float c0 = T.c0, c1 = T.c1, c2 = T.c2, c3 = T.c3;
+    const float lo = (j & 1u) ? c1 : c0, hi = (j & 1u) ? c3 : c2;
+    return (j & 2u) ? hi : lo;
 }
 
 __device__ __noinline__ float philox_gamma(PhiloxKey G, float alpha, uint32_t row, uint32_t stream) {
@@ -263,6 +270,29 @@ __device__ __forceinline__ Insn ld_insn(const uint4* code, uint32_t pc) {
 __device__ __forceinline__ bsvi_record ld_record(const bsvi_record* recs, uint32_t i) {
     return *((const BSVI_CONST_AS bsvi_record*)(recs) + i);
 }
+
+// Library-internal companion of an instruction (64 bytes, one s_load_dwordx16), built by
+// bsvi_program_create; addresses for top-level NAFF instructions whose adjoint cells are pairwise distinct:
+// everything the interpreter would otherwise derive from the operand words with scalar ALU work on
+// every visit.  Operand order: dst, a, b, c, s.
+//   off[k]   byte offset of the value (uniform region, or inside the lane's row)
+//   mask[k]  ~0 for a per-lane operand, 0 for a lane-uniform one: address = off + (lane_row & mask)
+//   cell[k]  byte offset INSIDE the lane's row of the operand's adjoint cell in the lds+lane_acc layout
+//            (slot adjoint, per-lane dU accumulator, or the write-only dummy)
+//   row      noise row of a sampled destination
+// The single-SIMD wave stream is issue-bound (every instruction, scalar or vector, costs ~4.7 cycles),
+// so this table roughly halves the cost of a node.
+//   w0, imm0, imm1   copies of the instruction's words (w0 of EVERY instruction, marked or not), so that the
+//            sweeps fetch only this table and read the 32-byte instruction on the generic path alone
+struct Aux { uint32_t off[5], mask[5], cell[5], row, w0, imm0, imm1, pad; };   // 20 words used, 128-byte stride
+constexpr uint32_t kAuxWords = 32;
+constexpr uint32_t kFastFlag = 4u;      // rflags bit set in the DEVICE copy of the code (not part of the ABI)
+__device__ __forceinline__ Aux ld_aux(const uint4* aux, uint32_t pc) {
+    return *((const BSVI_CONST_AS Aux*)((const BSVI_CONST_AS uint32_t*)(aux) + (size_t)pc * kAuxWords));
+}
+// log of a normal positive float (a scale): v_log_f32 * ln 2.  (`__logf` expands to a 12-instruction
+// sequence with denormal scaling and a compensated product)
+__device__ __forceinline__ float log_pos(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
 enum { SM_WSUM = 0, SM_LACC = 1, SM_ZG = 2 };
 #define ZG (SM == SM_ZG)
@@ -455,6 +485,98 @@ __device__ __forceinline__ void naff_sink(const KParams& K, const Lay& L, Lane& 
         add_adj<SM>(K, L, T, I.c, e, gloc);
         add_adj<SM>(K, L, T, I.s, e, gS);
     }
+}
+
+// ---- pre-resolved NAFF handlers (lds+lane_acc storage, no diagnostic outputs) ----------------
+// Same arithmetic as naff_sink / exec_forward / exec_backward below, addresses from the Aux table.
+// Every handler first turns its Aux entry into vector addresses and then loads the NEXT visit's entry
+// into the same scalar registers: the entry is dead by then, so prefetching costs no extra SGPRs and
+// its latency hides behind the rest of the visit.
+struct FastAddr { uint32_t v[5], c[5]; };
+__device__ __forceinline__ FastAddr fast_addr(const Lane& T, const Aux& X) {
+    FastAddr F;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        F.v[k] = X.off[k] + (T.zrow & X.mask[k]);
+        F.c[k] = T.zrow + X.cell[k];
+    }
+    return F;
+}
+__device__ __forceinline__ void fast_sink(const KParams& K, Lane& T, Aux& X, uint32_t next) {
+    const FastAddr F = fast_addr(T, X);
+    const float w = __uint_as_float(X.imm0);
+    X = ld_aux(K.aux, next);
+    const float v = lds_ld(F.v[0]), A = lds_ld(F.v[1]), B = lds_ld(F.v[2]), Cc = lds_ld(F.v[3]), S = lds_ld(F.v[4]);
+    const float od = lds_ld(F.c[0]), oa = lds_ld(F.c[1]), ob = lds_ld(F.c[2]), oc = lds_ld(F.c[3]), os = lds_ld(F.c[4]);
+    const float rS = __builtin_amdgcn_rcpf(S), logS = log_pos(S);
+    const float loc = A * B + Cc;
+    const float u = (v - loc) * rS;
+    T.f += w * (-0.5f * (u * u) - logS - kLogSqrt2Pi);
+    const float gw = w * T.mask;
+    const float gloc = gw * u * rS;                 // d lp / d loc = (v - loc) / S^2
+    const float gS = gw * (u * u - 1.0f) * rS;
+    lds_st(F.c[0], od - gloc);
+    lds_st(F.c[1], oa + gloc * B);
+    lds_st(F.c[2], ob + gloc * A);
+    lds_st(F.c[3], oc + gloc);
+    lds_st(F.c[4], os + gS);
+}
+__device__ __forceinline__ void fast_forward(const KParams& K, Lane& T, Aux& X, uint32_t next) {
+    const uint32_t flags = (X.w0 >> 8) & 0xFFu;
+    const FastAddr F = fast_addr(T, X);
+    const uint32_t row = X.row;
+    const float w_lp = __uint_as_float(X.imm0), w_ent = __uint_as_float(X.imm1);
+    X = ld_aux(K.aux, next);
+    const float A = lds_ld(F.v[1]), B = lds_ld(F.v[2]), Cc = lds_ld(F.v[3]), S = lds_ld(F.v[4]);
+    const float loc = A * B + Cc;
+    float v;
+    if (flags & BSVI_F_SAMPLE) {
+        const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+        v = loc + eps * S;
+        lds_st(F.v[0], v);
+    } else {
+        v = lds_ld(F.v[0]);
+    }
+    const float logS = log_pos(S);
+    if (flags & BSVI_F_ENT) T.f += w_ent * (kHalfLog2PiE + logS);
+    if (flags & BSVI_F_LOGP) {
+        const float u = (v - loc) * __builtin_amdgcn_rcpf(S);
+        T.f += w_lp * (-0.5f * (u * u) - logS - kLogSqrt2Pi);
+    }
+}
+__device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, Aux& X, uint32_t next) {
+    const uint32_t flags = (X.w0 >> 8) & 0xFFu;
+    const FastAddr F = fast_addr(T, X);
+    const uint32_t row = X.row;
+    const float w_lp = __uint_as_float(X.imm0), w_ent = __uint_as_float(X.imm1);
+    X = ld_aux(K.aux, next);
+    const float v = lds_ld(F.v[0]), A = lds_ld(F.v[1]), B = lds_ld(F.v[2]), Cc = lds_ld(F.v[3]), S = lds_ld(F.v[4]);
+    const float od = lds_ld(F.c[0]), oa = lds_ld(F.c[1]), ob = lds_ld(F.c[2]), oc = lds_ld(F.c[3]), os = lds_ld(F.c[4]);
+    const float loc = A * B + Cc;
+    const float rS = __builtin_amdgcn_rcpf(S);
+    float gloc = 0.0f, gS = 0.0f, gv = 0.0f;
+    if (flags & BSVI_F_LOGP) {
+        const float gw = w_lp * T.mask;
+        const float d = v - loc, t = d * (rS * rS);
+        gv = -gw * t;
+        gloc = gw * t;
+        gS = gw * (d * t * rS - rS);
+    }
+    if (flags & BSVI_F_ENT) gS += w_ent * T.mask * rS;
+    float gdst = gv;
+    if (flags & BSVI_F_SAMPLE) {
+        // a sampled latent's own cell holds its incoming adjoint: read, folded into loc/scale, written back unchanged
+        const float zb = od + gv;
+        const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+        gloc += zb;
+        gS += zb * eps;
+        gdst = 0.0f;
+    }
+    lds_st(F.c[0], od + gdst);
+    lds_st(F.c[1], oa + gloc * B);
+    lds_st(F.c[2], ob + gloc * A);
+    lds_st(F.c[3], oc + gloc);
+    lds_st(F.c[4], os + gS);
 }
 
 template <int SM, bool OUT, bool NODES, bool GEN>
@@ -661,6 +783,7 @@ __device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
 
 template <int SM, bool OUT, bool GEN>
 __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint32_t block_first_sample) {
+    constexpr bool FASTK = (SM == SM_LACC) && !OUT;     // pre-resolved NAFF handlers (Aux table) apply
     const uint32_t tid = threadIdx.x, nthreads = L.nthreads;
 #define BSVI_STAMP(i)                                                                      \
     if (OUT && K.stamps && blockIdx.x == 0 && tid == 0) {                                    \
@@ -703,7 +826,51 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     BSVI_STAMP(1)
 
     // ---------------- forward sweep (sink records: value AND adjoints, see BSVI_R_SINK)
-    {
+    if constexpr (FASTK) {
+        // the sweep walks the Aux table (w0 of every instruction is in it); the 32-byte instruction is read
+        // only on the generic path
+        uint32_t pc = 0;
+        Aux X = ld_aux(K.aux, 0);
+        while (pc < K.n_code) {
+            const uint32_t w0 = X.w0, op = w0 & 0xFFu;
+            const bool sink = (w0 >> 24) & BSVI_R_SINK;
+            if ((w0 >> 24) & kFastFlag) {
+                const uint32_t npc = pc + 1, nx = npc < K.n_code ? npc : 0;
+                if (sink) fast_sink(K, T, X, nx);
+                else fast_forward(K, T, X, nx);
+                pc = npc;
+            } else if (op == BSVI_OP_REC_BEGIN) {
+                const Insn I = ld_insn(K.code, pc);
+                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                for (uint32_t e = 0; e < n_elems; ++e) {
+                    for (uint32_t j = 1; j <= n; ++j) {
+                        const Insn J = ld_insn(K.code, pc + j);
+                        exec_forward<SM, OUT, true, GEN>(K, L, T, J, e);
+                    }
+                    if (sink) {
+                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
+                        for (uint32_t j = n; j >= 1; --j) {
+                            const Insn J = ld_insn(K.code, pc + j);
+                            exec_backward<SM, GEN>(K, L, T, J, e);
+                        }
+                    }
+                }
+                pc += n + 2;
+                X = ld_aux(K.aux, pc < K.n_code ? pc : 0);
+            } else {
+                const Insn I = ld_insn(K.code, pc);
+                const uint32_t npc = pc + 1;
+                X = ld_aux(K.aux, npc < K.n_code ? npc : 0);
+                if (sink && op == BSVI_OP_NAFF) {
+                    naff_sink<SM>(K, L, T, I, 0);
+                } else {
+                    exec_forward<SM, OUT, true, GEN>(K, L, T, I, 0);
+                    if (sink) exec_backward<SM, GEN>(K, L, T, I, 0);
+                }
+                pc = npc;
+            }
+        }
+    } else {
         uint32_t pc = 0;
         Insn I = ld_insn(K.code, 0);
         while (pc < K.n_code) {
@@ -750,7 +917,49 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     }
 
     // ---------------- reverse sweep: the posterior's sampling chain and the derived values
-    {
+    if constexpr (FASTK) {
+        uint32_t pc = K.n_code;
+        Aux X = ld_aux(K.aux, pc - 1);
+        while (pc > 0) {
+            const uint32_t w0 = X.w0, op = w0 & 0xFFu;
+            const bool sink = (w0 >> 24) & BSVI_R_SINK;
+            if (!sink && ((w0 >> 24) & kFastFlag)) {
+                const uint32_t npc = pc - 1;
+                fast_backward(K, T, X, npc > 0 ? npc - 1 : 0);
+                pc = npc;
+            } else if (op == BSVI_OP_REC_END) {
+                const Insn I = ld_insn(K.code, pc - 1);
+                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                const uint32_t first = pc - 1 - n;          // index of the first body instruction
+                if (!sink) {
+                    for (uint32_t e = n_elems; e-- > 0;) {
+                        // temps are shared by all records: re-materialise this record's, clear their adjoints
+                        for (uint32_t j = 0; j < n; ++j) {
+                            const Insn J = ld_insn(K.code, first + j);
+                            exec_forward<SM, false, false, GEN>(K, L, T, J, e);
+                        }
+                        for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
+                        for (uint32_t j = n; j-- > 0;) {
+                            const Insn J = ld_insn(K.code, first + j);
+                            exec_backward<SM, GEN>(K, L, T, J, e);
+                        }
+                    }
+                }
+                pc = first - 1;                              // skip the REC_BEGIN bracket too
+                X = ld_aux(K.aux, pc > 0 ? pc - 1 : 0);
+            } else {
+                const uint32_t npc = pc - 1;
+                if (!sink) {
+                    const Insn I = ld_insn(K.code, pc - 1);
+                    X = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
+                    exec_backward<SM, GEN>(K, L, T, I, 0);
+                } else {
+                    X = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
+                }
+                pc = npc;
+            }
+        }
+    } else {
         uint32_t pc = K.n_code;
         Insn I = ld_insn(K.code, pc - 1);
         while (pc > 0) {
@@ -963,46 +1172,78 @@ struct PParams {
     uint32_t pretraining_iterations;
 };
 
+// Scalar-register discipline: PParams is ~90 dwords of kernel arguments.  Read as `P.x` they are all
+// loaded at entry and stay live through the sweeps, which then spill scalars around every instruction
+// visit.  So each phase re-reads what it needs from the kernarg segment (scalar loads through a
+// pointer the optimizer cannot see through), and nothing but the sweeps' own state is live in them.
 template <int SM, bool GEN>
-__global__ void __launch_bounds__(1024) persistent_kernel(const PParams P) {
+__global__ void __launch_bounds__(1024) persistent_kernel(const PParams P_unused) {
+    (void)P_unused;
     const uint32_t n_waves = blockDim.x >> 6;
-    KParams K = P.K;
-    const Lay L = make_layout<SM>(K, n_waves);
-    for (uint32_t it = 0; it < P.n_iterations; ++it) {
-        elbo_block<SM, false, GEN>(K, L, 0);
+    const BSVI_CONST_AS char* ka = (const BSVI_CONST_AS char*)__builtin_amdgcn_kernarg_segment_ptr();
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSVI_RELOAD_ARGS() asm volatile("" : "+s"(ka))
+#else
+#define BSVI_RELOAD_ARGS()
+#endif
+    const uint32_t n_iterations = ((const BSVI_CONST_AS PParams*)ka)->n_iterations;
+    for (uint32_t it = 0; it < n_iterations; ++it) {
+        Lay L;
+        {
+            BSVI_RELOAD_ARGS();
+            KParams K = ((const BSVI_CONST_AS PParams*)ka)->K;
+            // one iteration = one Philox offset; a given-noise sequence is laid out [it][row][N]
+            const uint32_t lo = K.offset_lo + it;
+            K.offset_hi += (lo < K.offset_lo) ? 1u : 0u;
+            K.offset_lo = lo;
+            if (K.noise) K.noise += (size_t)it * K.n_noise * K.n_local;
+            L = make_layout<SM>(K, n_waves);
+            elbo_block<SM, false, GEN>(K, L, 0);
+        }
+        BSVI_RELOAD_ARGS();
+        const BSVI_CONST_AS PParams* P = (const BSVI_CONST_AS PParams*)ka;
+        const uint32_t n_global = P->K.n_global;
         if (threadIdx.x == 0) {
             const float vsum = g_lds[L.red], bad = g_lds[L.red + 1];
-            const float loss = -vsum / (float)K.n_global;
+            const float loss = -vsum / (float)n_global;
             const float finite = isfinite(loss) ? 1.0f : 0.0f;
             g_lds[L.red + 2] = finite;     // red[2..] is free once elbo_block has returned
-            P.loss_curve[it] = loss;
-            P.finite_curve[it] = finite;
-            P.R.out[0] = vsum; P.R.out[1] = bad; P.R.out[2] = loss; P.R.out[3] = finite;
+            P->loss_curve[it] = loss;
+            P->finite_curve[it] = finite;
+            float* out = P->R.out;
+            out[0] = vsum; out[1] = bad; out[2] = loss; out[3] = finite;
         }
         __syncthreads();
-        const float scale = -1.0f / (float)K.n_global;
-        const uint8_t* mask = (it > P.pretraining_iterations) ? P.R.active_mask : P.active_mask_first;
-        for (uint32_t i = threadIdx.x; i < P.R.n_params; i += blockDim.x) {
+        const float scale = -1.0f / (float)n_global;
+        float* const params = P->R.params;
+        float* const state = P->R.state;
+        float* const out = P->R.out;
+        const uint32_t* const pu_ptr = P->R.pu_ptr;
+        const uint32_t* const pu_idx = P->R.pu_idx;
+        const bsvi_uniform_entry* const uniform = P->R.uniform;
+        const uint32_t n_params = P->R.n_params;
+        const uint8_t* mask = (it > P->pretraining_iterations) ? P->R.active_mask : P->active_mask_first;
+        for (uint32_t i = threadIdx.x; i < n_params; i += blockDim.x) {
             float gsum = 0.0f;
-            const float theta = __hip_atomic_load(&P.R.params[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t j = P.R.pu_ptr[i]; j < P.R.pu_ptr[i + 1]; ++j) {
-                const uint32_t k = P.R.pu_idx[j];
-                const bsvi_uniform_entry e = P.R.uniform[k];
+            const float theta = __hip_atomic_load(&params[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t j = pu_ptr[i]; j < pu_ptr[i + 1]; ++j) {
+                const uint32_t k = pu_idx[j];
+                const bsvi_uniform_entry e = uniform[k];
                 gsum += g_lds[L.uadj + k * n_waves] * (e.b * utransform_grad(e.transform, theta));
             }
             const float grad = gsum * scale;
-            P.R.out[BSVI_OUT_HEADER + i] = grad;
-            if (g_lds[L.red + 2] != 0.0f && mask[i]) optimizer_update(P.R.cfg, P.R.params, P.R.state, P.R.n_params, i, grad);
+            out[BSVI_OUT_HEADER + i] = grad;
+            if (g_lds[L.red + 2] != 0.0f && mask[i]) {
+                const bsvi_opt_cfg cfg = P->R.cfg;
+                optimizer_update(cfg, params, state, n_params, i, grad);
+            }
         }
         // The parameters are written and re-read by this one workgroup only: the stores are
         // drained by the barrier below (s_waitcnt vmcnt(0) + s_barrier) and the next prologue
         // re-reads them with agent-scope loads that bypass the L1.
         __syncthreads();
-        // advance the Philox counter: one iteration = one offset
-        K.offset_lo += 1u;
-        if (K.offset_lo == 0u) K.offset_hi += 1u;
-        if (K.noise) K.noise += (size_t)K.n_noise * K.n_local;   // given-noise sequence [it][row][N]
     }
+#undef BSVI_RELOAD_ARGS
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1052,6 +1293,7 @@ struct bsvi_program {
     bsvi_program_desc d;
     void* dev_blob = nullptr;       // one allocation holding every table
     const uint4* code = nullptr;
+    const uint4* aux = nullptr;
     const bsvi_record* records = nullptr;
     const bsvi_uniform_entry* uniform = nullptr;
     const float* consts = nullptr;
@@ -1162,15 +1404,45 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
     bsvi_program* p = new bsvi_program();
     p->d = *desc;
     const size_t b_code = align_up((size_t)desc->n_code * 32, 256);
+    const size_t b_aux = align_up((size_t)desc->n_code * kAuxWords * 4, 256);
     const size_t b_rec = align_up((size_t)desc->n_records * sizeof(bsvi_record), 256);
     const size_t b_uni = align_up((size_t)desc->n_uniform * sizeof(bsvi_uniform_entry), 256);
     const size_t b_con = align_up((size_t)desc->n_consts * 4, 256);
     const size_t b_ptr = align_up(((size_t)desc->n_params + 1) * 4, 256);
     const size_t b_idx = align_up((size_t)desc->n_uniform_grad * 4, 256);
-    const size_t total = b_code + b_rec + b_uni + b_con + b_ptr + b_idx + 256;
+    const size_t total = b_code + b_aux + b_rec + b_uni + b_con + b_ptr + b_idx + 256;
     std::vector<char> host(total, 0);
     size_t o = 0;
     const size_t o_code = o; if (desc->n_code) memcpy(&host[o], desc->code, (size_t)desc->n_code * 32); o += b_code;
+    const size_t o_aux = o; o += b_aux;
+    {
+        // pre-resolve the top-level NAFF instructions (see struct Aux) and mark them in the device copy
+        uint32_t* code = reinterpret_cast<uint32_t*>(&host[o_code]);
+        uint32_t* aux = reinterpret_cast<uint32_t*>(&host[o_aux]);
+        const uint32_t uacc = 2u * desc->n_slots * 4u, ugrad = desc->n_uniform_grad * 4u, dummy = uacc + ugrad;
+        uint32_t body_left = 0;          // instructions of a bracketed record (and its closing bracket) keep the generic path
+        for (uint32_t i = 0; i < desc->n_code; ++i) {
+            uint32_t* w = code + 8 * (size_t)i;
+            uint32_t* x = aux + kAuxWords * (size_t)i;
+            const uint32_t op = w[0] & 0xFFu, flags = (w[0] >> 8) & 0xFFu, rflags = w[0] >> 24;
+            x[16] = w[0]; x[17] = w[6]; x[18] = w[7];
+            if (body_left) { --body_left; continue; }
+            if (op == BSVI_OP_REC_BEGIN) { body_left = w[1] + 1; continue; }
+            if (op != BSVI_OP_NAFF || !(rflags & BSVI_R_NOALIAS) || (flags & BSVI_F_WF)) continue;
+            bool ok = true;
+            for (int k = 0; k < 5; ++k) ok = ok && !((w[1 + k] >> 30) & 1u);
+            if (!ok) continue;
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t o_ = w[1 + k], off = o_ & 0x3FFFFFFFu, lane = o_ >> 31;
+                x[k] = off;
+                x[5 + k] = lane ? 0xFFFFFFFFu : 0u;
+                x[10 + k] = lane ? off + 4u : (off < ugrad ? uacc + off : dummy);
+            }
+            x[15] = (w[1] & 0x3FFFFFFFu) >> 3;
+            w[0] |= kFastFlag << 24;
+            x[16] = w[0];
+        }
+    }
     const size_t o_rec = o; if (desc->n_records) memcpy(&host[o], desc->records, (size_t)desc->n_records * sizeof(bsvi_record)); o += b_rec;
     const size_t o_uni = o; if (desc->n_uniform) memcpy(&host[o], desc->uniform, (size_t)desc->n_uniform * sizeof(bsvi_uniform_entry)); o += b_uni;
     const size_t o_con = o; if (desc->n_consts) memcpy(&host[o], desc->consts, (size_t)desc->n_consts * 4); o += b_con;
@@ -1182,6 +1454,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
     if (e != hipSuccess) { hipFree(p->dev_blob); delete p; return fail(BSVI_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
     char* base = (char*)p->dev_blob;
     p->code = (const uint4*)(base + o_code);
+    p->aux = (const uint4*)(base + o_aux);
     p->records = (const bsvi_record*)(base + o_rec);
     p->uniform = (const bsvi_uniform_entry*)(base + o_uni);
     p->consts = (const float*)(base + o_con);
@@ -1329,7 +1602,7 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     if (!a->obs_dev && p->d.n_obs) return fail(BSVI_ERR_INVALID, "obs_dev is null");
     if (!a->workspace_dev) return fail(BSVI_ERR_INVALID, "workspace_dev is null");
     if (!a->n_samples_local || !a->n_samples_global) return fail(BSVI_ERR_INVALID, "zero samples");
-    K.code = p->code; K.uniform = p->uniform; K.consts = p->consts;
+    K.code = p->code; K.aux = p->aux; K.uniform = p->uniform; K.consts = p->consts;
     K.params = a->params_dev; K.obs = a->obs_dev; K.noise = a->noise_dev;
     K.samples_out = a->samples_out_dev; K.noise_out = a->noise_out_dev; K.fvalue_out = a->fvalue_out_dev;
     K.partials = (float*)a->workspace_dev;
