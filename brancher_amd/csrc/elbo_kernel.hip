@@ -271,25 +271,41 @@ __device__ __forceinline__ bsvi_record ld_record(const bsvi_record* recs, uint32
     return *((const BSVI_CONST_AS bsvi_record*)(recs) + i);
 }
 
-// Library-internal companion of an instruction (64 bytes, one s_load_dwordx16), built by
-// bsvi_program_create; addresses for top-level NAFF instructions whose adjoint cells are pairwise distinct:
-// everything the interpreter would otherwise derive from the operand words with scalar ALU work on
-// every visit.  Operand order: dst, a, b, c, s.
+// Library-internal companion of an instruction (80 bytes), built by bsvi_program_create: everything the
+// interpreter would otherwise derive from the operand words with scalar ALU work on every visit, for
+// the top-level NAFF instructions whose adjoint cells are pairwise distinct (marked kFastFlag).
+// Operand order: dst, a, b, c, s.
+//   w0, imm0, imm1   copies of the instruction's words (w0 of EVERY instruction, marked or not): the sweeps
+//            walk this table and read the 32-byte instruction on the generic path only
+//   row      noise row of a sampled destination
 //   off[k]   byte offset of the value (uniform region, or inside the lane's row)
 //   mask[k]  ~0 for a per-lane operand, 0 for a lane-uniform one: address = off + (lane_row & mask)
 //   cell[k]  byte offset INSIDE the lane's row of the operand's adjoint cell in the lds+lane_acc layout
 //            (slot adjoint, per-lane dU accumulator, or the write-only dummy)
-//   row      noise row of a sampled destination
-// The single-SIMD wave stream is issue-bound (every instruction, scalar or vector, costs ~4.7 cycles),
-// so this table roughly halves the cost of a node.
-//   w0, imm0, imm1   copies of the instruction's words (w0 of EVERY instruction, marked or not), so that the
-//            sweeps fetch only this table and read the 32-byte instruction on the generic path alone
-struct Aux { uint32_t off[5], mask[5], cell[5], row, w0, imm0, imm1, pad; };   // 20 words used, 128-byte stride
-constexpr uint32_t kAuxWords = 32;
+// The entry is fetched with VECTOR loads (five global_load_dwordx4 from one wave-uniform address) into
+// vector registers, on purpose: (1) the kernels are short of scalar registers, not of vector ones — 40
+// more SGPRs for a double-buffered entry would spill around every visit; (2) scalar loads share the
+// lgkm counter with LDS and return out of order, so a prefetch in flight forces every LDS wait of the
+// visit to drain it; vector loads count on vmcnt.  The single-SIMD wave stream is issue-bound (every
+// instruction, scalar or vector, costs ~4.7 cycles), so this table roughly halves the cost of a node.
+struct Aux { uint32_t w0, imm0, imm1, row, off[5], mask[5], cell[5], pad; };
+constexpr uint32_t kAuxWords = 20;
 constexpr uint32_t kFastFlag = 4u;      // rflags bit set in the DEVICE copy of the code (not part of the ABI)
 __device__ __forceinline__ Aux ld_aux(const uint4* aux, uint32_t pc) {
-    return *((const BSVI_CONST_AS Aux*)((const BSVI_CONST_AS uint32_t*)(aux) + (size_t)pc * kAuxWords));
+    const uint4* p = aux + (size_t)pc * (kAuxWords / 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(p));        // keep the (uniform) address in vector registers: vector loads, see above
+#endif
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+    Aux X;
+    X.w0 = q0.x; X.imm0 = q0.y; X.imm1 = q0.z; X.row = q0.w;
+    X.off[0] = q1.x; X.off[1] = q1.y; X.off[2] = q1.z; X.off[3] = q1.w;
+    X.off[4] = q2.x; X.mask[0] = q2.y; X.mask[1] = q2.z; X.mask[2] = q2.w;
+    X.mask[3] = q3.x; X.mask[4] = q3.y; X.cell[0] = q3.z; X.cell[1] = q3.w;
+    X.cell[2] = q4.x; X.cell[3] = q4.y; X.cell[4] = q4.z; X.pad = 0;
+    return X;
 }
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // log of a normal positive float (a scale): v_log_f32 * ln 2.  (`__logf` expands to a 12-instruction
 // sequence with denormal scaling and a compensated product)
 __device__ __forceinline__ float log_pos(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
@@ -488,10 +504,8 @@ __device__ __forceinline__ void naff_sink(const KParams& K, const Lay& L, Lane& 
 }
 
 // ---- pre-resolved NAFF handlers (lds+lane_acc storage, no diagnostic outputs) ----------------
-// Same arithmetic as naff_sink / exec_forward / exec_backward below, addresses from the Aux table.
-// Every handler first turns its Aux entry into vector addresses and then loads the NEXT visit's entry
-// into the same scalar registers: the entry is dead by then, so prefetching costs no extra SGPRs and
-// its latency hides behind the rest of the visit.
+// Same arithmetic as naff_sink / exec_forward / exec_backward below, addresses from the Aux entry
+// (which the sweep prefetched one visit ahead).
 struct FastAddr { uint32_t v[5], c[5]; };
 __device__ __forceinline__ FastAddr fast_addr(const Lane& T, const Aux& X) {
     FastAddr F;
@@ -502,10 +516,9 @@ __device__ __forceinline__ FastAddr fast_addr(const Lane& T, const Aux& X) {
     }
     return F;
 }
-__device__ __forceinline__ void fast_sink(const KParams& K, Lane& T, Aux& X, uint32_t next) {
+__device__ __forceinline__ void fast_sink(Lane& T, const Aux& X) {
     const FastAddr F = fast_addr(T, X);
     const float w = __uint_as_float(X.imm0);
-    X = ld_aux(K.aux, next);
     const float v = lds_ld(F.v[0]), A = lds_ld(F.v[1]), B = lds_ld(F.v[2]), Cc = lds_ld(F.v[3]), S = lds_ld(F.v[4]);
     const float od = lds_ld(F.c[0]), oa = lds_ld(F.c[1]), ob = lds_ld(F.c[2]), oc = lds_ld(F.c[3]), os = lds_ld(F.c[4]);
     const float rS = __builtin_amdgcn_rcpf(S), logS = log_pos(S);
@@ -521,16 +534,15 @@ __device__ __forceinline__ void fast_sink(const KParams& K, Lane& T, Aux& X, uin
     lds_st(F.c[3], oc + gloc);
     lds_st(F.c[4], os + gS);
 }
-__device__ __forceinline__ void fast_forward(const KParams& K, Lane& T, Aux& X, uint32_t next) {
-    const uint32_t flags = (X.w0 >> 8) & 0xFFu;
+__device__ __forceinline__ void fast_forward(const KParams& K, Lane& T, const Aux& X, uint32_t w0) {
+    const uint32_t flags = (w0 >> 8) & 0xFFu;
     const FastAddr F = fast_addr(T, X);
-    const uint32_t row = X.row;
     const float w_lp = __uint_as_float(X.imm0), w_ent = __uint_as_float(X.imm1);
-    X = ld_aux(K.aux, next);
     const float A = lds_ld(F.v[1]), B = lds_ld(F.v[2]), Cc = lds_ld(F.v[3]), S = lds_ld(F.v[4]);
     const float loc = A * B + Cc;
     float v;
     if (flags & BSVI_F_SAMPLE) {
+        const uint32_t row = uniform_u32(X.row);
         const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
         v = loc + eps * S;
         lds_st(F.v[0], v);
@@ -544,12 +556,10 @@ __device__ __forceinline__ void fast_forward(const KParams& K, Lane& T, Aux& X, 
         T.f += w_lp * (-0.5f * (u * u) - logS - kLogSqrt2Pi);
     }
 }
-__device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, Aux& X, uint32_t next) {
-    const uint32_t flags = (X.w0 >> 8) & 0xFFu;
+__device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, const Aux& X, uint32_t w0) {
+    const uint32_t flags = (w0 >> 8) & 0xFFu;
     const FastAddr F = fast_addr(T, X);
-    const uint32_t row = X.row;
     const float w_lp = __uint_as_float(X.imm0), w_ent = __uint_as_float(X.imm1);
-    X = ld_aux(K.aux, next);
     const float v = lds_ld(F.v[0]), A = lds_ld(F.v[1]), B = lds_ld(F.v[2]), Cc = lds_ld(F.v[3]), S = lds_ld(F.v[4]);
     const float od = lds_ld(F.c[0]), oa = lds_ld(F.c[1]), ob = lds_ld(F.c[2]), oc = lds_ld(F.c[3]), os = lds_ld(F.c[4]);
     const float loc = A * B + Cc;
@@ -566,6 +576,7 @@ __device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, Aux& X,
     float gdst = gv;
     if (flags & BSVI_F_SAMPLE) {
         // a sampled latent's own cell holds its incoming adjoint: read, folded into loc/scale, written back unchanged
+        const uint32_t row = uniform_u32(X.row);
         const float zb = od + gv;
         const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
         gloc += zb;
@@ -827,17 +838,19 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
 
     // ---------------- forward sweep (sink records: value AND adjoints, see BSVI_R_SINK)
     if constexpr (FASTK) {
-        // the sweep walks the Aux table (w0 of every instruction is in it); the 32-byte instruction is read
-        // only on the generic path
+        // The sweep walks the Aux table (w0 of every instruction is in it); the 32-byte instruction is read
+        // only on the generic path.  Two entry buffers alternate: the entry of visit i+1 is requested at the
+        // start of visit i.
         uint32_t pc = 0;
-        Aux X = ld_aux(K.aux, 0);
-        while (pc < K.n_code) {
-            const uint32_t w0 = X.w0, op = w0 & 0xFFu;
+        Aux XA = ld_aux(K.aux, 0), XB = XA;
+        auto visit = [&](const Aux& X, Aux& Xn) {
+            const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
             const bool sink = (w0 >> 24) & BSVI_R_SINK;
             if ((w0 >> 24) & kFastFlag) {
-                const uint32_t npc = pc + 1, nx = npc < K.n_code ? npc : 0;
-                if (sink) fast_sink(K, T, X, nx);
-                else fast_forward(K, T, X, nx);
+                const uint32_t npc = pc + 1;
+                Xn = ld_aux(K.aux, npc < K.n_code ? npc : 0);
+                if (sink) fast_sink(T, X);
+                else fast_forward(K, T, X, w0);
                 pc = npc;
             } else if (op == BSVI_OP_REC_BEGIN) {
                 const Insn I = ld_insn(K.code, pc);
@@ -856,11 +869,11 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                     }
                 }
                 pc += n + 2;
-                X = ld_aux(K.aux, pc < K.n_code ? pc : 0);
+                Xn = ld_aux(K.aux, pc < K.n_code ? pc : 0);
             } else {
                 const Insn I = ld_insn(K.code, pc);
                 const uint32_t npc = pc + 1;
-                X = ld_aux(K.aux, npc < K.n_code ? npc : 0);
+                Xn = ld_aux(K.aux, npc < K.n_code ? npc : 0);
                 if (sink && op == BSVI_OP_NAFF) {
                     naff_sink<SM>(K, L, T, I, 0);
                 } else {
@@ -869,6 +882,11 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                 }
                 pc = npc;
             }
+        };
+        while (pc < K.n_code) {
+            visit(XA, XB);
+            if (pc >= K.n_code) break;
+            visit(XB, XA);
         }
     } else {
         uint32_t pc = 0;
@@ -919,13 +937,14 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     // ---------------- reverse sweep: the posterior's sampling chain and the derived values
     if constexpr (FASTK) {
         uint32_t pc = K.n_code;
-        Aux X = ld_aux(K.aux, pc - 1);
-        while (pc > 0) {
-            const uint32_t w0 = X.w0, op = w0 & 0xFFu;
+        Aux XA = ld_aux(K.aux, pc - 1), XB = XA;
+        auto visit = [&](const Aux& X, Aux& Xn) {
+            const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
             const bool sink = (w0 >> 24) & BSVI_R_SINK;
             if (!sink && ((w0 >> 24) & kFastFlag)) {
                 const uint32_t npc = pc - 1;
-                fast_backward(K, T, X, npc > 0 ? npc - 1 : 0);
+                Xn = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
+                fast_backward(K, T, X, w0);
                 pc = npc;
             } else if (op == BSVI_OP_REC_END) {
                 const Insn I = ld_insn(K.code, pc - 1);
@@ -946,18 +965,21 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                     }
                 }
                 pc = first - 1;                              // skip the REC_BEGIN bracket too
-                X = ld_aux(K.aux, pc > 0 ? pc - 1 : 0);
+                Xn = ld_aux(K.aux, pc > 0 ? pc - 1 : 0);
             } else {
                 const uint32_t npc = pc - 1;
+                Xn = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
                 if (!sink) {
                     const Insn I = ld_insn(K.code, pc - 1);
-                    X = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
                     exec_backward<SM, GEN>(K, L, T, I, 0);
-                } else {
-                    X = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
                 }
                 pc = npc;
             }
+        };
+        while (pc > 0) {
+            visit(XA, XB);
+            if (pc == 0) break;
+            visit(XB, XA);
         }
     } else {
         uint32_t pc = K.n_code;
@@ -1425,7 +1447,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
             uint32_t* w = code + 8 * (size_t)i;
             uint32_t* x = aux + kAuxWords * (size_t)i;
             const uint32_t op = w[0] & 0xFFu, flags = (w[0] >> 8) & 0xFFu, rflags = w[0] >> 24;
-            x[16] = w[0]; x[17] = w[6]; x[18] = w[7];
+            x[0] = w[0]; x[1] = w[6]; x[2] = w[7];
             if (body_left) { --body_left; continue; }
             if (op == BSVI_OP_REC_BEGIN) { body_left = w[1] + 1; continue; }
             if (op != BSVI_OP_NAFF || !(rflags & BSVI_R_NOALIAS) || (flags & BSVI_F_WF)) continue;
@@ -1434,13 +1456,13 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
             if (!ok) continue;
             for (int k = 0; k < 5; ++k) {
                 const uint32_t o_ = w[1 + k], off = o_ & 0x3FFFFFFFu, lane = o_ >> 31;
-                x[k] = off;
-                x[5 + k] = lane ? 0xFFFFFFFFu : 0u;
-                x[10 + k] = lane ? off + 4u : (off < ugrad ? uacc + off : dummy);
+                x[4 + k] = off;
+                x[9 + k] = lane ? 0xFFFFFFFFu : 0u;
+                x[14 + k] = lane ? off + 4u : (off < ugrad ? uacc + off : dummy);
             }
-            x[15] = (w[1] & 0x3FFFFFFFu) >> 3;
+            x[3] = (w[1] & 0x3FFFFFFFu) >> 3;
             w[0] |= kFastFlag << 24;
-            x[16] = w[0];
+            x[0] = w[0];
         }
     }
     const size_t o_rec = o; if (desc->n_records) memcpy(&host[o], desc->records, (size_t)desc->n_records * sizeof(bsvi_record)); o += b_rec;
