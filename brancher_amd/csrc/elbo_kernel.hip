@@ -292,9 +292,12 @@ struct Aux { uint32_t w0, imm0, imm1, row, off[5], mask[5], cell[5], pad; };
 constexpr uint32_t kAuxWords = 20;
 constexpr uint32_t kFastFlag = 4u;      // rflags bit set in the DEVICE copy of the code (not part of the ABI)
 __device__ __forceinline__ Aux ld_aux(const uint4* aux, uint32_t pc) {
-    const uint4* p = aux + (size_t)pc * (kAuxWords / 4);
 #if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(1))) uint4* gptr_t;    // global, not flat: flat loads also tick lgkmcnt
+    gptr_t p = (gptr_t)(aux + (size_t)pc * (kAuxWords / 4));
     asm volatile("" : "+v"(p));        // keep the (uniform) address in vector registers: vector loads, see above
+#else
+    const uint4* p = aux + (size_t)pc * (kAuxWords / 4);
 #endif
     const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
     Aux X;
