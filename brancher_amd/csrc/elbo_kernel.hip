@@ -120,6 +120,7 @@ extern __shared__ __attribute__((aligned(16))) float g_lds[];
 
 struct Lay {   // wave-uniform layout
     uint32_t obs, uadj, red, rows;      // float offsets
+    uint32_t aux;                       // SM_LACC: float offset of the LDS copy of the Aux table (behind the rows)
     uint32_t row_words;                 // 2 * n_slots + 1 (+ lane accumulators), odd
     uint32_t uacc, dummy;               // SM_LACC: byte offsets inside a row of the per-lane
                                         // dU accumulators and of the write-only dummy cell
@@ -282,23 +283,19 @@ __device__ __forceinline__ bsvi_record ld_record(const bsvi_record* recs, uint32
 //   mask[k]  ~0 for a per-lane operand, 0 for a lane-uniform one: address = off + (lane_row & mask)
 //   cell[k]  byte offset INSIDE the lane's row of the operand's adjoint cell in the lds+lane_acc layout
 //            (slot adjoint, per-lane dU accumulator, or the write-only dummy)
-// The entry is fetched with VECTOR loads (five global_load_dwordx4 from one wave-uniform address) into
-// vector registers, on purpose: (1) the kernels are short of scalar registers, not of vector ones — 40
-// more SGPRs for a double-buffered entry would spill around every visit; (2) scalar loads share the
-// lgkm counter with LDS and return out of order, so a prefetch in flight forces every LDS wait of the
-// visit to drain it; vector loads count on vmcnt.  The single-SIMD wave stream is issue-bound (every
-// instruction, scalar or vector, costs ~4.7 cycles), so this table roughly halves the cost of a node.
+// The table is copied to LDS once per launch and an entry is fetched one visit ahead with five
+// ds_read_b128 from a wave-uniform address, into VECTOR registers, on purpose: (1) the kernels are
+// short of scalar registers, not of vector ones — 40 more SGPRs for a double-buffered entry spill around
+// every visit; (2) scalar loads share the lgkm counter with LDS and return out of order, so a scalar
+// prefetch in flight forces every LDS wait of the visit to drain it; (3) global loads of the entry
+// (tried) cost an L1/L2 round trip longer than a visit.  The single-SIMD wave stream is issue-bound
+// (every instruction, scalar or vector, costs ~4.7 cycles), so this table roughly halves the cost of a node.
 struct Aux { uint32_t w0, imm0, imm1, row, off[5], mask[5], cell[5], pad; };
 constexpr uint32_t kAuxWords = 20;
 constexpr uint32_t kFastFlag = 4u;      // rflags bit set in the DEVICE copy of the code (not part of the ABI)
-__device__ __forceinline__ Aux ld_aux(const uint4* aux, uint32_t pc) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(1))) uint4* gptr_t;    // global, not flat: flat loads also tick lgkmcnt
-    gptr_t p = (gptr_t)(aux + (size_t)pc * (kAuxWords / 4));
-    asm volatile("" : "+v"(p));        // keep the (uniform) address in vector registers: vector loads, see above
-#else
-    const uint4* p = aux + (size_t)pc * (kAuxWords / 4);
-#endif
+__device__ __forceinline__ Aux ld_aux(uint32_t aux_float_offset, uint32_t pc) {
+    // five ds_read_b128 from one wave-uniform address (a broadcast read: no bank conflicts)
+    const uint4* p = reinterpret_cast<const uint4*>(&g_lds[aux_float_offset + pc * kAuxWords]);
     const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
     Aux X;
     X.w0 = q0.x; X.imm0 = q0.y; X.imm1 = q0.z; X.row = q0.w;
@@ -792,13 +789,20 @@ __device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
     L.uacc = 2 * K.n_slots * 4;
     L.dummy = L.uacc + L.ugrad_bytes;
     L.row_words = (SM == SM_LACC) ? ((2 * K.n_slots + K.n_uniform_grad + 1) | 1u) : (2 * K.n_slots + 1);
+    L.aux = (L.rows + L.nthreads * L.row_words + 3u) & ~3u;      // 16-byte aligned: entries are read as uint4
     return L;
 }
 
 template <int SM, bool OUT, bool GEN>
-__device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint32_t block_first_sample) {
+__device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint32_t block_first_sample, bool copy_aux = true) {
     constexpr bool FASTK = (SM == SM_LACC) && !OUT;     // pre-resolved NAFF handlers (Aux table) apply
     const uint32_t tid = threadIdx.x, nthreads = L.nthreads;
+    if (FASTK && copy_aux) {
+        // (the persistent trainer copies once: nothing else writes this region)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(K.aux);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&g_lds[L.aux]);
+        for (uint32_t i = tid; i < K.n_code * kAuxWords; i += nthreads) dst[i] = src[i];
+    }
 #define BSVI_STAMP(i)                                                                      \
     if (OUT && K.stamps && blockIdx.x == 0 && tid == 0) {                                    \
         K.stamps[2 * (i)] = __builtin_amdgcn_s_memtime();                                    \
@@ -845,13 +849,13 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         // only on the generic path.  Two entry buffers alternate: the entry of visit i+1 is requested at the
         // start of visit i.
         uint32_t pc = 0;
-        Aux XA = ld_aux(K.aux, 0), XB = XA;
+        Aux XA = ld_aux(L.aux, 0), XB = XA;
         auto visit = [&](const Aux& X, Aux& Xn) {
             const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
             const bool sink = (w0 >> 24) & BSVI_R_SINK;
             if ((w0 >> 24) & kFastFlag) {
                 const uint32_t npc = pc + 1;
-                Xn = ld_aux(K.aux, npc < K.n_code ? npc : 0);
+                Xn = ld_aux(L.aux, npc < K.n_code ? npc : 0);
                 if (sink) fast_sink(T, X);
                 else fast_forward(K, T, X, w0);
                 pc = npc;
@@ -872,11 +876,11 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                     }
                 }
                 pc += n + 2;
-                Xn = ld_aux(K.aux, pc < K.n_code ? pc : 0);
+                Xn = ld_aux(L.aux, pc < K.n_code ? pc : 0);
             } else {
                 const Insn I = ld_insn(K.code, pc);
                 const uint32_t npc = pc + 1;
-                Xn = ld_aux(K.aux, npc < K.n_code ? npc : 0);
+                Xn = ld_aux(L.aux, npc < K.n_code ? npc : 0);
                 if (sink && op == BSVI_OP_NAFF) {
                     naff_sink<SM>(K, L, T, I, 0);
                 } else {
@@ -940,13 +944,13 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     // ---------------- reverse sweep: the posterior's sampling chain and the derived values
     if constexpr (FASTK) {
         uint32_t pc = K.n_code;
-        Aux XA = ld_aux(K.aux, pc - 1), XB = XA;
+        Aux XA = ld_aux(L.aux, pc - 1), XB = XA;
         auto visit = [&](const Aux& X, Aux& Xn) {
             const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
             const bool sink = (w0 >> 24) & BSVI_R_SINK;
             if (!sink && ((w0 >> 24) & kFastFlag)) {
                 const uint32_t npc = pc - 1;
-                Xn = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
+                Xn = ld_aux(L.aux, npc > 0 ? npc - 1 : 0);
                 fast_backward(K, T, X, w0);
                 pc = npc;
             } else if (op == BSVI_OP_REC_END) {
@@ -968,10 +972,10 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                     }
                 }
                 pc = first - 1;                              // skip the REC_BEGIN bracket too
-                Xn = ld_aux(K.aux, pc > 0 ? pc - 1 : 0);
+                Xn = ld_aux(L.aux, pc > 0 ? pc - 1 : 0);
             } else {
                 const uint32_t npc = pc - 1;
-                Xn = ld_aux(K.aux, npc > 0 ? npc - 1 : 0);
+                Xn = ld_aux(L.aux, npc > 0 ? npc - 1 : 0);
                 if (!sink) {
                     const Insn I = ld_insn(K.code, pc - 1);
                     exec_backward<SM, GEN>(K, L, T, I, 0);
@@ -1223,7 +1227,7 @@ __global__ void __launch_bounds__(1024) persistent_kernel(const PParams P_unused
             K.offset_lo = lo;
             if (K.noise) K.noise += (size_t)it * K.n_noise * K.n_local;
             L = make_layout<SM>(K, n_waves);
-            elbo_block<SM, false, GEN>(K, L, 0);
+            elbo_block<SM, false, GEN>(K, L, 0, it == 0);
         }
         BSVI_RELOAD_ARGS();
         const BSVI_CONST_AS PParams* P = (const BSVI_CONST_AS PParams*)ka;
@@ -1560,7 +1564,8 @@ struct Geometry {
 static size_t lds_need(const bsvi_program* p, uint32_t n_waves, int mode) {
     size_t floats = (size_t)p->d.n_uniform + (size_t)p->d.n_obs + (size_t)p->d.n_uniform_grad * n_waves + 4 * (size_t)n_waves;
     if (mode == SM_WSUM) floats += (2 * (size_t)p->d.n_slots + 1) * n_waves * 64;
-    if (mode == SM_LACC) floats += ((2 * (size_t)p->d.n_slots + p->d.n_uniform_grad + 1) | 1) * n_waves * 64;
+    if (mode == SM_LACC) floats += ((2 * (size_t)p->d.n_slots + p->d.n_uniform_grad + 1) | 1) * n_waves * 64
+                                   + 4 + (size_t)p->d.n_code * kAuxWords;     // + LDS copy of the Aux table
     return floats * 4 + 64;
 }
 
