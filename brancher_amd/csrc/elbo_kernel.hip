@@ -1186,6 +1186,30 @@ __global__ void optimizer_kernel(const bsvi_opt_cfg cfg, float* params, const fl
     optimizer_update(cfg, params, state, n_params, i, out[BSVI_OUT_HEADER + i]);
 }
 
+// finalize + finite flag + optimizer step + loss log in ONE launch: what follows the all-reduce of the
+// output block on the multi-GPU path (four launches otherwise, in a step that is latency-bound)
+__global__ void finalize_step_kernel(const bsvi_opt_cfg cfg, float* params, float* out, float* state,
+                                     const uint8_t* active_mask, uint32_t n_params, uint32_t n_global,
+                                     float* loss_slot, float* finite_slot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float scale = -1.0f / (float)n_global;
+    const float loss = out[0] * scale;
+    const float finite = isfinite(loss) ? 1.0f : 0.0f;
+    if (i < n_params) {
+        const float grad = out[BSVI_OUT_HEADER + i] * scale;
+        out[BSVI_OUT_HEADER + i] = grad;
+        if (finite != 0.0f && active_mask[i]) optimizer_update(cfg, params, state, n_params, i, grad);
+    }
+    // (every thread has read out[0] before anyone overwrites the header: one workgroup per 256 parameters, and
+    //  the header words written below are not read above)
+    if (i == 0) {
+        out[2] = loss;
+        out[3] = finite;
+        if (loss_slot) *loss_slot = loss;
+        if (finite_slot) *finite_slot = finite;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Persistent trainer: the whole loop of brancher/inference.py:95-108 in one launch, for
 // sample counts that fit one workgroup.  Every iteration: ELBO fwd+bwd, chain rule,
@@ -1720,6 +1744,20 @@ extern "C" int bsvi_optimizer_step(const bsvi_opt_cfg* cfg, float* params_dev, c
     if (!params_dev || !out_dev || !state_dev || !active_mask_dev) return fail(BSVI_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(optimizer_kernel, dim3((n_params + 255) / 256), dim3(256), 0, (hipStream_t)stream, *cfg,
                        params_dev, out_dev, state_dev, active_mask_dev, n_params);
+    HIP_TRY(hipGetLastError());
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_finalize_step(const bsvi_opt_cfg* cfg, float* params_dev, float* out_dev, float* state_dev,
+                                  const uint8_t* active_mask_dev, uint32_t n_params, uint32_t n_samples_global,
+                                  float* loss_slot_dev, float* finite_slot_dev, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!out_dev || !n_samples_global) return fail(BSVI_ERR_INVALID, "null argument");
+    if (n_params && (!params_dev || !state_dev || !active_mask_dev)) return fail(BSVI_ERR_INVALID, "null argument");
+    const uint32_t n = n_params ? n_params : 1;
+    hipLaunchKernelGGL(finalize_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *cfg, params_dev,
+                       out_dev, state_dev, active_mask_dev, n_params, n_samples_global, loss_slot_dev, finite_slot_dev);
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }

@@ -314,7 +314,7 @@ class CompiledDense:
         return {par.name: t[off:off + size].reshape(par.shape).copy() for par, off, size, _ in self.program.parameters}
 
     def train(self, number_iterations, number_samples, optimizer="Adam", noise_seq=None, minibatch_seq=None, seed=None,
-              pretraining_iterations=0, allow_persistent=True, **opt_params):
+              pretraining_iterations=0, allow_persistent=True, _force_sharded_path=False, **opt_params):
         from brancher_amd import engine
         cfg = native.make_opt_cfg(optimizer, **opt_params)
         rank, world = engine.dist_info()
@@ -333,17 +333,15 @@ class CompiledDense:
             mb = None if minibatch_seq is None else self._indices_tensor(minibatch_seq[it])
             args = self._args(n_local, number_samples, base, nz, mb, seed, offset0 + it)
             mask = self.mask_all if it > pretraining_iterations else self.mask_first
-            if world == 1:
+            if world == 1 and not _force_sharded_path:
                 native.check(self.lib.bsvi_dense_step(self.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state),
                                                       ptr(mask), C.c_void_p(loss_curve.data_ptr() + 4 * it),
                                                       C.c_void_p(finite.data_ptr() + 4 * it)))
             else:
                 native.check(self.lib.bsvi_dense_fwd_bwd(self.handle, C.byref(args)))
                 engine.allreduce_sums(self.out)
-                native.check(self.lib.bsvi_dense_finalize(self.handle, ptr(self.out), number_samples, self._stream()))
-                native.check(self.lib.bsvi_optimizer_step(C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(mask),
-                                                          p.n_params, self._stream()))
-                loss_curve[it:it + 1].copy_(self.out[2:3])
-                finite[it:it + 1].copy_(self.out[3:4])
+                native.check(self.lib.bsvi_finalize_step(
+                    C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(mask), p.n_params, number_samples,
+                    C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         return loss_curve[:K], finite[:K]

@@ -251,7 +251,8 @@ class CompiledELBO:
 
     # ---- the optimisation loop --------------------------------------------------------------------
     def train(self, number_iterations, number_samples, optimizer="Adam", noise_seq=None, seed=None,
-              pretraining_iterations=0, allow_persistent=True, minibatch_seq=None, **opt_params):
+              pretraining_iterations=0, allow_persistent=True, minibatch_seq=None, _force_sharded_path=False,
+              **opt_params):
         """`brancher/inference.py:95-108` on the device.  Returns (loss_curve, finite_flags) as
         device tensors of length number_iterations; nothing synchronises with the host."""
         cfg = native.make_opt_cfg(optimizer, **opt_params)
@@ -279,7 +280,9 @@ class CompiledELBO:
         if K == 0:
             return loss_curve[:0], finite[:0]
 
-        persistent = (allow_persistent and world == 1 and self.native.persistent_supported(n_local))
+        # (_force_sharded_path: run the multi-GPU step sequence on one GPU — tests)
+        persistent = (allow_persistent and world == 1 and not _force_sharded_path
+                      and self.native.persistent_supported(n_local))
         if persistent:
             args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset0)
             native.check(self.lib.bsvi_train_persistent2(
@@ -292,18 +295,16 @@ class CompiledELBO:
             nz = None if noise_t is None else noise_t[it]
             args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
             mask = self.mask_all if it > pretraining_iterations else self.mask_first
-            if world == 1:
+            if world == 1 and not _force_sharded_path:
                 native.check(self.lib.bsvi_svi_step(
                     self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(mask),
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it)))
             else:
                 native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
                 allreduce_sums(self.out)
-                native.check(self.lib.bsvi_finalize(self.native.handle, ptr(self.out), number_samples, self._stream()))
-                native.check(self.lib.bsvi_optimizer_step(C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state),
-                                                          ptr(mask), p.n_params, self._stream()))
-                loss_curve[it:it + 1].copy_(self.out[2:3])
-                finite[it:it + 1].copy_(self.out[3:4])
+                native.check(self.lib.bsvi_finalize_step(
+                    C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(mask), p.n_params, number_samples,
+                    C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         return loss_curve, finite
 

@@ -95,6 +95,8 @@ EXPORTS = {
     "bsvi_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bsvi_optimizer_step": (C.c_int, [C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_void_p]),
+    "bsvi_finalize_step": (C.c_int, [C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                     C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsvi_svi_step": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsvi_train_persistent": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,

@@ -244,6 +244,15 @@ int bsvi_optimizer_step(const bsvi_opt_cfg* cfg, float* params_dev, const float*
                         float* state_dev, const uint8_t* active_mask_dev, uint32_t n_params,
                         void* stream);
 
+/* Multi-GPU step tail in ONE launch, after the caller has all-reduced the output block of bsvi_elbo_fwd_bwd
+ * over the sample shards: out[2] = loss = -out[0]/n_samples_global, out[3] = finite flag, out[4..] scaled to
+ * d loss/d theta, the optimizer step of every active parameter when the loss is finite
+ * (brancher/inference.py:98-104), and the loss / finite flag stored to the (optional) slots
+ * (inference.py:105-109).  Equivalent to bsvi_finalize + bsvi_optimizer_step + two device copies. */
+int bsvi_finalize_step(const bsvi_opt_cfg* cfg, float* params_dev, float* out_dev, float* state_dev,
+                       const uint8_t* active_mask_dev, uint32_t n_params, uint32_t n_samples_global,
+                       float* loss_slot_dev, float* finite_slot_dev, void* stream);
+
 /* Run `n_iterations` complete SVI iterations (ELBO fwd+bwd, finalize, optimizer step, loss
  * log) inside one kernel launch when the local sample count fits one workgroup; the whole
  * loop of brancher/inference.py:95-108 without returning to the host.  loss_curve_dev gets

@@ -256,3 +256,35 @@ def test_dense_training_reduces_the_loss():
     l = losses.cpu().numpy()
     assert finite.cpu().numpy().all() and np.isfinite(l).all()
     assert l[-20:].mean() < l[:20].mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer,kw", [("SGD", dict(lr=1e-3)), ("Adam", dict(lr=5e-3))])
+def test_sharded_step_sequence_equals_the_fused_single_gpu_step(optimizer, kw):
+    """The multi-GPU step (bsvi_elbo_fwd_bwd -> all-reduce of the output block -> bsvi_finalize_step) run on
+    one GPU must walk the same parameter trajectory as the fused single-GPU step and the persistent trainer."""
+    api = W.native_api()
+    runs = {}
+    for name, opts in (("persistent", dict()), ("stepwise", dict(allow_persistent=False)),
+                       ("sharded", dict(_force_sharded_path=True))):
+        c = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+        losses, finite = c.train(25, 300, optimizer, seed=5, **opts, **kw)
+        runs[name] = (losses.cpu().numpy(), c.params.detach().cpu().numpy().copy(), bool(finite.all()))
+    for name in ("stepwise", "sharded"):
+        assert runs[name][2]
+        np.testing.assert_allclose(runs[name][0], runs["persistent"][0], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(runs[name][1], runs["persistent"][1], rtol=2e-6, atol=1e-7)
+    np.testing.assert_array_equal(runs["sharded"][1], runs["stepwise"][1])     # same arithmetic, different launches
+
+
+@pytest.mark.gpu
+def test_dense_sharded_step_sequence_equals_the_fused_step():
+    api = W.native_api()
+    kw = dict(dataset_size=256, batch_size=64, n_features=64, n_classes=10, q_scale=0.05)
+    out = []
+    for opts in (dict(), dict(_force_sharded_path=True)):
+        c = engine.compile_model(W.build_logistic_regression(api, **kw), None, "pathwise")
+        losses, finite = c.train(10, 128, "Adam", seed=3, lr=5e-3, **opts)
+        out.append((losses.cpu().numpy(), c.params.detach().cpu().numpy().copy()))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-6)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-6, atol=1e-7)
