@@ -602,7 +602,7 @@ __device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lan
         if (flags & BSVI_F_SAMPLE) {
             const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
             const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
-            v = loc + eps * S;
+            v = (flags & BSVI_F_GIVEN) ? eps : loc + eps * S;
             st_slot<SM>(K, T, doff, v);
             if (OUT && T.mask != 0.0f) {
                 if (K.samples_out) K.samples_out[(size_t)row * K.n_local + T.n] = v;
@@ -645,7 +645,7 @@ __device__ __forceinline__ void exec_forward(const KParams& K, const Lay& L, Lan
             float noise;
             if (K.noise) {
                 noise = K.noise[(size_t)row * K.n_local + T.nc];
-                v = sample_from_noise_generic(dist, p0, p1, noise);
+                v = (flags & BSVI_F_GIVEN) ? noise : sample_from_noise_generic(dist, p0, p1, noise);
             } else {
                 const float2 d = philox_draw(philox_key(K, T), dist, p0, p1, row);
                 v = d.x;
@@ -1481,7 +1481,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
             x[0] = w[0]; x[1] = w[6]; x[2] = w[7];
             if (body_left) { --body_left; continue; }
             if (op == BSVI_OP_REC_BEGIN) { body_left = w[1] + 1; continue; }
-            if (op != BSVI_OP_NAFF || !(rflags & BSVI_R_NOALIAS) || (flags & BSVI_F_WF)) continue;
+            if (op != BSVI_OP_NAFF || !(rflags & BSVI_R_NOALIAS) || (flags & (BSVI_F_WF | BSVI_F_GIVEN))) continue;
             bool ok = true;
             for (int k = 0; k < 5; ++k) ok = ok && !((w[1 + k] >> 30) & 1u);
             if (!ok) continue;

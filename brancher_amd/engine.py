@@ -429,6 +429,26 @@ def get_posterior_sample_frame(model, number_samples, input_values={}):
     return _frame(posterior_sample(model, number_samples, input_values))
 
 
+def importance_log_weights(joint_model, posterior_model, q_samples):
+    """Per-sample log p(z, y) - log q(z) for caller-supplied posterior samples z — the two terms of
+    `ProbabilisticModel.get_importance_weights` (variables.py:821-841).  `q_samples` maps variables (or
+    names) to arrays in the reference layout [N, B, d...]; returns device tensors (log_p, log_q) of length N.
+    Served by the same fused kernel: an evaluation program whose posterior nodes take their values from the
+    caller (BSVI_F_GIVEN) and accumulate log q."""
+    named = {}
+    n = None
+    for var, value in q_samples.items():
+        arr = value.detach().cpu().numpy() if hasattr(value, "detach") else np.asarray(value)
+        named[getattr(var, "name", var)] = arr
+        if arr.ndim >= 1 and arr.shape[0] > 1:
+            n = arr.shape[0] if n is None else n
+    n = n or 1
+    compiled = compile_model(joint_model, posterior_model, "importance")
+    noise = noise_from_named(compiled.program, named, n)
+    res = compiled.evaluate(n, noise=noise, want_fvalues=True, offset=0)
+    return res["f"], res["lq"]
+
+
 def log_probability(variables, values, include_parents=True, model=None):
     raise NotImplementedError("calculate_log_probability on arbitrary supplied values is outside the ELBO-gradient hot "
                               "path this build covers (SURVEY §8f-3); the ELBO path evaluates log-probabilities in-kernel")

@@ -39,13 +39,16 @@ from brancher_amd.variables import RootVariable, RandomVariable, ProbabilisticMo
 OP = dict(NOP=0, NAFF=1, NODE=2, BIN=3, UN=4, REC_BEGIN=5, REC_END=6)
 R_SINK = 1     # record flag: complete (forward and reverse) in the forward sweep
 R_NOALIAS = 2  # instruction flag: no two operands share an adjoint cell (adjoint updates may be batched)
-F_SAMPLE, F_ENT, F_LOGP, F_WF = 1, 2, 4, 8
+F_SAMPLE, F_ENT, F_LOGP, F_WF, F_GIVEN = 1, 2, 4, 8, 16
 K_NONE, K_U, K_Z, K_OBS = 0, 1, 2, 3
 BINOP = dict(add=0, sub=1, mul=2, truediv=3, pow=4, delta=5)
 UNOP = dict(copy=0, neg=1, exp=2, log=3, sqrt=4, sin=5, cos=6, tanh=7, abs=8, sigmoid=9, softplus=10,
             relu=11, reciprocal=12, log1p=13, expm1=14, square=15, p2l=16, powi=17)
 UT = dict(identity=0, softplus=1, sigmoid=2, exp=3, log=4, tanh=5, sqrt=6, square=7)
-EST = dict(pathwise=0, blackbox=1)
+# "importance" is an evaluation program (no estimator of its own): the posterior's nodes take their values
+# from the caller and only accumulate log q; the kernel's value is then log p(z, y) and its second
+# per-sample output log q(z) — `ProbabilisticModel.get_importance_weights`, variables.py:821-841
+EST = dict(pathwise=0, blackbox=1, importance=0)
 
 UNARY_CALLS = set(UNOP) - {"copy", "powi"}
 
@@ -632,8 +635,9 @@ class _Lowering:
         for b in term_b:
             if b not in (1, bmax):
                 raise LoweringError("datapoint axes %r of the ELBO terms cannot be broadcast" % (sorted(set(term_b)),))
-        if self.estimator == "blackbox" and bmax != 1:
-            raise LoweringError("BlackBox estimator with a datapoint axis on latent terms is not lowered yet")
+        if self.estimator in ("blackbox", "importance") and bmax != 1:
+            raise LoweringError("BlackBox estimator / importance weights with a datapoint axis on latent terms are "
+                                "not lowered yet")
 
         def weight(b_term):
             return 1.0 if b_term == 1 else 1.0 / bmax
@@ -659,14 +663,18 @@ class _Lowering:
             w = weight(shape[0])
             flags = F_SAMPLE
             w_lp = 0.0
-            if dist.has_analytic_entropy:
+            w_ent = w
+            if self.estimator == "importance":
+                flags |= F_WF | F_GIVEN        # value supplied, log q accumulated, no entropy term
+                w_ent = 0.0
+            elif dist.has_analytic_entropy:
                 flags |= F_ENT
             else:
                 flags |= F_LOGP
                 w_lp = -w                      # entropy fallback -log q (variables.py:161-162)
             if self.estimator == "blackbox":
                 flags |= F_WF
-            self.emit_node(dist.kind, flags, params, slot=slot, w_lp=w_lp, w_ent=w)
+            self.emit_node(dist.kind, flags, params, slot=slot, w_lp=w_lp, w_ent=w_ent)
             self.end_record()
 
         # -- emit p records

@@ -352,6 +352,24 @@ class ProbabilisticModel(BrancherClass):
         from brancher_amd import engine
         return engine.log_probability(self._input_variables, rv_values, include_parents=True, model=self)
 
+    def get_importance_weights(self, q_samples, q_model, empirical_samples={}, for_gradient=False,
+                               give_normalization=False):
+        """Self-normalised importance weights of posterior samples, `variables.py:821-841`:
+        w_n ∝ exp(log p(z_n, y) − log q(z_n)).  The two log-densities come from the fused kernel
+        (`engine.importance_log_weights`); the max-shifted softmax over samples is host arithmetic exactly as in
+        the reference.  Returns a numpy array [N, 1] (and log normalisation when asked)."""
+        import numpy as np
+        from brancher_amd import engine
+        log_p, log_q = engine.importance_log_weights(self, q_model, q_samples)
+        log_weights = (log_p - log_q).detach().cpu().numpy().reshape(-1, 1)
+        alpha = np.max(log_weights)
+        weights = np.exp(log_weights - alpha)
+        norm = np.sum(weights)
+        weights /= norm
+        if not give_normalization:
+            return weights
+        return weights, np.log(norm) + alpha
+
     def estimate_log_model_evidence(self, number_samples, method="ELBO", input_values={},
                                     for_gradient=False, posterior_model=(), gradient_estimator=None):
         # `variables.py:843-870`

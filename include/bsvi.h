@@ -108,7 +108,12 @@ typedef enum bsvi_op {
 #define BSVI_R_SINK 1u
 #define BSVI_R_NOALIAS 2u   /* no two operands of the instruction share an adjoint cell */
 
-typedef enum bsvi_node_flags { BSVI_F_SAMPLE = 1, BSVI_F_ENT = 2, BSVI_F_LOGP = 4, BSVI_F_WF = 8 } bsvi_node_flags;
+/* BSVI_F_GIVEN (with BSVI_F_SAMPLE): the node's noise row holds the VALUE of the variable, not its noise —
+ * evaluation programs that score caller-supplied samples (importance weights, variables.py:821-841);
+ * requires noise_dev. */
+typedef enum bsvi_node_flags {
+    BSVI_F_SAMPLE = 1, BSVI_F_ENT = 2, BSVI_F_LOGP = 4, BSVI_F_WF = 8, BSVI_F_GIVEN = 16
+} bsvi_node_flags;
 
 typedef enum bsvi_binop {
     BSVI_B_ADD = 0, BSVI_B_SUB = 1, BSVI_B_MUL = 2, BSVI_B_DIV = 3, BSVI_B_POW = 4,

@@ -288,3 +288,23 @@ def test_dense_sharded_step_sequence_equals_the_fused_step():
         out.append((losses.cpu().numpy(), c.params.detach().cpu().numpy().copy()))
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-6)
     np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["readme_ar_T5_N7", "readme_ar_T20_N300", "beta_binomial_N512", "heavy_tails_N64"])
+def test_importance_weights_match_reference_log_densities(case):
+    """`ProbabilisticModel.get_importance_weights` (variables.py:821-841) on the posterior samples the reference
+    drew: the fixtures hold log p(z, y) ("lp") and log q(z) ("lq") computed by the reference itself."""
+    g = Golden(case)
+    model = g.build(W.native_api())
+    q_samples = {name: g.data["z/" + name] for name in [k[2:] for k in g.data.files if k.startswith("z/")]}
+    log_p, log_q = engine.importance_log_weights(model, model.posterior_model, q_samples)
+    lp, lq = g.data["lp"].reshape(-1), g.data["lq"].reshape(-1)
+    scale = max(1.0, float(np.abs(lp).max()), float(np.abs(lq).max()))
+    assert np.abs(log_p.cpu().numpy() - lp).max() <= 2e-5 * scale
+    assert np.abs(log_q.cpu().numpy() - lq).max() <= 2e-5 * scale
+    w = model.get_importance_weights(q_samples, model.posterior_model)
+    ref = np.exp((lp - lq) - (lp - lq).max())
+    ref /= ref.sum()
+    assert w.shape == (g.N, 1)
+    np.testing.assert_allclose(w.reshape(-1), ref, rtol=5e-4, atol=1e-7)

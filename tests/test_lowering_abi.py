@@ -32,8 +32,8 @@ def test_opcodes_match_header():
     for k, v in lowering.UNOP.items():
         assert unops[{"reciprocal": "RECIP"}.get(k, k.upper())] == v, k
     flags = header_enum("BSVI_F_")
-    assert (flags["SAMPLE"], flags["ENT"], flags["LOGP"], flags["WF"]) == (
-        lowering.F_SAMPLE, lowering.F_ENT, lowering.F_LOGP, lowering.F_WF)
+    assert (flags["SAMPLE"], flags["ENT"], flags["LOGP"], flags["WF"], flags["GIVEN"]) == (
+        lowering.F_SAMPLE, lowering.F_ENT, lowering.F_LOGP, lowering.F_WF, lowering.F_GIVEN)
     ut = header_enum("BSVI_UT_")
     for k, v in lowering.UT.items():
         assert ut[k.upper()] == v

@@ -1,3 +1,5 @@
+"""Diagnostic: host and device cost per iteration of the multi-GPU step sequence, run on one GPU
+(bsvi_elbo_fwd_bwd -> all_reduce (world size 1) -> bsvi_finalize_step)."""
 import os, time, ctypes as C, torch, torch.distributed as dist, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29513", RANK="0", WORLD_SIZE="1")
@@ -16,9 +18,8 @@ def run(K, with_ar):
         args = c._elbo_args(300, 300, 0, None, 0, it)
         native.check(c.lib.bsvi_elbo_fwd_bwd(c.native.handle, C.byref(args)))
         if with_ar: dist.all_reduce(c.out)
-        native.check(c.lib.bsvi_finalize(c.native.handle, ptr(c.out), 300, c._stream()))
-        native.check(c.lib.bsvi_optimizer_step(C.byref(cfg), ptr(c.params), ptr(c.out), ptr(state), ptr(c.mask_all), p.n_params, c._stream()))
-        loss_curve[it:it + 1].copy_(c.out[2:3]); finite[it:it + 1].copy_(c.out[3:4])
+        native.check(c.lib.bsvi_finalize_step(C.byref(cfg), ptr(c.params), ptr(c.out), ptr(state), ptr(c.mask_all), p.n_params, 300,
+                                              C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), c._stream()))
 for with_ar in (False, True):
     run(100, with_ar); torch.cuda.synchronize(); t = time.time(); run(1000, with_ar); t1 = time.time() - t; torch.cuda.synchronize(); t2 = time.time() - t
     print("allreduce" if with_ar else "no allreduce", "host us/iter %.1f  total us/iter %.1f" % (t1 * 1e3, t2 * 1e3))
