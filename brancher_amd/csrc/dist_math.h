@@ -208,7 +208,7 @@ __device__ __noinline__ float logp_generic(int dist, float x, float p0, float p1
     }
 }
 
-__device__ __noinline__ void logp_bwd_generic(int dist, float x, float p0, float p1, float g, float& gx, float& g0, float& g1) {
+__device__ __forceinline__ void logp_bwd_impl(int dist, float x, float p0, float p1, float g, float& gx, float& g0, float& g1) {
     switch (dist) {
     case BSVI_DIST_NORMAL: {
         const float d = x - p0, iv = 1.0f / (p1 * p1), t = d * iv;
@@ -277,7 +277,7 @@ __device__ __noinline__ float entropy_generic(int dist, float p0, float p1) {
     }
 }
 
-__device__ __noinline__ void entropy_bwd_generic(int dist, float p0, float p1, float g, float& g0, float& g1) {
+__device__ __forceinline__ void entropy_bwd_impl(int dist, float p0, float p1, float g, float& g0, float& g1) {
     switch (dist) {
     case BSVI_DIST_NORMAL: g1 += g / p1; break;
     case BSVI_DIST_LOGNORMAL: g0 += g; g1 += g / p1; break;
@@ -315,7 +315,7 @@ __device__ __noinline__ float sample_from_noise_generic(int dist, float p0, floa
 }
 
 // adjoint of the draw: zb = d loss / d z  ->  parameters (pathwise / implicit reparam.)
-__device__ __noinline__ void sample_bwd_generic(int dist, float z, float p0, float p1, float e, float zb, float& g0, float& g1) {
+__device__ __forceinline__ void sample_bwd_impl(int dist, float z, float p0, float p1, float e, float zb, float& g0, float& g1) {
     switch (dist) {
     case BSVI_DIST_NORMAL:
     case BSVI_DIST_CAUCHY: g0 += zb; g1 += zb * e; break;
@@ -336,6 +336,24 @@ __device__ __noinline__ void sample_bwd_generic(int dist, float z, float p0, flo
     case BSVI_DIST_DETERMINISTIC: g0 += zb; break;
     default: break;   // .sample(): no gradient path (distributions.py:123-124)
     }
+}
+
+// Out-of-line entry points return their adjoints BY VALUE (in registers): reference parameters of a
+// non-inlined function live in scratch memory, one store + one flat load each per call.
+__device__ __noinline__ float4 logp_bwd_generic(int dist, float x, float p0, float p1, float g) {
+    float gx = 0.0f, g0 = 0.0f, g1 = 0.0f;
+    logp_bwd_impl(dist, x, p0, p1, g, gx, g0, g1);
+    return make_float4(gx, g0, g1, 0.0f);
+}
+__device__ __noinline__ float2 entropy_bwd_generic(int dist, float p0, float p1, float g) {
+    float g0 = 0.0f, g1 = 0.0f;
+    entropy_bwd_impl(dist, p0, p1, g, g0, g1);
+    return make_float2(g0, g1);
+}
+__device__ __noinline__ float2 sample_bwd_generic(int dist, float z, float p0, float p1, float e, float zb) {
+    float g0 = 0.0f, g1 = 0.0f;
+    sample_bwd_impl(dist, z, p0, p1, e, zb, g0, g1);
+    return make_float2(g0, g1);
 }
 
 __device__ __noinline__ float pow_ff(float x, float y) { return powf(x, y); }

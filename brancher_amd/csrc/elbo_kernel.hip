@@ -753,16 +753,21 @@ __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, La
         float gv = 0.0f, g0 = 0.0f, g1 = 0.0f;
         if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
             const float gw = (__uint_as_float(I.imm0) + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
-            logp_bwd_generic(dist, v, p0, p1, gw, gv, g0, g1);
+            const float4 r = logp_bwd_generic(dist, v, p0, p1, gw);
+            gv += r.x; g0 += r.y; g1 += r.z;
         }
-        if (flags & BSVI_F_ENT) entropy_bwd_generic(dist, p0, p1, __uint_as_float(I.imm1) * T.mask, g0, g1);
+        if (flags & BSVI_F_ENT) {
+            const float2 r = entropy_bwd_generic(dist, p0, p1, __uint_as_float(I.imm1) * T.mask);
+            g0 += r.x; g1 += r.y;
+        }
         if (flags & BSVI_F_SAMPLE) {
             const uint32_t doff = opnd_offset(I.dst, e), row = doff >> 3;
             const float zb = ld_adj<SM>(K, T, doff) + gv;
             float noise = v;
             if (dist == BSVI_DIST_LOGNORMAL || dist == BSVI_DIST_CAUCHY || dist == BSVI_DIST_LAPLACE)
                 noise = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_noise_again(philox_key(K, T), dist, row);
-            sample_bwd_generic(dist, v, p0, p1, noise, zb, g0, g1);
+            const float2 r = sample_bwd_generic(dist, v, p0, p1, noise, zb);
+            g0 += r.x; g1 += r.y;
         } else {
             add_adj<SM>(K, L, T, I.dst, e, gv);
         }
@@ -795,7 +800,9 @@ __device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
 
 template <int SM, bool OUT, bool GEN>
 __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint32_t block_first_sample, bool copy_aux = true) {
-    constexpr bool FASTK = (SM == SM_LACC) && !OUT;     // pre-resolved NAFF handlers (Aux table) apply
+    // pre-resolved NAFF handlers (Aux table) apply.  Not in the generic build: its out-of-line distribution
+    // code already sits at the 128-VGPR limit of a 1024-thread workgroup, and the two entry buffers would spill
+    constexpr bool FASTK = (SM == SM_LACC) && !OUT && !GEN;
     const uint32_t tid = threadIdx.x, nthreads = L.nthreads;
     if (FASTK && copy_aux) {
         // (the persistent trainer copies once: nothing else writes this region)
@@ -1312,9 +1319,9 @@ __global__ void debug_math_kernel(int fn, int dist, const float* x, const float*
     case 0: r0 = digammaf_(xv); break;
     case 1: r0 = trigammaf_(xv); break;
     case 2: r0 = dirichlet_grad_one(xv, a, b); break;
-    case 3: r0 = logp_generic(dist, xv, a, b); logp_bwd_generic(dist, xv, a, b, 1.0f, r1, r2, r3); break;
-    case 4: r0 = entropy_generic(dist, a, b); entropy_bwd_generic(dist, a, b, 1.0f, r2, r3); break;
-    case 5: r0 = sample_from_noise_generic(dist, a, b, xv); sample_bwd_generic(dist, r0, a, b, xv, 1.0f, r2, r3); break;
+    case 3: { r0 = logp_generic(dist, xv, a, b); const float4 r = logp_bwd_generic(dist, xv, a, b, 1.0f); r1 = r.x; r2 = r.y; r3 = r.z; break; }
+    case 4: { r0 = entropy_generic(dist, a, b); const float2 r = entropy_bwd_generic(dist, a, b, 1.0f); r2 = r.x; r3 = r.y; break; }
+    case 5: { r0 = sample_from_noise_generic(dist, a, b, xv); const float2 r = sample_bwd_generic(dist, r0, a, b, xv, 1.0f); r2 = r.x; r3 = r.y; break; }
     case 6: r0 = lgammaf(xv); break;
     default: break;
     }
