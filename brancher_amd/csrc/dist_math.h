@@ -173,6 +173,8 @@ __device__ __noinline__ float dirichlet_grad_one(float xf, float alphaf, float t
 // =========================================================================================
 
 // ---- log-probability -------------------------------------------------------------------
+__device__ __forceinline__ float lgamma_count(float a) { return (a == 1.0f || a == 2.0f) ? 0.0f : lgammaf(a); }
+
 __device__ __noinline__ float logp_generic(int dist, float x, float p0, float p1) {
     switch (dist) {
     case BSVI_DIST_NORMAL: {
@@ -196,7 +198,10 @@ __device__ __noinline__ float logp_generic(int dist, float x, float p0, float p1
         return (t0 + t1) + lgammaf(p0 + p1) - (lgammaf(p0) + lgammaf(p1));
     }
     case BSVI_DIST_BINOMIAL: {   // p0 = total_count, p1 = logits
-        const float lfn = lgammaf(p0 + 1.0f), lfk = lgammaf(x + 1.0f), lfnmk = lgammaf(p0 - x + 1.0f);
+        // log-factorials of counts: lgamma(1) = lgamma(2) = 0 exactly (as in torch), and with total_count = 1
+        // (BASELINE config 2) all three arguments are 1 or 2 — three library lgamma calls per observation
+        // per sample were 80 % of that workload
+        const float lfn = lgamma_count(p0 + 1.0f), lfk = lgamma_count(x + 1.0f), lfnmk = lgamma_count(p0 - x + 1.0f);
         const float norm = p0 * fmaxf(p1, 0.0f) + p0 * log1pf(expf(-fabsf(p1))) - lfn;
         return x * p1 - lfk - lfnmk - norm;
     }
