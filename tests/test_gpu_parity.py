@@ -67,6 +67,11 @@ def test_loss_and_grads_match_reference_golden(case, estimator):
     by_name = c.samples_by_name(res["samples"])
     for name, z in by_name.items():
         assert rel_err(z.reshape(-1), g.data["z/" + name].reshape(-1)) <= 1e-6, name
+    # the launch above asked for per-sample outputs (diagnostic build of the kernel); the training launches use the
+    # lean build with the pre-resolved node handlers: same fixture through that one
+    res2 = c.evaluate(g.N, noise=g.noise, minibatch=g.minibatch)
+    assert abs(float(res2["loss"].item()) - ref) <= TOL * abs(ref)
+    grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL if estimator == "pathwise" else 1e-4)
 
 
 @pytest.mark.parametrize("case", [c for c in golden_cases() if Golden(c).meta["trajectory"]])
