@@ -293,16 +293,37 @@ __device__ __forceinline__ bsvi_record ld_record(const bsvi_record* recs, uint32
 struct Aux { uint32_t w0, imm0, imm1, row, off[5], mask[5], cell[5], pad; };
 constexpr uint32_t kAuxWords = 20;
 constexpr uint32_t kFastFlag = 4u;      // rflags bit set in the DEVICE copy of the code (not part of the ABI)
-__device__ __forceinline__ Aux ld_aux(uint32_t aux_float_offset, uint32_t pc) {
-    // five ds_read_b128 from one wave-uniform address (a broadcast read: no bank conflicts)
-    const uint4* p = reinterpret_cast<const uint4*>(&g_lds[aux_float_offset + pc * kAuxWords]);
-    const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+struct AuxRaw { u32x4v q0, q1, q2, q3, q4; };      // an entry in flight: five 16-byte LDS reads
+// Issue the five reads of entry `pc` (wave-uniform address: broadcast reads, no bank conflicts; 16-byte aligned:
+// L.aux is a multiple of 4 floats and an entry is 80 bytes).  Hand-written: left to the compiler some call
+// sites are scalarised and re-merged into nine 4-byte-aligned ds_read2_b32.  The compiler's own lgkmcnt
+// bookkeeping stays conservative-correct (LDS returns in order; extra older operations only make its counted
+// waits stricter); the consumer calls aux_wait() before touching the entry.
+__device__ __forceinline__ AuxRaw ld_aux(uint32_t aux_float_offset, uint32_t pc) {
+    AuxRaw R;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t addr = (aux_float_offset + pc * kAuxWords) * 4u;
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+                 "ds_read_b128 %3, %5 offset:48\n\tds_read_b128 %4, %5 offset:64"
+                 : "=&v"(R.q0), "=&v"(R.q1), "=&v"(R.q2), "=&v"(R.q3), "=&v"(R.q4) : "v"(addr) : "memory");
+#else
+    const u32x4v* p = reinterpret_cast<const u32x4v*>(&g_lds[aux_float_offset + pc * kAuxWords]);
+    R.q0 = p[0]; R.q1 = p[1]; R.q2 = p[2]; R.q3 = p[3]; R.q4 = p[4];
+#endif
+    return R;
+}
+// wait for the entry's reads (issued a whole visit earlier) and unpack it
+__device__ __forceinline__ Aux aux_wait(AuxRaw R) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.q0), "+v"(R.q1), "+v"(R.q2), "+v"(R.q3), "+v"(R.q4));
+#endif
     Aux X;
-    X.w0 = q0.x; X.imm0 = q0.y; X.imm1 = q0.z; X.row = q0.w;
-    X.off[0] = q1.x; X.off[1] = q1.y; X.off[2] = q1.z; X.off[3] = q1.w;
-    X.off[4] = q2.x; X.mask[0] = q2.y; X.mask[1] = q2.z; X.mask[2] = q2.w;
-    X.mask[3] = q3.x; X.mask[4] = q3.y; X.cell[0] = q3.z; X.cell[1] = q3.w;
-    X.cell[2] = q4.x; X.cell[3] = q4.y; X.cell[4] = q4.z; X.pad = 0;
+    X.w0 = R.q0.x; X.imm0 = R.q0.y; X.imm1 = R.q0.z; X.row = R.q0.w;
+    X.off[0] = R.q1.x; X.off[1] = R.q1.y; X.off[2] = R.q1.z; X.off[3] = R.q1.w;
+    X.off[4] = R.q2.x; X.mask[0] = R.q2.y; X.mask[1] = R.q2.z; X.mask[2] = R.q2.w;
+    X.mask[3] = R.q3.x; X.mask[4] = R.q3.y; X.cell[0] = R.q3.z; X.cell[1] = R.q3.w;
+    X.cell[2] = R.q4.x; X.cell[3] = R.q4.y; X.cell[4] = R.q4.z; X.pad = 0;
     return X;
 }
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -316,11 +337,21 @@ enum { SM_WSUM = 0, SM_LACC = 1, SM_ZG = 2 };
 // the lowering): uniform entries / observed data are read at byte_offset of the uniform region
 // (LDS offset 0), slots at lane_row + byte_offset, the adjoint of a slot 4 bytes further.
 // ONE ds_read per operand, no branches. ---------------------------------------------------------
-__device__ __forceinline__ float* lds_ptr(uint32_t byte_addr) {
-    return reinterpret_cast<float*>(reinterpret_cast<char*>(g_lds) + byte_addr);
+// Byte addresses are ABSOLUTE LDS addresses: the kernels that run elbo_block declare no static LDS, so the
+// dynamic array g_lds starts at 0 (checked once per launch in elbo_block).  Going through `g_lds + offset`
+// instead costs one `v_add_u32 v, 0, v` per access: the base is only known to be 0 after instruction selection.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) float lds_float_t;
+__device__ __forceinline__ float lds_ld(uint32_t byte_addr) { return *reinterpret_cast<lds_float_t*>(byte_addr); }
+__device__ __forceinline__ void lds_st(uint32_t byte_addr, float v) { *reinterpret_cast<lds_float_t*>(byte_addr) = v; }
+__device__ __forceinline__ uint32_t lds_base_of_dynamic_array() {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)g_lds;
 }
-__device__ __forceinline__ float lds_ld(uint32_t byte_addr) { return *lds_ptr(byte_addr); }
-__device__ __forceinline__ void lds_st(uint32_t byte_addr, float v) { *lds_ptr(byte_addr) = v; }
+#else
+__device__ __forceinline__ float lds_ld(uint32_t byte_addr) { return g_lds[byte_addr >> 2]; }
+__device__ __forceinline__ void lds_st(uint32_t byte_addr, float v) { g_lds[byte_addr >> 2] = v; }
+__device__ __forceinline__ uint32_t lds_base_of_dynamic_array() { return 0; }
+#endif
 __device__ __forceinline__ uint32_t opnd_offset(uint32_t o, uint32_t e) {
     const uint32_t per_lane = o >> 31;
     const uint32_t step = ((o >> 30) & 1u) * (4u + 4u * per_lane);      // 8 bytes per slot, 4 per entry
@@ -804,6 +835,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     // code already sits at the 128-VGPR limit of a 1024-thread workgroup, and the two entry buffers would spill
     constexpr bool FASTK = (SM == SM_LACC) && !OUT && !GEN;
     const uint32_t tid = threadIdx.x, nthreads = L.nthreads;
+    if (lds_base_of_dynamic_array() != 0u) __builtin_trap();      // lds_ld / lds_st use absolute addresses
     if (FASTK && copy_aux) {
         // (the persistent trainer copies once: nothing else writes this region)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(K.aux);
@@ -856,8 +888,9 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         // only on the generic path.  Two entry buffers alternate: the entry of visit i+1 is requested at the
         // start of visit i.
         uint32_t pc = 0;
-        Aux XA = ld_aux(L.aux, 0), XB = XA;
-        auto visit = [&](const Aux& X, Aux& Xn) {
+        AuxRaw XA = ld_aux(L.aux, 0), XB = XA;
+        auto visit = [&](const AuxRaw& Xr, AuxRaw& Xn) {
+            const Aux X = aux_wait(Xr);
             const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
             const bool sink = (w0 >> 24) & BSVI_R_SINK;
             if ((w0 >> 24) & kFastFlag) {
@@ -951,8 +984,9 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     // ---------------- reverse sweep: the posterior's sampling chain and the derived values
     if constexpr (FASTK) {
         uint32_t pc = K.n_code;
-        Aux XA = ld_aux(L.aux, pc - 1), XB = XA;
-        auto visit = [&](const Aux& X, Aux& Xn) {
+        AuxRaw XA = ld_aux(L.aux, pc - 1), XB = XA;
+        auto visit = [&](const AuxRaw& Xr, AuxRaw& Xn) {
+            const Aux X = aux_wait(Xr);
             const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
             const bool sink = (w0 >> 24) & BSVI_R_SINK;
             if (!sink && ((w0 >> 24) & kFastFlag)) {
