@@ -892,14 +892,16 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         auto visit = [&](const AuxRaw& Xr, AuxRaw& Xn) {
             const Aux X = aux_wait(Xr);
             const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
-            const bool sink = (w0 >> 24) & BSVI_R_SINK;
-            if ((w0 >> 24) & kFastFlag) {
+            if (w0 & (kFastFlag << 24)) {
                 const uint32_t npc = pc + 1;
                 Xn = ld_aux(L.aux, npc < K.n_code ? npc : 0);
-                if (sink) fast_sink(T, X);
+                if (w0 & (BSVI_R_SINK << 24)) fast_sink(T, X);
                 else fast_forward(K, T, X, w0);
                 pc = npc;
-            } else if (op == BSVI_OP_REC_BEGIN) {
+                return;
+            }
+            const bool sink = (w0 >> 24) & BSVI_R_SINK;
+            if (op == BSVI_OP_REC_BEGIN) {
                 const Insn I = ld_insn(K.code, pc);
                 const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
                 for (uint32_t e = 0; e < n_elems; ++e) {
@@ -988,13 +990,15 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         auto visit = [&](const AuxRaw& Xr, AuxRaw& Xn) {
             const Aux X = aux_wait(Xr);
             const uint32_t w0 = uniform_u32(X.w0), op = w0 & 0xFFu;
-            const bool sink = (w0 >> 24) & BSVI_R_SINK;
-            if (!sink && ((w0 >> 24) & kFastFlag)) {
+            if ((w0 & ((kFastFlag | BSVI_R_SINK) << 24)) == (kFastFlag << 24)) {
                 const uint32_t npc = pc - 1;
                 Xn = ld_aux(L.aux, npc > 0 ? npc - 1 : 0);
                 fast_backward(K, T, X, w0);
                 pc = npc;
-            } else if (op == BSVI_OP_REC_END) {
+                return;
+            }
+            const bool sink = (w0 >> 24) & BSVI_R_SINK;
+            if (op == BSVI_OP_REC_END) {
                 const Insn I = ld_insn(K.code, pc - 1);
                 const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
                 const uint32_t first = pc - 1 - n;          // index of the first body instruction
