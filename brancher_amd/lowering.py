@@ -283,6 +283,12 @@ class _Lowering:
 
     def p_value(self, var):
         if isinstance(var, RandomVariable) and var.is_observed:
+            if (not var.has_observed_value and getattr(var, "_type", None) == "Deterministic node"
+                    and not getattr(var, "has_random_dataset", False)):
+                # DeterministicVariable(data, name, is_observed=True) — the regressors of
+                # examples/multivariate_regression.py: the value is the link of its own observed root
+                # (datapoint axis first), `standard_variables.py:37-68,115-130`
+                return self.from_expr(var.link.expressions()["value"].expr, self.p_value)
             if not var.has_observed_value:
                 raise LoweringError("variable %r is observed through a random dataset (minibatch data path, "
                                     "SURVEY §8f-1): not lowered yet" % var.name)

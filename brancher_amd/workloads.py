@@ -118,6 +118,35 @@ def build_lognormal_normal(api, n_obs=20, seed=0):
     return model
 
 
+def build_multivariate_regression(api, n=100, seed=0):
+    """`examples/multivariate_regression.py:12-47`: observed regressors enter as
+    `DeterministicVariable(data, name, is_observed=True)` (datapoint axis of n rows), four Normal
+    weights and a LogNormal noise scale, Normal likelihood over the n datapoints."""
+    rng = np.random.RandomState(seed)
+    x_range = np.linspace(-1., 1., n)
+    x1 = api.DeterministicVariable(np.sin(2 * np.pi * 2 * x_range), name="x1", is_observed=True)
+    x2 = api.DeterministicVariable(x_range, name="x2", is_observed=True)
+    b = api.NormalVariable(0., 1., name="b")
+    w1 = api.NormalVariable(0., 1., name="w1")
+    w2 = api.NormalVariable(0., 1., name="w2")
+    w12 = api.NormalVariable(0., 1., name="w12")
+    nu = api.LogNormalVariable(0.2, 0.5, name="nu")
+    mean = b + w1 * x1 + w2 * x2 + w12 * x1 * x2
+    y = api.NormalVariable(mean, nu, name="y")
+    model = api.ProbabilisticModel([y])
+    Qb = api.NormalVariable(0., 1., name="b", learnable=True)
+    Qw1 = api.NormalVariable(0., 1., name="w1", learnable=True)
+    Qw2 = api.NormalVariable(0., 1., name="w2", learnable=True)
+    Qw12 = api.NormalVariable(0., 1., name="w12", learnable=True)
+    Qnu = api.LogNormalVariable(0.2, 0.5, name="nu", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qb, Qw1, Qw2, Qw12, Qnu]))
+    # data of the example's shape: one draw of the regression at fixed weights plus noise
+    truth = 0.3 - 0.8 * np.sin(2 * np.pi * 2 * x_range) + 0.5 * x_range + 1.2 * np.sin(2 * np.pi * 2 * x_range) * x_range
+    data = (truth + rng.normal(0., 0.4, size=n)).astype(np.float32)
+    y.observe(np.reshape(data, (n, 1, 1)))
+    return model
+
+
 def build_heavy_tails(api, n_obs=12, seed=1):
     """Cauchy / Laplace coverage (`examples/logNormal_normal.py` imports both): a Laplace
     location with Cauchy likelihood and an explicit nonlinear link."""
