@@ -118,6 +118,32 @@ def build_lognormal_normal(api, n_obs=20, seed=0):
     return model
 
 
+def build_observed_ar(api, T=200, seed=0, q_concentration=0.5):
+    """`examples/autoregressive.py:11-41`: a fully observed AR(1) chain; the latents are its coefficient
+    b ~ Beta and its noise scale nu ~ LogNormal, with a mean-field Beta / LogNormal posterior.
+    (The example initialises Qb = Beta(0.5, 0.5); its samples pile up at 0 and 1, where the fp32
+    reparameterisation gradient of the reference itself is 1e-3 away from the fp64 value — the parity
+    fixture uses q_concentration=2.)"""
+    rng = np.random.RandomState(seed)
+    series = np.zeros(T, dtype=np.float32)
+    series[0] = rng.normal(0., 1.)
+    for t in range(1, T):
+        series[t] = 0.7 * series[t - 1] + rng.normal(0., 0.6)
+    nu = api.LogNormalVariable(0.3, 1., "nu")
+    x0 = api.NormalVariable(0., 1., "x0")
+    b = api.BetaVariable(0.5, 1.5, "b")
+    x = [x0]
+    for t in range(1, T):
+        x.append(api.NormalVariable(b * x[t - 1], nu, "x{}".format(t)))
+    model = api.ProbabilisticModel(x)
+    for t, xt in enumerate(x):
+        xt.observe(np.array([series[t]], dtype=np.float32))
+    Qnu = api.LogNormalVariable(0.5, 1., "nu", learnable=True)
+    Qb = api.BetaVariable(q_concentration, q_concentration, "b", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qb, Qnu]))
+    return model
+
+
 def build_multivariate_regression(api, n=100, seed=0):
     """`examples/multivariate_regression.py:12-47`: observed regressors enter as
     `DeterministicVariable(data, name, is_observed=True)` (datapoint axis of n rows), four Normal

@@ -39,6 +39,7 @@ CASES = {
     "beta_binomial_N512": ("build_beta_binomial", dict(n_obs=30), 512, 4, dict(iters=6, n=128, optimizer="SGD", lr=0.1)),
     "lognormal_normal_N100": ("build_lognormal_normal", dict(n_obs=20), 100, 5,
                               dict(iters=5, n=50, optimizer="SGD", lr=1e-4)),
+    "observed_ar_T50_N40": ("build_observed_ar", dict(T=50, q_concentration=2.0), 40, 10, dict(iters=4, n=30, optimizer="Adam", lr=0.05)),
     "multivariate_regression_n100_N50": ("build_multivariate_regression", dict(n=100), 50, 9,
                                          dict(iters=5, n=40, optimizer="Adam", lr=1e-3)),
     "heavy_tails_N64": ("build_heavy_tails", dict(n_obs=12), 64, 6, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
