@@ -199,6 +199,28 @@ def logreg_data(dataset_size, n_features, n_classes, seed=0):
     return X, labels
 
 
+def build_binary_logistic_regression(api, dataset_size=50, batch_size=30, n_features=2, seed=0):
+    """`examples/minibatch_logistic_regression.py:13-43`: two Gaussian clouds, `BinomialVariable(1, logits =
+    matmul(weights, x))` observed through an `EmpiricalVariable` of labels that shares the minibatch indices of x."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    half = dataset_size // 2
+    x1 = rng.normal(1.5, 1.5, (half, n_features, 1))
+    x2 = rng.normal(-1.5, 1.5, (dataset_size - half, n_features, 1))
+    input_variable = np.concatenate((x1, x2), axis=0).astype(np.float32)
+    output_labels = np.concatenate((np.zeros((half, 1)), np.ones((dataset_size - half, 1))), axis=0).astype(np.float32)
+    indices = api.RandomIndices(dataset_size=dataset_size, batch_size=batch_size, name="indices", is_observed=True)
+    x = api.EmpiricalVariable(input_variable, indices=indices, name="x", is_observed=True)
+    labels = api.EmpiricalVariable(output_labels, indices=indices, name="labels", is_observed=True)
+    weights = api.NormalVariable(np.zeros((1, n_features)), 0.5 * np.ones((1, n_features)), "weights")
+    k = api.BinomialVariable(1, logits=BF.matmul(weights, x), name="k")
+    model = api.ProbabilisticModel([k])
+    k.observe(labels)
+    Qweights = api.NormalVariable(np.zeros((1, n_features)), np.ones((1, n_features)), "weights", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qweights]))
+    return model
+
+
 def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=784, n_classes=10, seed=0,
                               prior_scale=10., q_scale=0.1):
     """BASELINE config 4: Bayesian multinomial logistic regression with a dense `matmul` link and a

@@ -47,6 +47,9 @@ CASES = {
     "logreg_C3_P6_DS20_B12_N5": ("build_logistic_regression",
                                  dict(dataset_size=20, batch_size=12, n_features=6, n_classes=3), 5, 7,
                                  dict(iters=5, n=6, optimizer="Adam", lr=5e-3)),
+    # examples/minibatch_logistic_regression.py: Binomial(1, logits) likelihood, labels through a shared minibatch
+    "logreg_binary_P2_DS50_B30_N6": ("build_binary_logistic_regression", dict(dataset_size=50, batch_size=30, n_features=2),
+                                     6, 11, dict(iters=5, n=8, optimizer="Adam", lr=0.05)),
     "logreg_C10_P784_DS24_B16_N4": ("build_logistic_regression",
                                     dict(dataset_size=24, batch_size=16, n_features=784, n_classes=10), 4, 8, None),
 }
