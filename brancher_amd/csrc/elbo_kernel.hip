@@ -51,6 +51,7 @@ struct KParams {
     unsigned long long* stamps;   // diagnostic build only: phase time stamps of block 0 (or NULL)
     uint32_t n_code, n_uniform, n_uniform_grad, n_slots, n_noise, n_obs, estimator;
     uint32_t n_local, n_global, sample_base, n_pad;
+    uint32_t lpw;           // lanes of a wave that carry samples (64; fewer when a full wave's rows do not fit LDS)
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
 };
 
@@ -126,6 +127,7 @@ struct Lay {   // wave-uniform layout
                                         // dU accumulators and of the write-only dummy cell
     uint32_t ugrad_bytes;               // uniform entries below this byte offset carry gradients
     uint32_t nthreads, n_waves;
+    uint32_t lpw, rpw;                  // sample lanes per wave; rows per wave (lpw, +1 shared dummy row if lpw < 64)
 };
 
 // per-lane state — lives in registers: never take its address across a call
@@ -825,7 +827,9 @@ __device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
     L.uacc = 2 * K.n_slots * 4;
     L.dummy = L.uacc + L.ugrad_bytes;
     L.row_words = (SM == SM_LACC) ? ((2 * K.n_slots + K.n_uniform_grad + 1) | 1u) : (2 * K.n_slots + 1);
-    L.aux = (L.rows + L.nthreads * L.row_words + 3u) & ~3u;      // 16-byte aligned: entries are read as uint4
+    L.lpw = K.lpw;
+    L.rpw = K.lpw + (K.lpw < 64u ? 1u : 0u);
+    L.aux = (L.rows + n_waves * L.rpw * L.row_words + 3u) & ~3u;   // 16-byte aligned: entries are read as uint4
     return L;
 }
 
@@ -864,8 +868,10 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     T.tid = tid;
     T.wave = tid >> 6;
     T.lane = tid & 63u;
-    T.n = block_first_sample + tid;
-    const bool active = T.n < K.n_local;
+    // narrow geometry (lpw < 64): only the first lpw lanes of a wave carry samples; the others run along on one
+    // shared dummy row (their results are masked out everywhere), so that the rows of a wave fit LDS
+    T.n = block_first_sample + T.wave * L.lpw + T.lane;
+    const bool active = T.lane < L.lpw && T.n < K.n_local;
     T.nc = active ? T.n : (K.n_local - 1);
     T.mask = active ? 1.0f : 0.0f;
     T.f = 0.0f;
@@ -874,7 +880,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     T.nidx = K.sample_base + T.nc;
     T.cached_group = 0xFFFFFFFFu;
     T.c0 = T.c1 = T.c2 = T.c3 = 0.0f;
-    T.zrow = (L.rows + tid * L.row_words) * 4u;
+    T.zrow = (L.rows + (T.wave * L.rpw + min(T.lane, L.lpw)) * L.row_words) * 4u;
 
     for (uint32_t s = 0; s < K.n_slots; ++s) st_adj<SM>(K, T, s * 8u, 0.0f);
     if (SM == SM_LACC)
@@ -1084,7 +1090,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
         for (uint32_t i = tid; i < K.n_uniform_grad * L.n_waves; i += nthreads) {
             const uint32_t k = i / L.n_waves, wv = i - k * L.n_waves;
             float s = 0.0f;
-            for (uint32_t l = wv * 64u; l < wv * 64u + 64u; ++l) s += lds_ld(cell0 + 4u * k + l * row_bytes);
+            for (uint32_t l = wv * L.rpw; l < wv * L.rpw + L.lpw; ++l) s += lds_ld(cell0 + 4u * k + l * row_bytes);
             g_lds[L.uadj + i] = s;
         }
         __syncthreads();
@@ -1107,7 +1113,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
 template <int SM, bool OUT, bool GEN>
 __global__ void __launch_bounds__(1024) elbo_kernel(const KParams K) {
     const Lay L = make_layout<SM>(K, blockDim.x >> 6);
-    elbo_block<SM, OUT, GEN>(K, L, blockIdx.x * blockDim.x);
+    elbo_block<SM, OUT, GEN>(K, L, blockIdx.x * (blockDim.x >> 6) * K.lpw);
     float* part = K.partials + (size_t)blockIdx.x * (2 + K.n_uniform_grad);
     if (threadIdx.x == 0) { part[0] = g_lds[L.red]; part[1] = g_lds[L.red + 1]; }
     for (uint32_t k = threadIdx.x; k < K.n_uniform_grad; k += blockDim.x) part[2 + k] = g_lds[L.uadj + k * L.n_waves];
@@ -1628,12 +1634,13 @@ struct Geometry {
     bool zglobal = false;
     size_t lds_bytes = 0;
     uint32_t n_pad = 0;
+    uint32_t lpw = 64;      // sample lanes per wave (lds+lane_acc only: narrower when a full wave does not fit)
 };
 
-static size_t lds_need(const bsvi_program* p, uint32_t n_waves, int mode) {
+static size_t lds_need(const bsvi_program* p, uint32_t n_waves, int mode, uint32_t lpw = 64) {
     size_t floats = (size_t)p->d.n_uniform + (size_t)p->d.n_obs + (size_t)p->d.n_uniform_grad * n_waves + 4 * (size_t)n_waves;
     if (mode == SM_WSUM) floats += (2 * (size_t)p->d.n_slots + 1) * n_waves * 64;
-    if (mode == SM_LACC) floats += ((2 * (size_t)p->d.n_slots + p->d.n_uniform_grad + 1) | 1) * n_waves * 64
+    if (mode == SM_LACC) floats += ((2 * (size_t)p->d.n_slots + p->d.n_uniform_grad + 1) | 1) * n_waves * (lpw + (lpw < 64 ? 1 : 0))
                                    + 4 + (size_t)p->d.n_code * kAuxWords;     // + LDS copy of the Aux table
     return floats * 4 + 64;
 }
@@ -1660,16 +1667,25 @@ static Geometry choose_geometry(const bsvi_program* p, uint32_t n_local, bool si
     } else {
         uint32_t w = 4;
         while (w > 1 && best_lds_mode(w) < 0) w >>= 1;
-        if (best_lds_mode(w) >= 0) {
+        // a full wave's rows with per-lane accumulators do not fit: a narrower wave (32 or 16 sample lanes) keeps
+        // the lane_acc layout and its pre-resolved handlers, ~4x faster per visit than the wave_sum layout, which
+        // more than pays for the idle lanes (BASELINE config 3: T=200)
+        uint32_t narrow = 0;
+        if (!fits(1, SM_LACC))
+            for (uint32_t l = 32; l >= 16 && !narrow; l >>= 1)
+                if (lds_need(p, 1, SM_LACC, l) <= budget) narrow = l;
+        if (narrow) {
+            g.n_waves = 1; g.mode = SM_LACC; g.lpw = narrow;
+        } else if (best_lds_mode(w) >= 0) {
             g.n_waves = w; g.mode = best_lds_mode(w);
         } else {
             g.n_waves = 4; g.mode = SM_ZG;
             if (!fits(4, SM_ZG)) return Geometry();
         }
-        g.n_blocks = (waves_total + g.n_waves - 1) / g.n_waves;
+        g.n_blocks = (n_local + g.n_waves * g.lpw - 1) / (g.n_waves * g.lpw);
     }
     g.zglobal = g.mode == SM_ZG;
-    g.lds_bytes = lds_need(p, g.n_waves, g.mode);
+    g.lds_bytes = lds_need(p, g.n_waves, g.mode, g.lpw);
     g.n_pad = g.n_blocks * g.n_waves * 64;
     return g;
 }
@@ -1711,6 +1727,7 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     K.n_slots = p->d.n_slots; K.n_noise = p->d.n_noise; K.n_obs = p->d.n_obs; K.estimator = p->d.estimator;
     K.n_local = a->n_samples_local; K.n_global = a->n_samples_global; K.sample_base = a->sample_base;
     K.n_pad = g.n_pad;
+    K.lpw = g.lpw;
     K.seed_lo = (uint32_t)a->seed; K.seed_hi = (uint32_t)(a->seed >> 32);
     K.offset_lo = (uint32_t)a->offset; K.offset_hi = (uint32_t)(a->offset >> 32);
     return BSVI_OK;
@@ -1889,7 +1906,8 @@ extern "C" int bsvi_query_geometry(const bsvi_program* p, uint32_t n_local, uint
     if (!g.n_blocks) return fail(BSVI_ERR_RESOURCE, "program does not fit the LDS budget");
     if (n_blocks) *n_blocks = g.n_blocks;
     if (n_waves) *n_waves = g.n_waves;
-    if (zglobal) *zglobal = (uint32_t)g.mode;   // 0 LDS rows + wave sums, 1 LDS rows + lane accumulators, 2 global slots
+    // low byte: 0 LDS rows + wave sums, 1 LDS rows + lane accumulators, 2 global slots; next byte: sample lanes per wave
+    if (zglobal) *zglobal = (uint32_t)g.mode | (g.lpw << 8);
     if (lds_bytes) *lds_bytes = g.lds_bytes;
     return BSVI_OK;
 }

@@ -185,8 +185,10 @@ class NativeProgram:
     def geometry(self, n_local):
         nb, nw, zg, lds = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
         check(self.lib.bsvi_query_geometry(self.handle, n_local, C.byref(nb), C.byref(nw), C.byref(zg), C.byref(lds)))
-        return dict(n_blocks=nb.value, n_waves=nw.value, zglobal=zg.value == 2,
-                    storage=("lds+wave_sum", "lds+lane_acc", "global")[zg.value], lds_bytes=lds.value)
+        mode, lanes = zg.value & 0xFF, (zg.value >> 8) & 0xFF
+        return dict(n_blocks=nb.value, n_waves=nw.value, zglobal=mode == 2,
+                    storage=("lds+wave_sum", "lds+lane_acc", "global")[mode], lanes_per_wave=lanes or 64,
+                    lds_bytes=lds.value)
 
     def persistent_supported(self, n_local):
         return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))
