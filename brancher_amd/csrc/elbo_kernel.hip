@@ -1655,32 +1655,43 @@ static Geometry choose_geometry(const bsvi_program* p, uint32_t n_local, bool si
     const uint32_t waves_total = (n_local + 63) / 64;
     const size_t budget = (size_t)p->max_lds;
     auto fits = [&](uint32_t w, int mode) { return lds_need(p, w, mode) <= budget; };
-    auto best_lds_mode = [&](uint32_t w) { return fits(w, SM_LACC) ? SM_LACC : (fits(w, SM_WSUM) ? SM_WSUM : -1); };
-    if (waves_total <= 16 && best_lds_mode(waves_total) >= 0) {
-        g.n_waves = waves_total; g.n_blocks = 1; g.mode = best_lds_mode(waves_total);
+    const bool one_block = waves_total <= 16;
+    if (one_block && fits(waves_total, SM_LACC)) {
+        g.n_waves = waves_total; g.n_blocks = 1; g.mode = SM_LACC;
     } else if (single_block_only) {
-        if (waves_total <= 16 && fits(waves_total, SM_ZG)) {
+        if (one_block && fits(waves_total, SM_WSUM)) {
+            g.n_waves = waves_total; g.n_blocks = 1; g.mode = SM_WSUM;
+        } else if (one_block && fits(waves_total, SM_ZG)) {
             g.n_waves = waves_total; g.n_blocks = 1; g.mode = SM_ZG;
         } else {
             return g;
         }
     } else {
+        // several workgroups.  The lane_acc layout (pre-resolved handlers, ~4x cheaper per visit) is worth more
+        // than running as one workgroup: 4, 2 or 1 full waves, else a NARROW wave (32 or 16 sample lanes, the
+        // rest idle on a shared dummy row — BASELINE config 3, T=200: a sample's row is 3.2 KB); only then the
+        // wave_sum layout (one workgroup if the shard fits one), and global slots last.
         uint32_t w = 4;
-        while (w > 1 && best_lds_mode(w) < 0) w >>= 1;
-        // a full wave's rows with per-lane accumulators do not fit: a narrower wave (32 or 16 sample lanes) keeps
-        // the lane_acc layout and its pre-resolved handlers, ~4x faster per visit than the wave_sum layout, which
-        // more than pays for the idle lanes (BASELINE config 3: T=200)
+        while (w > 1 && !fits(w, SM_LACC)) w >>= 1;
         uint32_t narrow = 0;
         if (!fits(1, SM_LACC))
             for (uint32_t l = 32; l >= 16 && !narrow; l >>= 1)
                 if (lds_need(p, 1, SM_LACC, l) <= budget) narrow = l;
-        if (narrow) {
+        if (fits(w, SM_LACC)) {
+            g.n_waves = w; g.mode = SM_LACC;
+        } else if (narrow) {
             g.n_waves = 1; g.mode = SM_LACC; g.lpw = narrow;
-        } else if (best_lds_mode(w) >= 0) {
-            g.n_waves = w; g.mode = best_lds_mode(w);
+        } else if (one_block && fits(waves_total, SM_WSUM)) {
+            g.n_waves = waves_total; g.mode = SM_WSUM;
         } else {
-            g.n_waves = 4; g.mode = SM_ZG;
-            if (!fits(4, SM_ZG)) return Geometry();
+            w = 4;
+            while (w > 1 && !fits(w, SM_WSUM)) w >>= 1;
+            if (fits(w, SM_WSUM)) {
+                g.n_waves = w; g.mode = SM_WSUM;
+            } else {
+                g.n_waves = 4; g.mode = SM_ZG;
+                if (!fits(4, SM_ZG)) return Geometry();
+            }
         }
         g.n_blocks = (n_local + g.n_waves * g.lpw - 1) / (g.n_waves * g.lpw);
     }
@@ -1850,8 +1861,11 @@ extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, con
 
 extern "C" int bsvi_persistent_supported(const bsvi_program* p, uint32_t n_local) {
     if (!p || !n_local) return 0;
-    Geometry g = choose_geometry(p, n_local, true);
-    return (g.n_blocks == 1 && g.mode != SM_ZG) ? 1 : 0;   // a spilled (global-slot) workgroup is slower than many LDS ones
+    // One launch for the whole loop pays when the single workgroup runs the fast layout, or when several
+    // workgroups would not run it either; a spilled (global-slot) workgroup is always slower than many LDS ones.
+    const Geometry g = choose_geometry(p, n_local, true), m = choose_geometry(p, n_local, false);
+    if (g.n_blocks != 1 || g.mode == SM_ZG) return 0;
+    return (g.mode == SM_LACC || m.mode != SM_LACC) ? 1 : 0;
 }
 
 extern "C" int bsvi_train_persistent(const bsvi_program* p, const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
