@@ -107,6 +107,8 @@ typedef enum bsvi_op {
 
 #define BSVI_R_SINK 1u
 #define BSVI_R_NOALIAS 2u   /* no two operands of the instruction share an adjoint cell */
+/* (rflags bits 2..7 are reserved for the library: bsvi_program_create marks, in its device copy, the top-level
+ *  NAFF instructions it pre-resolves into its internal address table — DESIGN.md §4.2) */
 
 /* BSVI_F_GIVEN (with BSVI_F_SAMPLE): the node's noise row holds the VALUE of the variable, not its noise —
  * evaluation programs that score caller-supplied samples (importance weights, variables.py:821-841);
