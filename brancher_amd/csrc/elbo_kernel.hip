@@ -52,6 +52,8 @@ struct KParams {
     uint32_t n_code, n_uniform, n_uniform_grad, n_slots, n_noise, n_obs, estimator;
     uint32_t n_local, n_global, sample_base, n_pad;
     uint32_t lpw;           // lanes of a wave that carry samples (64; fewer when a full wave's rows do not fit LDS)
+    uint32_t stash;         // lds+lane_acc: rows carry one cell per noise row; the reverse sweep reads eps back
+                            // instead of regenerating it (Philox + Box-Muller are ~8 % of a wave's instructions)
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
 };
 
@@ -292,7 +294,7 @@ __device__ __forceinline__ bsvi_record ld_record(const bsvi_record* recs, uint32
 // prefetch in flight forces every LDS wait of the visit to drain it; (3) global loads of the entry
 // (tried) cost an L1/L2 round trip longer than a visit.  The single-SIMD wave stream is issue-bound
 // (every instruction, scalar or vector, costs ~4.7 cycles), so this table roughly halves the cost of a node.
-struct Aux { uint32_t w0, imm0, imm1, row, off[5], mask[5], cell[5], pad; };
+struct Aux { uint32_t w0, imm0, imm1, row, off[5], mask[5], cell[5], eps_cell; };   // eps_cell: stash of the node's noise
 constexpr uint32_t kAuxWords = 20;
 constexpr uint32_t kFastFlag = 4u;      // rflags bit set in the DEVICE copy of the code (not part of the ABI)
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
@@ -325,7 +327,7 @@ __device__ __forceinline__ Aux aux_wait(AuxRaw R) {
     X.off[0] = R.q1.x; X.off[1] = R.q1.y; X.off[2] = R.q1.z; X.off[3] = R.q1.w;
     X.off[4] = R.q2.x; X.mask[0] = R.q2.y; X.mask[1] = R.q2.z; X.mask[2] = R.q2.w;
     X.mask[3] = R.q3.x; X.mask[4] = R.q3.y; X.cell[0] = R.q3.z; X.cell[1] = R.q3.w;
-    X.cell[2] = R.q4.x; X.cell[3] = R.q4.y; X.cell[4] = R.q4.z; X.pad = 0;
+    X.cell[2] = R.q4.x; X.cell[3] = R.q4.y; X.cell[4] = R.q4.z; X.eps_cell = R.q4.w;
     return X;
 }
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -579,6 +581,7 @@ __device__ __forceinline__ void fast_forward(const KParams& K, Lane& T, const Au
         const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
         v = loc + eps * S;
         lds_st(F.v[0], v);
+        if (K.stash) lds_st(T.zrow + X.eps_cell, eps);
     } else {
         v = lds_ld(F.v[0]);
     }
@@ -609,9 +612,14 @@ __device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, const A
     float gdst = gv;
     if (flags & BSVI_F_SAMPLE) {
         // a sampled latent's own cell holds its incoming adjoint: read, folded into loc/scale, written back unchanged
-        const uint32_t row = uniform_u32(X.row);
         const float zb = od + gv;
-        const float eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+        float eps;
+        if (K.stash) {
+            eps = lds_ld(T.zrow + X.eps_cell);
+        } else {
+            const uint32_t row = uniform_u32(X.row);
+            eps = K.noise ? K.noise[(size_t)row * K.n_local + T.nc] : philox_normal(K, T, row);
+        }
         gloc += zb;
         gS += zb * eps;
         gdst = 0.0f;
@@ -826,7 +834,8 @@ __device__ __forceinline__ Lay make_layout(const KParams& K, uint32_t n_waves) {
     L.rows = L.red + 4 * n_waves;
     L.uacc = 2 * K.n_slots * 4;
     L.dummy = L.uacc + L.ugrad_bytes;
-    L.row_words = (SM == SM_LACC) ? ((2 * K.n_slots + K.n_uniform_grad + 1) | 1u) : (2 * K.n_slots + 1);
+    L.row_words = (SM == SM_LACC) ? ((2 * K.n_slots + K.n_uniform_grad + 1 + (K.stash ? K.n_noise : 0u)) | 1u)
+                                  : (2 * K.n_slots + 1);
     L.lpw = K.lpw;
     L.rpw = K.lpw + (K.lpw < 64u ? 1u : 0u);
     L.aux = (L.rows + n_waves * L.rpw * L.row_words + 3u) & ~3u;   // 16-byte aligned: entries are read as uint4
@@ -1543,6 +1552,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
                 x[14 + k] = lane ? off + 4u : (off < ugrad ? uacc + off : dummy);
             }
             x[3] = (w[1] & 0x3FFFFFFFu) >> 3;
+            x[19] = dummy + 4u + 4u * x[3];          // the node's cell in the eps stash behind the dummy cell
             w[0] |= kFastFlag << 24;
             x[0] = w[0];
         }
@@ -1635,12 +1645,14 @@ struct Geometry {
     size_t lds_bytes = 0;
     uint32_t n_pad = 0;
     uint32_t lpw = 64;      // sample lanes per wave (lds+lane_acc only: narrower when a full wave does not fit)
+    bool stash = false;     // lds+lane_acc rows also hold the sample's noise (KParams::stash)
 };
 
-static size_t lds_need(const bsvi_program* p, uint32_t n_waves, int mode, uint32_t lpw = 64) {
+static size_t lds_need(const bsvi_program* p, uint32_t n_waves, int mode, uint32_t lpw = 64, bool stash = false) {
     size_t floats = (size_t)p->d.n_uniform + (size_t)p->d.n_obs + (size_t)p->d.n_uniform_grad * n_waves + 4 * (size_t)n_waves;
     if (mode == SM_WSUM) floats += (2 * (size_t)p->d.n_slots + 1) * n_waves * 64;
-    if (mode == SM_LACC) floats += ((2 * (size_t)p->d.n_slots + p->d.n_uniform_grad + 1) | 1) * n_waves * (lpw + (lpw < 64 ? 1 : 0))
+    if (mode == SM_LACC) floats += ((2 * (size_t)p->d.n_slots + p->d.n_uniform_grad + 1 + (stash ? p->d.n_noise : 0)) | 1)
+                                   * n_waves * (lpw + (lpw < 64 ? 1 : 0))
                                    + 4 + (size_t)p->d.n_code * kAuxWords;     // + LDS copy of the Aux table
     return floats * 4 + 64;
 }
@@ -1696,7 +1708,10 @@ static Geometry choose_geometry(const bsvi_program* p, uint32_t n_local, bool si
         g.n_blocks = (n_local + g.n_waves * g.lpw - 1) / (g.n_waves * g.lpw);
     }
     g.zglobal = g.mode == SM_ZG;
-    g.lds_bytes = lds_need(p, g.n_waves, g.mode, g.lpw);
+    // the eps stash rides along whenever the chosen lane_acc geometry still fits with it (generic programs keep
+    // regenerating: their kernels do not have the pre-resolved handlers that use it)
+    g.stash = g.mode == SM_LACC && !p->generic && lds_need(p, g.n_waves, g.mode, g.lpw, true) <= budget;
+    g.lds_bytes = lds_need(p, g.n_waves, g.mode, g.lpw, g.stash);
     g.n_pad = g.n_blocks * g.n_waves * 64;
     return g;
 }
@@ -1739,6 +1754,7 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     K.n_local = a->n_samples_local; K.n_global = a->n_samples_global; K.sample_base = a->sample_base;
     K.n_pad = g.n_pad;
     K.lpw = g.lpw;
+    K.stash = g.stash ? 1u : 0u;
     K.seed_lo = (uint32_t)a->seed; K.seed_hi = (uint32_t)(a->seed >> 32);
     K.offset_lo = (uint32_t)a->offset; K.offset_hi = (uint32_t)(a->offset >> 32);
     return BSVI_OK;
