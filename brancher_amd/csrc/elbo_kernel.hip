@@ -587,9 +587,11 @@ __device__ __forceinline__ void fast_forward(const KParams& K, Lane& T, const Au
     }
     const float logS = log_pos(S);
     if (flags & BSVI_F_ENT) T.f += w_ent * (kHalfLog2PiE + logS);
-    if (flags & BSVI_F_LOGP) {
+    if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
         const float u = (v - loc) * __builtin_amdgcn_rcpf(S);
-        T.f += w_lp * (-0.5f * (u * u) - logS - kLogSqrt2Pi);
+        const float lp = -0.5f * (u * u) - logS - kLogSqrt2Pi;
+        T.f += w_lp * lp;
+        if (flags & BSVI_F_WF) T.lq += lp;          // score term of the BlackBox estimator (gradient_estimators.py:33)
     }
 }
 __device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, const Aux& X, uint32_t w0) {
@@ -601,8 +603,8 @@ __device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, const A
     const float loc = A * B + Cc;
     const float rS = __builtin_amdgcn_rcpf(S);
     float gloc = 0.0f, gS = 0.0f, gv = 0.0f;
-    if (flags & BSVI_F_LOGP) {
-        const float gw = w_lp * T.mask;
+    if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+        const float gw = (w_lp + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
         const float d = v - loc, t = d * (rS * rS);
         gv = -gw * t;
         gloc = gw * t;
@@ -1541,7 +1543,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
             x[0] = w[0]; x[1] = w[6]; x[2] = w[7];
             if (body_left) { --body_left; continue; }
             if (op == BSVI_OP_REC_BEGIN) { body_left = w[1] + 1; continue; }
-            if (op != BSVI_OP_NAFF || !(rflags & BSVI_R_NOALIAS) || (flags & (BSVI_F_WF | BSVI_F_GIVEN))) continue;
+            if (op != BSVI_OP_NAFF || !(rflags & BSVI_R_NOALIAS) || (flags & BSVI_F_GIVEN)) continue;
             bool ok = true;
             for (int k = 0; k < 5; ++k) ok = ok && !((w[1 + k] >> 30) & 1u);
             if (!ok) continue;
