@@ -5,18 +5,22 @@
 // fetched through the scalar cache.  Per workgroup:
 //
 //   prologue   U[k] = a + b*g(theta|const)  — every lane-uniform parameter transform, once
-//   forward    q records: link -> SAMPLE (noise from HBM [row][N], or in-register Philox)
-//              -> ENTROPY;  p records: link -> LOGP.  Samples live in LDS as Z[slot][lane]
-//              (bank-conflict-free: consecutive lanes, consecutive dwords); f and log q stay
-//              in registers.
-//   backward   records in reverse; each record re-evaluates its (tiny) link into registers
-//              and runs the hand-derived adjoints.  Adjoints of samples accumulate in LDS
-//              Zb[slot][lane]; adjoints of lane-uniform values are summed across the 64 lanes
-//              with DPP row reductions + v_readlane and accumulated per wave in LDS — no
-//              atomics, bitwise reproducible.
+//   forward    q nodes: link -> SAMPLE (noise from HBM [row][N], or in-register Philox) -> ENTROPY;
+//              p nodes (sinks): link -> LOGP and, in the same visit, their adjoints.  A sample's
+//              values and adjoints live in its own LDS row (odd row length: the 64 lanes of a wave
+//              hit 64 banks); f and log q stay in registers.
+//   reverse    the posterior's sampling chain in reverse, hand-derived adjoints.  Storage modes:
+//              lds+lane_acc — the row also carries one accumulator per parameter-sourced uniform
+//                entry (no cross-lane traffic in the sweeps, one fixed-order lane reduction per launch)
+//                and, when it fits, the node's noise; top-level Normal nodes run on handlers whose
+//                addresses bsvi_program_create resolved beforehand (struct Aux);
+//              lds+wave_sum — uniform adjoints are summed over the 64 lanes with DPP + v_readlane and
+//                accumulated per wave; global — rows spill to a [slot][N] workspace.
+//              No atomics anywhere: bitwise reproducible.
 //   epilogue   per-workgroup partial sums -> workspace; `reduce_kernel` (one workgroup) adds
 //              them in fixed order, applies dU/dtheta through a CSR map, and optionally fuses
-//              the .mean()/sign (`finalize`) and the optimizer step.
+//              the .mean()/sign (`finalize`) and the optimizer step.  `persistent_kernel` keeps
+//              the whole optimisation loop inside one launch.
 //
 // This replaces, per iteration, the ~18 400 ATen dispatches the reference issues from
 // brancher/variables.py:486-570,718-749,843-870 + gradient_estimators.py:29-44 +
