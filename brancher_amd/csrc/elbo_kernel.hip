@@ -53,6 +53,12 @@ struct KParams {
     float* partials;   // [grid][2 + n_uniform_grad]
     float* zglobal;    // ZG variant: [2 * n_slots][n_pad]
     unsigned long long* stamps;   // diagnostic build only: phase time stamps of block 0 (or NULL)
+    // single-workgroup launches of bsvi_elbo_fwd_bwd: the chain rule to theta runs in the kernel's own epilogue
+    // and the output block is written here (no reduce_kernel launch); NULL otherwise
+    float* fuse_out;
+    const uint32_t* pu_ptr;
+    const uint32_t* pu_idx;
+    uint32_t n_params;
     uint32_t n_code, n_uniform, n_uniform_grad, n_slots, n_noise, n_obs, estimator;
     uint32_t n_local, n_global, sample_base, n_pad;
     uint32_t lpw;           // lanes of a wave that carry samples (64; fewer when a full wave's rows do not fit LDS)
@@ -1129,6 +1135,22 @@ template <int SM, bool OUT, bool GEN>
 __global__ void __launch_bounds__(1024) elbo_kernel(const KParams K) {
     const Lay L = make_layout<SM>(K, blockDim.x >> 6);
     elbo_block<SM, OUT, GEN>(K, L, blockIdx.x * (blockDim.x >> 6) * K.lpw);
+    if (K.fuse_out) {
+        // the only workgroup: what reduce_kernel would do with its one block of partials (sums, not yet scaled)
+        float* out = K.fuse_out;
+        if (threadIdx.x == 0) { out[0] = g_lds[L.red]; out[1] = g_lds[L.red + 1]; }
+        for (uint32_t i = threadIdx.x; i < K.n_params; i += blockDim.x) {
+            float gsum = 0.0f;
+            const float theta = K.params[i];
+            for (uint32_t j = K.pu_ptr[i]; j < K.pu_ptr[i + 1]; ++j) {
+                const uint32_t k = K.pu_idx[j];
+                const bsvi_uniform_entry e = K.uniform[k];
+                gsum += g_lds[L.uadj + k * L.n_waves] * (e.b * utransform_grad(e.transform, theta));
+            }
+            out[BSVI_OUT_HEADER + i] = gsum;
+        }
+        return;
+    }
     float* part = K.partials + (size_t)blockIdx.x * (2 + K.n_uniform_grad);
     if (threadIdx.x == 0) { part[0] = g_lds[L.red]; part[1] = g_lds[L.red + 1]; }
     for (uint32_t k = threadIdx.x; k < K.n_uniform_grad; k += blockDim.x) part[2 + k] = g_lds[L.uadj + k * L.n_waves];
@@ -1755,6 +1777,7 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     K.partials = (float*)a->workspace_dev;
     K.zglobal = (float*)((char*)a->workspace_dev + partial_bytes(p, g));
     K.stamps = g_debug_stamps;
+    K.fuse_out = nullptr; K.pu_ptr = p->pu_ptr; K.pu_idx = p->pu_idx; K.n_params = p->d.n_params;
     K.n_code = p->d.n_code; K.n_uniform = p->d.n_uniform; K.n_uniform_grad = p->d.n_uniform_grad;
     K.n_slots = p->d.n_slots; K.n_noise = p->d.n_noise; K.n_obs = p->d.n_obs; K.estimator = p->d.estimator;
     K.n_local = a->n_samples_local; K.n_global = a->n_samples_global; K.sample_base = a->sample_base;
@@ -1809,6 +1832,10 @@ extern "C" int bsvi_elbo_fwd_bwd(const bsvi_program* p, const bsvi_elbo_args* a)
     KParams K;
     int rc = fill_kparams(p, a, g, K);
     if (rc) return rc;
+    if (g.n_blocks == 1) {
+        K.fuse_out = a->out_dev;          // one workgroup: its epilogue writes the output block, one launch in all
+        return launch_elbo(p, g, K, (hipStream_t)a->stream);
+    }
     rc = launch_elbo(p, g, K, (hipStream_t)a->stream);
     if (rc) return rc;
     RParams R;
