@@ -173,6 +173,23 @@ def build_multivariate_regression(api, n=100, seed=0):
     return model
 
 
+def build_discrete_latent(api, n_obs=8, seed=0):
+    """A discrete (non-reparameterisable) latent: z ~ Bernoulli shifts the mean of a Normal likelihood, q(z) is a
+    Bernoulli with a learnable logit.  Its gradient exists only through the score-function term of the BlackBox
+    estimator (`gradient_estimators.py:31-36`; `.sample()` at distributions.py:123-124); the Pathwise estimator
+    gives it none, exactly as in the reference."""
+    rng = np.random.RandomState(seed)
+    z = api.BernulliVariable(probs=0.3, name="z")
+    m = api.NormalVariable(0., 1., "m")
+    x = api.NormalVariable(m + z * 2.0, 0.7, "x")
+    model = api.ProbabilisticModel([x])
+    x.observe(rng.normal(1.5, 0.7, size=n_obs).astype(np.float32))
+    Qz = api.BernulliVariable(logits=0.2, name="z", learnable=True)
+    Qm = api.NormalVariable(0.1, 0.8, "m", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qz, Qm]))
+    return model
+
+
 def build_heavy_tails(api, n_obs=12, seed=1):
     """Cauchy / Laplace coverage (`examples/logNormal_normal.py` imports both): a Laplace
     location with Cauchy likelihood and an explicit nonlinear link."""
