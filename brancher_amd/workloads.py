@@ -173,6 +173,25 @@ def build_multivariate_regression(api, n=100, seed=0):
     return model
 
 
+def build_learnable_model(api, n_obs=15, seed=0):
+    """Learnable parameters in the JOINT model as well as in the posterior (type-II maximum likelihood): the
+    likelihood's scale and the prior's location are `learnable=True` roots of p.  `perform_inference` then runs two
+    optimizers — the posterior's always, the model's only when `iteration > pretraining_iterations`
+    (`inference.py:77-88,102-104`)."""
+    rng = np.random.RandomState(seed)
+    data = rng.normal(0.8, 1.3, size=n_obs).astype(np.float32)
+    # (an explicitly named root: the auto-created roots of a prior variable `mu` would be called mu_loc / mu_scale
+    #  like the posterior's, and the reference then silently substitutes the posterior's — DESIGN.md §2)
+    prior_loc = api.RootVariable(0.2, "prior_loc", learnable=True)  # learnable prior location
+    mu = api.NormalVariable(prior_loc, 2., "mu")
+    x = api.NormalVariable(mu, 1., "x", learnable=True)             # learnable likelihood scale (root x_scale)
+    model = api.ProbabilisticModel([x])
+    x.observe(data)
+    Qmu = api.NormalVariable(0., 1., "mu", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qmu]))
+    return model
+
+
 def build_discrete_latent(api, n_obs=8, seed=0):
     """A discrete (non-reparameterisable) latent: z ~ Bernoulli shifts the mean of a Normal likelihood, q(z) is a
     Bernoulli with a learnable logit.  Its gradient exists only through the score-function term of the BlackBox
