@@ -121,15 +121,26 @@ class IR:
         return "IR(%s%s)" % (self.op, "" if not self.args else "," + ",".join(a.op for a in self.args))
 
 
-def _stride_flag(leaf_shape, rec_shape):
-    """0 = broadcast (scalar leaf), 1 = walks the record's flattened element loop."""
-    size = int(np.prod(leaf_shape))
-    if size == 1:
-        return 0
-    if tuple(leaf_shape) != tuple(rec_shape):
-        raise LoweringError("partial broadcasting of a %r operand inside a %r node is not supported by the "
-                            "fused kernel" % (tuple(leaf_shape), tuple(rec_shape)))
-    return 1
+def _split_axis(rec_shape, leaf_shapes):
+    """Partial broadcasting.  An instruction's operand either stays put or walks the record's element loop
+    one element at a time, so inside ONE record every operand must be constant or contiguous.  A node of
+    canonical shape (B, D1, D2) whose operands broadcast over some axes only (a [1, D1, 1] latent inside a
+    [B, D1, 1] likelihood: the same vector for every datapoint) is therefore cut into one record per index of
+    its first k axes; over the remaining axes every operand is then either full (walks) or of extent 1 (fixed).
+    Returns the smallest such k (0 = one record over everything, the common case)."""
+    rec_shape = tuple(rec_shape)
+    for k in range(0, 3):
+        inner = [i for i in range(k, 3) if rec_shape[i] > 1]
+        ok = True
+        for s in leaf_shapes:
+            full = all(s[i] == rec_shape[i] for i in inner)
+            flat = all(s[i] == 1 for i in inner)
+            if not (full or flat):
+                ok = False
+                break
+        if ok:
+            return k
+    return 3
 
 
 class SlotInfo:
@@ -417,16 +428,63 @@ class _Lowering:
         for k in seen:
             self.use_count[k] = self.use_count.get(k, 0) + 1
 
-    def begin_record(self, shape, sink=False):
+    def begin_record(self, shape, sink=False, k=0, outer=()):
+        """One record covers the elements of `shape` whose first k indices are `outer` (k = 0: all of them)."""
         self.rec_sink = sink
         self.rec_shape = tuple(shape)
+        self.rec_k, self.rec_outer = k, tuple(outer)
+        self.rec_elems = int(np.prod(self.rec_shape[k:]))
         self.rec_begin = len(self.code)
         self.rec_operands = {}
         self.rec_ntemp = 0
 
     def end_record(self):
-        self.records.append((self.rec_begin, len(self.code), int(np.prod(self.rec_shape)), self.rec_ntemp, self.rec_sink))
+        self.records.append((self.rec_begin, len(self.code), self.rec_elems, self.rec_ntemp, self.rec_sink))
         self.max_temps = max(self.max_temps, self.rec_ntemp)
+
+    def place(self, leaf_shape):
+        """(element offset inside the leaf, stride flag) of a leaf operand in the current record."""
+        s = tuple(leaf_shape)
+        if int(np.prod(s)) == 1:
+            return 0, 0
+        for i in range(3):
+            if s[i] not in (1, self.rec_shape[i]):
+                raise LoweringError("a %r operand cannot be broadcast inside a %r node" % (s, self.rec_shape))
+        k = self.rec_k
+        inner = [i for i in range(k, 3) if self.rec_shape[i] > 1]
+        full = all(s[i] == self.rec_shape[i] for i in inner)
+        flat = all(s[i] == 1 for i in inner)
+        if not (full or flat):
+            raise LoweringError("partial broadcasting of a %r operand inside a %r node is not supported by the "
+                                "fused kernel" % (s, self.rec_shape))
+        strides = (s[1] * s[2], s[2], 1)
+        offset = sum((self.rec_outer[i] if s[i] > 1 else 0) * strides[i] for i in range(k))
+        return offset, (1 if (full and inner and any(s[i] > 1 for i in inner)) else 0)
+
+    def leaf_shapes(self, roots):
+        """shapes of every leaf operand (and shared derived value) the expressions in `roots` read"""
+        out, seen, stack = [], set(), [r for r in roots if r is not None]
+        while stack:
+            n = stack.pop()
+            if n.key in seen:
+                continue
+            seen.add(n.key)
+            m = self.match_uniform(n)
+            if m is not None:
+                out.append(tuple(m[0].shape))
+            elif n.op in ("z", "obs", "root", "carr") or n.key in self.derived_nodes:
+                out.append(tuple(n.shape))
+            else:
+                stack.extend(n.args)
+        return out
+
+    def for_each_record(self, shape, roots, sink, body):
+        """emit `body()` once per record of a node of `shape` reading the expressions `roots` (see _split_axis)"""
+        k = _split_axis(shape, self.leaf_shapes(roots) + [tuple(shape)])
+        for outer in (np.ndindex(*shape[:k]) if k else [()]):
+            self.begin_record(shape, sink=sink, k=k, outer=outer)
+            body()
+            self.end_record()
 
     def put(self, op, flags=0, dist=0, dst=None, a=None, b=None, c=None, s=None, imm0=0.0, imm1=0.0):
         w0 = OP[op] | (flags << 8) | (dist << 16)
@@ -455,17 +513,21 @@ class _Lowering:
         if m is not None:
             leaf, g, a, b = m
             is_param, k0 = self.uniform_entries(leaf, g, a, b)
-            res = operand(K_U if is_param else K_UCONST, k0, _stride_flag(leaf.shape, self.rec_shape))
+            off, stride = self.place(leaf.shape)
+            res = operand(K_U if is_param else K_UCONST, k0 + off, stride)
         elif node.op == "imm":
             _, k0 = self.const_operand(node.attr)
             res = operand(K_UCONST, k0, 0)
         elif node.op == "z":
             slot = self.slots[node.attr]
-            res = operand(K_Z, slot.base, _stride_flag(slot.shape, self.rec_shape))
+            off, stride = self.place(slot.shape)
+            res = operand(K_Z, slot.base + off, stride)
         elif node.op == "obs":
-            res = operand(K_OBS, self.obs_offset(node.attr), _stride_flag(node.shape, self.rec_shape))
+            off, stride = self.place(node.shape)
+            res = operand(K_OBS, self.obs_offset(node.attr) + off, stride)
         elif node.key in self.derived:
-            res = operand(K_Z, self.derived[node.key], _stride_flag(node.shape, self.rec_shape))
+            off, stride = self.place(node.shape)
+            res = operand(K_Z, self.derived[node.key] + off, stride)
         else:
             t = self.rec_ntemp
             self.rec_ntemp += 1
@@ -505,9 +567,10 @@ class _Lowering:
             base = self.n_latent + self.n_derived
             size = int(np.prod(n.shape))
             self.n_derived += size
-            self.begin_record(n.shape)
-            self.emit_compute(n, operand(K_Z, base, 1 if size > 1 else 0))
-            self.end_record()
+            def body(n=n, base=base):
+                off, stride = self.place(n.shape)
+                self.emit_compute(n, operand(K_Z, base + off, stride))
+            self.for_each_record(n.shape, list(n.args), False, body)
             self.derived[n.key] = base
 
     @staticmethod
@@ -537,7 +600,8 @@ class _Lowering:
             return self.operand_of(node)
 
         if flags & F_SAMPLE:
-            dst = operand(K_Z, slot.base, 1 if slot.size > 1 else 0)
+            off, stride = self.place(slot.shape)
+            dst = operand(K_Z, slot.base + off, stride)
         else:
             dst = opnd(value)
         if dist == D.DIST_NORMAL:
@@ -665,7 +729,6 @@ class _Lowering:
             dist = v.distribution
             slot = self.slots[v]
             self.ensure_derived(params)
-            self.begin_record(shape)
             w = weight(shape[0])
             flags = F_SAMPLE
             w_lp = 0.0
@@ -680,18 +743,17 @@ class _Lowering:
                 w_lp = -w                      # entropy fallback -log q (variables.py:161-162)
             if self.estimator == "blackbox":
                 flags |= F_WF
-            self.emit_node(dist.kind, flags, params, slot=slot, w_lp=w_lp, w_ent=w_ent)
-            self.end_record()
+            self.for_each_record(shape, params, False,
+                                 lambda: self.emit_node(dist.kind, flags, params, slot=slot, w_lp=w_lp, w_ent=w_ent))
 
         # -- emit p records
         for v, value, params, shape in p_nodes:
             self.ensure_derived([value] + params)
             # a model log-prob term has a constant weight and nothing depends on its value: the
             # kernel finishes it (value and adjoints) in the forward sweep
-            self.begin_record(shape, sink=True)
             w = 1.0 if v.is_observed else weight(shape[0])
-            self.emit_node(v.distribution.kind, F_LOGP, params, value=value, w_lp=w)
-            self.end_record()
+            self.for_each_record(shape, [value] + params, True,
+                                 lambda: self.emit_node(v.distribution.kind, F_LOGP, params, value=value, w_lp=w))
 
         return self.finish(bmax)
 
@@ -775,9 +837,8 @@ class _Lowering:
         self.temp_base = self.n_slots          # no derived slots in sampling programs
         self.derived_nodes = set()
         for v, params, shape, slot in self.outputs:
-            self.begin_record(shape)
-            self.emit_node(v.distribution.kind, F_SAMPLE, params, slot=slot)
-            self.end_record()
+            self.for_each_record(shape, params, False,
+                                 lambda: self.emit_node(v.distribution.kind, F_SAMPLE, params, slot=slot))
         prog = self.finish(1)
         prog.outputs = [(v, slot) for v, _, _, slot in self.outputs]
         return prog

@@ -173,6 +173,25 @@ def build_multivariate_regression(api, n=100, seed=0):
     return model
 
 
+def build_vector_latent(api, n_obs=9, dim=4, seed=0):
+    """Vector-valued nodes: a latent z in R^dim with an elementwise non-linear link into an observed x in R^dim
+    over n_obs datapoints, and a second vector latent whose scale is a LogNormal scalar (broadcast)."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    data = rng.normal(0.5, 1.0, size=(n_obs, dim, 1)).astype(np.float32)
+    s = api.LogNormalVariable(0., 0.3, "s")
+    z = api.NormalVariable(np.linspace(-1., 1., dim).reshape(dim, 1), 1.5 * np.ones((dim, 1)), "z")
+    u = api.NormalVariable(BF.tanh(z) * 0.5, s, "u")
+    x = api.NormalVariable(z * 2. + u, 0.8 * np.ones((dim, 1)), "x")
+    model = api.ProbabilisticModel([x])
+    x.observe(data)
+    Qs = api.LogNormalVariable(0.1, 0.2, "s", learnable=True)
+    Qz = api.NormalVariable(np.zeros((dim, 1)), np.ones((dim, 1)), "z", learnable=True)
+    Qu = api.NormalVariable(Qz * 0.3, 0.7 * np.ones((dim, 1)), "u", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qs, Qz, Qu]))
+    return model
+
+
 def build_learnable_model(api, n_obs=15, seed=0):
     """Learnable parameters in the JOINT model as well as in the posterior (type-II maximum likelihood): the
     likelihood's scale and the prior's location are `learnable=True` roots of p.  `perform_inference` then runs two

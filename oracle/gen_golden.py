@@ -42,6 +42,7 @@ CASES = {
     "observed_ar_T50_N40": ("build_observed_ar", dict(T=50, q_concentration=2.0), 40, 10, dict(iters=4, n=30, optimizer="Adam", lr=0.05)),
     "multivariate_regression_n100_N50": ("build_multivariate_regression", dict(n=100), 50, 9,
                                          dict(iters=5, n=40, optimizer="Adam", lr=1e-3)),
+    "vector_latent_d4_N70": ("build_vector_latent", dict(n_obs=9, dim=4), 70, 14, dict(iters=4, n=33, optimizer="SGD", lr=1e-3)),
     "learnable_model_N60": ("build_learnable_model", dict(n_obs=15), 60, 13, dict(iters=6, n=40, optimizer="Adam", lr=0.02)),
     "discrete_latent_N200": ("build_discrete_latent", dict(n_obs=8), 200, 12, None),
     "heavy_tails_N64": ("build_heavy_tails", dict(n_obs=12), 64, 6, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
