@@ -450,5 +450,20 @@ def importance_log_weights(joint_model, posterior_model, q_samples):
 
 
 def log_probability(variables, values, include_parents=True, model=None):
-    raise NotImplementedError("calculate_log_probability on arbitrary supplied values is outside the ELBO-gradient hot "
-                              "path this build covers (SURVEY §8f-3); the ELBO path evaluates log-probabilities in-kernel")
+    """`ProbabilisticModel.calculate_log_probability(rv_values)` (variables.py:718-727): the sum of the node
+    log-probabilities of a model at caller-supplied values of its latent variables (observed variables use their
+    observed values), one number per sample — a device tensor [N, 1].  Served by the evaluation program of
+    `importance_log_weights`: for a joint model it is the `log p` output, for its posterior model the `log q` output."""
+    if model is None:
+        raise NotImplementedError("calculate_log_probability of a single variable is not served by the fused kernel; "
+                                  "call it on the ProbabilisticModel")
+    joint = getattr(model, "joint_model", None)
+    if joint is not None:                                   # a PosteriorModel: log q(values)
+        _, log_q = importance_log_weights(joint, model, values)
+        return log_q.reshape(-1, 1)
+    posterior = model.posterior_model
+    if not posterior:
+        raise NotImplementedError("calculate_log_probability needs the model's posterior to be set: the values are "
+                                  "matched to the model's latent variables by name through it")
+    log_p, _ = importance_log_weights(model, posterior, values)
+    return log_p.reshape(-1, 1)

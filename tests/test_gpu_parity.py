@@ -308,6 +308,11 @@ def test_importance_weights_match_reference_log_densities(case):
     scale = max(1.0, float(np.abs(lp).max()), float(np.abs(lq).max()))
     assert np.abs(log_p.cpu().numpy() - lp).max() <= 2e-5 * scale
     assert np.abs(log_q.cpu().numpy() - lq).max() <= 2e-5 * scale
+    # the two public entry points that return these log-densities (variables.py:718-727)
+    lp_api = model.calculate_log_probability(q_samples).cpu().numpy()
+    lq_api = model.posterior_model.calculate_log_probability(q_samples).cpu().numpy()
+    assert lp_api.shape == (g.N, 1) and np.abs(lp_api.reshape(-1) - lp).max() <= 2e-5 * scale
+    assert np.abs(lq_api.reshape(-1) - lq).max() <= 2e-5 * scale
     w = model.get_importance_weights(q_samples, model.posterior_model)
     ref = np.exp((lp - lq) - (lp - lq).max())
     ref /= ref.sum()
