@@ -107,3 +107,28 @@ class ReverseKL(InferenceMethod):
         compiled = engine.compile_model(joint_model, posterior_model, self.gradient_estimator)
         return compiled.train(number_iterations, number_samples, optimizer,
                               pretraining_iterations=pretraining_iterations, **opt_params)
+
+
+class MAP(ReverseKL):
+    """Maximum a posteriori point estimates, `inference.py:251-275`: the "posterior" is a model of learnable
+    RootVariables carrying the latents' names; the loss is -log p(theta, data).  On this engine that is the ELBO
+    program of a posterior without random variables — nothing to sample, no entropy — evaluated on one sample
+    (the reference also ignores number_samples here)."""
+
+    def __init__(self):
+        super().__init__(gradient_estimator=gradient_estimators.PathwiseDerivativeEstimator)
+        self.learnable_model = False
+        self.needs_sampler = False
+        self.learnable_sampler = False
+
+    def check_model_compatibility(self, joint_model, posterior_model, sampler_model):
+        from brancher_amd.variables import RootVariable
+        assert all([isinstance(var, RootVariable) for var in posterior_model.flatten()])
+
+    def compute_loss(self, joint_model, posterior_model, sampler_model, number_samples, input_values={}):
+        return super().compute_loss(joint_model, posterior_model, sampler_model, 1, input_values)
+
+    def run(self, joint_model, posterior_model, sampler_model, number_iterations, number_samples, optimizer,
+            pretraining_iterations, **opt_params):
+        return super().run(joint_model, posterior_model, sampler_model, number_iterations, 1, optimizer,
+                           pretraining_iterations, **opt_params)

@@ -173,6 +173,21 @@ def build_multivariate_regression(api, n=100, seed=0):
     return model
 
 
+def build_map_estimate(api, n_obs=12, seed=0):
+    """Point estimates (MAP, `inference.py:251-275`; `examples/MAP_logistic_regression.py:46-56`): the "posterior" is a
+    model of learnable RootVariables carrying the latents' names.  No sampling and no entropy: the loss is
+    -log p(theta, data)."""
+    rng = np.random.RandomState(seed)
+    mu = api.NormalVariable(0., 10., "mu")
+    nu = api.LogNormalVariable(0., 1., "nu")
+    x = api.NormalVariable(mu, nu, "x")
+    model = api.ProbabilisticModel([x])
+    x.observe(rng.normal(1.0, 2.0, size=n_obs).astype(np.float32))
+    model.set_posterior_model(api.ProbabilisticModel([api.RootVariable(0.3, "mu", learnable=True),
+                                                      api.RootVariable(1.5, "nu", learnable=True)]))
+    return model
+
+
 def build_vector_latent(api, n_obs=9, dim=4, seed=0):
     """Vector-valued nodes: a latent z in R^dim with an elementwise non-linear link into an observed x in R^dim
     over n_obs datapoints, and a second vector latent whose scale is a LogNormal scalar (broadcast)."""

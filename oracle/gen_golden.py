@@ -42,6 +42,7 @@ CASES = {
     "observed_ar_T50_N40": ("build_observed_ar", dict(T=50, q_concentration=2.0), 40, 10, dict(iters=4, n=30, optimizer="Adam", lr=0.05)),
     "multivariate_regression_n100_N50": ("build_multivariate_regression", dict(n=100), 50, 9,
                                          dict(iters=5, n=40, optimizer="Adam", lr=1e-3)),
+    "map_estimate_N3": ("build_map_estimate", dict(n_obs=12), 3, 15, dict(iters=6, n=2, optimizer="SGD", lr=0.01)),
     "vector_latent_d4_N70": ("build_vector_latent", dict(n_obs=9, dim=4), 70, 14, dict(iters=4, n=33, optimizer="SGD", lr=1e-3)),
     "learnable_model_N60": ("build_learnable_model", dict(n_obs=15), 60, 13, dict(iters=6, n=40, optimizer="Adam", lr=0.02)),
     "discrete_latent_N200": ("build_discrete_latent", dict(n_obs=8), 200, 12, None),
@@ -238,6 +239,10 @@ def run_case(name, api):
             out["grad_%s/%s" % (est_name, pname)] = (np.zeros_like(out["param/" + pname]) if g is None
                                                      else g.detach().numpy().copy())
             out["gradnone_%s/%s" % (est_name, pname)] = np.array(g is None)
+
+    if all(type(v).__name__ == "RootVariable" for v in q.flatten()):
+        # point estimates: the reference's MAP inference method on the same model (inference.py:251-275)
+        out["loss_map"] = np.float32(inference.MAP().compute_loss(model, q, None, 1).detach().numpy().reshape(-1)[0])
 
     if traj is not None:
         # the optimisation loop of inference.py:77-108 (harness; one loss per iteration)

@@ -318,3 +318,22 @@ def test_importance_weights_match_reference_log_densities(case):
     ref /= ref.sum()
     assert w.shape == (g.N, 1)
     np.testing.assert_allclose(w.reshape(-1), ref, rtol=5e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_map_inference_through_the_public_api_matches_the_reference_trajectory():
+    """`perform_inference(..., inference_method=MAP())` (inference.py:251-275): no sampling, so the loss curve and the
+    parameters after 6 SGD steps are deterministic — compared with the reference's own run."""
+    from brancher_amd import inference
+    g = Golden("map_estimate_N3")
+    model = g.build(W.native_api())
+    tr = g.meta["trajectory"]
+    inference.perform_inference(model, inference_method=inference.MAP(), number_iterations=tr["iters"],
+                                number_samples=50, optimizer=tr["optimizer"], lr=tr["lr"])
+    losses = np.asarray(model.diagnostics["loss curve"], dtype=np.float64)
+    assert abs(losses[0] - float(g.data["loss_map"])) <= 1e-5 * abs(float(g.data["loss_map"]))
+    np.testing.assert_allclose(losses, g.data["traj/losses"], rtol=1e-5)
+    compiled = engine.compile_model(model, None, "pathwise")
+    after = g.group("traj/param_after/")
+    for name, value in compiled.named_params().items():
+        np.testing.assert_allclose(value.reshape(-1), after[name].reshape(-1), rtol=1e-5, atol=1e-6)
