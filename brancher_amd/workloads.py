@@ -173,6 +173,50 @@ def build_multivariate_regression(api, n=100, seed=0):
     return model
 
 
+def build_dynamic_causal_model(api, steps=30, seed=0):
+    """`examples/DynamicCausalModeling.py:12-56`: two coupled, fully observed Euler–Maruyama chains x_n, y_n driven
+    by a pulse input; the latents are the seven rate / coupling / noise parameters (LogNormal and Normal, mean
+    field).  Every transition mean is a four-term affine expression of two parents and three latents."""
+    rng = np.random.RandomState(seed)
+    T = 12.
+    dt = T / float(steps)
+    time_range = np.linspace(0., T, steps)
+    pulse = [1. if (1. < t < 2.) or (7. < t < 8.) else 0. for t in time_range]
+    # data: one Euler-Maruyama path at a=1, b=1, c=0, d=3, e=10, xi=chi=0.5
+    xs, ys = [float(rng.normal(0., 1.))], [float(rng.normal(0., 1.))]
+    for n in range(steps):
+        xs.append((1 - dt * 1.) * xs[-1] + dt * 0. * ys[-1] + dt * 10. * pulse[n] + np.sqrt(dt) * 0.5 * rng.normal())
+        ys.append((1 - dt * 1.) * ys[-2 + 1] + dt * 3. * xs[-2] + np.sqrt(dt) * 0.5 * rng.normal())
+    a = api.LogNormalVariable(0., 1., name="a")
+    b = api.LogNormalVariable(0., 1., name="b")
+    c = api.NormalVariable(0., 2., name="c")
+    d = api.NormalVariable(0., 2., name="d")
+    e = api.NormalVariable(0., 10., name="e")
+    xi = api.LogNormalVariable(0., 0.1, name="xi")
+    chi = api.LogNormalVariable(0., 0.1, name="chi")
+    x_series = [api.NormalVariable(0., 1., name="x_0")]
+    y_series = [api.NormalVariable(0., 1., name="y_0")]
+    for n in range(steps):
+        x_new_mean = (1 - dt * a) * x_series[-1] + dt * c * y_series[-1] + dt * e * pulse[n]
+        y_new_mean = (1 - dt * b) * y_series[-1] + dt * d * x_series[-1]
+        x_series += [api.NormalVariable(x_new_mean, np.sqrt(dt) * xi, name="x_{}".format(n + 1))]
+        y_series += [api.NormalVariable(y_new_mean, np.sqrt(dt) * chi, name="y_{}".format(n + 1))]
+    model = api.ProbabilisticModel([x_series[-1], y_series[-1]])
+    for v, val in zip(x_series, xs):
+        v.observe(np.array([val], dtype=np.float32))
+    for v, val in zip(y_series, ys):
+        v.observe(np.array([val], dtype=np.float32))
+    Qa = api.LogNormalVariable(0., 0.5, name="a", learnable=True)
+    Qb = api.LogNormalVariable(0., 0.5, name="b", learnable=True)
+    Qc = api.NormalVariable(0., 0.1, name="c", learnable=True)
+    Qd = api.NormalVariable(0., 0.1, name="d", learnable=True)
+    Qe = api.NormalVariable(0., 5., name="e", learnable=True)
+    Qxi = api.LogNormalVariable(0.1, 0.1, name="xi", learnable=True)
+    Qchi = api.LogNormalVariable(0.1, 0.1, name="chi", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qa, Qb, Qc, Qd, Qe, Qxi, Qchi]))
+    return model
+
+
 def build_map_estimate(api, n_obs=12, seed=0):
     """Point estimates (MAP, `inference.py:251-275`; `examples/MAP_logistic_regression.py:46-56`): the "posterior" is a
     model of learnable RootVariables carrying the latents' names.  No sampling and no entropy: the loss is

@@ -42,6 +42,8 @@ CASES = {
     "observed_ar_T50_N40": ("build_observed_ar", dict(T=50, q_concentration=2.0), 40, 10, dict(iters=4, n=30, optimizer="Adam", lr=0.05)),
     "multivariate_regression_n100_N50": ("build_multivariate_regression", dict(n=100), 50, 9,
                                          dict(iters=5, n=40, optimizer="Adam", lr=1e-3)),
+    "dynamic_causal_model_T30_N20": ("build_dynamic_causal_model", dict(steps=30), 20, 16,
+                                     dict(iters=4, n=5, optimizer="Adam", lr=0.01)),
     "map_estimate_N3": ("build_map_estimate", dict(n_obs=12), 3, 15, dict(iters=6, n=2, optimizer="SGD", lr=0.01)),
     "vector_latent_d4_N70": ("build_vector_latent", dict(n_obs=9, dim=4), 70, 14, dict(iters=4, n=33, optimizer="SGD", lr=1e-3)),
     "learnable_model_N60": ("build_learnable_model", dict(n_obs=15), 60, 13, dict(iters=6, n=40, optimizer="Adam", lr=0.02)),
