@@ -65,9 +65,17 @@ def lower_dense(joint, posterior, estimator="pathwise"):
             L.param_offset(v.parameter, 1)
 
     q_random = [v for v in q_flat if _is_random(v)]
-    if len(q_random) != 1 or q_random[0].distribution.kind != D.DIST_NORMAL:
-        raise LoweringError("dense path: the posterior must be one mean-field Normal weight variable")
-    Wq = q_random[0]
+    # point estimate (MAP, inference.py:251-275; examples/MAP_logistic_regression.py:46-56): the posterior is ONE
+    # learnable RootVariable carrying the weight variable's name -> W = its value, no noise, no entropy
+    point = None
+    if not q_random:
+        roots = [v for v in q_flat if isinstance(v, RootVariable) and v.learnable]
+        if len(roots) == 1:
+            point = roots[0]
+    if point is None and (len(q_random) != 1 or q_random[0].distribution.kind != D.DIST_NORMAL):
+        raise LoweringError("dense path: the posterior must be one mean-field Normal weight variable "
+                            "(or one learnable RootVariable: a point estimate)")
+    Wq = point if point is not None else q_random[0]
     p_random = [v for v in joint._flatten() if _is_random(v)]
     liks = [v for v in p_random if v.distribution.kind in (D.DIST_CATEGORICAL, D.DIST_BINOMIAL, D.DIST_BERNOULLI)]
     weights = [v for v in p_random if v.name == Wq.name and v.distribution.kind == D.DIST_NORMAL]
@@ -127,7 +135,14 @@ def lower_dense(joint, posterior, estimator="pathwise"):
             out.append((is_param, k0, size, leaf.shape))
         return out
 
-    (ql, qs) = row_params(Wq, L.q_value)
+    if point is not None:
+        leaf = L.q_value(point)
+        is_param, k0 = L.uniform_entries(leaf, "identity", 0.0, 1.0)
+        ql = (is_param, k0, int(np.prod(leaf.shape)), leaf.shape)
+        _, z0 = L.const_operand(0.0)                         # scale 0: W = loc exactly, whatever the noise
+        qs = (False, z0, 1, (1, 1, 1))
+    else:
+        (ql, qs) = row_params(Wq, L.q_value)
     (pl, ps) = row_params(Wp, L.p_value)
     shape = ql[3]
     C_, P_ = shape[1], shape[2]
@@ -161,8 +176,9 @@ def lower_dense(joint, posterior, estimator="pathwise"):
     prog.dataset = np.ascontiguousarray(Xm, dtype=np.float32)
     prog.labels = np.ascontiguousarray(Ym, dtype=np.float32)
     prog.latent_name = Wq.name
+    prog.point_estimate = point is not None
     prog.indices_name = ind_x.name
-    prog.lik_weight, prog.prior_weight, prog.entropy_weight = 1.0, 1.0, 1.0
+    prog.lik_weight, prog.prior_weight, prog.entropy_weight = 1.0, 1.0, (0.0 if point is not None else 1.0)
     prog.n_noise = C_ * P_
     prog.bmax = 1
     return prog
@@ -263,6 +279,8 @@ class CompiledDense:
         if noise is None:
             return None
         if isinstance(noise, dict):
+            if self.program.point_estimate and self.program.latent_name not in noise:
+                return None                  # nothing is sampled: the weights' scale is 0, any noise gives W = loc
             a = np.asarray(noise[self.program.latent_name], dtype=np.float32)       # [N, 1, C, P]
             noise = np.ascontiguousarray(a.reshape(a.shape[0], -1).T)               # [C*P, N]
         if isinstance(noise, np.ndarray):

@@ -335,6 +335,24 @@ def build_binary_logistic_regression(api, dataset_size=50, batch_size=30, n_feat
     return model
 
 
+def build_map_logistic_regression(api, dataset_size=30, n_features=4, n_classes=3, seed=0):
+    """`examples/MAP_logistic_regression.py:17-56`: multinomial logistic regression whose "posterior" is a learnable
+    RootVariable named like the weight matrix — a point estimate trained with `inference.MAP` on the full batch."""
+    BF = api.BF
+    X, labels = logreg_data(dataset_size, n_features, n_classes, seed)
+    X = (X * 6.0).astype(np.float32)                       # iris-like magnitudes
+    indices = api.RandomIndices(dataset_size=dataset_size, batch_size=dataset_size, name="indices", is_observed=True)
+    x = api.EmpiricalVariable(X.reshape(dataset_size, n_features, 1), indices=indices, name="x", is_observed=True)
+    lab = api.EmpiricalVariable(labels.astype(np.int32), indices=indices, name="labels", is_observed=True)
+    weights = api.NormalVariable(np.zeros((n_classes, n_features)), 10 * np.ones((n_classes, n_features)), "weights")
+    k = api.CategoricalVariable(logits=BF.matmul(weights, x), name="k")
+    model = api.ProbabilisticModel([k])
+    k.observe(lab)
+    init = np.random.RandomState(seed + 1).normal(0., 1., (n_classes, n_features))
+    model.set_posterior_model(api.ProbabilisticModel([api.RootVariable(init, name="weights", learnable=True)]))
+    return model
+
+
 def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=784, n_classes=10, seed=0,
                               prior_scale=10., q_scale=0.1):
     """BASELINE config 4: Bayesian multinomial logistic regression with a dense `matmul` link and a

@@ -56,6 +56,8 @@ CASES = {
     # examples/minibatch_logistic_regression.py: Binomial(1, logits) likelihood, labels through a shared minibatch
     "logreg_binary_P2_DS50_B30_N6": ("build_binary_logistic_regression", dict(dataset_size=50, batch_size=30, n_features=2),
                                      6, 11, dict(iters=5, n=8, optimizer="Adam", lr=0.05)),
+    "logreg_map_C3_P4_DS30_N2": ("build_map_logistic_regression", dict(dataset_size=30, n_features=4, n_classes=3), 2, 17,
+                                 dict(iters=5, n=1, optimizer="SGD", lr=0.0025)),
     "logreg_C10_P784_DS24_B16_N4": ("build_logistic_regression",
                                     dict(dataset_size=24, batch_size=16, n_features=784, n_classes=10), 4, 8, None),
 }
