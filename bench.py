@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r1")
 
 
-def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False):
+def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False, column="mean_KB_per_dispatch"):
     """HBM bytes per launch of the named kernel(s) from the committed rocprofv3 PMC summary (FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc passes by tools/pmc_hbm.sh, KB per dispatch).  double_fetch applies
     the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies the 128-B requests of 16-B-per-lane
@@ -58,7 +58,7 @@ def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False):
     hit = False
     for row in csv.DictReader(open(path)):
         if any(k in row["kernel"] for k in kernel_substrings):
-            kb = float(row["mean_KB_per_dispatch"])
+            kb = float(row[column])
             total += kb * 1024.0 * (2.0 if double_fetch and row["counter"] == "FETCH_SIZE" else 1.0)
             hit = True
     return total if hit else None
@@ -191,10 +191,11 @@ def main():
             kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
         achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
         if mode == "persistent":
-            # measured for the default launch (2100 iterations in one launch); a launch's HBM traffic is its
-            # parameter/observation reads and loss-curve writes, so it is reported as measured, not rescaled
-            traffic = pmc_traffic_bytes("cfg1_persistent_pmc_hbm_traffic.csv", ["persistent_kernel"]) \
-                if args.workload == "cfg1" and not args.samples else None
+            # measured for the default command (the summary holds the warm-up launch of 200 iterations and the
+            # timed one of 20000: the larger is the timed launch — parameters/observations read, loss and
+            # finite curves written)
+            traffic = pmc_traffic_bytes("cfg1_persistent_pmc_hbm_traffic.csv", ["persistent_kernel"], column="max_KB") \
+                if args.workload == "cfg1" and not args.samples and args.steps == 20000 else None
         else:
             traffic = pmc_traffic_bytes("pmc_hbm_traffic.csv", ["elbo_kernel"]) \
                 if args.workload == "cfg1" and not args.samples else None
