@@ -933,15 +933,20 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
             if (op == BSVI_OP_REC_BEGIN) {
                 const Insn I = ld_insn(K.code, pc);
                 const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                // a one-instruction body (an observed likelihood over its datapoints: the common record) is
+                // fetched once, not once per element and sweep — the fetch is an exposed scalar-cache round trip
+                const Insn J1 = ld_insn(K.code, pc + 1);
                 for (uint32_t e = 0; e < n_elems; ++e) {
                     for (uint32_t j = 1; j <= n; ++j) {
-                        const Insn J = ld_insn(K.code, pc + j);
+                        Insn J = J1;
+                        if (n != 1) J = ld_insn(K.code, pc + j);
                         exec_forward<SM, OUT, true, GEN>(K, L, T, J, e);
                     }
                     if (sink) {
                         for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
                         for (uint32_t j = n; j >= 1; --j) {
-                            const Insn J = ld_insn(K.code, pc + j);
+                            Insn J = J1;
+                            if (n != 1) J = ld_insn(K.code, pc + j);
                             exec_backward<SM, GEN>(K, L, T, J, e);
                         }
                     }
@@ -974,15 +979,20 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
             const bool sink = (I.w0 >> 24) & BSVI_R_SINK;
             if (op == BSVI_OP_REC_BEGIN) {
                 const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                // a one-instruction body (an observed likelihood over its datapoints: the common record) is
+                // fetched once, not once per element and sweep — the fetch is an exposed scalar-cache round trip
+                const Insn J1 = ld_insn(K.code, pc + 1);
                 for (uint32_t e = 0; e < n_elems; ++e) {
                     for (uint32_t j = 1; j <= n; ++j) {
-                        const Insn J = ld_insn(K.code, pc + j);
+                        Insn J = J1;
+                        if (n != 1) J = ld_insn(K.code, pc + j);
                         exec_forward<SM, OUT, true, GEN>(K, L, T, J, e);
                     }
                     if (sink) {
                         for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
                         for (uint32_t j = n; j >= 1; --j) {
-                            const Insn J = ld_insn(K.code, pc + j);
+                            Insn J = J1;
+                            if (n != 1) J = ld_insn(K.code, pc + j);
                             exec_backward<SM, GEN>(K, L, T, J, e);
                         }
                     }
@@ -1032,15 +1042,18 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                 const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
                 const uint32_t first = pc - 1 - n;          // index of the first body instruction
                 if (!sink) {
+                    const Insn J1 = ld_insn(K.code, first);
                     for (uint32_t e = n_elems; e-- > 0;) {
                         // temps are shared by all records: re-materialise this record's, clear their adjoints
                         for (uint32_t j = 0; j < n; ++j) {
-                            const Insn J = ld_insn(K.code, first + j);
+                            Insn J = J1;
+                            if (n != 1) J = ld_insn(K.code, first + j);
                             exec_forward<SM, false, false, GEN>(K, L, T, J, e);
                         }
                         for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
                         for (uint32_t j = n; j-- > 0;) {
-                            const Insn J = ld_insn(K.code, first + j);
+                            Insn J = J1;
+                            if (n != 1) J = ld_insn(K.code, first + j);
                             exec_backward<SM, GEN>(K, L, T, J, e);
                         }
                     }
@@ -1072,15 +1085,18 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
                 const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
                 const uint32_t first = pc - 1 - n;          // index of the first body instruction
                 if (!sink) {
+                    const Insn J1 = ld_insn(K.code, first);
                     for (uint32_t e = n_elems; e-- > 0;) {
                         // temps are shared by all records: re-materialise this record's, clear their adjoints
                         for (uint32_t j = 0; j < n; ++j) {
-                            const Insn J = ld_insn(K.code, first + j);
+                            Insn J = J1;
+                            if (n != 1) J = ld_insn(K.code, first + j);
                             exec_forward<SM, false, false, GEN>(K, L, T, J, e);
                         }
                         for (uint32_t t = 0; t < n_temps; ++t) st_adj<SM>(K, T, (temp_base + t) * 8u, 0.0f);
                         for (uint32_t j = n; j-- > 0;) {
-                            const Insn J = ld_insn(K.code, first + j);
+                            Insn J = J1;
+                            if (n != 1) J = ld_insn(K.code, first + j);
                             exec_backward<SM, GEN>(K, L, T, J, e);
                         }
                     }
