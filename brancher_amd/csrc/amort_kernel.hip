@@ -1,0 +1,711 @@
+// amort_kernel.hip — the amortised (encoder / decoder network) ELBO path for MI355X (gfx950).
+//
+// What it replaces in the reference (BASELINE config 5, examples/VAE_playground.py:18-88): per iteration
+// `perform_inference` (inference.py:95-108) draws, for EVERY Monte-Carlo sample, its own minibatch of B dataset
+// rows (EmpiricalDistribution._get_sample, distributions.py:410-457), runs the encoder module on the N*B rows
+// (BrancherFunction -> torch.nn.Module, functions.py:28-41), draws z = loc + scale*eps (distributions.py:111-124),
+// runs the decoder module, evaluates Binomial(1, logits) + Normal prior + Normal entropy per row
+// (variables.py:851-855) and back-propagates through both modules with autograd.
+//
+// Here the iteration is a fixed sequence of launches over R = N*B rows:
+//   amort_rows        minibatch indices of every sample (keyed bijection, distinct rows per sample)
+//   gemm<NT>          one per Linear layer of the encoder: y = act(x W^T + b)   (row gather fused into layer 1)
+//   amort_latent_fwd  eps (Philox or supplied), z, log p(z), H[q], log q per row
+//   gemm<NT>          decoder layers
+//   amort_lik         log p(x | z) per row and dlogits in place (one wave per row)
+//   per layer, last to first:  gemm<TN> dW += dY^T x (K = R split over workgroups, f32 atomics),
+//                              col_sum  db += 1^T dY,   gemm<NN> dX = (dY W) * act'(x)
+//   amort_latent_bwd  joins decoder dz with prior / entropy / score-function terms, loss sums
+// GEMMs: 128x128x16 workgroup tiles, four waves of 64x64, v_mfma_f32_32x32x2_f32, k-major LDS tiles (row stride 132
+// words: transposing stores and MFMA operand reads are both conflict-free), register-staged double-buffered global
+// loads, workgroup order remapped so that the tiles sharing rows of the tall operand sit on one XCD.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/bsvi.h"
+#include "bsvi_internal.h"
+#include "philox.h"
+
+namespace bsvi_amort_impl {
+using bsvi::philox4x32_10;
+using bsvi::u01;
+using bsvi::u32x4;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, NTHREADS = 256;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
+enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const int32_t* rows;   // gather of the R-indexed rows: A's rows (NT, NN) or B's rows (TN)
+    int M, N, K;
+    int lda, ldb, ldc;
+    int vecA, vecB;        // 16-byte loads allowed (pointer and leading dimension aligned)
+    const float* bias;     // NT
+    const float* Y;        // NN: value whose producing activation is differentiated
+    int ldy;
+    int act;
+    float post_add;
+    int accumulate;        // NN: C += result
+    int k_chunk;           // TN: rows of K per workgroup (multiple of BK)
+    int remap;             // XCD-aware workgroup order
+};
+
+__device__ __forceinline__ float act_forward(int act, float v, float post_add) {
+    if (act == BSVI_ACT_RELU) v = fmaxf(v, 0.0f);
+    if (act == BSVI_ACT_SOFTPLUS) v = v > 20.0f ? v : log1pf(expf(v));   // torch softplus, threshold 20
+    return v + post_add;
+}
+// derivative of the activation expressed through its OUTPUT y (what the forward pass kept)
+__device__ __forceinline__ float act_derivative(int act, float y, float post_add) {
+    if (act == BSVI_ACT_RELU) return y - post_add > 0.0f ? 1.0f : 0.0f;
+    if (act == BSVI_ACT_SOFTPLUS) {
+        const float sp = y - post_add;                    // softplus(v); sigmoid(v) = 1 - exp(-softplus(v))
+        return sp > 20.0f ? 1.0f : -expm1f(-sp);
+    }
+    return 1.0f;
+}
+
+// ---- tile loaders -------------------------------------------------------------------------------------------
+// KC: the operand is stored [rows][k] (k contiguous); the tile is rows r0.. x k kt..kt+15, transposed on the way
+//     into LDS.  Thread t owns rows (t>>2) and (t>>2)+64, k quad (t&3)*4.
+// MC: the operand is stored [k][cols] (cols contiguous); thread t owns k rows (t>>5) and (t>>5)+8, columns (t&31)*4.
+struct Frag { float4 v[2]; };
+
+__device__ __forceinline__ float4 load4(const float* p, int valid, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid >= 4 && vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else if (valid > 0) {
+        v.x = p[0];
+        if (valid > 1) v.y = p[1];
+        if (valid > 2) v.z = p[2];
+        if (valid > 3) v.w = p[3];
+    }
+    return v;
+}
+
+__device__ __forceinline__ Frag load_kc(const float* base, const int32_t* rows, int ld, int r0, int n_rows, int kt,
+                                        int k_end, bool vec) {
+    Frag f;
+    const int t = threadIdx.x, kq = kt + (t & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = r0 + (t >> 2) + 64 * i;
+        int valid = 0;
+        const float* p = base;
+        if (r < n_rows) {
+            const long phys = rows ? (long)rows[r] : (long)r;
+            p = base + phys * ld + kq;
+            valid = k_end - kq;
+        }
+        f.v[i] = load4(p, valid, vec);
+    }
+    return f;
+}
+__device__ __forceinline__ void store_kc(float* tile, const Frag& f) {
+    const int t = threadIdx.x, kq = (t & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (t >> 2) + 64 * i;
+        tile[(kq + 0) * LDT + r] = f.v[i].x;
+        tile[(kq + 1) * LDT + r] = f.v[i].y;
+        tile[(kq + 2) * LDT + r] = f.v[i].z;
+        tile[(kq + 3) * LDT + r] = f.v[i].w;
+    }
+}
+__device__ __forceinline__ Frag load_mc(const float* base, const int32_t* rows, int ld, int c0, int n_cols, int kt,
+                                        int k_end, bool vec) {
+    Frag f;
+    const int t = threadIdx.x, c = c0 + (t & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = kt + (t >> 5) + 8 * i;
+        int valid = 0;
+        const float* p = base;
+        if (k < k_end) {
+            const long phys = rows ? (long)rows[k] : (long)k;
+            p = base + phys * ld + c;
+            valid = n_cols - c;
+        }
+        f.v[i] = load4(p, valid, vec);
+    }
+    return f;
+}
+__device__ __forceinline__ void store_mc(float* tile, const Frag& f) {
+    const int t = threadIdx.x, c = (t & 31) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = (t >> 5) + 8 * i;
+        *reinterpret_cast<float4*>(&tile[k * LDT + c]) = f.v[i];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+
+    const int tiles_n = (G.N + BN - 1) / BN;
+    const int n_blocks = gridDim.x;
+    int bid = blockIdx.x;
+    if (G.remap) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // XCD x gets one contiguous range of tiles
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    int k_begin = 0, k_end = G.K;
+    if (MODE == MODE_TN) {
+        k_begin = blockIdx.y * G.k_chunk;
+        k_end = min(G.K, k_begin + G.k_chunk);
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto load_a = [&](int kt) {
+        if (MODE == MODE_TN) return load_mc(G.A, nullptr, G.lda, m0, G.M, kt, k_end, G.vecA);
+        return load_kc(G.A, G.rows, G.lda, m0, G.M, kt, k_end, G.vecA);
+    };
+    auto load_b = [&](int kt) {
+        if (MODE == MODE_NT) return load_kc(G.B, nullptr, G.ldb, n0, G.N, kt, k_end, G.vecB);
+        return load_mc(G.B, MODE == MODE_TN ? G.rows : nullptr, G.ldb, n0, G.N, kt, k_end, G.vecB);
+    };
+    auto store_a = [&](float* tile, const Frag& f) {
+        if (MODE == MODE_TN) store_mc(tile, f); else store_kc(tile, f);
+    };
+    auto store_b = [&](float* tile, const Frag& f) {
+        if (MODE == MODE_NT) store_kc(tile, f); else store_mc(tile, f);
+    };
+
+    Frag fa = load_a(k_begin), fb = load_b(k_begin);
+    store_a(As[0], fa);
+    store_b(Bs[0], fb);
+    __syncthreads();
+
+    const int n_steps = (k_end - k_begin + BK - 1) / BK;
+    const int lk = lane >> 5, lm = lane & 31;
+    for (int step = 0; step < n_steps; ++step) {
+        const int cur = step & 1;
+        const bool more = step + 1 < n_steps;
+        if (more) {
+            fa = load_a(k_begin + (step + 1) * BK);
+            fb = load_b(k_begin + (step + 1) * BK);
+        }
+        const float* at = As[cur];
+        const float* bt = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = at[(kk + lk) * LDT + wm + lm], a1 = at[(kk + lk) * LDT + wm + 32 + lm];
+            const float b0 = bt[(kk + lk) * LDT + wn + lm], b1 = bt[(kk + lk) * LDT + wn + 32 + lm];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            store_a(As[cur ^ 1], fa);
+            store_b(Bs[cur ^ 1], fb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  acc[i][j][r] is C[m][n] with m = 32i + 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lm;
+            if (n >= G.N) continue;
+            float bias = 0.0f;
+            if (MODE == MODE_NT && G.bias) bias = G.bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * lk + (r & 3);
+                if (m >= G.M) continue;
+                float v = acc[i][j][r];
+                float* c = G.C + (long)m * G.ldc + n;
+                if (MODE == MODE_NT) {
+                    *c = act_forward(G.act, v + bias, G.post_add);
+                } else if (MODE == MODE_NN) {
+                    if (G.act != BSVI_ACT_NONE) v *= act_derivative(G.act, G.Y[(long)m * G.ldy + n], G.post_add);
+                    *c = G.accumulate ? *c + v : v;
+                } else {
+                    unsafeAtomicAdd(c, v);
+                }
+            }
+        }
+}
+
+// ---- column sums: bias gradients db[n] += sum_r dY[r][n] ------------------------------------------------------
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* dY, int ld, int R, int N, int rows_per_block, float* db) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float s = 0.0f;
+    if (c < N)
+        for (int r = r0 + q; r < r1; r += 4) s += dY[(long)r * ld + c];
+    part[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < N) unsafeAtomicAdd(&db[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// ---- row-wise pieces -------------------------------------------------------------------------------------------
+struct RowParams {
+    int R, B, DS, P, Dz;
+    int n_local, sample_base;
+    uint32_t seed_lo, seed_hi, off_lo, off_hi;
+    int estimator;
+    float entropy_const;     // log(n_samples_global): the reference's entropy of the minibatch variable
+    const int32_t* indices_in;
+    int32_t* idx;            // [R] dataset row of every (sample, batch) row
+    int32_t* indices_out;
+    const float* noise_in;
+    float* noise_out;
+    const float* dataset;    // [DS][P] device
+    const float* loc;  int ld_loc;  int act_loc;  float add_loc;
+    const float* scale; int ld_scale; int act_scale; float add_scale;
+    float* dloc; float* dscale;
+    float* eps;              // [R][Dz]
+    float* z; int ld_z;      // decoder input
+    const float* dz;         // decoder-input gradient, [R][ld_z]
+    const float* prior_loc; const float* prior_scale;
+    float* rowf;             // [R] f per row
+    float* rowlq;            // [R] log q per row
+    float* logits; int ld_logits;
+    float* out;
+    float* fvalue_out; float* logq_out;
+};
+
+// minibatch of sample s: a keyed bijection of [0, DS) per (seed, iteration, sample) — 4-round Feistel on the next
+// power of four, cycle-walked — evaluated at b = 0..B-1: B distinct rows, like np.random.choice(replace=False)
+// (distributions.py:438-440)
+__device__ __forceinline__ uint32_t minibatch_row(const RowParams& D, uint32_t s_global, uint32_t b) {
+    uint32_t half_bits = 1;
+    while ((1u << (2 * half_bits)) < (uint32_t)D.DS) ++half_bits;
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t x = b;
+    for (int walk = 0; walk < 64; ++walk) {
+        uint32_t lft = (x >> half_bits) & mask, rgt = x & mask;
+        for (uint32_t round = 0; round < 4; ++round) {
+            const u32x4 h = philox4x32_10(rgt, round | (s_global << 2), D.off_lo, D.off_hi, D.seed_lo ^ 0x7f4a7c15u, D.seed_hi);
+            const uint32_t t = lft ^ (h.x & mask);
+            lft = rgt;
+            rgt = t;
+        }
+        x = (lft << half_bits) | rgt;
+        if (x < (uint32_t)D.DS) return x;
+    }
+    return b % (uint32_t)D.DS;
+}
+
+__global__ void amort_rows(const RowParams D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= D.R) return;
+    const int s = r / D.B, b = r - s * D.B;
+    const int32_t i = D.indices_in ? D.indices_in[r] : (int32_t)minibatch_row(D, (uint32_t)(D.sample_base + s), (uint32_t)b);
+    D.idx[r] = i;
+    if (D.indices_out) D.indices_out[r] = i;
+}
+
+// z = loc + scale * eps; per row: log p(z), H[q(z|x)], log q(z|x)   (torch normal.py:83-116)
+__global__ void amort_latent_fwd(const RowParams D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= D.R) return;
+    const uint32_t row_global = (uint32_t)(D.sample_base * D.B + r);
+    float lp = 0.0f, H = 0.0f, lq = 0.0f;
+    for (int d = 0; d < D.Dz; d += 2) {
+        float e0, e1 = 0.0f;
+        if (D.noise_in) {
+            e0 = D.noise_in[(long)r * D.Dz + d];
+            if (d + 1 < D.Dz) e1 = D.noise_in[(long)r * D.Dz + d + 1];
+        } else {
+            const u32x4 x = philox4x32_10(row_global, (uint32_t)(d >> 1), D.off_lo, D.off_hi, D.seed_lo, D.seed_hi);
+            bsvi::box_muller(x.x, x.y, e0, e1);
+        }
+        for (int j = 0; j < 2 && d + j < D.Dz; ++j) {
+            const int dd = d + j;
+            const float e = j ? e1 : e0;
+            const float m = D.loc[(long)r * D.ld_loc + dd], sd = D.scale[(long)r * D.ld_scale + dd];
+            const float z = m + sd * e;
+            D.eps[(long)r * D.Dz + dd] = e;
+            if (D.noise_out) D.noise_out[(long)r * D.Dz + dd] = e;
+            D.z[(long)r * D.ld_z + dd] = z;
+            const float pl = D.prior_loc[dd], ps = D.prior_scale[dd], u = (z - pl) / ps;
+            const float lsd = logf(sd);
+            lp += -0.5f * u * u - logf(ps) - kHalfLog2Pi;
+            H += 0.5f + kHalfLog2Pi + lsd;
+            lq += -0.5f * e * e - lsd - kHalfLog2Pi;
+        }
+    }
+    D.rowf[r] = lp + H + D.entropy_const;
+    D.rowlq[r] = lq;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// log p(x | z) = sum_j x_j l_j - softplus(l_j)  (torch binomial.py:140-160 with total_count = 1) and
+// dlogits = x - sigmoid(l), written over the logits.  One wave per row.
+__global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= D.R) return;
+    const float* x = D.dataset + (long)D.idx[r] * D.P;
+    float* l = D.logits + (long)r * D.ld_logits;
+    float lp = 0.0f;
+    for (int j = lane; j < D.P; j += 64) {
+        const float lj = l[j], xj = x[j];
+        const float e = __expf(-fabsf(lj));
+        lp += xj * lj - (fmaxf(lj, 0.0f) + log1pf(e));
+        const float sig = lj >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        l[j] = xj - sig;
+    }
+    lp = wave_sum64(lp);
+    if (lane == 0) D.rowf[r] += lp;
+}
+
+// joins the decoder's dz with the prior, entropy and (BlackBox) score-function terms and accumulates the loss sums.
+//   pathwise:  value_r = f_r
+//   BlackBox:  value_r = lq_r * stopgrad(f_r) + f_r;  d lq_r / d scale = -1/scale (z - loc = scale*eps cancels the rest)
+__global__ __launch_bounds__(256) void amort_latent_bwd(const RowParams D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float value = 0.0f, bad = 0.0f;
+    if (r < D.R) {
+        const float f = D.rowf[r], lq = D.rowlq[r];
+        value = D.estimator == 1 ? lq * f + f : f;
+        if (!isfinite(value)) bad = 1.0f;
+        if (D.fvalue_out) D.fvalue_out[r] = f;
+        if (D.logq_out) D.logq_out[r] = lq;
+        const float score = D.estimator == 1 ? f : 0.0f;
+        for (int d = 0; d < D.Dz; ++d) {
+            const float e = D.eps[(long)r * D.Dz + d];
+            const float m = D.loc[(long)r * D.ld_loc + d], sd = D.scale[(long)r * D.ld_scale + d];
+            const float z = D.z[(long)r * D.ld_z + d];
+            const float ps = D.prior_scale[d];
+            const float gz = D.dz[(long)r * D.ld_z + d] - (z - D.prior_loc[d]) / (ps * ps);
+            const float gsd = gz * e + (1.0f - score) / sd;
+            D.dloc[(long)r * D.ld_loc + d] = gz * act_derivative(D.act_loc, m, D.add_loc);
+            D.dscale[(long)r * D.ld_scale + d] = gsd * act_derivative(D.act_scale, sd, D.add_scale);
+        }
+    }
+    value = wave_sum64(value);
+    bad = wave_sum64(bad);
+    if ((threadIdx.x & 63) == 0) {
+        unsafeAtomicAdd(&D.out[0], value);
+        if (bad != 0.0f) unsafeAtomicAdd(&D.out[1], bad);
+    }
+}
+
+}  // namespace bsvi_amort_impl
+
+// =============================================================================================================
+//  C ABI
+// =============================================================================================================
+using namespace bsvi_amort_impl;
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return bsvi_fail(BSVI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+struct Net {
+    std::vector<bsvi_mlp_layer> layers;
+    std::vector<int> width;        // per value
+    std::vector<int> producer;     // layer index producing the value (-1: the input)
+    std::vector<int> ld;           // leading dimension of the value's buffers
+    std::vector<size_t> val_off, grad_off;   // float offsets into the workspace, per row-block base (times R at use)
+};
+
+struct bsvi_amort {
+    bsvi_amort_desc d;
+    Net enc, dec;
+    float* dataset_dev = nullptr;
+    float* prior_dev = nullptr;    // [2][Dz]
+    size_t floats_per_row = 0;     // workspace floats per row (values + gradients + per-row scalars)
+};
+
+static int pad4(int n) { return (n + 3) / 4 * 4; }
+
+static int build_net(Net& net, const bsvi_mlp_layer* layers, uint32_t n_layers, int input_width, uint32_t n_params) {
+    net.layers.assign(layers, layers + n_layers);
+    uint32_t n_values = 1;
+    for (const auto& l : net.layers) n_values = std::max(n_values, std::max(l.in_value, l.out_value) + 1);
+    net.width.assign(n_values, -1);
+    net.producer.assign(n_values, -1);
+    net.width[0] = input_width;
+    for (size_t i = 0; i < net.layers.size(); ++i) {
+        const auto& l = net.layers[i];
+        if (l.out_value == 0 || net.width[l.out_value] != -1) return bsvi_fail(BSVI_ERR_INVALID, "a network value is produced twice");
+        if (net.width[l.in_value] == -1) return bsvi_fail(BSVI_ERR_INVALID, "network layers are not in topological order");
+        if ((int)l.n_in != net.width[l.in_value]) return bsvi_fail(BSVI_ERR_INVALID, "layer input width mismatch");
+        if (l.activation > BSVI_ACT_SOFTPLUS) return bsvi_fail(BSVI_ERR_UNSUPPORTED, "unknown activation");
+        if ((size_t)l.weight_off + (size_t)l.n_in * l.n_out > n_params) return bsvi_fail(BSVI_ERR_INVALID, "layer weights exceed the parameter buffer");
+        if (l.bias_off != 0xFFFFFFFFu && (size_t)l.bias_off + l.n_out > n_params) return bsvi_fail(BSVI_ERR_INVALID, "layer bias exceeds the parameter buffer");
+        net.width[l.out_value] = (int)l.n_out;
+        net.producer[l.out_value] = (int)i;
+    }
+    net.ld.resize(n_values);
+    for (uint32_t v = 0; v < n_values; ++v) net.ld[v] = pad4(net.width[v]);
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) {
+    if (!desc || !out) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    if (desc->abi_version != BSVI_ABI_VERSION) return bsvi_fail(BSVI_ERR_INVALID, "ABI version mismatch");
+    if (!desc->n_enc_layers || !desc->n_dec_layers || !desc->enc_layers || !desc->dec_layers || !desc->dataset ||
+        !desc->prior_loc || !desc->prior_scale || !desc->latent_dim || !desc->batch_size || !desc->n_features)
+        return bsvi_fail(BSVI_ERR_INVALID, "incomplete amortised-model description");
+    if (desc->batch_size > desc->dataset_size) return bsvi_fail(BSVI_ERR_INVALID, "batch_size exceeds dataset_size");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return bsvi_fail(BSVI_ERR_NO_DEVICE, "no HIP device");
+    auto* a = new bsvi_amort();
+    a->d = *desc;
+    int rc = build_net(a->enc, desc->enc_layers, desc->n_enc_layers, (int)desc->n_features, desc->n_params);
+    if (!rc) rc = build_net(a->dec, desc->dec_layers, desc->n_dec_layers, (int)desc->latent_dim, desc->n_params);
+    auto bad = [&](const char* msg) { delete a; return bsvi_fail(BSVI_ERR_INVALID, msg); };
+    if (rc) { delete a; return rc; }
+    const uint32_t Dz = desc->latent_dim;
+    if (desc->enc_loc_value >= a->enc.width.size() || desc->enc_scale_value >= a->enc.width.size() ||
+        a->enc.width[desc->enc_loc_value] != (int)Dz || a->enc.width[desc->enc_scale_value] != (int)Dz ||
+        desc->enc_loc_value == 0 || desc->enc_scale_value == 0 || desc->enc_loc_value == desc->enc_scale_value)
+        return bad("encoder heads must be two distinct layer outputs of width latent_dim");
+    if (desc->dec_logits_value == 0 || desc->dec_logits_value >= a->dec.width.size() ||
+        a->dec.width[desc->dec_logits_value] != (int)desc->n_features)
+        return bad("decoder output must have width n_features");
+    // the heads and the logits must be leaves: their gradients come from the row kernels only
+    for (const auto& l : a->enc.layers)
+        if (l.in_value == desc->enc_loc_value || l.in_value == desc->enc_scale_value) return bad("encoder heads must not feed further layers");
+    for (const auto& l : a->dec.layers)
+        if (l.in_value == desc->dec_logits_value) return bad("decoder logits must not feed further layers");
+    // workspace layout per row: values and gradients of every non-input value, z / dz, eps, rowf, rowlq, idx
+    size_t off = 0;
+    int alias_grad = -1;
+    auto lay = [&](Net& net, bool input_buffers) {
+        const size_t nv = net.width.size();
+        net.val_off.assign(nv, 0);
+        net.grad_off.assign(nv, 0);
+        for (size_t v = input_buffers ? 0 : 1; v < nv; ++v) {
+            net.val_off[v] = off;  off += net.ld[v];
+            if (alias_grad == (int)v) { net.grad_off[v] = net.val_off[v]; continue; }
+            net.grad_off[v] = off; off += net.ld[v];
+        }
+    };
+    lay(a->enc, false);
+    alias_grad = (int)desc->dec_logits_value;    // the logits are overwritten by their own gradient
+    lay(a->dec, true);                           // decoder value 0 = z, its gradient = dz
+    off += Dz;                  // eps
+    off += 4;                   // rowf, rowlq, idx, spare
+    a->floats_per_row = off;
+    const size_t ds_bytes = (size_t)desc->dataset_size * desc->n_features * sizeof(float);
+    if (hipMalloc(&a->dataset_dev, ds_bytes) != hipSuccess || hipMalloc(&a->prior_dev, 2 * Dz * sizeof(float)) != hipSuccess) {
+        bsvi_amort_destroy(a);
+        return bsvi_fail(BSVI_ERR_HIP, "hipMalloc of the dataset failed");
+    }
+    (void)hipMemcpy(a->dataset_dev, desc->dataset, ds_bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(a->prior_dev, desc->prior_loc, Dz * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemcpy(a->prior_dev + Dz, desc->prior_scale, Dz * sizeof(float), hipMemcpyHostToDevice);
+    a->d.enc_layers = a->enc.layers.data();
+    a->d.dec_layers = a->dec.layers.data();
+    a->d.dataset = nullptr;
+    a->d.prior_loc = a->d.prior_scale = nullptr;
+    *out = a;
+    return BSVI_OK;
+}
+
+extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
+    if (!a) return;
+    if (a->dataset_dev) (void)hipFree(a->dataset_dev);
+    if (a->prior_dev) (void)hipFree(a->prior_dev);
+    delete a;
+}
+
+extern "C" size_t bsvi_amort_workspace_bytes(const bsvi_amort* a, uint32_t n_samples_local) {
+    if (!a) return 0;
+    const size_t R = (size_t)n_samples_local * a->d.batch_size;
+    return (R * a->floats_per_row + 64) * sizeof(float);
+}
+
+static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
+    if (G.M <= 0 || G.N <= 0 || G.K <= 0) return BSVI_OK;
+    auto aligned = [](const void* p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); };
+    G.vecA = aligned(G.A, G.lda);
+    G.vecB = aligned(G.B, G.ldb);
+    const int tiles = ((G.M + BM - 1) / BM) * ((G.N + BN - 1) / BN);
+    G.remap = (tiles % 8 == 0) ? 1 : 0;
+    dim3 grid(tiles, 1, 1);
+    if (mode == MODE_TN) {
+        // K = all rows: split it so that ~1024 workgroups are in flight
+        int splits = std::max(1, std::min((G.K + BK - 1) / BK, (1024 + tiles - 1) / tiles));
+        int chunk = ((G.K + splits - 1) / splits + BK - 1) / BK * BK;
+        G.k_chunk = chunk;
+        grid.y = (G.K + chunk - 1) / chunk;
+        hipLaunchKernelGGL(gemm_kernel<MODE_TN>, grid, dim3(NTHREADS), 0, stream, G);
+    } else if (mode == MODE_NT) {
+        hipLaunchKernelGGL(gemm_kernel<MODE_NT>, grid, dim3(NTHREADS), 0, stream, G);
+    } else {
+        hipLaunchKernelGGL(gemm_kernel<MODE_NN>, grid, dim3(NTHREADS), 0, stream, G);
+    }
+    HIP_TRY(hipGetLastError());
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev, float* c_dev, const int32_t* rows_dev,
+                               uint32_t m, uint32_t n, uint32_t k, uint32_t lda, uint32_t ldb, uint32_t ldc,
+                               const float* bias_or_y_dev, uint32_t ldy, uint32_t activation, float post_add,
+                               uint32_t accumulate, void* stream) {
+    if (mode < 0 || mode > 2 || !a_dev || !b_dev || !c_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
+    GemmArgs G{};
+    G.A = a_dev; G.B = b_dev; G.C = c_dev; G.rows = rows_dev;
+    G.M = (int)m; G.N = (int)n; G.K = (int)k; G.lda = (int)lda; G.ldb = (int)ldb; G.ldc = (int)ldc;
+    G.act = (int)activation; G.post_add = post_add; G.accumulate = (int)accumulate;
+    if (mode == MODE_NT) G.bias = bias_or_y_dev;
+    if (mode == MODE_NN) { G.Y = bias_or_y_dev; G.ldy = (int)ldy; if (!G.Y) G.act = BSVI_ACT_NONE; }
+    return launch_gemm(mode, G, (hipStream_t)stream);
+}
+
+extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args) {
+    if (!a || !args || !args->params_dev || !args->out_dev || !args->workspace_dev || !args->n_samples_local)
+        return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    if (args->estimator > 1) return bsvi_fail(BSVI_ERR_UNSUPPORTED, "estimator must be 0 (pathwise) or 1 (BlackBox)");
+    hipStream_t stream = (hipStream_t)args->stream;
+    const bsvi_amort_desc& d = a->d;
+    const int B = (int)d.batch_size, Dz = (int)d.latent_dim, P = (int)d.n_features;
+    const size_t R = (size_t)args->n_samples_local * B;
+    if (R > 0x7fffffffu / 1024) return bsvi_fail(BSVI_ERR_RESOURCE, "too many rows for one launch");
+    float* ws = (float*)args->workspace_dev;
+    float* out = args->out_dev;
+    const float* params = args->params_dev;
+    float* grads = out + BSVI_OUT_HEADER;
+
+    auto val = [&](const Net& net, uint32_t v) { return ws + net.val_off[v] * R; };
+    auto grad = [&](const Net& net, uint32_t v) { return ws + net.grad_off[v] * R; };
+    size_t tail = 0;
+    for (const Net* net : {&a->enc, &a->dec})
+        for (size_t v = 0; v < net->width.size(); ++v) tail = std::max(tail, std::max(net->val_off[v], net->grad_off[v]) + net->ld[v]);
+    float* eps = ws + tail * R;
+    float* rowf = eps + (size_t)Dz * R;
+    float* rowlq = rowf + R;
+    int32_t* idx = (int32_t*)(rowlq + R);
+
+    HIP_TRY(hipMemsetAsync(out, 0, (BSVI_OUT_HEADER + (size_t)d.n_params) * sizeof(float), stream));
+
+    RowParams D{};
+    D.R = (int)R; D.B = B; D.DS = (int)d.dataset_size; D.P = P; D.Dz = Dz;
+    D.n_local = (int)args->n_samples_local; D.sample_base = (int)args->sample_base;
+    D.seed_lo = (uint32_t)args->seed; D.seed_hi = (uint32_t)(args->seed >> 32);
+    D.off_lo = (uint32_t)args->offset; D.off_hi = (uint32_t)(args->offset >> 32);
+    D.estimator = (int)args->estimator;
+    // EmpiricalDistribution._get_entropy (distributions.py:464-473) is Categorical(ones(n)).entropy() with
+    // n = dataset.shape[0]; the posterior's dataset has been tiled to number_samples rows, so every row's entropy
+    // carries the constant log(number_samples).  Kept: it shifts the loss and weights BlackBox's score term.
+    D.entropy_const = logf((float)args->n_samples_global);
+    D.indices_in = args->indices_dev; D.idx = idx; D.indices_out = args->indices_out_dev;
+    D.noise_in = args->noise_dev; D.noise_out = args->noise_out_dev;
+    D.dataset = a->dataset_dev;
+    const bsvi_mlp_layer& Lloc = a->enc.layers[a->enc.producer[d.enc_loc_value]];
+    const bsvi_mlp_layer& Lscale = a->enc.layers[a->enc.producer[d.enc_scale_value]];
+    D.loc = val(a->enc, d.enc_loc_value); D.ld_loc = a->enc.ld[d.enc_loc_value]; D.act_loc = (int)Lloc.activation; D.add_loc = Lloc.post_add;
+    D.scale = val(a->enc, d.enc_scale_value); D.ld_scale = a->enc.ld[d.enc_scale_value]; D.act_scale = (int)Lscale.activation; D.add_scale = Lscale.post_add;
+    D.dloc = grad(a->enc, d.enc_loc_value); D.dscale = grad(a->enc, d.enc_scale_value);
+    D.eps = eps; D.z = val(a->dec, 0); D.ld_z = a->dec.ld[0]; D.dz = grad(a->dec, 0);
+    D.prior_loc = a->prior_dev; D.prior_scale = a->prior_dev + Dz;
+    D.rowf = rowf; D.rowlq = rowlq;
+    D.logits = val(a->dec, d.dec_logits_value); D.ld_logits = a->dec.ld[d.dec_logits_value];
+    D.out = out; D.fvalue_out = args->fvalue_out_dev; D.logq_out = args->logq_out_dev;
+
+    const dim3 row_grid((unsigned)((R + 255) / 256));
+    hipLaunchKernelGGL(amort_rows, row_grid, dim3(256), 0, stream, D);
+
+    auto forward = [&](const Net& net, bool gather) -> int {
+        for (const auto& l : net.layers) {
+            GemmArgs G{};
+            const bool from_data = gather && l.in_value == 0;
+            G.A = from_data ? a->dataset_dev : val(net, l.in_value);
+            G.lda = from_data ? P : net.ld[l.in_value];
+            G.rows = from_data ? idx : nullptr;
+            G.B = params + l.weight_off; G.ldb = (int)l.n_in;
+            G.C = val(net, l.out_value); G.ldc = net.ld[l.out_value];
+            G.M = (int)R; G.N = (int)l.n_out; G.K = (int)l.n_in;
+            G.bias = l.bias_off != 0xFFFFFFFFu ? params + l.bias_off : nullptr;
+            G.act = (int)l.activation; G.post_add = l.post_add;
+            int rc = launch_gemm(MODE_NT, G, stream);
+            if (rc) return rc;
+        }
+        return BSVI_OK;
+    };
+    auto backward = [&](const Net& net, bool gather, bool input_grad) -> int {
+        std::vector<char> written(net.width.size(), 0);
+        for (int i = (int)net.layers.size() - 1; i >= 0; --i) {
+            const auto& l = net.layers[i];
+            const float* dY = grad(net, l.out_value);
+            const int ldy = net.ld[l.out_value];
+            const bool from_data = gather && l.in_value == 0;
+            {   // dW[n_out][n_in] += dY^T x
+                GemmArgs G{};
+                G.A = dY; G.lda = ldy;
+                G.B = from_data ? a->dataset_dev : val(net, l.in_value);
+                G.ldb = from_data ? P : net.ld[l.in_value];
+                G.rows = from_data ? idx : nullptr;
+                G.C = grads + l.weight_off; G.ldc = (int)l.n_in;
+                G.M = (int)l.n_out; G.N = (int)l.n_in; G.K = (int)R;
+                int rc = launch_gemm(MODE_TN, G, stream);
+                if (rc) return rc;
+            }
+            if (l.bias_off != 0xFFFFFFFFu) {
+                const int rows_per_block = 1024;
+                dim3 grid((l.n_out + 63) / 64, (unsigned)((R + rows_per_block - 1) / rows_per_block));
+                hipLaunchKernelGGL(col_sum_kernel, grid, dim3(256), 0, stream, dY, ldy, (int)R, (int)l.n_out, rows_per_block,
+                                   grads + l.bias_off);
+            }
+            if (l.in_value != 0 || input_grad) {   // dX = (dY W) * act'(x)
+                GemmArgs G{};
+                G.A = dY; G.lda = ldy;
+                G.B = params + l.weight_off; G.ldb = (int)l.n_in;
+                G.C = grad(net, l.in_value); G.ldc = net.ld[l.in_value];
+                G.M = (int)R; G.N = (int)l.n_in; G.K = (int)l.n_out;
+                const int prod = net.producer[l.in_value];
+                if (prod >= 0) {
+                    G.act = (int)net.layers[prod].activation; G.post_add = net.layers[prod].post_add;
+                    G.Y = val(net, l.in_value); G.ldy = net.ld[l.in_value];
+                }
+                G.accumulate = written[l.in_value];
+                written[l.in_value] = 1;
+                int rc = launch_gemm(MODE_NN, G, stream);
+                if (rc) return rc;
+            }
+        }
+        return BSVI_OK;
+    };
+
+    int rc = forward(a->enc, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(amort_latent_fwd, row_grid, dim3(256), 0, stream, D);
+    rc = forward(a->dec, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(amort_lik, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, D);
+    rc = backward(a->dec, false, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(amort_latent_bwd, row_grid, dim3(256), 0, stream, D);
+    rc = backward(a->enc, true, false);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return BSVI_OK;
+}

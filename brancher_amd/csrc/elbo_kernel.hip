@@ -35,6 +35,7 @@
 #include "../../include/bsvi.h"
 #include "dist_math.h"
 #include "philox.h"
+#include "bsvi_internal.h"
 
 namespace bsvi {
 
@@ -1456,6 +1457,7 @@ static int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+int bsvi_fail(int code, const std::string& msg) { return fail(code, msg); }   // for amort_kernel.hip (bsvi_internal.h)
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \

@@ -328,7 +328,13 @@ def compile_model(joint_model, posterior_model=None, gradient_estimator=None):
             try:
                 compiled = dense.CompiledDense(joint_model, posterior_model, est)
             except lowering.LoweringError as dense_error:
-                raise lowering.LoweringError("{}; dense path: {}".format(scalar_error, dense_error)) from None
+                # encoder / decoder network links go to the amortised path (amortized.py)
+                from brancher_amd import amortized
+                try:
+                    compiled = amortized.CompiledAmortized(joint_model, posterior_model, est)
+                except lowering.LoweringError as amort_error:
+                    raise lowering.LoweringError("{}; dense path: {}; amortised path: {}".format(
+                        scalar_error, dense_error, amort_error)) from None
         if sibling is not None:
             if sibling.n_params != compiled.n_params:
                 raise RuntimeError("parameter layouts of two estimators of the same model differ")

@@ -14,6 +14,45 @@ from brancher_amd.variables import var2link, Variable, PartialLink
 from brancher_amd import symbolic as sym
 
 
+def _is_torch_module(fn):
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        return False
+    return isinstance(fn, torch.nn.Module)
+
+
+class ModuleLink:
+    """A ``torch.nn.Module`` used as a link (`functions.py:15-20`, `examples/VAE_playground.py:66-67`).
+
+    The reference calls the module on every ELBO evaluation and lets ``torch.optim`` update its
+    ``nn.Parameter``s.  Here the module is a *description*: `amortized.trace_network` reads its layer
+    structure once (torch.fx), its tensors are copied into ``Parameter`` objects (segments of the engine's
+    flat HBM buffer, torch layout kept) and the MFMA kernels of `csrc/amort_kernel.hip` do the arithmetic.
+    ``sync_to_module()`` writes the trained values back into the module."""
+    _count = 0
+
+    def __init__(self, module, name):
+        from brancher_amd.modules import Parameter
+        self.module = module
+        ModuleLink._count += 1
+        self.name = "{}#{}".format(name, ModuleLink._count)
+        self.named = {pname: Parameter(p.detach().cpu().numpy(), name="{}.{}".format(self.name, pname))
+                      for pname, p in module.named_parameters()}
+
+    def parameters(self):
+        return list(self.named.values())
+
+    def sync_to_module(self):
+        import torch
+        with torch.no_grad():
+            for pname, p in self.module.named_parameters():
+                p.copy_(torch.from_numpy(self.named[pname].numpy().copy()).to(p.device))
+
+    def __call__(self, *args, **kwargs):
+        raise RuntimeError("a ModuleLink is evaluated by the native engine, not called")
+
+
 class BrancherFunction(object):
     """Lifts a backend function (by name) or a user callable/module to symbolic links
     (`brancher/functions.py:9-45`)."""
@@ -23,7 +62,10 @@ class BrancherFunction(object):
         self.name = name if isinstance(fn, str) or name != "f_?" else getattr(fn, "__name__", name)
         self.links = set()
         if not isinstance(fn, str) and hasattr(fn, "parameters") and callable(getattr(fn, "parameters")):
-            # an optimizable module (`functions.py:15-20`)
+            # an optimizable module (`functions.py:15-20`).  A torch.nn.Module is held through a ModuleLink: its
+            # tensors become segments of the engine's flat parameter buffer, the module itself is never called
+            if _is_torch_module(fn):
+                fn = self.fn = ModuleLink(fn, self.name)
             self.links = {fn}
 
     def _get_string(self, *args, **kwargs):

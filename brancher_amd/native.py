@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 OUT_HEADER = 4
 
 
@@ -115,6 +115,43 @@ EXPORTS = {
     "bsvi_device_count": (C.c_int, []),
 }
 EXPORTS.update(DENSE_EXPORTS)
+
+
+class MlpLayer(C.Structure):
+    _fields_ = [("in_value", C.c_uint32), ("out_value", C.c_uint32), ("n_in", C.c_uint32), ("n_out", C.c_uint32),
+                ("weight_off", C.c_uint32), ("bias_off", C.c_uint32), ("activation", C.c_uint32),
+                ("post_add", C.c_float)]
+
+
+class AmortDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_params", C.c_uint32),
+                ("n_features", C.c_uint32), ("latent_dim", C.c_uint32), ("dataset_size", C.c_uint32),
+                ("batch_size", C.c_uint32), ("n_enc_layers", C.c_uint32), ("n_dec_layers", C.c_uint32),
+                ("enc_loc_value", C.c_uint32), ("enc_scale_value", C.c_uint32), ("dec_logits_value", C.c_uint32),
+                ("reserved", C.c_uint32),
+                ("enc_layers", C.POINTER(MlpLayer)), ("dec_layers", C.POINTER(MlpLayer)),
+                ("prior_loc", C.c_void_p), ("prior_scale", C.c_void_p), ("dataset", C.c_void_p)]
+
+
+class AmortArgs(C.Structure):
+    _fields_ = [("params_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("indices_dev", C.c_void_p),
+                ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
+                ("sample_base", C.c_uint32), ("estimator", C.c_uint32),
+                ("out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p), ("indices_out_dev", C.c_void_p),
+                ("fvalue_out_dev", C.c_void_p), ("logq_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p),
+                ("stream", C.c_void_p)]
+
+
+EXPORTS.update({
+    "bsvi_amort_create": (C.c_int, [C.POINTER(AmortDesc), C.POINTER(C.c_void_p)]),
+    "bsvi_amort_destroy": (None, [C.c_void_p]),
+    "bsvi_amort_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "bsvi_amort_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(AmortArgs)]),
+    "bsvi_debug_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                  C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                  C.c_float, C.c_uint32, C.c_void_p]),
+})
 
 _lib = None
 

@@ -372,3 +372,74 @@ def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=78
                                   "weights", learnable=True)
     model.set_posterior_model(api.ProbabilisticModel([Qweights]))
     return model
+
+
+def vae_modules(n_features, latent_size, hidden1, hidden2, seed=0):
+    """Encoder / decoder architectures of `examples/VAE_playground.py:27-62` (MLP 784-256-512-(2,2) and 2-512-256-784
+    there), as plain torch modules with a seeded initialisation.  They override ``__call__`` and return dicts like
+    the example's classes do."""
+    import torch
+    import torch.nn as nn
+
+    class EncoderArchitecture(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1 = nn.Linear(n_features, hidden2)
+            self.l2 = nn.Linear(hidden2, hidden1)
+            self.f1 = nn.ReLU()
+            self.f2 = nn.ReLU()
+            self.l3 = nn.Linear(hidden1, latent_size)
+            self.l4 = nn.Linear(hidden1, latent_size)
+            self.softplus = nn.Softplus()
+
+        def __call__(self, x):
+            h0 = self.f1(self.l1(x.squeeze()))
+            h1 = self.f2(self.l2(h0))
+            return {"mean": self.l3(h1), "sd": self.softplus(self.l4(h1)) + 0.1}
+
+    class DecoderArchitecture(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1 = nn.Linear(latent_size, hidden1)
+            self.l2 = nn.Linear(hidden1, hidden2)
+            self.f1 = nn.ReLU()
+            self.f2 = nn.ReLU()
+            self.l3 = nn.Linear(hidden2, n_features)
+
+        def __call__(self, x):
+            h0 = self.f1(self.l1(x))
+            h1 = self.f2(self.l2(h0))
+            return {"mean": self.l3(h1)}
+
+    state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    enc, dec = EncoderArchitecture(), DecoderArchitecture()
+    torch.random.set_rng_state(state)
+    return enc, dec
+
+
+def vae_data(dataset_size, n_features, seed=0):
+    """synthetic binary images (MNIST is not available offline): rand > 0.5, stored [DS, P, 1] like
+    `VAE_playground.py:24-26`"""
+    rng = np.random.RandomState(seed)
+    return (rng.rand(dataset_size, n_features, 1) > 0.5).astype("int32")
+
+
+def build_vae(api, dataset_size=64, batch_size=16, n_features=784, latent_size=2, hidden1=512, hidden2=256, seed=0):
+    """BASELINE config 5: `examples/VAE_playground.py:64-79` — amortised Normal posterior over a latent code,
+    Binomial(1, logits = decoder(z)) likelihood, every Monte-Carlo sample drawing its own minibatch."""
+    BF = api.BF
+    dataset = vae_data(dataset_size, n_features, seed)
+    enc, dec = vae_modules(n_features, latent_size, hidden1, hidden2, seed)
+    encoder = BF.BrancherFunction(enc)
+    decoder = BF.BrancherFunction(dec)
+    z = api.NormalVariable(np.zeros((latent_size,)), np.ones((latent_size,)), name="z")
+    decoder_output = api.DeterministicVariable(decoder(z), name="decoder_output")
+    x = api.BinomialVariable(total_count=1, logits=decoder_output["mean"], name="x")
+    model = api.ProbabilisticModel([x, z])
+    Qx = api.EmpiricalVariable(dataset, batch_size=batch_size, name="x", is_observed=True)
+    encoder_output = api.DeterministicVariable(encoder(Qx), name="encoder_output")
+    Qz = api.NormalVariable(encoder_output["mean"], encoder_output["sd"], name="z")
+    model.set_posterior_model(api.ProbabilisticModel([Qx, Qz]))
+    model.vae_modules = (enc, dec)
+    return model

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 3
+#define BSVI_ABI_VERSION 4
 
 typedef enum bsvi_status {
     BSVI_OK = 0,
@@ -358,6 +358,83 @@ int bsvi_dense_finalize(const bsvi_dense* d, float* out_dev, uint32_t n_samples_
 int bsvi_dense_step(const bsvi_dense* d, const bsvi_dense_args* args, const bsvi_opt_cfg* cfg,
                     float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                     float* loss_slot_dev, float* finite_slot_dev);
+
+/* =========================================================================================
+ *  Amortised path (BASELINE config 5, examples/VAE_playground.py:18-88): the posterior of a latent
+ *  vector z is a Normal whose loc / scale are the heads of an encoder network applied to a minibatch
+ *  row x that EVERY Monte-Carlo sample draws for itself (EmpiricalVariable(dataset, batch_size=B),
+ *  distributions.py:410-457 — number_samples * B rows per iteration), and the likelihood of x is
+ *  Binomial(1, logits = decoder(z)).  Both networks are `BF.BrancherFunction(torch.nn.Module)` links
+ *  (functions.py:15-41) made of Linear layers and elementwise activations; their weights are segments
+ *  of the flat parameter buffer in torch's own layout (Linear.weight [n_out][n_in], bias [n_out]).
+ *  Every Linear layer is an f32 MFMA GEMM over all R = n_samples * B rows (forward x W^T, backward-data
+ *  dY W and backward-weight dY^T x), with bias + activation (forward) and the activation derivative
+ *  (backward) as GEMM epilogues; the first layer gathers its rows from the dataset through the
+ *  minibatch indices, so the minibatch is never materialised.
+ *  Per row:  f = log p(x | z) + log p(z) + H[q(z | x)]  -> [N, B]; ELBO estimate = mean over N*B
+ *  (variables.py:851-855, gradient_estimators.py:29-44).  estimator 0 = pathwise, 1 = BlackBox.
+ * ========================================================================================= */
+typedef enum bsvi_mlp_activation {
+    BSVI_ACT_NONE = 0,
+    BSVI_ACT_RELU = 1,
+    BSVI_ACT_SOFTPLUS = 2
+} bsvi_mlp_activation;
+
+/* y[out_value] = activation(x[in_value] W^T + b) + post_add;  value 0 is the network's input */
+typedef struct bsvi_mlp_layer {
+    uint32_t in_value, out_value;
+    uint32_t n_in, n_out;
+    uint32_t weight_off, bias_off;   /* offsets into the flat parameter buffer; bias_off = 0xFFFFFFFF: no bias */
+    uint32_t activation;             /* bsvi_mlp_activation */
+    float post_add;
+} bsvi_mlp_layer;
+
+typedef struct bsvi_amort_desc {
+    uint32_t abi_version, n_params;
+    uint32_t n_features, latent_dim, dataset_size, batch_size;
+    uint32_t n_enc_layers, n_dec_layers;          /* topologically ordered */
+    uint32_t enc_loc_value, enc_scale_value;      /* encoder values feeding q(z | x) = Normal(loc, scale)  */
+    uint32_t dec_logits_value, reserved;          /* decoder value feeding Binomial(1, logits)             */
+    const bsvi_mlp_layer* enc_layers;
+    const bsvi_mlp_layer* dec_layers;
+    const float* prior_loc;                       /* [latent_dim] host: p(z) = Normal(prior_loc, prior_scale) */
+    const float* prior_scale;
+    const float* dataset;                         /* [dataset_size][n_features] host copy */
+} bsvi_amort_desc;
+
+typedef struct bsvi_amort bsvi_amort;
+
+typedef struct bsvi_amort_args {
+    const float* params_dev;      /* [n_params]                                                         */
+    const float* noise_dev;       /* eps [n_samples_local * B][latent_dim] or NULL -> Philox             */
+    const int32_t* indices_dev;   /* minibatch rows [n_samples_local][B] or NULL -> drawn on the device  */
+    uint64_t seed, offset;
+    uint32_t n_samples_local, n_samples_global, sample_base, estimator;
+    float* out_dev;               /* [BSVI_OUT_HEADER + n_params]: out[0] = sum over rows of the estimator value,
+                                     out[1] = non-finite rows, out[4..] = gradient sums; bsvi_finalize_step with
+                                     n_samples_global * batch_size turns the sums into loss and gradients        */
+    float* noise_out_dev;         /* eps used, or NULL                    */
+    int32_t* indices_out_dev;     /* minibatch used, or NULL              */
+    float* fvalue_out_dev;        /* f per row [n_samples_local * B], or NULL */
+    float* logq_out_dev;          /* log q(z | x) per row, or NULL        */
+    void* workspace_dev;
+    void* stream;
+} bsvi_amort_args;
+
+int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out);
+void bsvi_amort_destroy(bsvi_amort* a);
+size_t bsvi_amort_workspace_bytes(const bsvi_amort* a, uint32_t n_samples_local);
+int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args);
+
+/* Test hook: one launch of the f32 MFMA GEMM behind the amortised path.
+ * mode 0: C[M][N] = A[M][K] B[N][K]^T   (+ bias[n], activation)        forward
+ * mode 1: C[M][N] = A[M][K] B[K][N]     (* activation'(Y[m][n]))      backward-data
+ * mode 2: C[M][N] += A[K][M]^T B[K][N]  (atomic, K split over blocks) backward-weight
+ * rows_dev (or NULL) gathers the rows of A (modes 0, 1) / of B (mode 2). */
+int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev, float* c_dev, const int32_t* rows_dev,
+                    uint32_t m, uint32_t n, uint32_t k, uint32_t lda, uint32_t ldb, uint32_t ldc,
+                    const float* bias_or_y_dev, uint32_t ldy, uint32_t activation, float post_add,
+                    uint32_t accumulate, void* stream);
 
 /* Test hook, not used by the product path: evaluates one special function (fn 0 digamma,
  * 1 trigamma, 2 dirichlet_grad_one(x, alpha=p0, total=p1), 6 lgamma) or one node function of

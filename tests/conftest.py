@@ -15,8 +15,9 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+def golden_cases(vae=False):
+    # vae_* fixtures (amortised workload, oracle/gen_golden_vae.py) have their own tests
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("vae_") == vae)
 
 
 class Golden:
@@ -62,6 +63,11 @@ class Golden:
 
 @pytest.fixture(params=golden_cases())
 def golden(request):
+    return Golden(request.param)
+
+
+@pytest.fixture(params=golden_cases(vae=True))
+def vae_golden(request):
     return Golden(request.param)
 
 

@@ -1,0 +1,191 @@
+"""GPU parity of the amortised path (BASELINE config 5; csrc/amort_kernel.hip through bsvi_amort_* / bsvi_debug_gemm)
+against the reference-generated fixtures tests/golden/vae_*.npz and against oracle/vae_oracle.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5   # north_star: 1e-5 relative on ELBO and grads
+
+
+def _module_view(compiled, named):
+    """{"enc/l1.weight": array} from the engine's flat buffers"""
+    enc_link, dec_link = compiled.program.links
+    out = {}
+    for tag, link in (("enc", enc_link), ("dec", dec_link)):
+        for pname, par in link.named.items():
+            out["%s/%s" % (tag, pname)] = named[par.name]
+    return out
+
+
+# ---- the GEMM behind every Linear layer ------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 16), (300, 70, 50), (64, 2, 512), (257, 784, 2), (1000, 136, 40), (130, 3, 3)])
+def test_gemm_matches_torch(mode, shape):
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + mode)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    if mode == 0:      # C = act(A B^T + bias) + post_add, rows of A gathered
+        src = rnd(M + 5, K)
+        rows = torch.randint(0, M + 5, (M,), generator=g).to(torch.int32).to(dev)
+        Bm, bias = rnd(N, K), rnd(N)
+        Cm = torch.full((M, N + 3), 7.0, device=dev)
+        native.check(lib.bsvi_debug_gemm(0, ptr(src), ptr(Bm), ptr(Cm), ptr(rows), M, N, K, K, K, N + 3, ptr(bias), 0, 2, 0.1, 0, None))
+        ref = torch.nn.functional.softplus(src[rows.long()].double() @ Bm.double().T + bias.double()) + 0.1
+        got = Cm[:, :N]
+        assert torch.all(Cm[:, N:] == 7.0)
+    elif mode == 1:    # C = (A B) * relu'(Y), accumulated on top of C
+        A, Bm, Y = rnd(M, K), rnd(K, N), rnd(M, N)
+        C0 = rnd(M, N)
+        Cm = C0.clone()
+        native.check(lib.bsvi_debug_gemm(1, ptr(A), ptr(Bm), ptr(Cm), None, M, N, K, K, N, N, ptr(Y), N, 1, 0.0, 1, None))
+        ref = C0.double() + (A.double() @ Bm.double()) * (Y > 0).double()
+        got = Cm
+    else:              # C += A^T B with K = rows split over workgroups, rows of B gathered
+        A = rnd(K, M)
+        src = rnd(K + 3, N)
+        rows = torch.randint(0, K + 3, (K,), generator=g).to(torch.int32).to(dev)
+        Cm = torch.zeros(M, N, device=dev)
+        native.check(lib.bsvi_debug_gemm(2, ptr(A), ptr(src), ptr(Cm), ptr(rows), M, N, K, M, N, N, None, 0, 0, 0.0, 0, None))
+        ref = A.double().T @ src[rows.long()].double()
+        got = Cm
+    torch.cuda.synchronize()
+    err = (got.double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+    assert err < 2e-6, err
+
+
+def test_gemm_tall_split_k():
+    """backward-weight shape of the workload: K = all rows (tens of thousands), small output"""
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    K, M, N = 40000, 72, 200
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A, Bm = torch.randn(K, M, generator=g).to(dev), torch.randn(K, N, generator=g).to(dev)
+    Cm = torch.zeros(M, N, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    native.check(lib.bsvi_debug_gemm(2, ptr(A), ptr(Bm), ptr(Cm), None, M, N, K, M, N, N, None, 0, 0, 0.0, 0, None))
+    ref = A.double().T @ Bm.double()
+    assert ((Cm.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+# ---- the ELBO gradient against the reference's own outputs ------------------------------------------------------
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_vae_golden_loss_and_grads(vae_golden, estimator):
+    from brancher_amd import engine
+    g = vae_golden
+    model = g.build()
+    compiled = engine.compile_model(model, model.posterior_model, estimator)
+    assert type(compiled).__name__ == "CompiledAmortized"
+    res = compiled.evaluate(g.N, noise=g.data["noise/z"], minibatch=g.data["minibatch/x"], want_fvalues=True)
+    ref_loss = float(g.data["loss_" + estimator])
+    assert abs(float(res["loss"]) - ref_loss) <= TOL * abs(ref_loss)
+    assert float(res["finite"]) == 1.0
+    grads = _module_view(compiled, compiled.named_grads())
+    ref_grads = g.group("grad_%s/" % estimator)
+    scale = max(np.abs(v).max() for v in ref_grads.values())
+    for name, g_ref in ref_grads.items():
+        assert np.abs(grads[name] - g_ref).max() <= TOL * scale, name
+    f_ref = (g.data["lp"] + g.data["H"]).reshape(-1)
+    assert rel_err(res["f"].cpu().numpy(), f_ref) <= TOL
+    assert rel_err(res["logq"].cpu().numpy(), g.data["lq"].reshape(-1)) <= TOL
+
+
+def test_vae_golden_trajectory(vae_golden):
+    from brancher_amd import engine
+    g = vae_golden
+    tr = g.meta["trajectory"]
+    if tr is None:
+        pytest.skip("no trajectory in this fixture")
+    model = g.build()
+    compiled = engine.compile_model(model, model.posterior_model, "pathwise")
+    losses, finite = compiled.train(tr["iters"], tr["n"], tr["optimizer"], noise_seq=list(g.data["traj/noise/z"]),
+                                    minibatch_seq=list(g.data["traj/minibatch/x"]), **g.opt_kwargs())
+    assert rel_err(losses.cpu().numpy(), g.data["traj/losses"]) <= TOL
+    assert float(finite.min()) == 1.0
+    params = _module_view(compiled, compiled.named_params())
+    for name, ref in g.group("traj/param_after/").items():
+        assert np.abs(params[name] - ref).max() <= 1e-5 * (1 + np.abs(ref).max()), name
+    # the trained tensors go back into the user's torch modules
+    compiled.sync_modules()
+    enc = compiled.program.links[0].module
+    assert np.array_equal(enc.l1.weight.detach().numpy(), params["enc/l1.weight"])
+
+
+# ---- against the oracle at the example's full architecture -------------------------------------------------------
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_vae_full_architecture_matches_oracle(estimator):
+    from brancher_amd import engine, workloads as W
+    from oracle.vae_oracle import VaeOracle
+    N, B, DS = 6, 50, 300
+    model = W.build_vae(W.native_api(), dataset_size=DS, batch_size=B, n_features=784, hidden1=512, hidden2=256, seed=3)
+    rng = np.random.RandomState(11)
+    rows = np.stack([rng.choice(DS, B, replace=False) for _ in range(N)])
+    eps = rng.randn(N, B, 2).astype(np.float32)
+    ref = VaeOracle(model, dtype=torch.float64).loss_and_grads(rows, eps, estimator)
+    compiled = engine.compile_model(model, model.posterior_model, estimator)
+    res = compiled.evaluate(N, noise=eps, minibatch=rows)
+    assert abs(float(res["loss"]) - ref["loss"]) <= TOL * abs(ref["loss"])
+    grads = _module_view(compiled, compiled.named_grads())
+    scale = max(np.abs(v).max() for v in ref["grads"].values())
+    for name, g_ref in ref["grads"].items():
+        assert np.abs(grads[name] - g_ref).max() <= TOL * scale, name
+
+
+def test_vae_device_rng_properties():
+    """in-kernel minibatches and noise: distinct rows per sample, different per sample and per iteration, standard
+    normal eps, reproducible for a given (seed, offset); the loss agrees with the oracle fed the same draws"""
+    from brancher_amd import engine, workloads as W
+    from oracle.vae_oracle import VaeOracle
+    N, B, DS = 64, 20, 97
+    model = W.build_vae(W.native_api(), dataset_size=DS, batch_size=B, n_features=40, hidden1=24, hidden2=16, seed=1)
+    compiled = engine.compile_model(model, model.posterior_model, "pathwise")
+    r1 = compiled.evaluate(N, seed=5, offset=0, want_noise=True, want_indices=True)
+    idx, eps, loss1 = r1["indices"].cpu().numpy(), r1["noise"].cpu().numpy(), float(r1["loss"])
+    assert idx.shape == (N, B) and idx.min() >= 0 and idx.max() < DS
+    assert all(len(set(row)) == B for row in idx)
+    assert len({tuple(row) for row in idx}) == N
+    assert abs(eps.mean()) < 0.1 and abs(eps.std() - 1) < 0.1
+    r2 = compiled.evaluate(N, seed=5, offset=0, want_indices=True)
+    assert float(r2["loss"]) == loss1 or abs(float(r2["loss"]) - loss1) <= 1e-6 * abs(loss1)   # atomics reorder sums
+    r3 = compiled.evaluate(N, seed=5, offset=1, want_indices=True)
+    assert not np.array_equal(r3["indices"].cpu().numpy(), idx)
+    ref = VaeOracle(model, dtype=torch.float64).loss_and_grads(idx, eps.reshape(N, B, 2), "pathwise")
+    assert abs(loss1 - ref["loss"]) <= TOL * abs(ref["loss"])
+
+
+def test_vae_perform_inference_api():
+    """the user-facing loop of examples/VAE_playground.py:81-87 runs on the native engine and the loss goes down"""
+    from brancher_amd import inference, workloads as W
+    from brancher_amd.gradient_estimators import PathwiseDerivativeEstimator
+    model = W.build_vae(W.native_api(), dataset_size=200, batch_size=25, n_features=64, hidden1=48, hidden2=32, seed=2)
+    inference.perform_inference(model, inference_method=inference.ReverseKL(gradient_estimator=PathwiseDerivativeEstimator),
+                                number_iterations=150, number_samples=4, optimizer="Adam", lr=0.005)
+    curve = model.diagnostics["loss curve"]
+    assert len(curve) == 150 and np.all(np.isfinite(curve))
+    assert curve[-20:].mean() < curve[:20].mean()
+
+
+def test_vae_sharded_path_matches_single():
+    """the sequence a rank runs under torch.distributed (fwd_bwd -> all-reduce -> fused finalize step), on one GPU"""
+    from brancher_amd import engine, workloads as W
+    kw = dict(dataset_size=60, batch_size=10, n_features=30, hidden1=20, hidden2=12, seed=4)
+    rng = np.random.RandomState(0)
+    rows = [np.stack([rng.choice(60, 10, replace=False) for _ in range(8)]) for _ in range(4)]
+    eps = [rng.randn(8, 10, 2).astype(np.float32) for _ in range(4)]
+    out = []
+    for forced in (False, True):
+        model = W.build_vae(W.native_api(), **kw)
+        compiled = engine.compile_model(model, model.posterior_model, "pathwise")
+        losses, _ = compiled.train(4, 8, "Adam", noise_seq=eps, minibatch_seq=rows, lr=1e-2, _force_sharded_path=forced)
+        out.append((losses.cpu().numpy(), compiled.params.cpu().numpy()))
+    assert rel_err(out[1][0], out[0][0]) <= 1e-6
+    assert np.abs(out[1][1] - out[0][1]).max() <= 1e-6
