@@ -38,6 +38,11 @@ WORKLOADS = {
              1024, "Adam", dict(lr=5e-3),
              "Bayesian multinomial logistic regression, dense matmul link 10x784, minibatch 512 of 60000 synthetic "
              "rows, number_samples=1024, Adam lr=5e-3 (BASELINE config 4)"),
+    "cfg5": ("build_vae", dict(dataset_size=60000, batch_size=100, n_features=784, latent_size=2, hidden1=512, hidden2=256),
+             256, "Adam", dict(lr=1e-3),
+             "VAE_playground.py MLP VAE 784-256-512-(2,2) / 2-512-256-784, Binomial(1, logits) likelihood, every sample "
+             "draws its own minibatch of 100 of 60000 synthetic binary rows, number_samples=2048 sharded as 256 per GPU "
+             "(25600 rows per GPU), Adam lr=1e-3 (BASELINE config 5)"),
     "cfg1_big": ("build_readme_ar", dict(T=20), 262144, "SGD", dict(lr=1e-3),
                  "README AR T=20 at number_samples=262144 (throughput regime of the same kernel)"),
 }
@@ -75,6 +80,49 @@ def algorithmic_bytes_per_iteration(program, n_local):
     """N*L*4 noise bytes (the eps the estimator consumes; generated in registers here)
     + parameters read + gradients written."""
     return n_local * program.n_noise * 4 + 2 * program.n_params * 4
+
+
+def amort_flops_per_iteration(program, n_local):
+    """SURVEY §8d cfg 5: every Linear layer is three GEMMs of 2*R*n_in*n_out flops over the R = N*B rows of the
+    iteration — forward, weight gradient, input gradient (the last not for layers reading the data rows)."""
+    rows = n_local * program.batch_size
+    flops = 0.0
+    for net, input_grad in ((program.enc_layers, False), (program.dec_layers, True)):
+        for l in net:
+            flops += 2.0 * rows * l.n_in * l.n_out * (3 if (l.in_value != 0 or input_grad) else 2)
+    return flops
+
+
+def cpu_baseline_vae(kwargs, optimizer, opt_kwargs, budget_s=12.0, n_cpu=8):
+    """oracle/vae_oracle.py (PyTorch-CPU autograd through the same torch modules the reference calls) on a bounded
+    sample: number_samples=8 (800 rows) per iteration, up to 16 threads."""
+    import numpy as np
+    import torch
+    from brancher_amd import workloads as W
+    from oracle.vae_oracle import VaeOracle
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    oracle = VaeOracle(getattr(W, "build_vae")(W.native_api(), **kwargs))
+    rng = np.random.RandomState(0)
+    DS, B = kwargs["dataset_size"], kwargs["batch_size"]
+
+    def draws(k):
+        rows = [np.stack([rng.choice(DS, B, replace=False) for _ in range(n_cpu)]) for _ in range(k)]
+        eps = [rng.randn(n_cpu, B, oracle.Dz).astype(np.float32) for _ in range(k)]
+        return rows, eps
+
+    oracle.train(1, *draws(1), optimizer, **opt_kwargs)
+    iters, spent = 0, 0.0
+    while spent < budget_s and iters < 400:
+        rows, eps = draws(4)
+        t0 = time.perf_counter()
+        oracle.train(4, rows, eps, optimizer, **opt_kwargs)
+        spent += time.perf_counter() - t0
+        iters += 4
+    return dict(value=iters / spent * (n_cpu / 300.0), unit="it/s", cores=cores, kind="port",
+                sample="%d iterations of the same workload at number_samples=%d (%d rows) in %.1f s, oracle/vae_oracle.py "
+                       "on PyTorch-CPU, %d thread(s)" % (iters, n_cpu, n_cpu * B, spent, cores),
+                iters_per_sec=iters / spent, number_samples=n_cpu)
 
 
 def cpu_baseline(builder, kwargs, n_samples, optimizer, opt_kwargs, dense=False, budget_s=12.0, max_iters=400):
@@ -179,10 +227,11 @@ def main():
         iters_per_sec = args.steps / dt
         value = iters_per_sec * (n_global / 300.0)
         dense = hasattr(program, "n_classes")
-        geom = dict(kind="dense") if dense else compiled.native.geometry(n_per_gpu)
+        amort = hasattr(program, "enc_layers")
+        geom = dict(kind="dense") if dense else dict(kind="amortized") if amort else compiled.native.geometry(n_per_gpu)
         # roofline of the dominant kernel (the fused ELBO kernel; in persistent mode one launch
         # covers all K iterations).  Launch duration from HIP events on the launch stream.
-        alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu)
+        alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu * (program.batch_size if amort else 1))
         if mode == "persistent":
             launch_ms, launches, units_per_launch = dev_ms, 1, args.steps
             kernel = "bsvi::persistent_kernel<%s>" % geom.get("storage", "")
@@ -217,6 +266,18 @@ def main():
                             algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / args.steps,
                             note="f32-input MFMA (v_mfma_f32_16x16x4_f32); achieved = GEMM flops of one iteration / "
                                  "duration of the whole iteration")
+        if amort:
+            # the whole iteration (~35 launches) is timed; the 20 MFMA GEMMs carry the flops
+            flops = amort_flops_per_iteration(program, n_per_gpu)
+            tf = flops / (dev_ms * 1e-3 / args.steps) / 1e12
+            roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                            kernel="bsvi_amort_impl::gemm_kernel<0|1|2>",
+                            algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / args.steps,
+                            rows_per_iteration=n_per_gpu * program.batch_size,
+                            note="f32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = GEMM flops of one iteration "
+                                 "(forward + weight gradient + input gradient of every Linear layer) / duration of "
+                                 "the whole iteration")
         line = dict(metric="ELBO iters/sec at num_samples=%d per GPU (300-sample-equivalent iterations, whole job)"
                            % n_per_gpu,
                     value=value, unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -230,7 +291,8 @@ def main():
                     device_ms_per_step=dev_ms / args.steps, all_finite=ok,
                     final_loss=float(losses[-1].item()), roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(builder, kwargs, n_per_gpu, optimizer, opt_kwargs, dense=dense)
+            line["cpu_baseline"] = cpu_baseline_vae(kwargs, optimizer, opt_kwargs) if amort else \
+                cpu_baseline(builder, kwargs, n_per_gpu, optimizer, opt_kwargs, dense=dense)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -14,7 +14,8 @@
 //   gemm<NT>          decoder layers
 //   amort_lik         log p(x | z) per row and dlogits in place (one wave per row)
 //   per layer, last to first:  gemm<TN> dW += dY^T x (K = R split over workgroups, f32 atomics),
-//                              col_sum  db += 1^T dY,   gemm<NN> dX = (dY W) * act'(x)
+//                              (db += 1^T dY in the same launch),  gemm<NN> dX = (dY W) * act'(x)
+//   layers with a side of width <= 8 (latent heads, first decoder layer) use memory-bound skinny_* kernels instead
 //   amort_latent_bwd  joins decoder dz with prior / entropy / score-function terms, loss sums
 // GEMMs: 128x128x16 workgroup tiles, four waves of 64x64, v_mfma_f32_32x32x2_f32, k-major LDS tiles (row stride 132
 // words: transposing stores and MFMA operand reads are both conflict-free), register-staged double-buffered global
@@ -24,6 +25,7 @@
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bsvi.h"
@@ -37,7 +39,7 @@ using bsvi::u32x4;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, NTHREADS = 256;
+constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
 enum { MODE_NT = 0, MODE_NN = 1, MODE_TN = 2 };
@@ -58,6 +60,7 @@ struct GemmArgs {
     int accumulate;        // NN: C += result
     int k_chunk;           // TN: rows of K per workgroup (multiple of BK)
     int remap;             // XCD-aware workgroup order
+    float* bias_grad;      // TN: db[m] += sum_k A[k][m], taken from the A tiles the n = 0 workgroups stream anyway
 };
 
 __device__ __forceinline__ float act_forward(int act, float v, float post_add) {
@@ -79,7 +82,7 @@ __device__ __forceinline__ float act_derivative(int act, float y, float post_add
 // KC: the operand is stored [rows][k] (k contiguous); the tile is rows r0.. x k kt..kt+15, transposed on the way
 //     into LDS.  Thread t owns rows (t>>2) and (t>>2)+64, k quad (t&3)*4.
 // MC: the operand is stored [k][cols] (cols contiguous); thread t owns k rows (t>>5) and (t>>5)+8, columns (t&31)*4.
-struct Frag { float4 v[2]; };
+template <int W> struct Frag { float4 v[W / 64]; };   // W = tile extent along m / n: 128 or 64
 
 __device__ __forceinline__ float4 load4(const float* p, int valid, bool vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -94,12 +97,14 @@ __device__ __forceinline__ float4 load4(const float* p, int valid, bool vec) {
     return v;
 }
 
-__device__ __forceinline__ Frag load_kc(const float* base, const int32_t* rows, int ld, int r0, int n_rows, int kt,
-                                        int k_end, bool vec) {
-    Frag f;
+// KC: rows (t>>2) + 64 i, k quad (t&3)*4
+template <int W>
+__device__ __forceinline__ Frag<W> load_kc(const float* base, const int32_t* rows, int ld, int r0, int n_rows, int kt,
+                                           int k_end, bool vec) {
+    Frag<W> f;
     const int t = threadIdx.x, kq = kt + (t & 3) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < W / 64; ++i) {
         const int r = r0 + (t >> 2) + 64 * i;
         int valid = 0;
         const float* p = base;
@@ -112,24 +117,29 @@ __device__ __forceinline__ Frag load_kc(const float* base, const int32_t* rows, 
     }
     return f;
 }
-__device__ __forceinline__ void store_kc(float* tile, const Frag& f) {
+template <int W>
+__device__ __forceinline__ void store_kc(float* tile, const Frag<W>& f) {
+    constexpr int LD = W + 4;
     const int t = threadIdx.x, kq = (t & 3) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < W / 64; ++i) {
         const int r = (t >> 2) + 64 * i;
-        tile[(kq + 0) * LDT + r] = f.v[i].x;
-        tile[(kq + 1) * LDT + r] = f.v[i].y;
-        tile[(kq + 2) * LDT + r] = f.v[i].z;
-        tile[(kq + 3) * LDT + r] = f.v[i].w;
+        tile[(kq + 0) * LD + r] = f.v[i].x;
+        tile[(kq + 1) * LD + r] = f.v[i].y;
+        tile[(kq + 2) * LD + r] = f.v[i].z;
+        tile[(kq + 3) * LD + r] = f.v[i].w;
     }
 }
-__device__ __forceinline__ Frag load_mc(const float* base, const int32_t* rows, int ld, int c0, int n_cols, int kt,
-                                        int k_end, bool vec) {
-    Frag f;
-    const int t = threadIdx.x, c = c0 + (t & 31) * 4;
+// MC: W/4 threads per k row, 1024/W k rows per pass, W/64 passes
+template <int W>
+__device__ __forceinline__ Frag<W> load_mc(const float* base, const int32_t* rows, int ld, int c0, int n_cols, int kt,
+                                           int k_end, bool vec) {
+    constexpr int TPR = W / 4, KR = NTHREADS / TPR;
+    Frag<W> f;
+    const int t = threadIdx.x, c = c0 + (t % TPR) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int k = kt + (t >> 5) + 8 * i;
+    for (int i = 0; i < W / 64; ++i) {
+        const int k = kt + t / TPR + KR * i;
         int valid = 0;
         const float* p = base;
         if (k < k_end) {
@@ -141,25 +151,30 @@ __device__ __forceinline__ Frag load_mc(const float* base, const int32_t* rows, 
     }
     return f;
 }
-__device__ __forceinline__ void store_mc(float* tile, const Frag& f) {
-    const int t = threadIdx.x, c = (t & 31) * 4;
+template <int W>
+__device__ __forceinline__ void store_mc(float* tile, const Frag<W>& f) {
+    constexpr int TPR = W / 4, KR = NTHREADS / TPR, LD = W + 4;
+    const int t = threadIdx.x, c = (t % TPR) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int k = (t >> 5) + 8 * i;
-        *reinterpret_cast<float4*>(&tile[k * LDT + c]) = f.v[i];
+    for (int i = 0; i < W / 64; ++i) {
+        const int k = t / TPR + KR * i;
+        *reinterpret_cast<float4*>(&tile[k * LD + c]) = f.v[i];
     }
 }
 
-template <int MODE>
+// TBM x 128 workgroup tile (TBM = 128: waves 2x2 of 64x64; TBM = 64: waves 2x2 of 32x64 — twice the workgroups when
+// the tall operand alone does not fill the chip)
+template <int MODE, int TBM>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+    constexpr int LDA = TBM + 4, LDB = BN + 4, TM = TBM / 64;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
     const int tiles_n = (G.N + BN - 1) / BN;
     const int n_blocks = gridDim.x;
     int bid = blockIdx.x;
     if (G.remap) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // XCD x gets one contiguous range of tiles
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int m0 = (bid / tiles_n) * TBM, n0 = (bid % tiles_n) * BN;
     int k_begin = 0, k_end = G.K;
     if (MODE == MODE_TN) {
         k_begin = blockIdx.y * G.k_chunk;
@@ -167,65 +182,137 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    const int wm = (wave >> 1) * (TBM / 2), wn = (wave & 1) * 64;
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     auto load_a = [&](int kt) {
-        if (MODE == MODE_TN) return load_mc(G.A, nullptr, G.lda, m0, G.M, kt, k_end, G.vecA);
-        return load_kc(G.A, G.rows, G.lda, m0, G.M, kt, k_end, G.vecA);
+        if (MODE == MODE_TN) return load_mc<TBM>(G.A, nullptr, G.lda, m0, G.M, kt, k_end, G.vecA);
+        return load_kc<TBM>(G.A, G.rows, G.lda, m0, G.M, kt, k_end, G.vecA);
     };
     auto load_b = [&](int kt) {
-        if (MODE == MODE_NT) return load_kc(G.B, nullptr, G.ldb, n0, G.N, kt, k_end, G.vecB);
-        return load_mc(G.B, MODE == MODE_TN ? G.rows : nullptr, G.ldb, n0, G.N, kt, k_end, G.vecB);
+        if (MODE == MODE_NT) return load_kc<BN>(G.B, nullptr, G.ldb, n0, G.N, kt, k_end, G.vecB);
+        return load_mc<BN>(G.B, MODE == MODE_TN ? G.rows : nullptr, G.ldb, n0, G.N, kt, k_end, G.vecB);
     };
-    auto store_a = [&](float* tile, const Frag& f) {
-        if (MODE == MODE_TN) store_mc(tile, f); else store_kc(tile, f);
+    auto store_a = [&](float* tile, const Frag<TBM>& f) {
+        if (MODE == MODE_TN) store_mc<TBM>(tile, f); else store_kc<TBM>(tile, f);
     };
-    auto store_b = [&](float* tile, const Frag& f) {
-        if (MODE == MODE_NT) store_kc(tile, f); else store_mc(tile, f);
+    auto store_b = [&](float* tile, const Frag<BN>& f) {
+        if (MODE == MODE_NT) store_kc<BN>(tile, f); else store_mc<BN>(tile, f);
     };
 
-    Frag fa = load_a(k_begin), fb = load_b(k_begin);
-    store_a(As[0], fa);
-    store_b(Bs[0], fb);
-    __syncthreads();
+    // bias gradient on the side (TN, TBM = 128): every thread sums the A values it stages — 4 columns, its k rows
+    const bool col_sums = MODE == MODE_TN && G.bias_grad != nullptr && n0 == 0;
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_cols = [&](const Frag<TBM>& f) {
+#pragma unroll
+        for (int i = 0; i < TBM / 64; ++i) { bs.x += f.v[i].x; bs.y += f.v[i].y; bs.z += f.v[i].z; bs.w += f.v[i].w; }
+    };
 
     const int n_steps = (k_end - k_begin + BK - 1) / BK;
     const int lk = lane >> 5, lm = lane & 31;
-    for (int step = 0; step < n_steps; ++step) {
-        const int cur = step & 1;
-        const bool more = step + 1 < n_steps;
-        if (more) {
-            fa = load_a(k_begin + (step + 1) * BK);
-            fb = load_b(k_begin + (step + 1) * BK);
-        }
-        const float* at = As[cur];
-        const float* bt = Bs[cur];
+
+    // Workgroup-uniform fast path: the tile lies inside the matrices, every row is 16-byte loadable and the k range
+    // is whole steps -> per-thread pointers are resolved once (row gather included) and a step's staging is 3-4
+    // straight-line global_load_dwordx4; the generic loaders (bounds, scalar tails, per-step gather) take the rest.
+    const bool fast = G.vecA && G.vecB && m0 + TBM <= G.M && n0 + BN <= G.N && (k_end - k_begin) % BK == 0 &&
+                      k_end > k_begin && !(MODE == MODE_TN && G.rows);
+    const float* pa[TBM / 64];
+    const float* pb[BN / 64];
+    long sa = BK, sb = BK;       // pointer advance per step
+    if (fast) {
+        const int t = threadIdx.x;
+        if (MODE == MODE_TN) {
+            constexpr int TPR = TBM / 4, KR = NTHREADS / TPR;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = at[(kk + lk) * LDT + wm + lm], a1 = at[(kk + lk) * LDT + wm + 32 + lm];
-            const float b0 = bt[(kk + lk) * LDT + wn + lm], b1 = bt[(kk + lk) * LDT + wn + 32 + lm];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int i = 0; i < TBM / 64; ++i) pa[i] = G.A + (long)(k_begin + t / TPR + KR * i) * G.lda + m0 + (t % TPR) * 4;
+            sa = (long)BK * G.lda;
+        } else {
+#pragma unroll
+            for (int i = 0; i < TBM / 64; ++i) {
+                const int r = m0 + (t >> 2) + 64 * i;
+                pa[i] = G.A + (G.rows ? (long)G.rows[r] : (long)r) * G.lda + k_begin + (t & 3) * 4;
+            }
         }
-        if (more) {
-            store_a(As[cur ^ 1], fa);
-            store_b(Bs[cur ^ 1], fb);
+        if (MODE == MODE_NT) {
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i) pb[i] = G.B + (long)(n0 + (t >> 2) + 64 * i) * G.ldb + k_begin + (t & 3) * 4;
+        } else {
+            constexpr int TPR = BN / 4, KR = NTHREADS / TPR;
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i) pb[i] = G.B + (long)(k_begin + t / TPR + KR * i) * G.ldb + n0 + (t % TPR) * 4;
+            sb = (long)BK * G.ldb;
         }
+    }
+
+    auto main_loop = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        auto stage = [&](int step, Frag<TBM>& fa, Frag<BN>& fb) {
+            if (FAST) {
+#pragma unroll
+                for (int i = 0; i < TBM / 64; ++i) fa.v[i] = *reinterpret_cast<const float4*>(pa[i] + step * sa);
+#pragma unroll
+                for (int i = 0; i < BN / 64; ++i) fb.v[i] = *reinterpret_cast<const float4*>(pb[i] + step * sb);
+            } else {
+                fa = load_a(k_begin + step * BK);
+                fb = load_b(k_begin + step * BK);
+            }
+        };
+        Frag<TBM> fa;
+        Frag<BN> fb;
+        stage(0, fa, fb);
+        if (col_sums) add_cols(fa);
+        store_a(As[0], fa);
+        store_b(Bs[0], fb);
         __syncthreads();
+        for (int step = 0; step < n_steps; ++step) {
+            const int cur = step & 1;
+            const bool more = step + 1 < n_steps;
+            if (more) stage(step + 1, fa, fb);
+            const float* at = As[cur];
+            const float* bt = Bs[cur];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float a[TM], b[2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = at[(kk + lk) * LDA + wm + 32 * i + lm];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = bt[(kk + lk) * LDB + wn + 32 * j + lm];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) {
+                if (col_sums) add_cols(fa);      // here, not at the load: the values are awaited for the LDS store anyway
+                store_a(As[cur ^ 1], fa);
+                store_b(Bs[cur ^ 1], fb);
+            }
+            __syncthreads();
+        }
+    };
+    if (fast) main_loop(std::true_type{}); else main_loop(std::false_type{});
+
+    if (col_sums) {   // fold the 8 k-row groups of the workgroup through LDS
+        float* red = As[0];
+        *reinterpret_cast<float4*>(&red[(threadIdx.x >> 5) * LDA + (threadIdx.x & 31) * 4]) = bs;
+        __syncthreads();
+        if (threadIdx.x < TBM && m0 + (int)threadIdx.x < G.M) {
+            float s = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[q * LDA + threadIdx.x];
+            unsafeAtomicAdd(&G.bias_grad[m0 + threadIdx.x], s);
+        }
     }
 
     // epilogue.  acc[i][j][r] is C[m][n] with m = 32i + 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn + 32 * j + lm;
@@ -250,17 +337,106 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
         }
 }
 
-// ---- column sums: bias gradients db[n] += sum_r dY[r][n] ------------------------------------------------------
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* dY, int ld, int R, int N, int rows_per_block, float* db) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float s = 0.0f;
-    if (c < N)
-        for (int r = r0 + q; r < r1; r += 4) s += dY[(long)r * ld + c];
-    part[q][threadIdx.x & 63] = s;
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- layers with a side of width <= 8 (latent heads, first decoder layer): memory-bound, no matrix cores ----------
+constexpr int SKINNY = 8;
+
+__device__ __forceinline__ float skinny_epilogue(const GemmArgs& G, int mode, float v, long r, int n) {
+    float* c = G.C + r * G.ldc + n;
+    if (mode == MODE_NT) return act_forward(G.act, v + (G.bias ? G.bias[n] : 0.0f), G.post_add);
+    if (G.act != BSVI_ACT_NONE) v *= act_derivative(G.act, G.Y[r * G.ldy + n], G.post_add);
+    return G.accumulate ? *c + v : v;
+}
+
+// K <= 8:  C[r][n] = epilogue(sum_k A[r][k] * B(k, n)),  B(k, n) = B[k * sbk + n * sbn].  One thread per output.
+__global__ __launch_bounds__(256) void skinny_k_kernel(const GemmArgs G, int sbk, int sbn, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)G.M * G.N) return;
+    const long r = i / G.N;
+    const int n = (int)(i - r * G.N);
+    const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
+    float acc = 0.0f;
+    for (int k = 0; k < G.K; ++k) acc += a[k] * G.B[(long)k * sbk + (long)n * sbn];
+    G.C[r * G.ldc + n] = skinny_epilogue(G, mode, acc, r, n);
+}
+
+// N <= 8:  row dot products.  B is staged transposed in LDS ([n][k]); one wave per row, lanes stride over k.
+__global__ __launch_bounds__(256) void skinny_n_kernel(const GemmArgs G, int sbk, int sbn, int mode, int rows_per_block) {
+    extern __shared__ float bt[];   // [N][K]
+    for (int i = threadIdx.x; i < G.N * G.K; i += 256) {
+        const int n = i / G.K, k = i - n * G.K;
+        bt[i] = G.B[(long)k * sbk + (long)n * sbn];
+    }
     __syncthreads();
-    if (q == 0 && c < N) unsafeAtomicAdd(&db[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long r_end = min((long)G.M, ((long)blockIdx.x + 1) * rows_per_block);
+    for (long r = (long)blockIdx.x * rows_per_block + wave; r < r_end; r += 4) {
+        const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
+        float acc[SKINNY];
+#pragma unroll
+        for (int n = 0; n < SKINNY; ++n) acc[n] = 0.0f;
+        for (int k = lane; k < G.K; k += 64) {
+            const float av = a[k];
+#pragma unroll
+            for (int n = 0; n < SKINNY; ++n)
+                if (n < G.N) acc[n] += av * bt[n * G.K + k];
+        }
+#pragma unroll
+        for (int n = 0; n < SKINNY; ++n) {
+            if (n >= G.N) break;
+            const float v = wave_sum64(acc[n]);
+            if (lane == n) G.C[r * G.ldc + n] = skinny_epilogue(G, mode, v, r, n);
+        }
+    }
+}
+
+// weight gradient with a narrow side: out(w, j) += sum_r Wide[r][w] * Narrow[r][j], j < narrow <= 8, one thread per w
+// and a chunk of rows per workgroup.  narrow_is_a: A (dY) is the narrow operand -> out = C[j][w], else out = C[w][j].
+// bias_grad: column sums of A (dY) on the side.
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const GemmArgs G, int narrow_is_a, int rows_per_block) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const int wide = narrow_is_a ? G.N : G.M, narrow = narrow_is_a ? G.M : G.N;
+    const float* Wd = narrow_is_a ? G.B : G.A;
+    const float* Nr = narrow_is_a ? G.A : G.B;
+    const int ldw = narrow_is_a ? G.ldb : G.lda, ldn = narrow_is_a ? G.lda : G.ldb;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min((long)G.K, r0 + rows_per_block);
+    float acc[SKINNY], nsum[SKINNY], wsum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SKINNY; ++j) acc[j] = nsum[j] = 0.0f;
+    if (w < wide) {
+#pragma unroll 4
+        for (long r = r0; r < r1; ++r) {
+            // the gathered operand (data rows) is always B
+            const long rw = (!narrow_is_a || !G.rows) ? r : (long)G.rows[r];
+            const long rn = (narrow_is_a || !G.rows) ? r : (long)G.rows[r];
+            const float wv = Wd[rw * ldw + w];
+            wsum += wv;
+#pragma unroll
+            for (int j = 0; j < SKINNY; ++j)
+                if (j < narrow) {
+                    const float nv = Nr[rn * ldn + j];
+                    acc[j] += wv * nv;
+                    nsum[j] += nv;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < SKINNY; ++j)
+            if (j < narrow) unsafeAtomicAdd(narrow_is_a ? &G.C[(long)j * G.ldc + w] : &G.C[(long)w * G.ldc + j], acc[j]);
+        if (G.bias_grad) {
+            if (!narrow_is_a) {
+                unsafeAtomicAdd(&G.bias_grad[w], wsum);
+            } else if (w == 0) {
+#pragma unroll
+                for (int j = 0; j < SKINNY; ++j)
+                    if (j < narrow) unsafeAtomicAdd(&G.bias_grad[j], nsum[j]);
+            }
+        }
+    }
 }
 
 // ---- row-wise pieces -------------------------------------------------------------------------------------------
@@ -353,12 +529,6 @@ __global__ void amort_latent_fwd(const RowParams D) {
     }
     D.rowf[r] = lp + H + D.entropy_const;
     D.rowlq[r] = lq;
-}
-
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
 
 // log p(x | z) = sum_j x_j l_j - softplus(l_j)  (torch binomial.py:140-160 with total_count = 1) and
@@ -548,20 +718,55 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     auto aligned = [](const void* p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); };
     G.vecA = aligned(G.A, G.lda);
     G.vecB = aligned(G.B, G.ldb);
-    const int tiles = ((G.M + BM - 1) / BM) * ((G.N + BN - 1) / BN);
-    G.remap = (tiles % 8 == 0) ? 1 : 0;
-    dim3 grid(tiles, 1, 1);
+    // a side of width <= 8: the memory-bound kernels
+    if (mode == MODE_TN && (G.M <= SKINNY || G.N <= SKINNY)) {
+        const int narrow_is_a = G.M <= G.N ? 1 : 0;
+        const int wide = narrow_is_a ? G.N : G.M;
+        const int rows_per_block = 64;
+        dim3 grid((wide + 255) / 256, (G.K + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(skinny_tn_kernel, grid, dim3(256), 0, stream, G, narrow_is_a, rows_per_block);
+        HIP_TRY(hipGetLastError());
+        return BSVI_OK;
+    }
+    if (mode != MODE_TN) {
+        const int sbk = mode == MODE_NT ? 1 : G.ldb, sbn = mode == MODE_NT ? G.ldb : 1;
+        if (G.N <= SKINNY && (size_t)G.N * G.K <= 8192) {
+            const int rows_per_block = 32;
+            hipLaunchKernelGGL(skinny_n_kernel, dim3((G.M + rows_per_block - 1) / rows_per_block), dim3(256),
+                               (size_t)G.N * G.K * sizeof(float), stream, G, sbk, sbn, mode, rows_per_block);
+            HIP_TRY(hipGetLastError());
+            return BSVI_OK;
+        }
+        if (G.K <= SKINNY) {
+            const long total = (long)G.M * G.N;
+            hipLaunchKernelGGL(skinny_k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, G, sbk, sbn, mode);
+            HIP_TRY(hipGetLastError());
+            return BSVI_OK;
+        }
+    }
+    const int tiles_n = (G.N + BN - 1) / BN;
+    int tiles = ((G.M + BM - 1) / BM) * tiles_n;
     if (mode == MODE_TN) {
-        // K = all rows: split it so that ~1024 workgroups are in flight
-        int splits = std::max(1, std::min((G.K + BK - 1) / BK, (1024 + tiles - 1) / tiles));
+        // K = all rows: split it so that about three workgroups per CU are in flight
+        G.remap = 0;
+        int splits = std::max(1, std::min((G.K + BK - 1) / BK, (768 + tiles / 2) / tiles));
         int chunk = ((G.K + splits - 1) / splits + BK - 1) / BK * BK;
         G.k_chunk = chunk;
-        grid.y = (G.K + chunk - 1) / chunk;
-        hipLaunchKernelGGL(gemm_kernel<MODE_TN>, grid, dim3(NTHREADS), 0, stream, G);
-    } else if (mode == MODE_NT) {
-        hipLaunchKernelGGL(gemm_kernel<MODE_NT>, grid, dim3(NTHREADS), 0, stream, G);
+        dim3 grid(tiles, (G.K + chunk - 1) / chunk, 1);
+        hipLaunchKernelGGL((gemm_kernel<MODE_TN, 128>), grid, dim3(NTHREADS), 0, stream, G);
     } else {
-        hipLaunchKernelGGL(gemm_kernel<MODE_NN>, grid, dim3(NTHREADS), 0, stream, G);
+        // 64-row tiles when 128-row tiles would leave most CUs with one or two workgroups
+        const bool half = tiles < 1536 && G.M > 64;
+        if (half) tiles = ((G.M + 63) / 64) * tiles_n;
+        G.remap = (tiles % 8 == 0) ? 1 : 0;
+        dim3 grid(tiles, 1, 1);
+        if (mode == MODE_NT) {
+            if (half) hipLaunchKernelGGL((gemm_kernel<MODE_NT, 64>), grid, dim3(NTHREADS), 0, stream, G);
+            else hipLaunchKernelGGL((gemm_kernel<MODE_NT, 128>), grid, dim3(NTHREADS), 0, stream, G);
+        } else {
+            if (half) hipLaunchKernelGGL((gemm_kernel<MODE_NN, 64>), grid, dim3(NTHREADS), 0, stream, G);
+            else hipLaunchKernelGGL((gemm_kernel<MODE_NN, 128>), grid, dim3(NTHREADS), 0, stream, G);
+        }
     }
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
@@ -578,6 +783,7 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
     G.act = (int)activation; G.post_add = post_add; G.accumulate = (int)accumulate;
     if (mode == MODE_NT) G.bias = bias_or_y_dev;
     if (mode == MODE_NN) { G.Y = bias_or_y_dev; G.ldy = (int)ldy; if (!G.Y) G.act = BSVI_ACT_NONE; }
+    if (mode == MODE_TN) G.bias_grad = const_cast<float*>(bias_or_y_dev);   // [M] accumulator of the column sums of A, or NULL
     return launch_gemm(mode, G, (hipStream_t)stream);
 }
 
@@ -666,14 +872,9 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 G.rows = from_data ? idx : nullptr;
                 G.C = grads + l.weight_off; G.ldc = (int)l.n_in;
                 G.M = (int)l.n_out; G.N = (int)l.n_in; G.K = (int)R;
+                G.bias_grad = l.bias_off != 0xFFFFFFFFu ? grads + l.bias_off : nullptr;   // db += 1^T dY, same launch
                 int rc = launch_gemm(MODE_TN, G, stream);
                 if (rc) return rc;
-            }
-            if (l.bias_off != 0xFFFFFFFFu) {
-                const int rows_per_block = 1024;
-                dim3 grid((l.n_out + 63) / 64, (unsigned)((R + rows_per_block - 1) / rows_per_block));
-                hipLaunchKernelGGL(col_sum_kernel, grid, dim3(256), 0, stream, dY, ldy, (int)R, (int)l.n_out, rows_per_block,
-                                   grads + l.bias_off);
             }
             if (l.in_value != 0 || input_grad) {   // dX = (dY W) * act'(x)
                 GemmArgs G{};

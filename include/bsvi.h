@@ -430,7 +430,8 @@ int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args);
  * mode 0: C[M][N] = A[M][K] B[N][K]^T   (+ bias[n], activation)        forward
  * mode 1: C[M][N] = A[M][K] B[K][N]     (* activation'(Y[m][n]))      backward-data
  * mode 2: C[M][N] += A[K][M]^T B[K][N]  (atomic, K split over blocks) backward-weight
- * rows_dev (or NULL) gathers the rows of A (modes 0, 1) / of B (mode 2). */
+ * rows_dev (or NULL) gathers the rows of A (modes 0, 1) / of B (mode 2).
+ * bias_or_y_dev: mode 0 bias[N]; mode 1 Y[M][ldy]; mode 2 an [M] accumulator that receives += column sums of A. */
 int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev, float* c_dev, const int32_t* rows_dev,
                     uint32_t m, uint32_t n, uint32_t k, uint32_t lda, uint32_t ldb, uint32_t ldc,
                     const float* bias_or_y_dev, uint32_t ldy, uint32_t activation, float post_add,
