@@ -270,8 +270,13 @@ def main():
             # the whole iteration (~35 launches) is timed; the 20 MFMA GEMMs carry the flops
             flops = amort_flops_per_iteration(program, n_per_gpu)
             tf = flops / (dev_ms * 1e-3 / args.steps) / 1e12
+            # HBM bytes of ALL launches of one iteration (tools/pmc_hbm.sh over 5 iterations of this workload;
+            # FETCH_SIZE doubled per the guide's gfx950 rule for 16-byte-per-lane reads)
+            traffic = pmc_traffic_bytes("cfg5_pmc_hbm_traffic.csv", ["bsvi_amort_impl"], double_fetch=True,
+                                        column="total_KB") if args.workload == "cfg5" and not args.samples else None
+            traffic = traffic / 5.0 if traffic else None
             roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
                             kernel="bsvi_amort_impl::gemm_kernel<0|1|2>",
                             algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / args.steps,
                             rows_per_iteration=n_per_gpu * program.batch_size,

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
     // is whole steps -> per-thread pointers are resolved once (row gather included) and a step's staging is 3-4
     // straight-line global_load_dwordx4; the generic loaders (bounds, scalar tails, per-step gather) take the rest.
     const bool fast = G.vecA && G.vecB && m0 + TBM <= G.M && n0 + BN <= G.N && (k_end - k_begin) % BK == 0 &&
-                      k_end > k_begin && !(MODE == MODE_TN && G.rows);
+                      k_end > k_begin;
+    const bool gather_b = MODE == MODE_TN && G.rows != nullptr;   // weight gradient of the layer that reads the data rows
+    int ridx[BN / 64];
     const float* pa[TBM / 64];
     const float* pb[BN / 64];
     long sa = BK, sb = BK;       // pointer advance per step
@@ -245,7 +247,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
         } else {
             constexpr int TPR = BN / 4, KR = NTHREADS / TPR;
 #pragma unroll
-            for (int i = 0; i < BN / 64; ++i) pb[i] = G.B + (long)(k_begin + t / TPR + KR * i) * G.ldb + n0 + (t % TPR) * 4;
+            for (int i = 0; i < BN / 64; ++i) {
+                pb[i] = G.B + (long)(k_begin + t / TPR + KR * i) * G.ldb + n0 + (t % TPR) * 4;
+                if (gather_b) ridx[i] = G.rows[k_begin + t / TPR + KR * i];
+            }
             sb = (long)BK * G.ldb;
         }
     }
@@ -256,8 +261,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
             if (FAST) {
 #pragma unroll
                 for (int i = 0; i < TBM / 64; ++i) fa.v[i] = *reinterpret_cast<const float4*>(pa[i] + step * sa);
+                if (gather_b) {
+                    // rows of this step were fetched one step ahead, so index and data latencies do not chain
+                    constexpr int TPR = BN / 4, KR = NTHREADS / TPR;
+                    const int t = threadIdx.x;
 #pragma unroll
-                for (int i = 0; i < BN / 64; ++i) fb.v[i] = *reinterpret_cast<const float4*>(pb[i] + step * sb);
+                    for (int i = 0; i < BN / 64; ++i)
+                        fb.v[i] = *reinterpret_cast<const float4*>(G.B + (long)ridx[i] * G.ldb + n0 + (t % TPR) * 4);
+                    if (step + 1 < n_steps) {
+#pragma unroll
+                        for (int i = 0; i < BN / 64; ++i) ridx[i] = G.rows[k_begin + (step + 1) * BK + t / TPR + KR * i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < BN / 64; ++i) fb.v[i] = *reinterpret_cast<const float4*>(pb[i] + step * sb);
+                }
             } else {
                 fa = load_a(k_begin + step * BK);
                 fb = load_b(k_begin + step * BK);
@@ -274,20 +292,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
             const int cur = step & 1;
             const bool more = step + 1 < n_steps;
             if (more) stage(step + 1, fa, fb);
-            const float* at = As[cur];
-            const float* bt = Bs[cur];
+            // all operand fragments of the step first (immediate-offset ds_reads off one base per tile), then the
+            // MFMAs back to back: the matrix pipe is not stalled on an LDS round trip every second instruction
+            const float* at = (cur ? As[1] : As[0]) + lk * LDA + wm + lm;
+            const float* bt = (cur ? Bs[1] : Bs[0]) + lk * LDB + wn + lm;
+            float a[BK / 2][TM], b[BK / 2][2];
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float a[TM], b[2];
+            for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = at[(kk + lk) * LDA + wm + 32 * i + lm];
+                for (int i = 0; i < TM; ++i) a[kk][i] = at[2 * kk * LDA + 32 * i];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = bt[(kk + lk) * LDB + wn + 32 * j + lm];
+                for (int j = 0; j < 2; ++j) b[kk][j] = bt[2 * kk * LDB + 32 * j];
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
             if (more) {
                 if (col_sums) add_cols(fa);      // here, not at the load: the values are awaited for the LDS store anyway
                 store_a(As[cur ^ 1], fa);
@@ -367,24 +390,37 @@ __global__ __launch_bounds__(256) void skinny_k_kernel(const GemmArgs G, int sbk
 
 // N <= 8:  row dot products.  B is staged transposed in LDS ([n][k]); one wave per row, lanes stride over k.
 __global__ __launch_bounds__(256) void skinny_n_kernel(const GemmArgs G, int sbk, int sbn, int mode, int rows_per_block) {
-    extern __shared__ float bt[];   // [N][K]
+    extern __shared__ __attribute__((aligned(16))) float bt[];   // [N][K]
     for (int i = threadIdx.x; i < G.N * G.K; i += 256) {
         const int n = i / G.K, k = i - n * G.K;
         bt[i] = G.B[(long)k * sbk + (long)n * sbn];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = G.vecA && (G.K & 3) == 0;
     const long r_end = min((long)G.M, ((long)blockIdx.x + 1) * rows_per_block);
     for (long r = (long)blockIdx.x * rows_per_block + wave; r < r_end; r += 4) {
         const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
         float acc[SKINNY];
 #pragma unroll
         for (int n = 0; n < SKINNY; ++n) acc[n] = 0.0f;
-        for (int k = lane; k < G.K; k += 64) {
-            const float av = a[k];
+        if (vec) {
+            for (int k = lane * 4; k < G.K; k += 256) {
+                const float4 av = *reinterpret_cast<const float4*>(a + k);
 #pragma unroll
-            for (int n = 0; n < SKINNY; ++n)
-                if (n < G.N) acc[n] += av * bt[n * G.K + k];
+                for (int n = 0; n < SKINNY; ++n)
+                    if (n < G.N) {
+                        const float4 bv = *reinterpret_cast<const float4*>(&bt[n * G.K + k]);
+                        acc[n] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+                    }
+            }
+        } else {
+            for (int k = lane; k < G.K; k += 64) {
+                const float av = a[k];
+#pragma unroll
+                for (int n = 0; n < SKINNY; ++n)
+                    if (n < G.N) acc[n] += av * bt[n * G.K + k];
+            }
         }
 #pragma unroll
         for (int n = 0; n < SKINNY; ++n) {

@@ -100,3 +100,76 @@ def test_shard_partition_is_exact():
             assert spans[-1][0] + spans[-1][1] == n
             sizes = [s[1] for s in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- amortised path (BASELINE config 5): the same sample-axis shards, rows = samples x minibatch ------------------
+def _vae_worker(rank, world, port, case, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brancher_amd import amortized, engine
+    from brancher_amd.native import OUT_HEADER
+    from oracle.vae_oracle import VaeOracle
+    g = Golden(case)
+    model = g.build()
+    prog = amortized.lower_amortized(model, model.posterior_model, "pathwise")
+    oracle = VaeOracle(model)
+    N, B = g.N, prog.batch_size
+    base, n_local = engine.shard(N, rank, world)
+    rows, eps = g.data["minibatch/x"][base:base + n_local], g.data["noise/z"][base:base + n_local]
+    # what bsvi_amort_fwd_bwd leaves in out_dev for this shard: sums over its rows, with the GLOBAL log(N) constant
+    t = oracle.terms(rows, eps)
+    f = t["lp"] + t["H"] - float(np.log(n_local)) + float(np.log(N))
+    for p in oracle.named_parameters().values():
+        p.grad = None
+    f.sum().backward()
+    out = torch.zeros(OUT_HEADER + prog.n_params)
+    out[0] = float(f.sum().detach())
+    enc_link, dec_link = prog.links
+    named = oracle.named_parameters()
+    by_par = {}
+    for tag, link in (("enc", enc_link), ("dec", dec_link)):
+        for pname, par in link.named.items():
+            by_par[id(par)] = named["%s/%s" % (tag, pname)]
+    for par, off, size, _ in prog.parameters:
+        out[OUT_HEADER + off:OUT_HEADER + off + size] = by_par[id(par)].grad.reshape(-1)
+    engine.allreduce_sums(out)
+    loss = -out[0] / (N * B)                                   # bsvi_finalize_step with n = N * B
+    grads = -out[OUT_HEADER:] / (N * B)
+    if rank == 0:
+        res = {}
+        for tag, link in (("enc", enc_link), ("dec", dec_link)):
+            for pname, par in link.named.items():
+                off = next(o for p_, o, _, _ in prog.parameters if p_ is par)
+                res["%s/%s" % (tag, pname)] = grads[off:off + par.size].numpy().copy()
+        out_q.put((float(loss), res))
+    else:
+        out_q.put((None, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_shards_of_the_amortised_path():
+    case = "vae_P150_H136_H40_DS40_B16_N9"
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vae_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = Golden(case)
+    loss, grads = next(r for r in results if r[0] is not None)
+    ref = float(g.data["loss_pathwise"])
+    assert abs(loss - ref) <= 1e-5 * abs(ref)
+    ref_grads = g.group("grad_pathwise/")
+    scale = max(np.abs(v).max() for v in ref_grads.values())
+    for name, gr in ref_grads.items():
+        assert np.abs(grads[name].reshape(gr.shape) - gr).max() <= 1e-5 * scale, name

@@ -21,10 +21,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         acc[k].append(v)
     for k, v in acc.items():
         if "bsvi" in k:
-            rows.append((k, ctr, len(v), sum(v) / len(v), max(v)))
+            rows.append((k, ctr, len(v), sum(v) / len(v), max(v), sum(v)))
 with open("$OUT/${tag}_hbm.csv", "w") as o:
-    o.write("kernel,counter,dispatches,mean_KB_per_dispatch,max_KB\n")
-    for k, c, n, m, mx in rows:
-        o.write('"%s",%s,%d,%.4f,%.4f\n' % (k, c, n, m, mx))
+    o.write("kernel,counter,dispatches,mean_KB_per_dispatch,max_KB,total_KB\n")
+    for k, c, n, m, mx, tot in rows:
+        o.write('"%s",%s,%d,%.4f,%.4f,%.4f\n' % (k, c, n, m, mx, tot))
 print(open("$OUT/${tag}_hbm.csv").read())
 PY
