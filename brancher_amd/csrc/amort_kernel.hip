@@ -22,6 +22,7 @@
 // loads, workgroup order remapped so that the tiles sharing rows of the tall operand sit on one XCD.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <string>
@@ -60,6 +61,7 @@ struct GemmArgs {
     int accumulate;        // NN: C += result
     int k_chunk;           // TN: rows of K per workgroup (multiple of BK)
     int remap;             // XCD-aware workgroup order
+    int tiles;             // TN: output tiles per k split
     float* bias_grad;      // TN: db[m] += sum_k A[k][m], taken from the A tiles the n = 0 workgroups stream anyway
 };
 
@@ -174,12 +176,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
     const int n_blocks = gridDim.x;
     int bid = blockIdx.x;
     if (G.remap) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // XCD x gets one contiguous range of tiles
-    const int m0 = (bid / tiles_n) * TBM, n0 = (bid % tiles_n) * BN;
     int k_begin = 0, k_end = G.K;
     if (MODE == MODE_TN) {
-        k_begin = blockIdx.y * G.k_chunk;
+        // the remapped index runs over (k split, tile) with the tile fastest: an XCD owns whole k splits, so the rows
+        // of both operands in a split are fetched into ONE L2 (launch order would spread a split's tiles over all
+        // eight and every XCD would pull every row through the fabric)
+        const int split = bid / G.tiles;
+        bid -= split * G.tiles;
+        k_begin = split * G.k_chunk;
         k_end = min(G.K, k_begin + G.k_chunk);
+        if (k_begin >= G.K) return;                                   // padding split (grid rounded up to 8)
     }
+    const int m0 = (bid / tiles_n) * TBM, n0 = (bid % tiles_n) * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * (TBM / 2), wn = (wave & 1) * 64;
@@ -217,11 +225,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
     const int n_steps = (k_end - k_begin + BK - 1) / BK;
     const int lk = lane >> 5, lm = lane & 31;
 
-    // Workgroup-uniform fast path: the tile lies inside the matrices, every row is 16-byte loadable and the k range
-    // is whole steps -> per-thread pointers are resolved once (row gather included) and a step's staging is 3-4
-    // straight-line global_load_dwordx4; the generic loaders (bounds, scalar tails, per-step gather) take the rest.
-    const bool fast = G.vecA && G.vecB && m0 + TBM <= G.M && n0 + BN <= G.N && (k_end - k_begin) % BK == 0 &&
-                      k_end > k_begin;
+    // Workgroup-uniform fast path: every row is 16-byte loadable and the k range is whole steps -> per-thread
+    // pointers are resolved once (row gather included) and a step's staging is 3-4 straight-line global_load_dwordx4.
+    // A tile that sticks out of the matrix along m / n stays on this path: the out-of-range rows / column quads are
+    // clamped onto valid ones (their products land in outputs the epilogue never stores), so edge tiles are not the
+    // stragglers of the launch.  The generic loaders (scalar tails, k tails) take what is left.
+    const bool fast = G.vecA && G.vecB && (k_end - k_begin) % BK == 0 && k_end > k_begin;
     const bool gather_b = MODE == MODE_TN && G.rows != nullptr;   // weight gradient of the layer that reads the data rows
     int ridx[BN / 64];
     const float* pa[TBM / 64];
@@ -232,23 +241,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
         if (MODE == MODE_TN) {
             constexpr int TPR = TBM / 4, KR = NTHREADS / TPR;
 #pragma unroll
-            for (int i = 0; i < TBM / 64; ++i) pa[i] = G.A + (long)(k_begin + t / TPR + KR * i) * G.lda + m0 + (t % TPR) * 4;
+            for (int i = 0; i < TBM / 64; ++i)
+                pa[i] = G.A + (long)(k_begin + t / TPR + KR * i) * G.lda + min(m0 + (t % TPR) * 4, G.lda - 4);
             sa = (long)BK * G.lda;
         } else {
 #pragma unroll
             for (int i = 0; i < TBM / 64; ++i) {
-                const int r = m0 + (t >> 2) + 64 * i;
+                const int r = min(m0 + (t >> 2) + 64 * i, G.M - 1);
                 pa[i] = G.A + (G.rows ? (long)G.rows[r] : (long)r) * G.lda + k_begin + (t & 3) * 4;
             }
         }
         if (MODE == MODE_NT) {
 #pragma unroll
-            for (int i = 0; i < BN / 64; ++i) pb[i] = G.B + (long)(n0 + (t >> 2) + 64 * i) * G.ldb + k_begin + (t & 3) * 4;
+            for (int i = 0; i < BN / 64; ++i)
+                pb[i] = G.B + (long)min(n0 + (t >> 2) + 64 * i, G.N - 1) * G.ldb + k_begin + (t & 3) * 4;
         } else {
             constexpr int TPR = BN / 4, KR = NTHREADS / TPR;
 #pragma unroll
             for (int i = 0; i < BN / 64; ++i) {
-                pb[i] = G.B + (long)(k_begin + t / TPR + KR * i) * G.ldb + n0 + (t % TPR) * 4;
+                pb[i] = G.B + (long)(k_begin + t / TPR + KR * i) * G.ldb + min(n0 + (t % TPR) * 4, G.ldb - 4);
                 if (gather_b) ridx[i] = G.rows[k_begin + t / TPR + KR * i];
             }
             sb = (long)BK * G.ldb;
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
                     const int t = threadIdx.x;
 #pragma unroll
                     for (int i = 0; i < BN / 64; ++i)
-                        fb.v[i] = *reinterpret_cast<const float4*>(G.B + (long)ridx[i] * G.ldb + n0 + (t % TPR) * 4);
+                        fb.v[i] = *reinterpret_cast<const float4*>(G.B + (long)ridx[i] * G.ldb + min(n0 + (t % TPR) * 4, G.ldb - 4));
                     if (step + 1 < n_steps) {
 #pragma unroll
                         for (int i = 0; i < BN / 64; ++i) ridx[i] = G.rows[k_begin + (step + 1) * BK + t / TPR + KR * i];
@@ -321,14 +332,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
     };
     if (fast) main_loop(std::true_type{}); else main_loop(std::false_type{});
 
-    if (col_sums) {   // fold the 8 k-row groups of the workgroup through LDS
+    if (col_sums) {   // fold the k-row groups of the workgroup (MC loader: TBM/4 threads per k row) through LDS
+        constexpr int TPR = TBM / 4, KR = NTHREADS / TPR;
         float* red = As[0];
-        *reinterpret_cast<float4*>(&red[(threadIdx.x >> 5) * LDA + (threadIdx.x & 31) * 4]) = bs;
+        *reinterpret_cast<float4*>(&red[(threadIdx.x / TPR) * LDA + (threadIdx.x % TPR) * 4]) = bs;
         __syncthreads();
         if (threadIdx.x < TBM && m0 + (int)threadIdx.x < G.M) {
             float s = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += red[q * LDA + threadIdx.x];
+            for (int q = 0; q < KR; ++q) s += red[q * LDA + threadIdx.x];
             unsafeAtomicAdd(&G.bias_grad[m0 + threadIdx.x], s);
         }
     }
@@ -646,6 +658,13 @@ struct bsvi_amort {
     float* dataset_dev = nullptr;
     float* prior_dev = nullptr;    // [2][Dz]
     size_t floats_per_row = 0;     // workspace floats per row (values + gradients + per-row scalars)
+    // the weight-gradient GEMM of a layer and its input-gradient GEMM are independent: the former runs on a side
+    // stream (fork on an event per layer, one join before the function returns) and fills the CUs the latter's
+    // last wave of workgroups leaves idle
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ready;
+    hipEvent_t joined = nullptr;
+    bool overlap = true;
 };
 
 static int pad4(int n) { return (n + 3) / 4 * 4; }
@@ -728,6 +747,18 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     (void)hipMemcpy(a->dataset_dev, desc->dataset, ds_bytes, hipMemcpyHostToDevice);
     (void)hipMemcpy(a->prior_dev, desc->prior_loc, Dz * sizeof(float), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->prior_dev + Dz, desc->prior_scale, Dz * sizeof(float), hipMemcpyHostToDevice);
+    const char* ov = getenv("BSVI_AMORT_OVERLAP");
+    a->overlap = !(ov && ov[0] == '0');
+    if (a->overlap) {
+        bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&a->joined, hipEventDisableTiming) == hipSuccess;
+        a->ready.resize(desc->n_enc_layers + desc->n_dec_layers, nullptr);
+        for (auto& e : a->ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            bsvi_amort_destroy(a);
+            return bsvi_fail(BSVI_ERR_HIP, "side stream / event creation failed");
+        }
+    }
     a->d.enc_layers = a->enc.layers.data();
     a->d.dec_layers = a->dec.layers.data();
     a->d.dataset = nullptr;
@@ -740,6 +771,10 @@ extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
     if (!a) return;
     if (a->dataset_dev) (void)hipFree(a->dataset_dev);
     if (a->prior_dev) (void)hipFree(a->prior_dev);
+    for (auto e : a->ready)
+        if (e) (void)hipEventDestroy(e);
+    if (a->joined) (void)hipEventDestroy(a->joined);
+    if (a->side) (void)hipStreamDestroy(a->side);
     delete a;
 }
 
@@ -783,13 +818,19 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     const int tiles_n = (G.N + BN - 1) / BN;
     int tiles = ((G.M + BM - 1) / BM) * tiles_n;
     if (mode == MODE_TN) {
-        // K = all rows: split it so that about three workgroups per CU are in flight
-        G.remap = 0;
-        int splits = std::max(1, std::min((G.K + BK - 1) / BK, (768 + tiles / 2) / tiles));
+        // K = all rows: split it so that about three workgroups per CU are in flight.  64-row output tiles: twice the
+        // tiles, so half the splits — every split costs one float atomic per output element — and less padding
+        tiles = ((G.M + 63) / 64) * tiles_n;
+        // at most 768 workgroups = three per CU in ONE round: a 769th would make some CU run four (3.05 per CU on
+        // average is a 4-deep critical path)
+        int splits = std::max(1, std::min((G.K + BK - 1) / BK, 768 / tiles));
         int chunk = ((G.K + splits - 1) / splits + BK - 1) / BK * BK;
+        splits = ((G.K + chunk - 1) / chunk + 7) / 8 * 8;             // whole splits per XCD; the padding ones exit
         G.k_chunk = chunk;
-        dim3 grid(tiles, (G.K + chunk - 1) / chunk, 1);
-        hipLaunchKernelGGL((gemm_kernel<MODE_TN, 128>), grid, dim3(NTHREADS), 0, stream, G);
+        G.tiles = tiles;
+        G.remap = 1;
+        dim3 grid(tiles * splits, 1, 1);
+        hipLaunchKernelGGL((gemm_kernel<MODE_TN, 64>), grid, dim3(NTHREADS), 0, stream, G);
     } else {
         // 64-row tiles when 128-row tiles would leave most CUs with one or two workgroups
         const bool half = tiles < 1536 && G.M > 64;
@@ -893,9 +934,17 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         }
         return BSVI_OK;
     };
+    size_t next_event = 0;
     auto backward = [&](const Net& net, bool gather, bool input_grad) -> int {
         std::vector<char> written(net.width.size(), 0);
         for (int i = (int)net.layers.size() - 1; i >= 0; --i) {
+            hipStream_t wstream = stream;
+            if (a->overlap) {          // dY of this layer is complete on `stream` here
+                hipEvent_t e = a->ready[next_event++];
+                HIP_TRY(hipEventRecord(e, stream));
+                HIP_TRY(hipStreamWaitEvent(a->side, e, 0));
+                wstream = a->side;
+            }
             const auto& l = net.layers[i];
             const float* dY = grad(net, l.out_value);
             const int ldy = net.ld[l.out_value];
@@ -909,7 +958,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 G.C = grads + l.weight_off; G.ldc = (int)l.n_in;
                 G.M = (int)l.n_out; G.N = (int)l.n_in; G.K = (int)R;
                 G.bias_grad = l.bias_off != 0xFFFFFFFFu ? grads + l.bias_off : nullptr;   // db += 1^T dY, same launch
-                int rc = launch_gemm(MODE_TN, G, stream);
+                int rc = launch_gemm(MODE_TN, G, wstream);
                 if (rc) return rc;
             }
             if (l.in_value != 0 || input_grad) {   // dX = (dY W) * act'(x)
@@ -943,6 +992,10 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     hipLaunchKernelGGL(amort_latent_bwd, row_grid, dim3(256), 0, stream, D);
     rc = backward(a->enc, true, false);
     if (rc) return rc;
+    if (a->overlap) {
+        HIP_TRY(hipEventRecord(a->joined, a->side));
+        HIP_TRY(hipStreamWaitEvent(stream, a->joined, 0));
+    }
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }
