@@ -7,6 +7,7 @@ same fused kernel (include/bsvi.h `bsvi_estimator`), which evaluates
 
   Pathwise :  mean_s f(z_s),                      z = reparameterised draw      (:39-44)
   BlackBox :  mean_s [ log q(z_s) * stopgrad(f(z_s)) + f(z_s) ]                  (:29-36)
+  Taylor1  :  mean_s f(E[q | sampled parents]_s)  — a different program, same accumulation  (:47-56)
 
 BlackBox reproduces the reference exactly, including that its value is not the ELBO and that
 reparameterisable nodes still carry the pathwise term (the ``differentiable=False`` flag is
@@ -43,5 +44,7 @@ class BlackBoxEstimator(_Fused):
 
 
 class Taylor1Estimator(_Fused):
-    # `gradient_estimators.py:47-56` — "next" row f-2 of SURVEY §8; not lowered yet.
-    kernel_name = None
+    # `gradient_estimators.py:47-56`: f at the analytic means of the posterior given the sampled parents.  Lowered for
+    # Normal posteriors (lowering._Lowering.mean_value); the reference itself raises for Bernoulli latents under
+    # torch >= 1.8 (validate_args rejects the value 0.5).
+    kernel_name = "taylor1"

@@ -48,7 +48,9 @@ UT = dict(identity=0, softplus=1, sigmoid=2, exp=3, log=4, tanh=5, sqrt=6, squar
 # "importance" is an evaluation program (no estimator of its own): the posterior's nodes take their values
 # from the caller and only accumulate log q; the kernel's value is then log p(z, y) and its second
 # per-sample output log q(z) — `ProbabilisticModel.get_importance_weights`, variables.py:821-841
-EST = dict(pathwise=0, blackbox=1, importance=0)
+# "taylor1" (`gradient_estimators.py:47-56`) is the pathwise accumulation of f evaluated at the posterior's analytic
+# means given the sampled parents: a different PROGRAM for the same kernel estimator (see _Lowering.mean_value)
+EST = dict(pathwise=0, blackbox=1, importance=0, taylor1=0)
 
 UNARY_CALLS = set(UNOP) - {"copy", "powi"}
 
@@ -292,6 +294,26 @@ class _Lowering:
             return self.mk("z", (), var, self.slots[var].shape)
         raise LoweringError("unsupported posterior variable %r" % (var,))
 
+    def mean_value(self, var):
+        """Taylor1Estimator (`gradient_estimators.py:47-56`): f is evaluated at
+        ``means[v] = v._get_mean(input_values=samples)`` — the analytic mean of q_v given the SAMPLED values of its
+        parents (`variables.py:85-86,522-525`, `distributions.py:77-82,126-139`) — for every variable of the sampler;
+        everything else keeps its sampled value.  The samples still carry gradient (the ``differentiable=False`` of
+        `gradient_estimators.py:50` is dropped at `variables.py:567`), so the means back-propagate into
+        the parents' reparameterised draws.  Normal: mean = loc (torch normal.py:55-56)."""
+        if isinstance(var, RootVariable) or getattr(var, "_type", None) == "Deterministic node":
+            return self.q_value(var)          # the mean of a deterministic node is its value on the sampled parents
+        if not isinstance(var, RandomVariable) or var not in self.slots:
+            raise LoweringError("posterior variable %r is used before it is sampled" % getattr(var, "name", var))
+        params = self.node_params(var, self.q_value)
+        if var.distribution.kind == D.DIST_NORMAL:
+            return params[0]
+        if var.distribution.kind == D.DIST_LOGNORMAL:          # exp(loc + scale^2 / 2)   (torch log_normal.py:53-54)
+            half_var = self.mk("mul", (self.mk("imm", (), 0.5), self.mk("call:square", (params[1],))))
+            return self.mk("call:exp", (self.mk("add", (params[0], half_var)),))
+        raise LoweringError("Taylor1 estimator: the analytic mean of %r (%s) is not lowered yet (Normal / LogNormal "
+                            "posteriors)" % (var.name, type(var.distribution).__name__))
+
     def p_value(self, var):
         if isinstance(var, RandomVariable) and var.is_observed:
             if (not var.has_observed_value and getattr(var, "_type", None) == "Deterministic node"
@@ -305,7 +327,10 @@ class _Lowering:
                                     "SURVEY §8f-1): not lowered yet" % var.name)
             return self.mk("obs", (), var, canonical_elem_shape(var._observed_value.shape[1:]))
         if var.name in self.q_by_name:
-            return self.q_value(self.q_by_name[var.name])
+            qv = self.q_by_name[var.name]
+            if self.estimator == "taylor1":
+                return self.mean_value(qv)
+            return self.q_value(qv)
         if isinstance(var, RootVariable):
             return self.mk("root", (), var, self.root_shape(var))
         if getattr(var, "_type", None) == "Deterministic node":
@@ -678,6 +703,15 @@ class _Lowering:
             if v.distribution.kind not in supported:
                 raise LoweringError("distribution of %r is not supported by the fused kernel yet" % v.name)
             params = self.node_params(v, self.q_value)
+            if self.estimator == "taylor1":
+                # the entropy is evaluated on the means too (`variables.py:851-855` with samples := means): for a
+                # Normal it depends on the scale only, which must therefore not depend on sampled parents
+                kind = v.distribution.kind
+                ok = (kind == D.DIST_NORMAL and not params[1].has_z) or \
+                     (kind == D.DIST_LOGNORMAL and not params[0].has_z and not params[1].has_z)
+                if not ok:
+                    raise LoweringError("Taylor1 estimator: %r needs a Normal posterior whose scale (LogNormal: loc and "
+                                        "scale) does not depend on other latent variables" % v.name)
             shape = broadcast_shapes3(*[p.shape for p in params])
             self.slots[v] = SlotInfo(v, self.n_slots, shape, v.distribution.kind)
             self.n_slots += self.slots[v].size

@@ -63,6 +63,10 @@ CASES = {
 }
 
 
+# workloads whose posterior is made of Normal variables: the Taylor1 estimator is recorded for them too
+TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_learnable_model", "build_vector_latent")
+
+
 def reference_api():
     sys.path.insert(0, REF)
     sys.path.insert(0, ROOT)
@@ -243,6 +247,23 @@ def run_case(name, api):
             out["grad_%s/%s" % (est_name, pname)] = (np.zeros_like(out["param/" + pname]) if g is None
                                                      else g.detach().numpy().copy())
             out["gradnone_%s/%s" % (est_name, pname)] = np.array(g is None)
+
+    if CASES[name][0] in TAYLOR1_BUILDERS:
+        # third estimator of the reference on the same draws (gradient_estimators.py:47-56)
+        for root in roots.values():
+            root.link.parameter.grad = None
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        with DrawRecorder() as rec:
+            loss = inference.ReverseKL(gradient_estimator=ge.Taylor1Estimator).compute_loss(model, q, None, N)
+        loss.backward()
+        noise = match_noise(q, captured["z"], rec.draws)
+        for k, v in noise.items():
+            assert np.array_equal(out["noise/" + k], v), "estimators drew different noise"
+        out["loss_taylor1"] = np.float32(loss.detach().numpy())
+        for pname, root in roots.items():
+            g = root.link.parameter.grad
+            out["grad_taylor1/" + pname] = np.zeros_like(out["param/" + pname]) if g is None else g.detach().numpy().copy()
 
     if all(type(v).__name__ == "RootVariable" for v in q.flatten()):
         # point estimates: the reference's MAP inference method on the same model (inference.py:251-275)

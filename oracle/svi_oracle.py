@@ -387,6 +387,19 @@ class Oracle:
             return sum_from_dim(ent, 2)
         return -self.var_log_prob(var, input_values, set(), reevaluate=True, include_parents=False)
 
+    def var_mean(self, var, input_values):
+        # RootVariable._get_statistic returns the value (variables.py:362-365); RandomVariable._get_statistic evaluates
+        # the parameters on the input values and asks the distribution (:522-525; Deterministic mean = value,
+        # distributions.py:359-368; torch distributions' .mean otherwise, :137)
+        if isinstance(var, RootVariable):
+            return self.root_value(var)
+        params = self.parameters_from_input_values(var, input_values)
+        if var.distribution.kind == D.DIST_DETERMINISTIC:
+            return params["value"]
+        keys = list(params.keys())
+        vals = broadcast_and_squeeze(*[params[k] for k in keys])
+        return TORCHDIST[var.distribution.kind](**dict(zip(keys, vals))).mean
+
     def posterior_entropy(self, samples):
         # ProbabilisticModel._get_entropy (variables.py:744-749)
         ents = [self.var_entropy(v, samples) for v in self.q.variables]
@@ -428,6 +441,17 @@ class Oracle:
             lq = self.model_log_prob(self.q, samples)
             f = self.function(samples, empirical)
             value = (lq * f.detach() + self.function(samples, empirical)).mean()
+        elif estimator == "taylor1":
+            # Taylor1Estimator (gradient_estimators.py:47-56): f at the analytic means of the sampler's unobserved
+            # variables given the SAMPLED values (Variable._get_mean, variables.py:85-86 -> _get_statistic :522-525 ->
+            # Distribution.get_mean, distributions.py:77-82,126-139); everything else keeps its sampled value
+            means = {v: self.var_mean(v, samples) for v in self.q.variables if not v.is_observed}
+            for k, v in samples.items():
+                if k not in means:
+                    means[k] = v
+            f = self.function(means, empirical)
+            value = f.mean()
+            lq = None
         else:
             raise ValueError(estimator)
         if return_parts:

@@ -74,6 +74,22 @@ def test_loss_and_grads_match_reference_golden(case, estimator):
     grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL if estimator == "pathwise" else 1e-4)
 
 
+@pytest.mark.parametrize("case", [c for c in golden_cases() if "loss_taylor1" in Golden(c).data.files])
+def test_taylor1_estimator_matches_reference_golden(case):
+    """Taylor1Estimator (gradient_estimators.py:47-56): f at the posterior's analytic means given the sampled parents —
+    a different program for the same kernel; both the diagnostic and the lean build, and through the public API"""
+    from brancher_amd.gradient_estimators import Taylor1Estimator
+    g = Golden(case)
+    model, c = compiled_for(g, "taylor1")
+    ref = float(g.data["loss_taylor1"])
+    for kwargs in (dict(want_fvalues=True), dict()):
+        res = c.evaluate(g.N, noise=g.noise, minibatch=g.minibatch, **kwargs)
+        assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref), (float(res["loss"].item()), ref)
+        grad_check(c.named_grads(), g.group("grad_taylor1/"), TOL)
+    from brancher_amd import engine
+    assert engine.compile_model(model, None, Taylor1Estimator) is c
+
+
 @pytest.mark.parametrize("case", [c for c in golden_cases() if Golden(c).meta["trajectory"]])
 @pytest.mark.parametrize("persistent", [True, False])
 def test_training_trajectory_matches_reference_golden(case, persistent):
