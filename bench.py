@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "persistent", "stepwise"])
     ap.add_argument("--samples", type=int, default=0, help="override number_samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--estimator", default="pathwise", choices=["pathwise", "blackbox", "taylor1"],
+                    help="gradient estimator (BASELINE config 5 names both Pathwise and BlackBox)")
     args = ap.parse_args()
 
     import torch
@@ -189,7 +191,7 @@ def main():
         kwargs = dict(kwargs, dataset_size=args.dataset_size)
     n_global = n_per_gpu * world
     model = getattr(W, builder)(W.native_api(), **kwargs)
-    compiled = engine.compile_model(model, None, "pathwise")
+    compiled = engine.compile_model(model, None, args.estimator)
     program = compiled.program
     allow_persistent = args.mode != "stepwise"
     if args.mode == "persistent" and not (world == 1 and hasattr(compiled, "native") and compiled.native.persistent_supported(n_per_gpu)):
@@ -290,7 +292,7 @@ def main():
                     dtype="f32", data="synthetic",
                     config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
                                 optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
-                                estimator="pathwise", mode=mode, parallelism="sample-shard x%d" % world,
+                                estimator=args.estimator, mode=mode, parallelism="sample-shard x%d" % world,
                                 grid=geom),
                     iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
                     device_ms_per_step=dev_ms / args.steps, all_finite=ok,

@@ -261,6 +261,7 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     prog.parameters, off = [], 0
     offsets = {}
     for group, link in ((0, enc_link), (1, dec_link)):
+        off = (off + 3) // 4 * 4          # every network starts 16-byte aligned (padding elements stay inactive)
         pars = sorted(link.parameters(), key=lambda p: (p.size % 4 != 0, len(p.shape) < 2))
         for par in pars:
             if id(par) in offsets:
@@ -269,7 +270,9 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
             prog.parameters.append((par, off, par.size, group))
             off += par.size
     prog.n_params = off
-    prog.param_active = np.ones(off, dtype=np.uint8)
+    prog.param_active = np.zeros(off, dtype=np.uint8)
+    for par, o, size, g in prog.parameters:
+        prog.param_active[o:o + size] = 1
     group = np.zeros(off, dtype=np.uint8)
     for par, o, size, g in prog.parameters:
         group[o:o + size] = g
@@ -282,6 +285,7 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     if any(l.in_value == 0 and l.n_in != Dz for l in dec_layers):
         raise LoweringError("amortised path: the decoder's input width does not match the latent")
     prog.enc_layers, prog.dec_layers = enc_layers, dec_layers
+    prog.enc_outputs, prog.dec_outputs, prog.logits_key = enc_out, dec_out, logits_key
     prog.enc_loc_value, prog.enc_scale_value = enc_out[loc_key], enc_out[scale_key]
     prog.dec_logits_value = dec_out[logits_key]
     prog.n_features, prog.latent_dim, prog.dataset_size, prog.batch_size = P, Dz, DS, B
@@ -456,6 +460,30 @@ class CompiledAmortized:
             res["f"] = fvals
             res["logq"] = logq
         return res
+
+    def _apply(self, network, rows, key, outputs):
+        p = self.program
+        if key not in outputs:
+            raise KeyError("the network has no output %r (it has %s)" % (key, sorted(map(str, outputs))))
+        x = torch.as_tensor(np.asarray(rows, dtype=np.float32)) if not torch.is_tensor(rows) else rows.float()
+        x = x.reshape(x.shape[0], -1).contiguous().to(self.device)
+        layers = p.enc_layers if network == 0 else p.dec_layers
+        width = next(l.n_out for l in layers if l.out_value == outputs[key])
+        out = torch.empty((x.shape[0], width), device=self.device)
+        ws = self.workspace((x.shape[0] + p.batch_size - 1) // p.batch_size)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        native.check(self.lib.bsvi_amort_apply(self.handle, network, ptr(self.params), ptr(x), x.shape[0], outputs[key],
+                                               ptr(out), ptr(ws), self._stream()))
+        return out
+
+    def decode(self, z, key=None):
+        """decoder(z)[key] on the current parameters: the posterior-predictive step of `examples/VAE_playground.py:90-103`
+        (`model.get_sample(1, input_values={z: ...})["decoder_output"]`), rows [n, latent_dim] -> [n, width]"""
+        return self._apply(1, z, self.program.logits_key if key is None else key, self.program.dec_outputs)
+
+    def encode(self, x, key="mean"):
+        """encoder(x)[key] on rows [n, n_features] (the amortised posterior's parameters for new data)"""
+        return self._apply(0, x, key, self.program.enc_outputs)
 
     def named_grads(self):
         g = self.out[OUT_HEADER:].detach().cpu().numpy()

@@ -630,6 +630,15 @@ __global__ __launch_bounds__(256) void amort_latent_bwd(const RowParams D) {
     }
 }
 
+// dst[r][c] = src[r][c] for c < n: moves caller-layout rows into / out of the padded value buffers
+__global__ void copy_rows(const float* src, int lds, float* dst, int ldd, long rows, int n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const long r = i / n;
+    const int c = (int)(i - r * n);
+    dst[r * ldd + c] = src[r * lds + c];
+}
+
 }  // namespace bsvi_amort_impl
 
 // =============================================================================================================
@@ -996,6 +1005,47 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         HIP_TRY(hipEventRecord(a->joined, a->side));
         HIP_TRY(hipStreamWaitEvent(stream, a->joined, 0));
     }
+    HIP_TRY(hipGetLastError());
+    return BSVI_OK;
+}
+
+// Forward pass of ONE network on caller-supplied rows (posterior predictive / encoding: the step after training in
+// examples/VAE_playground.py:90-103 — `model.get_sample(1, input_values={z: ...})["decoder_output"]`).
+extern "C" int bsvi_amort_apply(const bsvi_amort* a, int network, const float* params_dev, const float* input_dev,
+                                uint32_t n_rows, uint32_t value, float* out_dev, void* workspace_dev, void* stream_) {
+    if (!a || !params_dev || !input_dev || !out_dev || !workspace_dev || !n_rows) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    if (network != 0 && network != 1) return bsvi_fail(BSVI_ERR_INVALID, "network must be 0 (encoder) or 1 (decoder)");
+    const Net& net = network == 0 ? a->enc : a->dec;
+    if (value == 0 || value >= net.width.size()) return bsvi_fail(BSVI_ERR_INVALID, "no such network value");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t R = n_rows;
+    if (R * a->floats_per_row > bsvi_amort_workspace_bytes(a, (n_rows + a->d.batch_size - 1) / a->d.batch_size) / sizeof(float))
+        return bsvi_fail(BSVI_ERR_INVALID, "workspace too small for this many rows");
+    float* ws = (float*)workspace_dev;
+    // private layout of this call: value v at offsets accumulated over the network's values
+    std::vector<size_t> off(net.width.size());
+    size_t acc = 0;
+    for (size_t v = 0; v < net.width.size(); ++v) { off[v] = acc; acc += (size_t)net.ld[v]; }
+    auto val = [&](uint32_t v) { return ws + off[v] * R; };
+    {
+        const long total = (long)R * net.width[0];
+        hipLaunchKernelGGL(copy_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, input_dev, net.width[0],
+                           val(0), net.ld[0], (long)R, net.width[0]);
+    }
+    for (const auto& l : net.layers) {
+        GemmArgs G{};
+        G.A = val(l.in_value); G.lda = net.ld[l.in_value];
+        G.B = params_dev + l.weight_off; G.ldb = (int)l.n_in;
+        G.C = val(l.out_value); G.ldc = net.ld[l.out_value];
+        G.M = (int)R; G.N = (int)l.n_out; G.K = (int)l.n_in;
+        G.bias = l.bias_off != 0xFFFFFFFFu ? params_dev + l.bias_off : nullptr;
+        G.act = (int)l.activation; G.post_add = l.post_add;
+        int rc = launch_gemm(MODE_NT, G, stream);
+        if (rc) return rc;
+    }
+    const long total = (long)R * net.width[value];
+    hipLaunchKernelGGL(copy_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, val(value), net.ld[value],
+                       out_dev, net.width[value], (long)R, net.width[value]);
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }

@@ -426,6 +426,12 @@ void bsvi_amort_destroy(bsvi_amort* a);
 size_t bsvi_amort_workspace_bytes(const bsvi_amort* a, uint32_t n_samples_local);
 int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args);
 
+/* Forward pass of one network (0 = encoder, 1 = decoder) on caller-supplied rows input_dev [n_rows][input width]; the
+ * network value `value` (a layer output id) is written to out_dev [n_rows][its width].  Posterior predictive / encoding:
+ * examples/VAE_playground.py:90-103.  workspace_dev: bsvi_amort_workspace_bytes(a, ceil(n_rows / batch_size)) bytes. */
+int bsvi_amort_apply(const bsvi_amort* a, int network, const float* params_dev, const float* input_dev, uint32_t n_rows,
+                     uint32_t value, float* out_dev, void* workspace_dev, void* stream);
+
 /* Test hook: one launch of the f32 MFMA GEMM behind the amortised path.
  * mode 0: C[M][N] = A[M][K] B[N][K]^T   (+ bias[n], activation)        forward
  * mode 1: C[M][N] = A[M][K] B[K][N]     (* activation'(Y[m][n]))      backward-data

@@ -1,0 +1,122 @@
+"""Host side of the amortised path (brancher_amd/amortized.py) on CPU: the torch.fx lowering of encoder / decoder
+modules, the graph pattern match, the parameter layout and the C-ABI descriptors.  No compute calls."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from brancher_amd import amortized, workloads as W
+from brancher_amd import functions as BF
+from brancher_amd.lowering import LoweringError
+
+
+def _link(module):
+    return BF.BrancherFunction(module).fn
+
+
+def test_trace_reference_style_modules():
+    enc, dec = W.vae_modules(n_features=12, latent_size=2, hidden1=8, hidden2=6, seed=0)
+    layers, outs = amortized.trace_network(_link(enc))
+    assert [(l.in_value, l.out_value, l.n_in, l.n_out, l.activation) for l in layers] == \
+        [(0, 1, 12, 6, amortized.ACT_RELU), (1, 2, 6, 8, amortized.ACT_RELU), (2, 3, 8, 2, amortized.ACT_NONE),
+         (2, 4, 8, 2, amortized.ACT_SOFTPLUS)]
+    assert layers[3].post_add == pytest.approx(0.1) and layers[2].post_add == 0.0
+    assert outs == {"mean": 3, "sd": 4}
+    layers, outs = amortized.trace_network(_link(dec))
+    assert [(l.n_in, l.n_out, l.activation) for l in layers] == [(2, 8, 1), (8, 6, 1), (6, 12, 0)] and outs == {"mean": 3}
+
+
+def test_trace_sequential_and_functional_forms():
+    import torch.nn.functional as F
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = nn.Sequential(nn.Linear(5, 7), nn.ReLU(), nn.Linear(7, 3, bias=False))
+
+        def forward(self, x):
+            return F.softplus(self.body(x.flatten(1))) + 0.5
+
+    layers, outs = amortized.trace_network(_link(Net()))
+    assert [(l.n_in, l.n_out, l.activation, l.post_add) for l in layers] == [(5, 7, 1, 0.0), (7, 3, 2, 0.5)]
+    assert layers[1].bias is None and outs == {None: 2}
+
+
+@pytest.mark.parametrize("bad", ["tanh", "shared_preactivation", "relu_after_shift", "two_inputs"])
+def test_unsupported_networks_fail_loudly(bad):
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l = nn.Linear(4, 4)
+
+        def forward(self, x, y=None):
+            h = self.l(x)
+            if bad == "tanh":
+                return torch.tanh(h)
+            if bad == "shared_preactivation":
+                return {"a": torch.relu(h), "b": h}
+            if bad == "relu_after_shift":
+                return torch.relu(h + 1.0)
+            return h + y
+
+    with pytest.raises(LoweringError):
+        amortized.trace_network(_link(Net()))
+
+
+def test_lowering_of_the_vae_graph():
+    model = W.build_vae(W.native_api(), dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6)
+    p = amortized.lower_amortized(model, model.posterior_model, "blackbox")
+    assert (p.n_features, p.latent_dim, p.dataset_size, p.batch_size) == (12, 2, 20, 5)
+    assert np.array_equal(p.prior_loc, [0, 0]) and np.allclose(p.prior_scale, [1, 1])
+    assert p.dataset.shape == (20, 12) and set(np.unique(p.dataset)) <= {0.0, 1.0}
+    # one flat buffer: encoder tensors (optimizer group 0) then decoder tensors (group 1), no gaps, torch layout
+    enc, dec = model.vae_modules
+    n_tensors = sum(t.numel() for m in (enc, dec) for t in m.parameters())
+    assert n_tensors <= p.n_params <= n_tensors + 3            # at most one alignment gap between the two networks
+    cover = np.zeros(p.n_params, dtype=int)
+    for par, off, size, group in p.parameters:
+        cover[off:off + size] += 1
+        assert np.all(p.param_group[off:off + size] == group)
+    assert cover.max() == 1 and np.array_equal(cover, p.param_active)   # padding elements are inactive
+    l1 = p.enc_layers[0]
+    assert np.array_equal(l1.weight.numpy(), enc.l1.weight.detach().numpy()) and l1.weight.shape == (6, 12)
+    # every weight matrix whose size allows it starts 16-byte aligned
+    for l in p.enc_layers + p.dec_layers:
+        if (l.n_in * l.n_out) % 4 == 0:
+            assert l.weight_off % 4 == 0
+
+
+def test_graphs_outside_the_pattern_are_rejected():
+    api = W.native_api()
+    enc, dec = W.vae_modules(12, 2, 8, 6)
+    data = W.vae_data(20, 12)
+    z = api.NormalVariable(np.zeros((2,)), np.ones((2,)), name="z")
+    out = api.DeterministicVariable(BF.BrancherFunction(dec)(z), name="decoder_output")
+    x = api.NormalVariable(out["mean"], 1.0, name="x")                 # a Normal likelihood through the decoder
+    model = api.ProbabilisticModel([x, z])
+    Qx = api.EmpiricalVariable(data, batch_size=5, name="x", is_observed=True)
+    eo = api.DeterministicVariable(BF.BrancherFunction(enc)(Qx), name="encoder_output")
+    Qz = api.NormalVariable(eo["mean"], eo["sd"], name="z")
+    model.set_posterior_model(api.ProbabilisticModel([Qx, Qz]))
+    with pytest.raises(LoweringError):
+        amortized.lower_amortized(model, model.posterior_model, "pathwise")
+    with pytest.raises(LoweringError):
+        amortized.lower_amortized(W.build_vae(api, dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6),
+                                  None if False else W.build_vae(api, dataset_size=20, batch_size=5, n_features=12,
+                                                                  hidden1=8, hidden2=6).posterior_model, "taylor1")
+
+
+def test_c_abi_structs_match_the_header():
+    import ctypes as C
+    import re
+    from brancher_amd import native
+    from conftest import ROOT
+    import os
+    header = open(os.path.join(ROOT, "include", "bsvi.h")).read()
+    assert C.sizeof(native.MlpLayer) == 32
+    body = re.search(r"typedef struct bsvi_amort_args \{(.*?)\} bsvi_amort_args;", header, re.S).group(1)
+    names = re.findall(r"(\w+)\s*(?:,|;)", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert [n for n, _ in native.AmortArgs._fields_] == names
+    body = re.search(r"typedef struct bsvi_amort_desc \{(.*?)\} bsvi_amort_desc;", header, re.S).group(1)
+    names = re.findall(r"(\w+)\s*(?:,|;)", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert [n for n, _ in native.AmortDesc._fields_] == names

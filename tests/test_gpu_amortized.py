@@ -195,3 +195,20 @@ def test_vae_sharded_path_matches_single():
         out.append((losses.cpu().numpy(), compiled.params.cpu().numpy()))
     assert rel_err(out[1][0], out[0][0]) <= 1e-6
     assert np.abs(out[1][1] - out[0][1]).max() <= 1e-6
+
+
+def test_vae_decode_and_encode_match_the_torch_modules():
+    """posterior-predictive step of examples/VAE_playground.py:90-103: the networks applied to caller-supplied rows"""
+    from brancher_amd import engine, workloads as W
+    model = W.build_vae(W.native_api(), dataset_size=50, batch_size=10, n_features=150, hidden1=136, hidden2=40, latent_size=3, seed=6)
+    compiled = engine.compile_model(model, model.posterior_model, "pathwise")
+    enc, dec = model.vae_modules
+    rng = np.random.RandomState(3)
+    z = rng.randn(333, 3).astype(np.float32)
+    x = (rng.rand(77, 150) > 0.5).astype(np.float32)
+    with torch.no_grad():
+        ref_logits = dec(torch.from_numpy(z).double() if False else torch.from_numpy(z))["mean"].numpy()
+        ref_enc = enc(torch.from_numpy(x).unsqueeze(-1))
+    assert rel_err(compiled.decode(z).cpu().numpy(), ref_logits) <= 2e-6
+    assert rel_err(compiled.encode(x, "mean").cpu().numpy(), ref_enc["mean"].numpy()) <= 2e-6
+    assert rel_err(compiled.encode(x, "sd").cpu().numpy(), ref_enc["sd"].numpy()) <= 2e-6
