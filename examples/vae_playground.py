@@ -84,6 +84,6 @@ print("1000 iterations of 800 rows in %.2f s; loss %.1f -> %.1f" % (time.time() 
 # posterior predictive: decode a grid of latent codes (the image grid of the reference example)
 compiled = engine.compile_model(model, None, PathwiseDerivativeEstimator)
 grid = np.stack(np.meshgrid(np.linspace(-3, 3, 8), np.linspace(-3, 3, 8)), -1).reshape(-1, 2)
-probs = 1.0 / (1.0 + np.exp(-compiled.decode(grid).cpu().numpy()))
+probs = 1.0 / (1.0 + np.exp(-np.clip(compiled.decode(grid).cpu().numpy(), -30, 30)))
 print("decoded %d latent codes -> images of mean intensity %.3f (data: %.3f)" % (len(grid), probs.mean(), dataset.mean()))
 compiled.sync_modules()          # the trained tensors are back in the torch modules

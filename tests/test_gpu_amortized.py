@@ -212,3 +212,43 @@ def test_vae_decode_and_encode_match_the_torch_modules():
     assert rel_err(compiled.decode(z).cpu().numpy(), ref_logits) <= 2e-6
     assert rel_err(compiled.encode(x, "mean").cpu().numpy(), ref_enc["mean"].numpy()) <= 2e-6
     assert rel_err(compiled.encode(x, "sd").cpu().numpy(), ref_enc["sd"].numpy()) <= 2e-6
+
+
+def test_vae_full_size_shard_linearity():
+    """BASELINE config 5 at its per-GPU size (number_samples=256 x batch 100 = 25 600 rows, 784-256-512-(2,2)): the sums
+    of one evaluation equal the sums of its two half shards replayed on the same minibatches and noise — the property
+    the multi-GPU step relies on — and the per-row values agree row by row."""
+    from brancher_amd import engine, workloads as W
+    N, B = 256, 100
+    model = W.build_vae(W.native_api(), dataset_size=4000, batch_size=B, n_features=784, hidden1=512, hidden2=256, seed=7)
+    c = engine.compile_model(model, model.posterior_model, "blackbox")
+    full = c.evaluate(N, seed=3, offset=0, want_noise=True, want_indices=True, want_fvalues=True)
+    loss, grads = float(full["loss"]), full["grads"].clone()
+    f_rows, eps, rows = full["f"].clone(), full["noise"].cpu().numpy().reshape(N, B, 2), full["indices"].cpu().numpy()
+    assert float(full["finite"]) == 1.0 and all(len(set(r)) == B for r in rows[:16])
+    half = N // 2
+    sums, parts = 0.0, []
+    gsum = torch.zeros_like(grads)
+    for h in range(2):
+        sl = slice(h * half, (h + 1) * half)
+        r = c.evaluate(half, noise=eps[sl], minibatch=rows[sl], want_fvalues=True)
+        # f carries the entropy constant log(number_samples) (DESIGN 4.6): log 128 here, log 256 in the full run
+        parts.append(r["f"] + float(np.log(N) - np.log(half)))
+        gsum += r["grads"] * half
+    f_halves = torch.cat(parts)
+    assert rel_err(f_halves.cpu().numpy(), f_rows.cpu().numpy()) <= 1e-6
+    # BlackBox weights every row's score term with f, which contains that constant: only the pathwise part of the
+    # gradient is shard-additive for a fixed N, so compare through the pathwise program on the same draws
+    cp = engine.compile_model(model, model.posterior_model, "pathwise")
+    full_p = cp.evaluate(N, noise=eps, minibatch=rows)
+    gp, loss_p = full_p["grads"].clone(), float(full_p["loss"])     # views of the engine's output block: copy now
+    gsum.zero_()
+    lsum = 0.0
+    for h in range(2):
+        sl = slice(h * half, (h + 1) * half)
+        r = cp.evaluate(half, noise=eps[sl], minibatch=rows[sl])
+        gsum += r["grads"] * half
+        lsum += (float(r["loss"]) + float(np.log(half))) * half        # loss = -mean f, f contains +log(n)
+    assert abs(lsum / N - (loss_p + float(np.log(N)))) <= 1e-5 * abs(loss_p)
+    scale = float(gp.abs().max())
+    assert float((gsum / N - gp).abs().max()) <= 1e-5 * scale
