@@ -842,7 +842,8 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_kernel<MODE_TN, 64>), grid, dim3(NTHREADS), 0, stream, G);
     } else {
         // 64-row tiles when 128-row tiles would leave most CUs with one or two workgroups
-        const bool half = tiles < 1536 && G.M > 64;
+        static const int half_below = [] { const char* e = getenv("BSVI_GEMM_HALF_BELOW"); return e ? atoi(e) : 1536; }();
+        const bool half = tiles < half_below && G.M > 64;
         if (half) tiles = ((G.M + 63) / 64) * tiles_n;
         G.remap = (tiles % 8 == 0) ? 1 : 0;
         dim3 grid(tiles, 1, 1);
