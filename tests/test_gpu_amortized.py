@@ -252,3 +252,86 @@ def test_vae_full_size_shard_linearity():
     assert abs(lsum / N - (loss_p + float(np.log(N)))) <= 1e-5 * abs(loss_p)
     scale = float(gp.abs().max())
     assert float((gsum / N - gp).abs().max()) <= 1e-5 * scale
+
+
+def _custom_vae(api, enc_module, dec_module, dataset, batch_size, latent, prior_loc=None, prior_scale=None, bernoulli=False):
+    import brancher_amd.functions as BF
+    encoder, decoder = BF.BrancherFunction(enc_module), BF.BrancherFunction(dec_module)
+    z = api.NormalVariable(np.zeros((latent,)) if prior_loc is None else prior_loc,
+                           np.ones((latent,)) if prior_scale is None else prior_scale, name="z")
+    out = api.DeterministicVariable(decoder(z), name="decoder_output")
+    if bernoulli:
+        x = api.BernulliVariable(logits=out["mean"], name="x")
+    else:
+        x = api.BinomialVariable(total_count=1, logits=out["mean"], name="x")
+    model = api.ProbabilisticModel([x, z])
+    Qx = api.EmpiricalVariable(dataset, batch_size=batch_size, name="x", is_observed=True)
+    eo = api.DeterministicVariable(encoder(Qx), name="encoder_output")
+    Qz = api.NormalVariable(eo["mean"], eo["sd"], name="z")
+    model.set_posterior_model(api.ProbabilisticModel([Qx, Qz]))
+    model.vae_modules = (enc_module, dec_module)
+    return model
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_architectures_match_oracle(seed):
+    """less-travelled shapes: heads straight off the data rows (gathered narrow layers), single-layer decoders, no
+    biases, latent sizes 1..9, batch == dataset, widths around the tile edges — against the fp64 oracle, both estimators"""
+    import torch.nn as nn
+    from brancher_amd import engine, workloads as W
+    from oracle.vae_oracle import VaeOracle
+    rng = np.random.RandomState(100 + seed)
+    P = int(rng.choice([5, 17, 64, 129, 200]))
+    latent = int(rng.choice([1, 2, 3, 8, 9]))
+    DS = int(rng.choice([7, 33, 64]))
+    B = DS if seed % 4 == 0 else int(rng.randint(1, DS + 1))
+    N = int(rng.choice([1, 3, 10]))
+    enc_hidden = [int(rng.choice([4, 9, 65, 130])) for _ in range(int(rng.randint(0, 3)))]
+    dec_hidden = [int(rng.choice([3, 8, 66, 128])) for _ in range(int(rng.randint(0, 3)))]
+    bias = bool(rng.randint(0, 2))
+    torch.manual_seed(seed)
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            dims = [P] + enc_hidden
+            self.trunk = nn.ModuleList([nn.Linear(a, b, bias=bias) for a, b in zip(dims[:-1], dims[1:])])
+            self.mean = nn.Linear(dims[-1], latent, bias=bias)
+            self.sd = nn.Linear(dims[-1], latent)
+            self.sp = nn.Softplus()
+
+        def forward(self, x):
+            h = x.squeeze(-1)
+            for l in self.trunk:
+                h = torch.relu(l(h))
+            return {"mean": self.mean(h), "sd": self.sp(self.sd(h)) + 0.05}
+
+    class Dec(nn.Module):
+        def __init__(self):
+            super().__init__()
+            dims = [latent] + dec_hidden
+            self.trunk = nn.ModuleList([nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+            self.out = nn.Linear(dims[-1], P, bias=bias)
+
+        def forward(self, z):
+            h = z
+            for l in self.trunk:
+                h = torch.relu(l(h))
+            return {"mean": self.out(h)}
+
+    enc, dec = Enc(), Dec()
+    data = (rng.rand(DS, P, 1) > 0.5).astype("int32")
+    prior_loc, prior_scale = rng.randn(latent) * 0.3, 0.5 + rng.rand(latent)
+    build = lambda: _custom_vae(W.native_api(), enc, dec, data, B, latent, prior_loc, prior_scale, bernoulli=seed % 2 == 1)
+    rows = np.stack([rng.choice(DS, B, replace=False) for _ in range(N)])
+    eps = rng.randn(N, B, latent).astype(np.float32)
+    for estimator in ("pathwise", "blackbox"):
+        model = build()
+        ref = VaeOracle(model, dtype=torch.float64).loss_and_grads(rows, eps, estimator)
+        c = engine.compile_model(model, model.posterior_model, estimator)
+        res = c.evaluate(N, noise=eps, minibatch=rows)
+        assert abs(float(res["loss"]) - ref["loss"]) <= TOL * max(abs(ref["loss"]), 1.0), (estimator, float(res["loss"]), ref["loss"])
+        grads = _module_view(c, c.named_grads())
+        scale = max(np.abs(v).max() for v in ref["grads"].values())
+        for name, g_ref in ref["grads"].items():
+            assert np.abs(grads[name] - g_ref).max() <= 2e-5 * scale, (estimator, name)
