@@ -307,21 +307,24 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
             // MFMAs back to back: the matrix pipe is not stalled on an LDS round trip every second instruction
             const float* at = (cur ? As[1] : As[0]) + lk * LDA + wm + lm;
             const float* bt = (cur ? Bs[1] : Bs[0]) + lk * LDB + wn + lm;
-            float a[BK / 2][TM], b[BK / 2][2];
 #pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
+            for (int h = 0; h < 2; ++h) {       // two batches of four k pairs: 12-16 live operand registers, not 24-32
+                float a[BK / 4][TM], b[BK / 4][2];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[kk][i] = at[2 * kk * LDA + 32 * i];
+                for (int kk = 0; kk < BK / 4; ++kk) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[kk][j] = bt[2 * kk * LDB + 32 * j];
+                    for (int i = 0; i < TM; ++i) a[kk][i] = at[(BK / 2 * h + 2 * kk) * LDA + 32 * i];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[kk][j] = bt[(BK / 2 * h + 2 * kk) * LDB + 32 * j];
+                }
+#pragma unroll
+                for (int kk = 0; kk < BK / 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
             if (more) {
                 if (col_sums) add_cols(fa);      // here, not at the load: the values are awaited for the LDS store anyway
                 store_a(As[cur ^ 1], fa);
