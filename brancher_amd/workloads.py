@@ -375,45 +375,39 @@ def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=78
 
 
 def vae_modules(n_features, latent_size, hidden1, hidden2, seed=0):
-    """Encoder / decoder architectures of `examples/VAE_playground.py:27-62` (MLP 784-256-512-(2,2) and 2-512-256-784
-    there), as plain torch modules with a seeded initialisation.  They override ``__call__`` and return dicts like
-    the example's classes do."""
+    """Encoder / decoder networks with the layer plan of `examples/VAE_playground.py:27-62` (there: 784-256-512-(2,2)
+    and 2-512-256-784): two ReLU layers, then a mean head and a softplus(+0.1) scale head; the decoder mirrors the
+    trunk and ends in the logits.  Plain torch modules with a seeded initialisation, returning dicts keyed like the
+    example's ("mean", "sd").  Layers are created in the order l1..l4 / l1..l3 so that a seed fixes every tensor."""
     import torch
     import torch.nn as nn
+    import torch.nn.functional as F
 
-    class EncoderArchitecture(nn.Module):
-        def __init__(self):
+    class Encoder(nn.Module):
+        def __init__(self, widths):
             super().__init__()
-            self.l1 = nn.Linear(n_features, hidden2)
-            self.l2 = nn.Linear(hidden2, hidden1)
-            self.f1 = nn.ReLU()
-            self.f2 = nn.ReLU()
-            self.l3 = nn.Linear(hidden1, latent_size)
-            self.l4 = nn.Linear(hidden1, latent_size)
-            self.softplus = nn.Softplus()
+            self.l1 = nn.Linear(widths[0], widths[1])
+            self.l2 = nn.Linear(widths[1], widths[2])
+            self.l3 = nn.Linear(widths[2], latent_size)      # location head
+            self.l4 = nn.Linear(widths[2], latent_size)      # scale head (pre-activation)
 
-        def __call__(self, x):
-            h0 = self.f1(self.l1(x.squeeze()))
-            h1 = self.f2(self.l2(h0))
-            return {"mean": self.l3(h1), "sd": self.softplus(self.l4(h1)) + 0.1}
+        def forward(self, rows):
+            hidden = torch.relu(self.l2(torch.relu(self.l1(rows.squeeze(-1)))))
+            return {"mean": self.l3(hidden), "sd": F.softplus(self.l4(hidden)) + 0.1}
 
-    class DecoderArchitecture(nn.Module):
-        def __init__(self):
+    class Decoder(nn.Module):
+        def __init__(self, widths):
             super().__init__()
-            self.l1 = nn.Linear(latent_size, hidden1)
-            self.l2 = nn.Linear(hidden1, hidden2)
-            self.f1 = nn.ReLU()
-            self.f2 = nn.ReLU()
-            self.l3 = nn.Linear(hidden2, n_features)
+            self.l1 = nn.Linear(latent_size, widths[0])
+            self.l2 = nn.Linear(widths[0], widths[1])
+            self.l3 = nn.Linear(widths[1], widths[2])
 
-        def __call__(self, x):
-            h0 = self.f1(self.l1(x))
-            h1 = self.f2(self.l2(h0))
-            return {"mean": self.l3(h1)}
+        def forward(self, code):
+            return {"mean": self.l3(torch.relu(self.l2(torch.relu(self.l1(code)))))}
 
     state = torch.random.get_rng_state()
     torch.manual_seed(seed)
-    enc, dec = EncoderArchitecture(), DecoderArchitecture()
+    enc, dec = Encoder((n_features, hidden2, hidden1)), Decoder((hidden1, hidden2, n_features))
     torch.random.set_rng_state(state)
     return enc, dec
 

@@ -14,7 +14,22 @@ def _link(module):
     return BF.BrancherFunction(module).fn
 
 
-def test_trace_reference_style_modules():
+def test_trace_modules_that_override_call():
+    """the reference's examples define networks by overriding __call__ and use activation MODULES
+    (examples/VAE_playground.py:27-62); torch.fx must see through both"""
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.act, self.sp = nn.Linear(6, 4), nn.Linear(4, 3), nn.ReLU(), nn.Softplus()
+
+        def __call__(self, x):
+            return {"s": self.sp(self.b(self.act(self.a(x.squeeze())))) + 0.25}
+
+    layers, outs = amortized.trace_network(_link(Net()))
+    assert [(l.n_in, l.n_out, l.activation, l.post_add) for l in layers] == [(6, 4, 1, 0.0), (4, 3, 2, 0.25)] and outs == {"s": 2}
+
+
+def test_trace_workload_modules():
     enc, dec = W.vae_modules(n_features=12, latent_size=2, hidden1=8, hidden2=6, seed=0)
     layers, outs = amortized.trace_network(_link(enc))
     assert [(l.in_value, l.out_value, l.n_in, l.n_out, l.activation) for l in layers] == \
