@@ -1,58 +1,57 @@
 """
-Optimizer registry (`brancher/optimizers.py:19-73`).
+Optimizer registry (API of `brancher/optimizers.py:19-73`).
 
-The reference collects the ``ParameterModule``/``LinkConstructor`` links of a model into an
-``EmptyModule`` and instantiates ``getattr(torch.optim, name)(params, **kwargs)``.  Here the
-same object records *which* parameters belong to it and the ``torch.optim`` configuration;
-the update itself is the fused device optimizer (``bsvi_optimizer_step`` / the step fused
-into ``reduce_kernel``), which follows torch.optim.SGD / torch.optim.Adam element for element.
+The reference walks a model's variables, gathers their ``ParameterModule`` / ``LinkConstructor`` links into an
+``EmptyModule`` and hands ``module.parameters()`` to ``getattr(torch.optim, name)(..., **kwargs)``.  Here a
+``ProbabilisticOptimizer`` only *records* which ``Parameter`` objects it owns and the validated ``torch.optim``
+configuration: the update itself is the fused device optimizer (``bsvi_finalize_step`` / the step fused into the
+reduction kernels), element for element torch.optim.SGD / torch.optim.Adam.  `inference.perform_inference` builds one
+per model exactly like the reference (`inference.py:77-88`) and uses ``.optimizer`` (None when the model has nothing to
+learn) to decide which groups exist.
 """
-from collections.abc import Iterable
-
 from brancher_amd import native
-from brancher_amd.modules import ParameterModule, EmptyModule
+from brancher_amd.modules import EmptyModule, ParameterModule
 from brancher_amd.standard_variables import LinkConstructor
-from brancher_amd.variables import BrancherClass, Variable, ProbabilisticModel
+from brancher_amd.variables import ProbabilisticModel, Variable
+
+
+def _variables_of(model):
+    if isinstance(model, ProbabilisticModel):
+        return model.flatten()
+    if isinstance(model, Variable):
+        return model.ancestors
+    raise ValueError("Only brancher variables and iterable of variables can be added to a probabilistic optimizer")
+
+
+def _parameter_holders(link):
+    """the objects of a link that own parameters: the link itself, or the modules a LinkConstructor collected"""
+    if isinstance(link, ParameterModule):
+        return [link]
+    if isinstance(link, LinkConstructor):
+        return list(link)
+    return []
 
 
 class ProbabilisticOptimizer:
 
     def __init__(self, model, optimizer='SGD', **kwargs):
         assert isinstance(optimizer, str), 'Optimizer should be a name of available pytoch optimizers'
+        self.optimizer_name, self.kwargs = optimizer, dict(kwargs)
         self.link_set = set()
-        self.module = None
-        self.optimizer_name = optimizer
-        self.kwargs = dict(kwargs)
-        self.setup(model, optimizer, **kwargs)
-
-    def _update_link_set(self, model):
-        assert isinstance(model, BrancherClass)
-        variable_set = model.flatten() if isinstance(model, ProbabilisticModel) else model.ancestors
-        for var in variable_set:
-            link = var.link if hasattr(var, 'link') else None
-            if isinstance(link, (ParameterModule, LinkConstructor)):
-                self.link_set.add(link)
-
-    def add_variable2module(self, random_variable):
-        self._update_link_set(random_variable)
-        for link in self.link_set:
-            if isinstance(link, ParameterModule):
-                self.module.append(link)
-            elif isinstance(link, LinkConstructor):
-                [self.module.append(l) for l in link]
-
-    def setup(self, model, optimizer, **kwargs):
         self.module = EmptyModule()
-        if isinstance(model, (Variable, ProbabilisticModel)):
-            self.add_variable2module(model)
-        elif isinstance(model, Iterable) and all([isinstance(sub, (Variable, ProbabilisticModel)) for sub in model]):
-            [self.add_variable2module(sub) for sub in model]
-        else:
-            raise ValueError("Only brancher variables and iterable of variables can be added to a probabilistic optimizer")
-        if list(self.module.parameters()):
-            self.optimizer = native.make_opt_cfg(optimizer, **kwargs)     # validates the configuration
-        else:
-            self.optimizer = None
+        models = [model] if isinstance(model, (Variable, ProbabilisticModel)) else list(model)
+        for m in models:
+            self.add_variable2module(m)
+        # validates the configuration against what the fused optimizer implements; None = nothing to optimise
+        self.optimizer = native.make_opt_cfg(optimizer, **kwargs) if self.module.parameters() else None
+
+    def add_variable2module(self, model):
+        """register the parameter holders of every variable of `model` (`optimizers.py:42-51`)"""
+        fresh = {getattr(v, "link", None) for v in _variables_of(model)} - self.link_set - {None}
+        fresh = {link for link in fresh if _parameter_holders(link)}
+        self.link_set |= fresh
+        for link in fresh:
+            self.module.extend(_parameter_holders(link))
 
     def parameters(self):
         return self.module.parameters()
