@@ -393,6 +393,8 @@ class CompiledAmortized:
         if isinstance(noise, dict):
             noise = noise[p.latent_name]
         if isinstance(noise, np.ndarray):
+            if noise.size % (p.batch_size * p.latent_dim):
+                raise ValueError("noise must have shape [number_samples, %d, %d]" % (p.batch_size, p.latent_dim))
             a = np.asarray(noise, dtype=np.float32).reshape(-1, p.batch_size, p.latent_dim)[base:base + n_local]
             return torch.from_numpy(np.ascontiguousarray(a.reshape(-1, p.latent_dim))).to(self.device)
         return noise.reshape(-1, p.batch_size, p.latent_dim)[base:base + n_local].reshape(-1, p.latent_dim).contiguous()
@@ -403,8 +405,10 @@ class CompiledAmortized:
         p = self.program
         if isinstance(minibatch, dict):
             minibatch = minibatch[p.data_name]
-        a = np.asarray(minibatch, dtype=np.int32).reshape(-1, p.batch_size)[base:base + n_local]
-        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        a = np.asarray(minibatch, dtype=np.int64).reshape(-1, p.batch_size)[base:base + n_local]
+        if a.size and (a.min() < 0 or a.max() >= p.dataset_size):
+            raise ValueError("minibatch rows must lie in [0, %d)" % p.dataset_size)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
 
     def _args(self, n_local, n_global, base, noise=None, indices=None, seed=None, offset=0, noise_out=None,
               indices_out=None, fvalue_out=None, logq_out=None):
