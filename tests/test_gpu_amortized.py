@@ -273,7 +273,7 @@ def _custom_vae(api, enc_module, dec_module, dataset, batch_size, latent, prior_
     return model
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSVI_TEST_SEEDS", "20"))))
 def test_random_architectures_match_oracle(seed):
     """less-travelled shapes: heads straight off the data rows (gathered narrow layers), single-layer decoders, no
     biases, latent sizes 1..9, batch == dataset, widths around the tile edges — against the fp64 oracle, both estimators"""
