@@ -158,6 +158,8 @@ typedef struct bsvi_record {
 typedef enum bsvi_estimator {
     BSVI_EST_PATHWISE = 0,  /* gradient_estimators.py:39-44 */
     BSVI_EST_BLACKBOX = 1   /* gradient_estimators.py:29-36 */
+    /* Taylor1Estimator (gradient_estimators.py:47-56) is BSVI_EST_PATHWISE on a different program: the host lowering
+     * substitutes the posterior's analytic means for its values wherever the model reads them. */
 } bsvi_estimator;
 
 typedef struct bsvi_program_desc {
