@@ -292,18 +292,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
                 fb = load_b(k_begin + step * BK);
             }
         };
+        // ONE register set, two LDS buffers, tiles two steps ahead: tile s+1 is written to LDS right AFTER the barrier
+        // that frees its buffer — a whole step before it is read, so the ds_write -> barrier -> ds_read chain is off the
+        // critical path — and the loads of tile s+2 are re-issued into the same registers at once; they stay in flight
+        // across the step's MFMAs and its barrier (plain global loads survive __syncthreads()).
         Frag<TBM> fa;
         Frag<BN> fb;
         stage(0, fa, fb);
         if (col_sums) add_cols(fa);
         store_a(As[0], fa);
         store_b(Bs[0], fb);
+        if (n_steps > 1) stage(1, fa, fb);
         __syncthreads();
         for (int step = 0; step < n_steps; ++step) {
             const int cur = step & 1;
-            const bool more = step + 1 < n_steps;
-            if (more) stage(step + 1, fa, fb);
-            // all operand fragments of the step first (immediate-offset ds_reads off one base per tile), then the
+            if (step + 1 < n_steps) {
+                if (col_sums) add_cols(fa);
+                store_a(As[cur ^ 1], fa);
+                store_b(Bs[cur ^ 1], fb);
+                if (step + 2 < n_steps) stage(step + 2, fa, fb);
+            }
+            // all operand fragments of a batch first (immediate-offset ds_reads off one base per tile), then the
             // MFMAs back to back: the matrix pipe is not stalled on an LDS round trip every second instruction
             const float* at = (cur ? As[1] : As[0]) + lk * LDA + wm + lm;
             const float* bt = (cur ? Bs[1] : Bs[0]) + lk * LDB + wn + lm;
@@ -324,11 +333,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-            }
-            if (more) {
-                if (col_sums) add_cols(fa);      // here, not at the load: the values are awaited for the LDS store anyway
-                store_a(As[cur ^ 1], fa);
-                store_b(Bs[cur ^ 1], fb);
             }
             __syncthreads();
         }
