@@ -36,7 +36,7 @@ NO_BIAS = 0xFFFFFFFF
 
 class Layer:
     __slots__ = ("in_value", "out_value", "n_in", "n_out", "weight", "bias", "activation", "post_add",
-                 "weight_off", "bias_off")
+                 "weight_off", "bias_off", "split_col", "activation2", "post_add2", "parts")
 
     def __repr__(self):
         return "Layer(%d -> %d, %dx%d, act=%d, +%g)" % (self.in_value, self.out_value, self.n_out, self.n_in,
@@ -108,6 +108,7 @@ def trace_network(link):
                 lay.weight = link.named[prefix + ".weight"]
                 lay.bias = link.named[prefix + ".bias"] if sub.bias is not None else None
                 lay.activation, lay.post_add = ACT_NONE, 0.0
+                lay.split_col, lay.activation2, lay.post_add2, lay.parts = 0, ACT_NONE, 0.0, None
                 layers.append(lay)
                 value_of[node] = lay.out_value
                 produced_by[lay.out_value] = lay
@@ -146,6 +147,40 @@ def trace_network(link):
         else:
             raise LoweringError("amortised path: unsupported graph node %s" % node.op)
     return layers, outputs
+
+
+def merge_sibling_heads(layers, outputs):
+    """Two narrow layers that read the same value and feed nothing further — the latent's loc and scale heads — become
+    ONE layer: their weight rows (and biases) are laid out adjacently in the parameter buffer, the output columns of
+    the second keep their own activation (`bsvi_mlp_layer.split_col`).  One pass over the trunk value instead of two,
+    forward and backward.  Returns (layers, {key: (value, first column)}, [(weights...), (biases...)] adjacency groups)."""
+    consumed = {l.in_value for l in layers}
+    cols = {k: (v, 0) for k, v in outputs.items()}
+    groups = []
+    heads = [l for l in layers if l.out_value not in consumed and l.n_out <= 4]
+    by_input = {}
+    for l in heads:
+        by_input.setdefault(l.in_value, []).append(l)
+    for sibs in by_input.values():
+        if len(sibs) != 2 or (sibs[0].bias is None) != (sibs[1].bias is None):
+            continue
+        first, second = sibs
+        merged = Layer()
+        merged.in_value, merged.out_value = first.in_value, first.out_value
+        merged.n_in, merged.n_out = first.n_in, first.n_out + second.n_out
+        merged.weight, merged.bias = first.weight, first.bias
+        merged.activation, merged.post_add = first.activation, first.post_add
+        merged.split_col, merged.activation2, merged.post_add2 = first.n_out, second.activation, second.post_add
+        merged.parts = (first, second)
+        groups.append((first.weight, second.weight))
+        if first.bias is not None:
+            groups.append((first.bias, second.bias))
+        layers = [merged if l is first else l for l in layers if l is not second]
+        for k, (v, c) in list(cols.items()):
+            if v == second.out_value:
+                cols[k] = (first.out_value, first.n_out)
+    # value ids stay as they are (gaps are fine: the C side sizes its tables by the largest id)
+    return layers, cols, groups
 
 
 class AmortizedProgram:
@@ -253,6 +288,7 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     for key, outs, what in ((loc_key, enc_out, "encoder"), (scale_key, enc_out, "encoder"), (logits_key, dec_out, "decoder")):
         if key not in outs:
             raise LoweringError("amortised path: the %s has no output %r" % (what, key))
+    enc_layers, enc_cols, adjacent = merge_sibling_heads(enc_layers, enc_out)
 
     prog = AmortizedProgram()
     prog.estimator = estimator
@@ -263,6 +299,12 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     for group, link in ((0, enc_link), (1, dec_link)):
         off = (off + 3) // 4 * 4          # every network starts 16-byte aligned (padding elements stay inactive)
         pars = sorted(link.parameters(), key=lambda p: (p.size % 4 != 0, len(p.shape) < 2))
+        # merged sibling layers need their tensors back to back, in layer order
+        for grp in adjacent:
+            if all(any(q is g for q in pars) for g in grp):
+                at = min(i for i, q in enumerate(pars) if any(q is g for g in grp))
+                rest = [q for q in pars if not any(q is g for g in grp)]
+                pars = rest[:at] + list(grp) + rest[at:]
         for par in pars:
             if id(par) in offsets:
                 continue
@@ -285,8 +327,8 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     if any(l.in_value == 0 and l.n_in != Dz for l in dec_layers):
         raise LoweringError("amortised path: the decoder's input width does not match the latent")
     prog.enc_layers, prog.dec_layers = enc_layers, dec_layers
-    prog.enc_outputs, prog.dec_outputs, prog.logits_key = enc_out, dec_out, logits_key
-    prog.enc_loc_value, prog.enc_scale_value = enc_out[loc_key], enc_out[scale_key]
+    prog.enc_outputs, prog.dec_outputs, prog.logits_key = enc_cols, {k: (v, 0) for k, v in dec_out.items()}, logits_key
+    (prog.enc_loc_value, prog.enc_loc_col), (prog.enc_scale_value, prog.enc_scale_col) = enc_cols[loc_key], enc_cols[scale_key]
     prog.dec_logits_value = dec_out[logits_key]
     prog.n_features, prog.latent_dim, prog.dataset_size, prog.batch_size = P, Dz, DS, B
     prog.prior_loc = np.ascontiguousarray(prior_loc, dtype=np.float32)
@@ -314,7 +356,7 @@ class CompiledAmortized:
             arr = (MlpLayer * len(layers))()
             for k, l in enumerate(layers):
                 arr[k] = MlpLayer(l.in_value, l.out_value, l.n_in, l.n_out, l.weight_off, l.bias_off, l.activation,
-                                  l.post_add)
+                                  l.post_add, l.split_col, l.activation2, l.post_add2, 0)
             return arr
 
         self._keep = dict(enc=pack(p.enc_layers), dec=pack(p.dec_layers), loc=p.prior_loc, scale=p.prior_scale,
@@ -325,6 +367,7 @@ class CompiledAmortized:
                       latent_dim=p.latent_dim, dataset_size=p.dataset_size, batch_size=p.batch_size,
                       n_enc_layers=len(p.enc_layers), n_dec_layers=len(p.dec_layers),
                       enc_loc_value=p.enc_loc_value, enc_scale_value=p.enc_scale_value,
+                      enc_loc_col=p.enc_loc_col, enc_scale_col=p.enc_scale_col,
                       dec_logits_value=p.dec_logits_value, enc_layers=k["enc"], dec_layers=k["dec"],
                       prior_loc=ptr(k["loc"]), prior_scale=ptr(k["scale"]), dataset=ptr(k["dataset"]))
         handle = C.c_void_p()
@@ -472,13 +515,17 @@ class CompiledAmortized:
         x = torch.as_tensor(np.asarray(rows, dtype=np.float32)) if not torch.is_tensor(rows) else rows.float()
         x = x.reshape(x.shape[0], -1).contiguous().to(self.device)
         layers = p.enc_layers if network == 0 else p.dec_layers
-        width = next(l.n_out for l in layers if l.out_value == outputs[key])
-        out = torch.empty((x.shape[0], width), device=self.device)
+        value, col = outputs[key]
+        producer = next(l for l in layers if l.out_value == value)
+        width = producer.n_out
+        if producer.parts is not None:                      # merged heads: this key's own columns
+            width = producer.parts[0].n_out if col == 0 else producer.parts[1].n_out
+        full = torch.empty((x.shape[0], producer.n_out), device=self.device)
         ws = self.workspace((x.shape[0] + p.batch_size - 1) // p.batch_size)
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        native.check(self.lib.bsvi_amort_apply(self.handle, network, ptr(self.params), ptr(x), x.shape[0], outputs[key],
-                                               ptr(out), ptr(ws), self._stream()))
-        return out
+        native.check(self.lib.bsvi_amort_apply(self.handle, network, ptr(self.params), ptr(x), x.shape[0], value,
+                                               ptr(full), ptr(ws), self._stream()))
+        return full[:, col:col + width].contiguous()
 
     def decode(self, z, key=None):
         """decoder(z)[key] on the current parameters: the posterior-predictive step of `examples/VAE_playground.py:90-103`

@@ -58,6 +58,9 @@ struct GemmArgs {
     int ldy;
     int act;
     float post_add;
+    int split;             // output columns >= split use act2 / post_add2 (merged sibling layers); 0 = no split
+    int act2;
+    float post_add2;
     int accumulate;        // NN: C += result
     int k_chunk;           // TN: rows of K per workgroup (multiple of BK)
     int remap;             // XCD-aware workgroup order
@@ -70,6 +73,9 @@ __device__ __forceinline__ float act_forward(int act, float v, float post_add) {
     if (act == BSVI_ACT_SOFTPLUS) v = v > 20.0f ? v : log1pf(expf(v));   // torch softplus, threshold 20
     return v + post_add;
 }
+// merged sibling layers: the activation of output column n
+#define ACT_OF(G, n) (((G).split > 0 && (n) >= (G).split) ? (G).act2 : (G).act)
+#define ADD_OF(G, n) (((G).split > 0 && (n) >= (G).split) ? (G).post_add2 : (G).post_add)
 // derivative of the activation expressed through its OUTPUT y (what the forward pass kept)
 __device__ __forceinline__ float act_derivative(int act, float y, float post_add) {
     if (act == BSVI_ACT_RELU) return y - post_add > 0.0f ? 1.0f : 0.0f;
@@ -368,9 +374,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
                 float v = acc[i][j][r];
                 float* c = G.C + (long)m * G.ldc + n;
                 if (MODE == MODE_NT) {
-                    *c = act_forward(G.act, v + bias, G.post_add);
+                    *c = act_forward(ACT_OF(G, n), v + bias, ADD_OF(G, n));
                 } else if (MODE == MODE_NN) {
-                    if (G.act != BSVI_ACT_NONE) v *= act_derivative(G.act, G.Y[(long)m * G.ldy + n], G.post_add);
+                    if (G.Y) v *= act_derivative(ACT_OF(G, n), G.Y[(long)m * G.ldy + n], ADD_OF(G, n));
                     *c = G.accumulate ? *c + v : v;
                 } else {
                     unsafeAtomicAdd(c, v);
@@ -390,8 +396,8 @@ constexpr int SKINNY = 8;
 
 __device__ __forceinline__ float skinny_epilogue(const GemmArgs& G, int mode, float v, long r, int n) {
     float* c = G.C + r * G.ldc + n;
-    if (mode == MODE_NT) return act_forward(G.act, v + (G.bias ? G.bias[n] : 0.0f), G.post_add);
-    if (G.act != BSVI_ACT_NONE) v *= act_derivative(G.act, G.Y[r * G.ldy + n], G.post_add);
+    if (mode == MODE_NT) return act_forward(ACT_OF(G, n), v + (G.bias ? G.bias[n] : 0.0f), ADD_OF(G, n));
+    if (G.Y) v *= act_derivative(ACT_OF(G, n), G.Y[r * G.ldy + n], ADD_OF(G, n));
     return G.accumulate ? *c + v : v;
 }
 
@@ -697,7 +703,7 @@ static int build_net(Net& net, const bsvi_mlp_layer* layers, uint32_t n_layers, 
         if (l.out_value == 0 || net.width[l.out_value] != -1) return bsvi_fail(BSVI_ERR_INVALID, "a network value is produced twice");
         if (net.width[l.in_value] == -1) return bsvi_fail(BSVI_ERR_INVALID, "network layers are not in topological order");
         if ((int)l.n_in != net.width[l.in_value]) return bsvi_fail(BSVI_ERR_INVALID, "layer input width mismatch");
-        if (l.activation > BSVI_ACT_SOFTPLUS) return bsvi_fail(BSVI_ERR_UNSUPPORTED, "unknown activation");
+        if (l.activation > BSVI_ACT_SOFTPLUS || l.activation2 > BSVI_ACT_SOFTPLUS) return bsvi_fail(BSVI_ERR_UNSUPPORTED, "unknown activation");
         if ((size_t)l.weight_off + (size_t)l.n_in * l.n_out > n_params) return bsvi_fail(BSVI_ERR_INVALID, "layer weights exceed the parameter buffer");
         if (l.bias_off != 0xFFFFFFFFu && (size_t)l.bias_off + l.n_out > n_params) return bsvi_fail(BSVI_ERR_INVALID, "layer bias exceeds the parameter buffer");
         net.width[l.out_value] = (int)l.n_out;
@@ -724,10 +730,13 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     auto bad = [&](const char* msg) { delete a; return bsvi_fail(BSVI_ERR_INVALID, msg); };
     if (rc) { delete a; return rc; }
     const uint32_t Dz = desc->latent_dim;
-    if (desc->enc_loc_value >= a->enc.width.size() || desc->enc_scale_value >= a->enc.width.size() ||
-        a->enc.width[desc->enc_loc_value] != (int)Dz || a->enc.width[desc->enc_scale_value] != (int)Dz ||
-        desc->enc_loc_value == 0 || desc->enc_scale_value == 0 || desc->enc_loc_value == desc->enc_scale_value)
-        return bad("encoder heads must be two distinct layer outputs of width latent_dim");
+    auto head_ok = [&](uint32_t v, uint32_t col) {
+        return v != 0 && v < a->enc.width.size() && (int)(col + Dz) <= a->enc.width[v];
+    };
+    if (!head_ok(desc->enc_loc_value, desc->enc_loc_col) || !head_ok(desc->enc_scale_value, desc->enc_scale_col) ||
+        (desc->enc_loc_value == desc->enc_scale_value &&
+         desc->enc_loc_col < desc->enc_scale_col + Dz && desc->enc_scale_col < desc->enc_loc_col + Dz))
+        return bad("encoder heads must be two disjoint column ranges of width latent_dim in layer outputs");
     if (desc->dec_logits_value == 0 || desc->dec_logits_value >= a->dec.width.size() ||
         a->dec.width[desc->dec_logits_value] != (int)desc->n_features)
         return bad("decoder output must have width n_features");
@@ -876,7 +885,7 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
     G.M = (int)m; G.N = (int)n; G.K = (int)k; G.lda = (int)lda; G.ldb = (int)ldb; G.ldc = (int)ldc;
     G.act = (int)activation; G.post_add = post_add; G.accumulate = (int)accumulate;
     if (mode == MODE_NT) G.bias = bias_or_y_dev;
-    if (mode == MODE_NN) { G.Y = bias_or_y_dev; G.ldy = (int)ldy; if (!G.Y) G.act = BSVI_ACT_NONE; }
+    if (mode == MODE_NN) { G.Y = bias_or_y_dev; G.ldy = (int)ldy; }
     if (mode == MODE_TN) G.bias_grad = const_cast<float*>(bias_or_y_dev);   // [M] accumulator of the column sums of A, or NULL
     return launch_gemm(mode, G, (hipStream_t)stream);
 }
@@ -922,9 +931,16 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.dataset = a->dataset_dev;
     const bsvi_mlp_layer& Lloc = a->enc.layers[a->enc.producer[d.enc_loc_value]];
     const bsvi_mlp_layer& Lscale = a->enc.layers[a->enc.producer[d.enc_scale_value]];
-    D.loc = val(a->enc, d.enc_loc_value); D.ld_loc = a->enc.ld[d.enc_loc_value]; D.act_loc = (int)Lloc.activation; D.add_loc = Lloc.post_add;
-    D.scale = val(a->enc, d.enc_scale_value); D.ld_scale = a->enc.ld[d.enc_scale_value]; D.act_scale = (int)Lscale.activation; D.add_scale = Lscale.post_add;
-    D.dloc = grad(a->enc, d.enc_loc_value); D.dscale = grad(a->enc, d.enc_scale_value);
+    auto head_act = [](const bsvi_mlp_layer& L, uint32_t col, int& act, float& add) {
+        const bool second = L.split_col > 0 && L.split_col < L.n_out && col >= L.split_col;
+        act = (int)(second ? L.activation2 : L.activation);
+        add = second ? L.post_add2 : L.post_add;
+    };
+    D.loc = val(a->enc, d.enc_loc_value) + d.enc_loc_col; D.ld_loc = a->enc.ld[d.enc_loc_value];
+    D.scale = val(a->enc, d.enc_scale_value) + d.enc_scale_col; D.ld_scale = a->enc.ld[d.enc_scale_value];
+    head_act(Lloc, d.enc_loc_col, D.act_loc, D.add_loc);
+    head_act(Lscale, d.enc_scale_col, D.act_scale, D.add_scale);
+    D.dloc = grad(a->enc, d.enc_loc_value) + d.enc_loc_col; D.dscale = grad(a->enc, d.enc_scale_value) + d.enc_scale_col;
     D.eps = eps; D.z = val(a->dec, 0); D.ld_z = a->dec.ld[0]; D.dz = grad(a->dec, 0);
     D.prior_loc = a->prior_dev; D.prior_scale = a->prior_dev + Dz;
     D.rowf = rowf; D.rowlq = rowlq;
@@ -946,6 +962,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
             G.M = (int)R; G.N = (int)l.n_out; G.K = (int)l.n_in;
             G.bias = l.bias_off != 0xFFFFFFFFu ? params + l.bias_off : nullptr;
             G.act = (int)l.activation; G.post_add = l.post_add;
+            if (l.split_col > 0 && l.split_col < l.n_out) { G.split = (int)l.split_col; G.act2 = (int)l.activation2; G.post_add2 = l.post_add2; }
             int rc = launch_gemm(MODE_NT, G, stream);
             if (rc) return rc;
         }
@@ -986,8 +1003,11 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 G.M = (int)R; G.N = (int)l.n_in; G.K = (int)l.n_out;
                 const int prod = net.producer[l.in_value];
                 if (prod >= 0) {
-                    G.act = (int)net.layers[prod].activation; G.post_add = net.layers[prod].post_add;
-                    G.Y = val(net, l.in_value); G.ldy = net.ld[l.in_value];
+                    const auto& pl = net.layers[prod];
+                    G.act = (int)pl.activation; G.post_add = pl.post_add;
+                    if (pl.split_col > 0 && pl.split_col < pl.n_out) { G.split = (int)pl.split_col; G.act2 = (int)pl.activation2; G.post_add2 = pl.post_add2; }
+                    const bool any_act = G.act != BSVI_ACT_NONE || (G.split > 0 && G.act2 != BSVI_ACT_NONE);
+                    if (any_act) { G.Y = val(net, l.in_value); G.ldy = net.ld[l.in_value]; }
                 }
                 G.accumulate = written[l.in_value];
                 written[l.in_value] = 1;
@@ -1048,6 +1068,7 @@ extern "C" int bsvi_amort_apply(const bsvi_amort* a, int network, const float* p
         G.M = (int)R; G.N = (int)l.n_out; G.K = (int)l.n_in;
         G.bias = l.bias_off != 0xFFFFFFFFu ? params_dev + l.bias_off : nullptr;
         G.act = (int)l.activation; G.post_add = l.post_add;
+        if (l.split_col > 0 && l.split_col < l.n_out) { G.split = (int)l.split_col; G.act2 = (int)l.activation2; G.post_add2 = l.post_add2; }
         int rc = launch_gemm(MODE_NT, G, stream);
         if (rc) return rc;
     }

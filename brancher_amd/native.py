@@ -120,15 +120,17 @@ EXPORTS.update(DENSE_EXPORTS)
 class MlpLayer(C.Structure):
     _fields_ = [("in_value", C.c_uint32), ("out_value", C.c_uint32), ("n_in", C.c_uint32), ("n_out", C.c_uint32),
                 ("weight_off", C.c_uint32), ("bias_off", C.c_uint32), ("activation", C.c_uint32),
-                ("post_add", C.c_float)]
+                ("post_add", C.c_float), ("split_col", C.c_uint32), ("activation2", C.c_uint32),
+                ("post_add2", C.c_float), ("reserved", C.c_uint32)]
 
 
 class AmortDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_params", C.c_uint32),
                 ("n_features", C.c_uint32), ("latent_dim", C.c_uint32), ("dataset_size", C.c_uint32),
                 ("batch_size", C.c_uint32), ("n_enc_layers", C.c_uint32), ("n_dec_layers", C.c_uint32),
-                ("enc_loc_value", C.c_uint32), ("enc_scale_value", C.c_uint32), ("dec_logits_value", C.c_uint32),
-                ("reserved", C.c_uint32),
+                ("enc_loc_value", C.c_uint32), ("enc_scale_value", C.c_uint32),
+                ("enc_loc_col", C.c_uint32), ("enc_scale_col", C.c_uint32),
+                ("dec_logits_value", C.c_uint32), ("reserved", C.c_uint32),
                 ("enc_layers", C.POINTER(MlpLayer)), ("dec_layers", C.POINTER(MlpLayer)),
                 ("prior_loc", C.c_void_p), ("prior_scale", C.c_void_p), ("dataset", C.c_void_p)]
 

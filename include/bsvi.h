@@ -389,6 +389,13 @@ typedef struct bsvi_mlp_layer {
     uint32_t weight_off, bias_off;   /* offsets into the flat parameter buffer; bias_off = 0xFFFFFFFF: no bias */
     uint32_t activation;             /* bsvi_mlp_activation */
     float post_add;
+    /* sibling layers reading the same value (the latent's loc and scale heads) may be given as ONE layer whose weight
+     * rows are adjacent in the parameter buffer: output columns >= split_col use activation2 / post_add2.
+     * split_col >= n_out (or 0): no split. */
+    uint32_t split_col;
+    uint32_t activation2;
+    float post_add2;
+    uint32_t reserved;
 } bsvi_mlp_layer;
 
 typedef struct bsvi_amort_desc {
@@ -396,6 +403,7 @@ typedef struct bsvi_amort_desc {
     uint32_t n_features, latent_dim, dataset_size, batch_size;
     uint32_t n_enc_layers, n_dec_layers;          /* topologically ordered */
     uint32_t enc_loc_value, enc_scale_value;      /* encoder values feeding q(z | x) = Normal(loc, scale)  */
+    uint32_t enc_loc_col, enc_scale_col;          /* first column of loc / scale inside those values (merged heads) */
     uint32_t dec_logits_value, reserved;          /* decoder value feeding Binomial(1, logits)             */
     const bsvi_mlp_layer* enc_layers;
     const bsvi_mlp_layer* dec_layers;

@@ -101,6 +101,21 @@ def test_lowering_of_the_vae_graph():
             assert l.weight_off % 4 == 0
 
 
+def test_sibling_heads_are_merged_into_one_layer():
+    model = W.build_vae(W.native_api(), dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6)
+    p = amortized.lower_amortized(model, model.posterior_model, "pathwise")
+    assert [(l.n_in, l.n_out) for l in p.enc_layers] == [(12, 6), (6, 8), (8, 4)]
+    head = p.enc_layers[-1]
+    assert (head.split_col, head.activation, head.activation2, head.post_add2) == (2, amortized.ACT_NONE, amortized.ACT_SOFTPLUS,
+                                                                                   pytest.approx(0.1))
+    assert (p.enc_loc_value, p.enc_loc_col, p.enc_scale_value, p.enc_scale_col) == (head.out_value, 0, head.out_value, 2)
+    # the two heads' tensors are adjacent, in head order: the merged layer reads them as one [4][8] matrix / [4] bias
+    first, second = head.parts
+    off = {id(par): o for par, o, _, _ in p.parameters}
+    assert off[id(second.weight)] == off[id(first.weight)] + first.weight.size == head.weight_off + first.weight.size
+    assert off[id(second.bias)] == off[id(first.bias)] + first.bias.size
+
+
 def test_graphs_outside_the_pattern_are_rejected():
     api = W.native_api()
     enc, dec = W.vae_modules(12, 2, 8, 6)
@@ -128,7 +143,10 @@ def test_c_abi_structs_match_the_header():
     from conftest import ROOT
     import os
     header = open(os.path.join(ROOT, "include", "bsvi.h")).read()
-    assert C.sizeof(native.MlpLayer) == 32
+    assert C.sizeof(native.MlpLayer) == 48
+    body = re.search(r"typedef struct bsvi_mlp_layer \{(.*?)\} bsvi_mlp_layer;", header, re.S).group(1)
+    names = re.findall(r"(\w+)\s*(?:,|;)", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert [n for n, _ in native.MlpLayer._fields_] == names
     body = re.search(r"typedef struct bsvi_amort_args \{(.*?)\} bsvi_amort_args;", header, re.S).group(1)
     names = re.findall(r"(\w+)\s*(?:,|;)", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert [n for n, _ in native.AmortArgs._fields_] == names
