@@ -424,7 +424,45 @@ __global__ __launch_bounds__(256) void skinny_n_kernel(const GemmArgs G, int sbk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool vec = G.vecA && (G.K & 3) == 0;
     const long r_end = min((long)G.M, ((long)blockIdx.x + 1) * rows_per_block);
-    for (long r = (long)blockIdx.x * rows_per_block + wave; r < r_end; r += 4) {
+    long r = (long)blockIdx.x * rows_per_block + wave;
+    if (vec) {
+        // RP rows per wave and pass: all their loads are in flight before the first is reduced
+        constexpr int RP = 2;
+        for (; r + 4 * (RP - 1) < r_end; r += 4 * RP) {
+            const float* a[RP];
+            float acc[RP][SKINNY];
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+                const long rq = r + 4 * q;
+                a[q] = G.A + (G.rows ? (long)G.rows[rq] : rq) * G.lda;
+#pragma unroll
+                for (int n = 0; n < SKINNY; ++n) acc[q][n] = 0.0f;
+            }
+            for (int k = lane * 4; k < G.K; k += 256) {
+                float4 av[RP];
+#pragma unroll
+                for (int q = 0; q < RP; ++q) av[q] = *reinterpret_cast<const float4*>(a[q] + k);
+#pragma unroll
+                for (int n = 0; n < SKINNY; ++n)
+                    if (n < G.N) {
+                        const float4 bv = *reinterpret_cast<const float4*>(&bt[n * G.K + k]);
+#pragma unroll
+                        for (int q = 0; q < RP; ++q)
+                            acc[q][n] += av[q].x * bv.x + av[q].y * bv.y + av[q].z * bv.z + av[q].w * bv.w;
+                    }
+            }
+#pragma unroll
+            for (int n = 0; n < SKINNY; ++n) {
+                if (n >= G.N) break;
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                    const float v = wave_sum64(acc[q][n]);
+                    if (lane == n) G.C[(r + 4 * q) * G.ldc + n] = skinny_epilogue(G, mode, v, r + 4 * q, n);
+                }
+            }
+        }
+    }
+    for (; r < r_end; r += 4) {
         const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
         float acc[SKINNY];
 #pragma unroll
@@ -827,7 +865,7 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     if (mode != MODE_TN) {
         const int sbk = mode == MODE_NT ? 1 : G.ldb, sbn = mode == MODE_NT ? G.ldb : 1;
         if (G.N <= SKINNY && (size_t)G.N * G.K <= 8192) {
-            const int rows_per_block = 32;
+            static const int rows_per_block = [] { const char* e = getenv("BSVI_SKINNY_ROWS"); return e ? atoi(e) : 16; }();
             hipLaunchKernelGGL(skinny_n_kernel, dim3((G.M + rows_per_block - 1) / rows_per_block), dim3(256),
                                (size_t)G.N * G.K * sizeof(float), stream, G, sbk, sbn, mode, rows_per_block);
             HIP_TRY(hipGetLastError());
