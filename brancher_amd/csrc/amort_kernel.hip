@@ -413,6 +413,54 @@ __global__ __launch_bounds__(256) void skinny_k_kernel(const GemmArgs G, int sbk
     G.C[r * G.ldc + n] = skinny_epilogue(G, mode, acc, r, n);
 }
 
+// the same for 16-byte-aligned operands and N % 4 == 0: four adjacent outputs per thread, vector loads of B (when it
+// is stored [K][N]), of the bias / of Y / of C, and one 16-byte store
+__global__ __launch_bounds__(256) void skinny_k4_kernel(const GemmArgs G, int sbk, int sbn, int mode) {
+    const int quads = G.N >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)G.M * quads) return;
+    const long r = i / quads;
+    const int n = (int)(i - r * quads) * 4;
+    const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < G.K; ++k) {
+        const float av = a[k];
+        float b[4];
+        if (sbn == 1) {
+            const float4 bv = *reinterpret_cast<const float4*>(G.B + (long)k * sbk + n);
+            b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = G.B[(long)k * sbk + (long)(n + j) * sbn];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += av * b[j];
+    }
+    float* c = G.C + r * G.ldc + n;
+    float out[4];
+    if (mode == MODE_NT) {
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (G.bias) bias = *reinterpret_cast<const float4*>(G.bias + n);
+        const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = act_forward(ACT_OF(G, n + j), acc[j] + bb[j], ADD_OF(G, n + j));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = acc[j];
+        if (G.Y) {
+            const float4 y = *reinterpret_cast<const float4*>(G.Y + r * G.ldy + n);
+            const float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] *= act_derivative(ACT_OF(G, n + j), yy[j], ADD_OF(G, n + j));
+        }
+        if (G.accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(c);
+            out[0] += old.x; out[1] += old.y; out[2] += old.z; out[3] += old.w;
+        }
+    }
+    *reinterpret_cast<float4*>(c) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 // N <= 8:  row dot products.  B is staged transposed in LDS ([n][k]); one wave per row, lanes stride over k.
 __global__ __launch_bounds__(256) void skinny_n_kernel(const GemmArgs G, int sbk, int sbn, int mode, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float bt[];   // [N][K]
@@ -872,6 +920,16 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
             return BSVI_OK;
         }
         if (G.K <= SKINNY) {
+            auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+            // (B stored [N][K], the forward layout, would need strided scalar loads per output: measured slower)
+            const bool vec4 = sbn == 1 && (sbk & 3) == 0 && al16(G.B) && (G.N & 3) == 0 && (G.ldc & 3) == 0 && al16(G.C) &&
+                              (!G.bias || al16(G.bias)) && (!G.Y || ((G.ldy & 3) == 0 && al16(G.Y)));
+            if (vec4) {
+                const long quads = (long)G.M * (G.N >> 2);
+                hipLaunchKernelGGL(skinny_k4_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, G, sbk, sbn, mode);
+                HIP_TRY(hipGetLastError());
+                return BSVI_OK;
+            }
             const long total = (long)G.M * G.N;
             hipLaunchKernelGGL(skinny_k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, G, sbk, sbn, mode);
             HIP_TRY(hipGetLastError());
