@@ -236,7 +236,12 @@ def main():
         alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu * (program.batch_size if amort else 1))
         if mode == "persistent":
             launch_ms, launches, units_per_launch = dev_ms, 1, args.steps
-            kernel = "bsvi::persistent_kernel<%s>" % geom.get("storage", "")
+            # five or more waves run as one wave per workgroup (persistent_multi_kernel)
+            multi = (n_per_gpu + 63) // 64 >= 5 and os.environ.get("BSVI_PERSISTENT_MULTI", "1") != "0"
+            kernel = "bsvi::persistent_%skernel<%s>" % ("multi_" if multi else "", geom.get("storage", "") or "lds+lane_acc")
+            if multi:
+                geom = dict(geom, n_blocks=(n_per_gpu + 63) // 64, n_waves=1, storage="lds+lane_acc",
+                            note="one wave per workgroup, one exchange of partial sums per iteration")
         else:
             launch_ms, launches, units_per_launch = dev_ms / args.steps, args.steps, 1
             kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
@@ -245,7 +250,7 @@ def main():
             # measured for the default command (the summary holds the warm-up launch of 200 iterations and the
             # timed one of 20000: the larger is the timed launch — parameters/observations read, loss and
             # finite curves written)
-            traffic = pmc_traffic_bytes("cfg1_persistent_pmc_hbm_traffic.csv", ["persistent_kernel"], column="max_KB") \
+            traffic = pmc_traffic_bytes("cfg1_persistent_pmc_hbm_traffic.csv", ["persistent_kernel", "persistent_multi_kernel"], column="max_KB") \
                 if args.workload == "cfg1" and not args.samples and args.steps == 20000 else None
         else:
             traffic = pmc_traffic_bytes("pmc_hbm_traffic.csv", ["elbo_kernel"]) \

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -1345,6 +1346,12 @@ struct PParams {
     float* finite_curve;
     const uint8_t* active_mask_first;   // mask used while iteration <= pretraining_iterations
     uint32_t pretraining_iterations;
+    // persistent_multi_kernel: one wave per workgroup, one workgroup per CU
+    float* mw_xchg;          // [2][n_wg][2 + n_uniform_grad] partial sums, double-buffered over iterations
+    uint32_t* mw_counter;    // arrivals, monotonic over the launch
+    float* mw_params;        // private parameter copies of workgroups 1.. (workgroup 0 owns the caller's buffer)
+    float* mw_state;         // private optimizer state copies
+    uint32_t mw_stride;      // floats between two private parameter copies
 };
 
 // Scalar-register discipline: PParams is ~90 dwords of kernel arguments.  Read as `P.x` they are all
@@ -1416,6 +1423,136 @@ __global__ void __launch_bounds__(1024) persistent_kernel(const PParams P_unused
         // The parameters are written and re-read by this one workgroup only: the stores are
         // drained by the barrier below (s_waitcnt vmcnt(0) + s_barrier) and the next prologue
         // re-reads them with agent-scope loads that bypass the L1.
+        __syncthreads();
+    }
+#undef BSVI_RELOAD_ARGS
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent trainer over SEVERAL workgroups of one wave each.  A 300-sample shard is five waves: in one
+// workgroup two of them share a SIMD, and that SIMD — issue-bound, ~4.7 cycles per instruction per wave — sets the
+// iteration time.  Here every wave has a CU (and a SIMD) to itself.  Per iteration ONE exchange: each workgroup
+// publishes its [2 + n_uniform_grad] partial sums, all meet at a counter (agent-scope release / acquire), and every
+// workgroup then adds the partials in the same fixed order and applies the same chain rule and optimizer update to
+// its OWN copy of the parameters and the optimizer state — bitwise the same everywhere, so no second exchange is
+// needed.  Workgroup 0 owns the caller's buffers and writes the loss curve and the gradient block.
+// ---------------------------------------------------------------------------------------
+template <int SM, bool GEN>
+__global__ void __launch_bounds__(1024) persistent_multi_kernel(const PParams P_unused) {
+    (void)P_unused;
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t wg = blockIdx.x, n_wg = gridDim.x;
+    const BSVI_CONST_AS char* ka = (const BSVI_CONST_AS char*)__builtin_amdgcn_kernarg_segment_ptr();
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BSVI_RELOAD_ARGS() asm volatile("" : "+s"(ka))
+#else
+#define BSVI_RELOAD_ARGS()
+#endif
+    const uint32_t n_iterations = ((const BSVI_CONST_AS PParams*)ka)->n_iterations;
+    if (wg > 0) {      // private copies of the parameters and of the optimizer state
+        const BSVI_CONST_AS PParams* P = (const BSVI_CONST_AS PParams*)ka;
+        const uint32_t n_params = P->R.n_params;
+        float* mp = P->mw_params + (size_t)(wg - 1) * P->mw_stride;
+        float* ms = P->mw_state + (size_t)(wg - 1) * 4 * P->mw_stride;
+        for (uint32_t i = threadIdx.x; i < n_params; i += blockDim.x) mp[i] = P->R.params[i];
+        for (uint32_t i = threadIdx.x; i < 4 * n_params; i += blockDim.x) ms[i] = P->R.state[i];
+        __syncthreads();
+    }
+    for (uint32_t it = 0; it < n_iterations; ++it) {
+        Lay L;
+        {
+            BSVI_RELOAD_ARGS();
+            KParams K = ((const BSVI_CONST_AS PParams*)ka)->K;
+            const uint32_t lo = K.offset_lo + it;
+            K.offset_hi += (lo < K.offset_lo) ? 1u : 0u;
+            K.offset_lo = lo;
+            if (K.noise) K.noise += (size_t)it * K.n_noise * K.n_local;
+            if (wg > 0) {
+                const BSVI_CONST_AS PParams* P0 = (const BSVI_CONST_AS PParams*)ka;
+                K.params = P0->mw_params + (size_t)(wg - 1) * P0->mw_stride;
+            }
+            L = make_layout<SM>(K, n_waves);
+            elbo_block<SM, false, GEN>(K, L, wg * n_waves * K.lpw, it == 0);
+        }
+        BSVI_RELOAD_ARGS();
+        const BSVI_CONST_AS PParams* P = (const BSVI_CONST_AS PParams*)ka;
+        const uint32_t n_ug = P->R.n_uniform_grad, stride = 2 + n_ug;
+        {   // publish this workgroup's sums, meet the others, add everybody's in workgroup order
+            float* slot = P->mw_xchg + (size_t)(it & 1u) * n_wg * stride;
+            float* mine = slot + (size_t)wg * stride;
+            for (uint32_t k = threadIdx.x; k < n_ug; k += blockDim.x)
+                __hip_atomic_store(&mine[2 + k], g_lds[L.uadj + k * n_waves], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&mine[0], g_lds[L.red], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&mine[1], g_lds[L.red + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                       // every wave's stores are issued and drained (vmcnt(0) + barrier)
+            if (threadIdx.x == 0) {
+                uint32_t* counter = P->mw_counter;
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t target = (it + 1u) * n_wg;
+                uint32_t polls = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > (1u << 27)) __builtin_trap();     // a lost workgroup must not hang the device
+                }
+            }
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < n_ug; k += blockDim.x) {
+                float s = 0.0f;
+                for (uint32_t b = 0; b < n_wg; ++b)
+                    s += __hip_atomic_load(&slot[(size_t)b * stride + 2 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g_lds[L.uadj + k * n_waves] = s;
+            }
+            if (threadIdx.x == 0) {
+                float s = 0.0f, c = 0.0f;
+                for (uint32_t b = 0; b < n_wg; ++b) {
+                    s += __hip_atomic_load(&slot[(size_t)b * stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    c += __hip_atomic_load(&slot[(size_t)b * stride + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                g_lds[L.red] = s;
+                g_lds[L.red + 1] = c;
+            }
+            __syncthreads();
+        }
+        const uint32_t n_global = P->K.n_global;
+        if (threadIdx.x == 0) {
+            const float vsum = g_lds[L.red], bad = g_lds[L.red + 1];
+            const float loss = -vsum / (float)n_global;
+            const float finite = isfinite(loss) ? 1.0f : 0.0f;
+            g_lds[L.red + 2] = finite;
+            if (wg == 0) {
+                P->loss_curve[it] = loss;
+                P->finite_curve[it] = finite;
+                float* out = P->R.out;
+                out[0] = vsum; out[1] = bad; out[2] = loss; out[3] = finite;
+            }
+        }
+        __syncthreads();
+        const float scale = -1.0f / (float)n_global;
+        float* const params = wg == 0 ? P->R.params : P->mw_params + (size_t)(wg - 1) * P->mw_stride;
+        float* const state = wg == 0 ? P->R.state : P->mw_state + (size_t)(wg - 1) * 4 * P->mw_stride;
+        float* const out = P->R.out;
+        const uint32_t* const pu_ptr = P->R.pu_ptr;
+        const uint32_t* const pu_idx = P->R.pu_idx;
+        const bsvi_uniform_entry* const uniform = P->R.uniform;
+        const uint32_t n_params = P->R.n_params;
+        const uint8_t* mask = (it > P->pretraining_iterations) ? P->R.active_mask : P->active_mask_first;
+        for (uint32_t i = threadIdx.x; i < n_params; i += blockDim.x) {
+            float gsum = 0.0f;
+            const float theta = __hip_atomic_load(&params[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t j = pu_ptr[i]; j < pu_ptr[i + 1]; ++j) {
+                const uint32_t k = pu_idx[j];
+                const bsvi_uniform_entry e = uniform[k];
+                gsum += g_lds[L.uadj + k * n_waves] * (e.b * utransform_grad(e.transform, theta));
+            }
+            const float grad = gsum * scale;
+            if (wg == 0) out[BSVI_OUT_HEADER + i] = grad;
+            if (g_lds[L.red + 2] != 0.0f && mask[i]) {
+                const bsvi_opt_cfg cfg = P->R.cfg;
+                optimizer_update(cfg, params, state, n_params, i, grad);
+            }
+        }
         __syncthreads();
     }
 #undef BSVI_RELOAD_ARGS
@@ -1671,6 +1808,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
         (const void*)persistent_kernel<SM_WSUM, false>, (const void*)persistent_kernel<SM_LACC, false>,
         (const void*)persistent_kernel<SM_ZG, false>, (const void*)persistent_kernel<SM_WSUM, true>,
         (const void*)persistent_kernel<SM_LACC, true>, (const void*)persistent_kernel<SM_ZG, true>,
+        (const void*)persistent_multi_kernel<SM_LACC, false>, (const void*)persistent_multi_kernel<SM_LACC, true>,
         (const void*)reduce_kernel};
     // a kernel with static LDS cannot opt in to the full 160 KiB: leave 256 B of head-room there
     int granted = lds;
@@ -1788,12 +1926,25 @@ static size_t ws_bytes(const bsvi_program* p, const Geometry& g) {
     return partial_bytes(p, g) + (g.zglobal ? 2 * (size_t)p->d.n_slots * g.n_pad * 4 : 0) + 256;
 }
 
-extern "C" size_t bsvi_workspace_bytes(const bsvi_program* p, uint32_t n_local) {
-    if (!p || !n_local) return 0;
+static size_t base_ws_bytes(const bsvi_program* p, uint32_t n_local) {
     // cover both the multi-workgroup and the single-workgroup (persistent) geometry
     const size_t a = ws_bytes(p, choose_geometry(p, n_local, false));
     const size_t b = ws_bytes(p, choose_geometry(p, n_local, true));
-    return a > b ? a : b;
+    return ((a > b ? a : b) + 255) / 256 * 256;
+}
+
+// region behind the base workspace used by persistent_multi_kernel (up to 16 workgroups):
+// [counter: 256 B][exchange: 2 x 16 x (2 + nUg) floats][parameter copies: 15 x stride][state copies: 15 x 4 x stride]
+constexpr uint32_t kMaxMultiWg = 16;
+static uint32_t mw_stride(const bsvi_program* p) { return (p->d.n_params + 63u) / 64u * 64u + 64u; }
+static size_t mw_xchg_floats(const bsvi_program* p) { return 2 * (size_t)kMaxMultiWg * (2 + p->d.n_uniform_grad); }
+static size_t mw_bytes(const bsvi_program* p) {
+    return 256 + (mw_xchg_floats(p) + (size_t)(kMaxMultiWg - 1) * 5 * mw_stride(p)) * sizeof(float) + 256;
+}
+
+extern "C" size_t bsvi_workspace_bytes(const bsvi_program* p, uint32_t n_local) {
+    if (!p || !n_local) return 0;
+    return base_ws_bytes(p, n_local) + mw_bytes(p);
 }
 
 static unsigned long long* g_debug_stamps = nullptr;
@@ -1953,8 +2104,17 @@ extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, con
     return launch_reduce(p, R, (hipStream_t)a->stream);
 }
 
+// persistent_multi_kernel applies: 5..16 waves of 64 sample lanes, one lane-accumulator wave fits a CU's LDS
+static bool multi_persistent_applies(const bsvi_program* p, uint32_t n_local) {
+    const char* e = getenv("BSVI_PERSISTENT_MULTI");       // read per call: tests and tools flip it
+    if (e && e[0] == '0') return false;
+    const uint32_t waves = (n_local + 63) / 64;
+    return waves >= 5 && waves <= kMaxMultiWg && lds_need(p, 1, SM_LACC, 64, false) <= (size_t)p->max_lds;
+}
+
 extern "C" int bsvi_persistent_supported(const bsvi_program* p, uint32_t n_local) {
     if (!p || !n_local) return 0;
+    if (multi_persistent_applies(p, n_local)) return 1;
     // One launch for the whole loop pays when the single workgroup runs the fast layout, or when several
     // workgroups would not run it either; a spilled (global-slot) workgroup is always slower than many LDS ones.
     const Geometry g = choose_geometry(p, n_local, true), m = choose_geometry(p, n_local, false);
@@ -1979,7 +2139,12 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
     if (!a->out_dev || !params_dev || !state_dev || !active_mask_dev || !active_mask_first_dev || !loss_curve_dev || !finite_dev)
         return fail(BSVI_ERR_INVALID, "null argument");
     if (a->n_samples_local != a->n_samples_global) return fail(BSVI_ERR_INVALID, "persistent trainer is the single-GPU path");
+    const bool multi = multi_persistent_applies(p, a->n_samples_local);
     Geometry g = choose_geometry(p, a->n_samples_local, true);
+    if (multi && g.n_blocks != 1) {      // does not fit ONE workgroup, but one wave per workgroup does
+        g = Geometry();
+        g.n_waves = (a->n_samples_local + 63) / 64; g.n_blocks = 1; g.mode = SM_LACC; g.lpw = 64;
+    }
     if (g.n_blocks != 1) return fail(BSVI_ERR_RESOURCE, "sample count does not fit one workgroup");
     PParams P;
     memset(&P, 0, sizeof(P));
@@ -1991,8 +2156,32 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
     P.R.state = state_dev; P.R.active_mask = active_mask_dev; P.R.cfg = *cfg; P.R.do_finalize = 1; P.R.do_step = 1;
     P.n_iterations = n_iterations; P.loss_curve = loss_curve_dev; P.finite_curve = finite_dev;
     P.active_mask_first = active_mask_first_dev; P.pretraining_iterations = pretraining_iterations;
-    dim3 grid(1), block(g.n_waves * 64);
     hipStream_t st = (hipStream_t)a->stream;
+    // five or more waves in ONE workgroup put two of them on one SIMD of the CU, and that SIMD sets the pace: give
+    // every wave its own CU instead (persistent_multi_kernel; BSVI_PERSISTENT_MULTI=0 keeps the single workgroup)
+    if (multi) {
+        const uint32_t n_wg = g.n_waves;
+        Geometry g1 = g;
+        g1.n_waves = 1; g1.n_blocks = n_wg;
+        g1.stash = !p->generic && lds_need(p, 1, SM_LACC, 64, true) <= (size_t)p->max_lds;
+        g1.lds_bytes = lds_need(p, 1, SM_LACC, 64, g1.stash);
+        g1.n_pad = n_wg * 64;
+        rc = fill_kparams(p, &aa, g1, P.K);
+        if (rc) return rc;
+        char* region = (char*)a->workspace_dev + base_ws_bytes(p, a->n_samples_local);
+        P.mw_counter = (uint32_t*)region;
+        P.mw_xchg = (float*)(region + 256);
+        P.mw_params = P.mw_xchg + mw_xchg_floats(p);
+        P.mw_stride = mw_stride(p);
+        P.mw_state = P.mw_params + (size_t)(kMaxMultiWg - 1) * P.mw_stride;
+        HIP_TRY(hipMemsetAsync(region, 0, 256 + mw_xchg_floats(p) * sizeof(float), st));
+        dim3 mgrid(n_wg), mblock(64);
+        if (p->generic) hipLaunchKernelGGL((persistent_multi_kernel<SM_LACC, true>), mgrid, mblock, g1.lds_bytes, st, P);
+        else hipLaunchKernelGGL((persistent_multi_kernel<SM_LACC, false>), mgrid, mblock, g1.lds_bytes, st, P);
+        HIP_TRY(hipGetLastError());
+        return BSVI_OK;
+    }
+    dim3 grid(1), block(g.n_waves * 64);
 #define BSVI_LAUNCH_P(SM_, GEN_) hipLaunchKernelGGL((persistent_kernel<SM_, GEN_>), grid, block, g.lds_bytes, st, P)
     if (p->generic) {
         if (g.mode == SM_LACC) BSVI_LAUNCH_P(SM_LACC, true); else if (g.mode == SM_ZG) BSVI_LAUNCH_P(SM_ZG, true); else BSVI_LAUNCH_P(SM_WSUM, true);

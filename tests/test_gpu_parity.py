@@ -353,3 +353,29 @@ def test_map_inference_through_the_public_api_matches_the_reference_trajectory()
     after = g.group("traj/param_after/")
     for name, value in compiled.named_params().items():
         np.testing.assert_allclose(value.reshape(-1), after[name].reshape(-1), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,optimizer,kw", [(300, "SGD", dict(lr=1e-3)), (330, "Adam", dict(lr=5e-3)), (448, "SGD", dict(lr=1e-3)), (1000, "Adam", dict(lr=1e-3)), (1024, "SGD", dict(lr=1e-3))])
+def test_multi_workgroup_persistent_trainer_matches_the_single_workgroup_one(n, optimizer, kw):
+    """five or more waves: persistent_multi_kernel gives every wave its own CU and exchanges partial sums once per
+    iteration; same Philox draws, so the loss curves and the parameters must agree with the one-workgroup trainer to
+    summation-order rounding, and every workgroup's private parameter copy stays in step (the curve would drift)"""
+    import os
+    from brancher_amd import workloads as W
+    runs = []
+    for flag in ("0", "1"):
+        os.environ["BSVI_PERSISTENT_MULTI"] = flag
+        try:
+            model = W.build_readme_ar(W.native_api(), T=20)
+            c = engine.compile_model(model, None, "pathwise")
+            # (with the flag off, sample counts that do not fit ONE workgroup train launch by launch: also a yardstick)
+            losses, finite = c.train(300, n, optimizer, seed=11, **kw)
+            assert bool(finite.all()) and (flag == "0" or c.last_mode == "persistent")
+            runs.append((losses.cpu().numpy(), c.params.cpu().numpy().copy(), c.out.cpu().numpy().copy()))
+        finally:
+            os.environ.pop("BSVI_PERSISTENT_MULTI", None)
+    (l0, p0, o0), (l1, p1, o1) = runs
+    assert rel_err(l1, l0) <= 2e-6
+    assert np.abs(p1 - p0).max() <= 2e-5 * (1 + np.abs(p0).max())
+    assert np.abs(o1[4:] - o0[4:]).max() <= 1e-4 * np.abs(o0[4:]).max()
