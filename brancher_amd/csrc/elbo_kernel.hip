@@ -1352,6 +1352,12 @@ struct PParams {
     float* mw_params;        // private parameter copies of workgroups 1.. (workgroup 0 owns the caller's buffer)
     float* mw_state;         // private optimizer state copies
     uint32_t mw_stride;      // floats between two private parameter copies
+    // shares of the program (bsvi_train_persistent_split): workgroup w runs share w % n_shares on sample wave
+    // w / n_shares; every share samples the posterior but evaluates only its part of the model's log-prob records
+    uint32_t n_shares;       // 0 / 1: the whole program
+    const uint4* share_code[4];
+    const uint4* share_aux[4];
+    uint32_t share_n_code[4];
 };
 
 // Scalar-register discipline: PParams is ~90 dwords of kernel arguments.  Read as `P.x` they are all
@@ -1467,12 +1473,18 @@ __global__ void __launch_bounds__(1024) persistent_multi_kernel(const PParams P_
             K.offset_hi += (lo < K.offset_lo) ? 1u : 0u;
             K.offset_lo = lo;
             if (K.noise) K.noise += (size_t)it * K.n_noise * K.n_local;
-            if (wg > 0) {
-                const BSVI_CONST_AS PParams* P0 = (const BSVI_CONST_AS PParams*)ka;
-                K.params = P0->mw_params + (size_t)(wg - 1) * P0->mw_stride;
+            const BSVI_CONST_AS PParams* P0 = (const BSVI_CONST_AS PParams*)ka;
+            if (wg > 0) K.params = P0->mw_params + (size_t)(wg - 1) * P0->mw_stride;
+            uint32_t sample_wave = wg;
+            if (P0->n_shares > 1) {
+                const uint32_t share = wg % P0->n_shares;
+                sample_wave = wg / P0->n_shares;
+                K.code = P0->share_code[share];
+                K.aux = P0->share_aux[share];
+                K.n_code = P0->share_n_code[share];
             }
             L = make_layout<SM>(K, n_waves);
-            elbo_block<SM, false, GEN>(K, L, wg * n_waves * K.lpw, it == 0);
+            elbo_block<SM, false, GEN>(K, L, sample_wave * n_waves * K.lpw, it == 0);
         }
         BSVI_RELOAD_ARGS();
         const BSVI_CONST_AS PParams* P = (const BSVI_CONST_AS PParams*)ka;
@@ -2129,10 +2141,55 @@ extern "C" int bsvi_train_persistent(const bsvi_program* p, const bsvi_elbo_args
                                   n_iterations, loss_curve_dev, finite_dev);
 }
 
+static int train_persistent_impl(const bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares,
+                                 const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
+                                 float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
+                                 const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
+                                 uint32_t n_iterations, float* loss_curve_dev, float* finite_dev);
+
 extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
                                       float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                                       const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
                                       uint32_t n_iterations, float* loss_curve_dev, float* finite_dev) {
+    return train_persistent_impl(p, nullptr, 0, a, cfg, params_dev, state_dev, active_mask_dev, active_mask_first_dev,
+                                 pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);
+}
+
+// how many shares of the program (2, 3 or 1 = none) the multi-workgroup trainer would run for this sample count
+extern "C" int bsvi_persistent_split_shares(const bsvi_program* p, uint32_t n_local) {
+    if (!p || !n_local || !multi_persistent_applies(p, n_local)) return 1;
+    const char* e = getenv("BSVI_PERSISTENT_SHARES");
+    const uint32_t waves = (n_local + 63) / 64;
+    uint32_t want = e ? (uint32_t)atoi(e) : 2u;      // two and three shares measure the same at N = 300 (10 / 15 workgroups)
+    if (want > 3) want = 3;
+    while (want > 1 && waves * want > kMaxMultiWg) --want;
+    return (int)(want < 1 ? 1 : want);
+}
+
+// the multi-workgroup trainer with the model's log-prob records split over `n_shares` programs (same tables, every
+// share samples the posterior; lowering.Program.shares): shares[0..n_shares) are programs created from the shares
+extern "C" int bsvi_train_persistent_split(const bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares,
+                                           const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
+                                           float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
+                                           const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
+                                           uint32_t n_iterations, float* loss_curve_dev, float* finite_dev) {
+    if (!shares || n_shares < 2 || n_shares > 4) return fail(BSVI_ERR_INVALID, "2..4 program shares expected");
+    for (uint32_t v = 0; v < n_shares; ++v) {
+        if (!shares[v]) return fail(BSVI_ERR_INVALID, "null program share");
+        if (shares[v]->d.n_uniform != p->d.n_uniform || shares[v]->d.n_uniform_grad != p->d.n_uniform_grad ||
+            shares[v]->d.n_slots != p->d.n_slots || shares[v]->d.n_params != p->d.n_params ||
+            shares[v]->d.n_code > p->d.n_code || shares[v]->generic != p->generic)
+            return fail(BSVI_ERR_INVALID, "a program share does not match the program's tables");
+    }
+    return train_persistent_impl(p, shares, n_shares, a, cfg, params_dev, state_dev, active_mask_dev, active_mask_first_dev,
+                                 pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);
+}
+
+static int train_persistent_impl(const bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares,
+                                 const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
+                                 float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
+                                 const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
+                                 uint32_t n_iterations, float* loss_curve_dev, float* finite_dev) {
     if (!p || !a) return fail(BSVI_ERR_INVALID, "null argument");
     int rc = check_cfg(cfg);
     if (rc) return rc;
@@ -2159,8 +2216,17 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
     hipStream_t st = (hipStream_t)a->stream;
     // five or more waves in ONE workgroup put two of them on one SIMD of the CU, and that SIMD sets the pace: give
     // every wave its own CU instead (persistent_multi_kernel; BSVI_PERSISTENT_MULTI=0 keeps the single workgroup)
+    if (shares && !multi) return fail(BSVI_ERR_INVALID, "program shares need the multi-workgroup trainer");
     if (multi) {
-        const uint32_t n_wg = g.n_waves;
+        const uint32_t sample_waves = g.n_waves;
+        const uint32_t n_wg = sample_waves * (shares ? n_shares : 1u);
+        if (n_wg > kMaxMultiWg) return fail(BSVI_ERR_INVALID, "too many workgroups for the exchange region");
+        if (shares) {
+            P.n_shares = n_shares;
+            for (uint32_t v = 0; v < n_shares; ++v) {
+                P.share_code[v] = shares[v]->code; P.share_aux[v] = shares[v]->aux; P.share_n_code[v] = shares[v]->d.n_code;
+            }
+        }
         Geometry g1 = g;
         g1.n_waves = 1; g1.n_blocks = n_wg;
         g1.stash = !p->generic && lds_need(p, 1, SM_LACC, 64, true) <= (size_t)p->max_lds;

@@ -285,9 +285,16 @@ class CompiledELBO:
                       and self.native.persistent_supported(n_local))
         if persistent:
             args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset0)
-            native.check(self.lib.bsvi_train_persistent2(
-                self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(self.mask_all),
-                ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite)))
+            shares = self.native.split_shares(n_local)
+            if shares is not None:
+                # one wave per workgroup AND the model's log-prob records split over workgroups
+                native.check(self.lib.bsvi_train_persistent_split(
+                    self.native.handle, shares, len(shares), C.byref(args), C.byref(cfg), ptr(self.params), ptr(state),
+                    ptr(self.mask_all), ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite)))
+            else:
+                native.check(self.lib.bsvi_train_persistent2(
+                    self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(self.mask_all),
+                    ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite)))
             self.last_mode = "persistent"
             return loss_curve, finite
 

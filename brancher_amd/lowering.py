@@ -915,8 +915,6 @@ class _Lowering:
         # over a single element (the overwhelmingly common case) is that instruction; anything
         # else is bracketed by REC_BEGIN / REC_END pseudo-instructions that carry the loop
         # extent and the temp range, so that both sweeps find record boundaries in the stream.
-        words, recs_out = [], []
-
         def no_alias(ins, n_elems):
             """True when the adjoint cells of the instruction's operands are pairwise distinct for
             every element of the record's loop (constants / observed data have no adjoint)."""
@@ -931,25 +929,50 @@ class _Lowering:
                         return False
             return True
 
-        for (b, e, n_elems, n_temps, sink) in self.records:
-            body = [[ins[0] | ((R_NOALIAS << 24) if no_alias(ins, n_elems) else 0)]
-                    + [encode_operand(o, n_up, n_uni) for o in ins[1:6]] + [ins[6], ins[7]]
-                    for ins in self.code[b:e]]
-            rflag = (R_SINK if sink else 0) << 24
-            if len(body) == 1 and n_elems == 1:
-                body[0][0] |= rflag
-                recs_out.append((len(words), len(words) + 1, n_elems, self.temp_base, n_temps, int(sink)))
-                words.extend(body)
-            else:
-                bracket = [len(body), n_elems, self.temp_base, n_temps, 0, 0, 0]
-                words.append([OP["REC_BEGIN"] | rflag] + bracket)
-                recs_out.append((len(words), len(words) + len(body), n_elems, self.temp_base, n_temps, int(sink)))
-                words.extend(body)
-                words.append([OP["REC_END"] | rflag] + bracket)
-        code = np.array(words, dtype=np.uint32).reshape(-1, 8) if words else np.zeros((0, 8), np.uint32)
-        recs = np.zeros(len(recs_out), dtype=RECORD_DTYPE)
-        for i, r in enumerate(recs_out):
-            recs[i] = r
+        def assemble(records, own_terms=True):
+            """records -> (code words, record table).  own_terms=False: the posterior's sampling nodes keep sampling
+            but contribute no entropy / log q term of their own (a share other than the first of a split program)."""
+            words, recs_out = [], []
+            for (b, e, n_elems, n_temps, sink) in records:
+                body = []
+                for ins in self.code[b:e]:
+                    imm0, imm1 = ins[6], ins[7]
+                    if not own_terms and (ins[0] & 0xFF) in (OP["NAFF"], OP["NODE"]) and ((ins[0] >> 8) & F_SAMPLE):
+                        imm0 = imm1 = _fbits(0.0)
+                    body.append([ins[0] | ((R_NOALIAS << 24) if no_alias(ins, n_elems) else 0)]
+                                + [encode_operand(o, n_up, n_uni) for o in ins[1:6]] + [imm0, imm1])
+                rflag = (R_SINK if sink else 0) << 24
+                if len(body) == 1 and n_elems == 1:
+                    body[0][0] |= rflag
+                    recs_out.append((len(words), len(words) + 1, n_elems, self.temp_base, n_temps, int(sink)))
+                    words.extend(body)
+                else:
+                    bracket = [len(body), n_elems, self.temp_base, n_temps, 0, 0, 0]
+                    words.append([OP["REC_BEGIN"] | rflag] + bracket)
+                    recs_out.append((len(words), len(words) + len(body), n_elems, self.temp_base, n_temps, int(sink)))
+                    words.extend(body)
+                    words.append([OP["REC_END"] | rflag] + bracket)
+            code = np.array(words, dtype=np.uint32).reshape(-1, 8) if words else np.zeros((0, 8), np.uint32)
+            recs = np.zeros(len(recs_out), dtype=RECORD_DTYPE)
+            for i, r in enumerate(recs_out):
+                recs[i] = r
+            return code, recs
+
+        code, recs = assemble(self.records)
+        # Shares of the program for the multi-workgroup persistent trainer (engine.train, DESIGN.md 4.4): every share
+        # samples the posterior (all non-sink records) but evaluates only every V-th model log-prob record; the
+        # estimator value and all adjoints are linear in those records, so the shares' partial sums add up to the
+        # full program's.  Pathwise only: BlackBox multiplies per-sample totals.
+        prog.shares = {}
+        sinks = [i for i, r in enumerate(self.records) if r[4]]
+        if self.estimator == "pathwise" and len(sinks) >= 6:
+            for V in (2, 3):
+                parts = []
+                for v in range(V):
+                    keep = set(sinks[v::V])
+                    records = [r for i, r in enumerate(self.records) if not r[4] or i in keep]
+                    parts.append(assemble(records, own_terms=(v == 0)))
+                prog.shares[V] = parts
         prog.uniform, prog.records, prog.code = uni, recs, code
         prog.consts = np.concatenate(self.consts) if self.consts else np.zeros(0, np.float32)
         prog.obs = np.concatenate(self.obs) if self.obs else np.zeros(0, np.float32)

@@ -104,6 +104,10 @@ EXPORTS = {
     "bsvi_train_persistent2": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bsvi_persistent_supported": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bsvi_persistent_split_shares": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bsvi_train_persistent_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(ElboArgs),
+                                              C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bsvi_max_lds_bytes": (C.c_int, [C.c_void_p]),
     "bsvi_query_geometry": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
@@ -219,6 +223,7 @@ class NativeProgram:
         check(lib.bsvi_program_create(C.byref(d), C.byref(handle)))
         self.handle = handle
         self.lib = lib
+        self.program = program
 
     def workspace_bytes(self, n_local):
         return int(self.lib.bsvi_workspace_bytes(self.handle, n_local))
@@ -233,6 +238,25 @@ class NativeProgram:
 
     def persistent_supported(self, n_local):
         return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))
+
+    def split_shares(self, n_local):
+        """program shares for the multi-workgroup persistent trainer at this sample count: None, or a ctypes array of
+        `bsvi_program*` created (once) from `Program.shares[V]` — same tables, every share its own code"""
+        import copy
+        V = int(self.lib.bsvi_persistent_split_shares(self.handle, n_local))
+        parts = getattr(self.program, "shares", {}).get(V) if V > 1 else None
+        if not parts:
+            return None
+        cache = self.__dict__.setdefault("_share_programs", {})
+        if V not in cache:
+            progs = []
+            for code, records in parts:
+                share = copy.copy(self.program)
+                share.code, share.records, share.shares = code, records, {}
+                progs.append(NativeProgram(share))
+            cache[V] = progs
+        arr = (C.c_void_p * V)(*[sp.handle for sp in cache[V]])
+        return arr
 
     def __del__(self):
         try:

@@ -283,6 +283,18 @@ int bsvi_train_persistent2(const bsvi_program* prog, const bsvi_elbo_args* args,
 
 /* 1 if bsvi_train_persistent supports (prog, n_samples_local), else 0. */
 int bsvi_persistent_supported(const bsvi_program* prog, uint32_t n_samples_local);
+/* The multi-workgroup persistent trainer (5..16 waves: one wave per workgroup, one exchange of partial sums per
+ * iteration) can also split the MODEL's log-prob records over workgroups: every share samples the posterior but
+ * evaluates only its part of the records; value and adjoints are linear in them, so the partial sums add up.
+ * bsvi_persistent_split_shares: how many shares (1 = none, 2 or 3) the trainer would use for this sample count;
+ * bsvi_train_persistent_split: shares[v] = programs created from the shares of the same lowering (identical tables,
+ * own code), otherwise the arguments of bsvi_train_persistent2.  Pathwise estimator only. */
+int bsvi_persistent_split_shares(const bsvi_program* p, uint32_t n_samples_local);
+int bsvi_train_persistent_split(const bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares,
+                                const bsvi_elbo_args* args, const bsvi_opt_cfg* cfg, float* params_dev, float* state_dev,
+                                const uint8_t* active_mask_dev, const uint8_t* active_mask_first_dev,
+                                uint32_t pretraining_iterations, uint32_t n_iterations, float* loss_curve_dev,
+                                float* finite_dev);
 
 /* One complete single-GPU SVI iteration in two launches: ELBO fwd+bwd, then reduction fused
  * with finalize and the optimizer step (inference.py:96-104).  Optionally logs the loss and the

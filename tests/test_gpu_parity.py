@@ -364,8 +364,9 @@ def test_multi_workgroup_persistent_trainer_matches_the_single_workgroup_one(n, 
     import os
     from brancher_amd import workloads as W
     runs = []
-    for flag in ("0", "1"):
+    for flag, shares in (("0", "1"), ("1", "1"), ("1", "2"), ("1", "3")):
         os.environ["BSVI_PERSISTENT_MULTI"] = flag
+        os.environ["BSVI_PERSISTENT_SHARES"] = shares      # the model's log-prob records split over workgroups too
         try:
             model = W.build_readme_ar(W.native_api(), T=20)
             c = engine.compile_model(model, None, "pathwise")
@@ -375,7 +376,9 @@ def test_multi_workgroup_persistent_trainer_matches_the_single_workgroup_one(n, 
             runs.append((losses.cpu().numpy(), c.params.cpu().numpy().copy(), c.out.cpu().numpy().copy()))
         finally:
             os.environ.pop("BSVI_PERSISTENT_MULTI", None)
-    (l0, p0, o0), (l1, p1, o1) = runs
-    assert rel_err(l1, l0) <= 2e-6
-    assert np.abs(p1 - p0).max() <= 2e-5 * (1 + np.abs(p0).max())
-    assert np.abs(o1[4:] - o0[4:]).max() <= 1e-4 * np.abs(o0[4:]).max()
+            os.environ.pop("BSVI_PERSISTENT_SHARES", None)
+    l0, p0, o0 = runs[0]
+    for l1, p1, o1 in runs[1:]:
+        assert rel_err(l1, l0) <= 2e-6
+        assert np.abs(p1 - p0).max() <= 2e-5 * (1 + np.abs(p0).max())
+        assert np.abs(o1[4:] - o0[4:]).max() <= 1e-4 * np.abs(o0[4:]).max()
