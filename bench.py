@@ -240,8 +240,13 @@ def main():
             multi = (n_per_gpu + 63) // 64 >= 5 and os.environ.get("BSVI_PERSISTENT_MULTI", "1") != "0"
             kernel = "bsvi::persistent_%skernel<%s>" % ("multi_" if multi else "", geom.get("storage", "") or "lds+lane_acc")
             if multi:
-                geom = dict(geom, n_blocks=(n_per_gpu + 63) // 64, n_waves=1, storage="lds+lane_acc",
-                            note="one wave per workgroup, one exchange of partial sums per iteration")
+                shares = int(compiled.lib.bsvi_persistent_split_shares(compiled.native.handle, n_per_gpu))
+                if not getattr(program, "shares", {}).get(shares):
+                    shares = 1
+                geom = dict(geom, n_blocks=(n_per_gpu + 63) // 64 * shares, n_waves=1, storage="lds+lane_acc",
+                            program_shares=shares,
+                            note="one wave per workgroup; workgroup w runs share w %% %d of the model's log-prob records "
+                                 "on sample wave w / %d; one exchange of partial sums per iteration" % (shares, shares))
         else:
             launch_ms, launches, units_per_launch = dev_ms / args.steps, args.steps, 1
             kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
