@@ -382,3 +382,28 @@ def test_multi_workgroup_persistent_trainer_matches_the_single_workgroup_one(n, 
         assert rel_err(l1, l0) <= 2e-6
         assert np.abs(p1 - p0).max() <= 2e-5 * (1 + np.abs(p0).max())
         assert np.abs(o1[4:] - o0[4:]).max() <= 1e-4 * np.abs(o0[4:]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["beta_binomial_N512", "lognormal_normal_N100", "vector_latent_d4_N70", "multivariate_regression_n100_N50",
+                                  "heavy_tails_N64", "learnable_model_N60", "beta_ar_T20_N100", "observed_ar_T50_N40"])
+def test_split_persistent_trainer_on_other_workloads(case):
+    """the multi-workgroup trainer with program shares against the launch-per-iteration path on models with generic
+    (non-Normal) nodes, derived slots, datapoint axes, two optimizer groups — 320 samples, same Philox draws"""
+    import os
+    g = Golden(case)
+    n = 320
+    runs = []
+    for persistent in (False, True):
+        model = g.build()
+        c = engine.compile_model(model, None, "pathwise")
+        if persistent and not c.native.persistent_supported(n):
+            pytest.skip("no persistent geometry for this program")
+        losses, finite = c.train(40, n, "Adam", seed=3, allow_persistent=persistent, lr=1e-3)
+        runs.append((losses.cpu().numpy(), c.params.cpu().numpy().copy(), finite.cpu().numpy(), c.last_mode))
+    (l0, p0, f0, m0), (l1, p1, f1, m1) = runs
+    assert m0 == "stepwise" and m1 == "persistent"
+    assert np.array_equal(f0, f1)
+    ok = f0 != 0
+    assert rel_err(l1[ok], l0[ok]) <= 1e-5
+    assert np.abs(p1 - p0).max() <= 1e-4 * (1 + np.abs(p0).max())
