@@ -407,3 +407,26 @@ def test_split_persistent_trainer_on_other_workloads(case):
     ok = f0 != 0
     assert rel_err(l1[ok], l0[ok]) <= 1e-5
     assert np.abs(p1 - p0).max() <= 1e-4 * (1 + np.abs(p0).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("estimator", ["blackbox", "taylor1"])
+def test_multi_workgroup_persistent_trainer_other_estimators(estimator):
+    """BlackBox (per-sample products, no program shares) and Taylor1 (its own program) through the one-wave-per-workgroup
+    trainer against the single workgroup"""
+    import os
+    from brancher_amd import workloads as W
+    runs = []
+    for flag in ("0", "1"):
+        os.environ["BSVI_PERSISTENT_MULTI"] = flag
+        try:
+            c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, estimator)
+            losses, finite = c.train(200, 300, "SGD", seed=5, lr=1e-4)
+            assert flag == "0" or c.last_mode == "persistent"      # (five waves of the Taylor1 program do not fit ONE workgroup)
+            runs.append((losses.cpu().numpy(), c.params.cpu().numpy().copy(), finite.cpu().numpy()))
+        finally:
+            os.environ.pop("BSVI_PERSISTENT_MULTI", None)
+    (l0, p0, f0), (l1, p1, f1) = runs
+    assert np.array_equal(f0, f1) and f0.all()
+    assert rel_err(l1, l0) <= 1e-5
+    assert np.abs(p1 - p0).max() <= 1e-4 * (1 + np.abs(p0).max())
