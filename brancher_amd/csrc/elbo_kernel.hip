@@ -67,6 +67,12 @@ struct KParams {
     uint32_t stash;         // lds+lane_acc: rows carry one cell per noise row; the reverse sweep reads eps back
                             // instead of regenerating it (Philox + Box-Muller are ~8 % of a wave's instructions)
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
+    // shares of the program over workgroups (multi-workgroup launches of elbo_kernel): workgroup b runs share
+    // b % n_shares on sample group b / n_shares (bsvi_program_set_shares); 0 / 1 = the whole program
+    uint32_t n_shares;
+    uint32_t share_n_code[3];
+    const uint4* share_code[3];
+    const uint4* share_aux[3];
 };
 
 // ---------------------------------------------------------------------------------------
@@ -1153,6 +1159,21 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
 
 template <int SM, bool OUT, bool GEN>
 __global__ void __launch_bounds__(1024) elbo_kernel(const KParams K) {
+    if (K.n_shares > 1) {
+        // every share samples the posterior but evaluates only its part of the model's log-prob records: value and
+        // adjoints are linear in them, so the rows of partial sums add up in reduce_kernel like those of sample groups
+        KParams S = K;
+        const uint32_t share = blockIdx.x % K.n_shares;
+        S.code = K.share_code[share];
+        S.aux = K.share_aux[share];
+        S.n_code = K.share_n_code[share];
+        const Lay LS = make_layout<SM>(S, blockDim.x >> 6);
+        elbo_block<SM, OUT, GEN>(S, LS, (blockIdx.x / K.n_shares) * (blockDim.x >> 6) * K.lpw);
+        float* part = K.partials + (size_t)blockIdx.x * (2 + K.n_uniform_grad);
+        if (threadIdx.x == 0) { part[0] = g_lds[LS.red]; part[1] = g_lds[LS.red + 1]; }
+        for (uint32_t k = threadIdx.x; k < K.n_uniform_grad; k += blockDim.x) part[2 + k] = g_lds[LS.uadj + k * LS.n_waves];
+        return;
+    }
     const Lay L = make_layout<SM>(K, blockDim.x >> 6);
     elbo_block<SM, OUT, GEN>(K, L, blockIdx.x * (blockDim.x >> 6) * K.lpw);
     if (K.fuse_out) {
@@ -1626,6 +1647,8 @@ struct bsvi_program {
     const uint32_t* pu_idx = nullptr;
     int max_lds = 0;
     bool generic = false;   // contains instructions other than NAFF
+    const bsvi_program* shares[3] = {nullptr, nullptr, nullptr};   // bsvi_program_set_shares
+    uint32_t n_shares = 0;
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -1930,7 +1953,7 @@ static Geometry choose_geometry(const bsvi_program* p, uint32_t n_local, bool si
 }
 
 static size_t partial_bytes(const bsvi_program* p, const Geometry& g) {
-    return align_up(((size_t)g.n_blocks + 1) * (2 + p->d.n_uniform_grad) * 4, 256);   // + the row of column sums
+    return align_up(((size_t)g.n_blocks * 3 + 1) * (2 + p->d.n_uniform_grad) * 4, 256);   // x3: program shares; + the row of column sums
 }
 
 static size_t ws_bytes(const bsvi_program* p, const Geometry& g) {
@@ -1984,6 +2007,8 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     K.stash = g.stash ? 1u : 0u;
     K.seed_lo = (uint32_t)a->seed; K.seed_hi = (uint32_t)(a->seed >> 32);
     K.offset_lo = (uint32_t)a->offset; K.offset_hi = (uint32_t)(a->offset >> 32);
+    K.n_shares = 0;
+    for (int v = 0; v < 3; ++v) { K.share_code[v] = nullptr; K.share_aux[v] = nullptr; K.share_n_code[v] = 0; }
     return BSVI_OK;
 }
 
@@ -1996,9 +2021,23 @@ static void fill_rparams(const bsvi_program* p, const Geometry& g, const KParams
     R.n_global = K.n_global;
 }
 
-static int launch_elbo(const bsvi_program* p, const Geometry& g, const KParams& K, hipStream_t s) {
-    dim3 grid(g.n_blocks), block(g.n_waves * 64);
+static int launch_elbo(const bsvi_program* p, const Geometry& g, const KParams& K_in, hipStream_t s,
+                       uint32_t* blocks_out = nullptr) {
+    KParams K = K_in;
     const bool out = K.samples_out || K.noise_out || K.fvalue_out || K.stamps;
+    uint32_t n_blocks = g.n_blocks;
+    // program shares (bsvi_program_set_shares): when every (sample group, share) workgroup still gets a CU of its own,
+    // split the model's log-prob records three ways; reduce_kernel adds the extra rows of partial sums like any others
+    const char* se = getenv("BSVI_ELBO_SHARES");
+    if (p->n_shares > 1 && !K.fuse_out && !out && g.n_blocks * p->n_shares <= 256 && !(se && se[0] == '0')) {
+        K.n_shares = p->n_shares;
+        for (uint32_t v = 0; v < p->n_shares; ++v) {
+            K.share_code[v] = p->shares[v]->code; K.share_aux[v] = p->shares[v]->aux; K.share_n_code[v] = p->shares[v]->d.n_code;
+        }
+        n_blocks = g.n_blocks * p->n_shares;
+    }
+    if (blocks_out) *blocks_out = n_blocks;
+    dim3 grid(n_blocks), block(g.n_waves * 64);
 #define BSVI_LAUNCH_ELBO(SM_, OUT_, GEN_) hipLaunchKernelGGL((elbo_kernel<SM_, OUT_, GEN_>), grid, block, g.lds_bytes, s, K)
 #define BSVI_LAUNCH_SM(OUT_, GEN_)                                       \
     do {                                                                 \
@@ -2040,14 +2079,20 @@ extern "C" int bsvi_elbo_fwd_bwd(const bsvi_program* p, const bsvi_elbo_args* a)
     KParams K;
     int rc = fill_kparams(p, a, g, K);
     if (rc) return rc;
-    if (g.n_blocks == 1) {
+    const char* se = getenv("BSVI_ELBO_SHARES");
+    const bool diag = a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || g_debug_stamps;
+    const bool shares = p->n_shares > 1 && !diag && !(se && se[0] == '0');
+    if (g.n_blocks == 1 && !shares) {
         K.fuse_out = a->out_dev;          // one workgroup: its epilogue writes the output block, one launch in all
         return launch_elbo(p, g, K, (hipStream_t)a->stream);
     }
-    rc = launch_elbo(p, g, K, (hipStream_t)a->stream);
+    // (with program shares the three workgroups + reduce_kernel beat the single fused workgroup: 33.9 vs 43.5 us at cfg 1)
+    uint32_t rows = g.n_blocks;
+    rc = launch_elbo(p, g, K, (hipStream_t)a->stream, &rows);
     if (rc) return rc;
     RParams R;
     fill_rparams(p, g, K, (float*)a->params_dev, a->out_dev, R);
+    R.n_blocks = rows;
     return launch_reduce(p, R, (hipStream_t)a->stream);
 }
 
@@ -2107,10 +2152,12 @@ extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, con
     aa.params_dev = params_dev;
     rc = fill_kparams(p, &aa, g, K);
     if (rc) return rc;
-    rc = launch_elbo(p, g, K, (hipStream_t)a->stream);
+    uint32_t rows = g.n_blocks;
+    rc = launch_elbo(p, g, K, (hipStream_t)a->stream, &rows);
     if (rc) return rc;
     RParams R;
     fill_rparams(p, g, K, params_dev, a->out_dev, R);
+    R.n_blocks = rows;
     R.state = state_dev; R.active_mask = active_mask_dev; R.loss_slot = loss_slot_dev; R.finite_slot = finite_slot_dev;
     R.do_finalize = 1; R.do_step = 1; R.cfg = *cfg;
     return launch_reduce(p, R, (hipStream_t)a->stream);
@@ -2155,6 +2202,24 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
                                  pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);
 }
 
+// Attach the shares of a program (programs created from lowering.Program.shares[n]: identical tables, own code) for the
+// multi-workgroup launches of bsvi_elbo_fwd_bwd / bsvi_svi_step.  The shares must outlive `p`'s use.
+extern "C" int bsvi_program_set_shares(bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares) {
+    if (!p) return fail(BSVI_ERR_INVALID, "null argument");
+    if (!shares || n_shares < 2) { p->n_shares = 0; return BSVI_OK; }
+    if (n_shares > 3) return fail(BSVI_ERR_INVALID, "at most 3 program shares");
+    for (uint32_t v = 0; v < n_shares; ++v) {
+        if (!shares[v]) return fail(BSVI_ERR_INVALID, "null program share");
+        if (shares[v]->d.n_uniform != p->d.n_uniform || shares[v]->d.n_uniform_grad != p->d.n_uniform_grad ||
+            shares[v]->d.n_slots != p->d.n_slots || shares[v]->d.n_params != p->d.n_params ||
+            shares[v]->d.n_code > p->d.n_code || (shares[v]->generic && !p->generic))
+            return fail(BSVI_ERR_INVALID, "a program share does not match the program's tables");
+    }
+    for (uint32_t v = 0; v < n_shares; ++v) p->shares[v] = shares[v];
+    p->n_shares = n_shares;
+    return BSVI_OK;
+}
+
 // how many shares of the program (2, 3 or 1 = none) the multi-workgroup trainer would run for this sample count
 extern "C" int bsvi_persistent_split_shares(const bsvi_program* p, uint32_t n_local) {
     if (!p || !n_local || !multi_persistent_applies(p, n_local)) return 1;
@@ -2178,7 +2243,7 @@ extern "C" int bsvi_train_persistent_split(const bsvi_program* p, const bsvi_pro
         if (!shares[v]) return fail(BSVI_ERR_INVALID, "null program share");
         if (shares[v]->d.n_uniform != p->d.n_uniform || shares[v]->d.n_uniform_grad != p->d.n_uniform_grad ||
             shares[v]->d.n_slots != p->d.n_slots || shares[v]->d.n_params != p->d.n_params ||
-            shares[v]->d.n_code > p->d.n_code || shares[v]->generic != p->generic)
+            shares[v]->d.n_code > p->d.n_code || (shares[v]->generic && !p->generic))
             return fail(BSVI_ERR_INVALID, "a program share does not match the program's tables");
     }
     return train_persistent_impl(p, shares, n_shares, a, cfg, params_dev, state_dev, active_mask_dev, active_mask_first_dev,

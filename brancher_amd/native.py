@@ -105,6 +105,7 @@ EXPORTS = {
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bsvi_persistent_supported": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bsvi_persistent_split_shares": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bsvi_program_set_shares": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]),
     "bsvi_train_persistent_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(ElboArgs),
                                               C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -224,6 +225,12 @@ class NativeProgram:
         self.handle = handle
         self.lib = lib
         self.program = program
+        # three-way shares of the model's log-prob records for the multi-workgroup launches
+        parts = getattr(program, "shares", {}).get(3)
+        if parts:
+            self._elbo_shares = [NativeProgram(self._share_program(code, records)) for code, records in parts]
+            arr = (C.c_void_p * 3)(*[sp.handle for sp in self._elbo_shares])
+            check(lib.bsvi_program_set_shares(handle, arr, 3))
 
     def workspace_bytes(self, n_local):
         return int(self.lib.bsvi_workspace_bytes(self.handle, n_local))
@@ -239,6 +246,12 @@ class NativeProgram:
     def persistent_supported(self, n_local):
         return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))
 
+    def _share_program(self, code, records):
+        import copy
+        share = copy.copy(self.program)
+        share.code, share.records, share.shares = code, records, {}
+        return share
+
     def split_shares(self, n_local):
         """program shares for the multi-workgroup persistent trainer at this sample count: None, or a ctypes array of
         `bsvi_program*` created (once) from `Program.shares[V]` — same tables, every share its own code"""
@@ -249,12 +262,7 @@ class NativeProgram:
             return None
         cache = self.__dict__.setdefault("_share_programs", {})
         if V not in cache:
-            progs = []
-            for code, records in parts:
-                share = copy.copy(self.program)
-                share.code, share.records, share.shares = code, records, {}
-                progs.append(NativeProgram(share))
-            cache[V] = progs
+            cache[V] = [NativeProgram(self._share_program(code, records)) for code, records in parts]
         arr = (C.c_void_p * V)(*[sp.handle for sp in cache[V]])
         return arr
 
