@@ -250,11 +250,11 @@ def main():
         else:
             launch_ms, launches, units_per_launch = dev_ms / args.steps, args.steps, 1
             kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
-            if (not dense and not amort and getattr(program, "shares", {}).get(3) and geom.get("n_blocks", 0) * 3 <= 256
-                    and os.environ.get("BSVI_ELBO_SHARES", "1") != "0"):
-                geom = dict(geom, n_blocks=geom["n_blocks"] * 3, program_shares=3,
-                            note="workgroup b runs share b % 3 of the model's log-prob records on sample group b / 3; "
-                                 "reduce_kernel adds the rows of partial sums")
+            V = getattr(getattr(compiled, "native", None), "_elbo_shares_set", 0)
+            if not dense and not amort and V >= 2 and os.environ.get("BSVI_ELBO_SHARES", "1") != "0":
+                geom = dict(geom, n_blocks=geom["n_blocks"] * V, program_shares=V,
+                            note="workgroup b runs share b %% %d of the model's log-prob records on sample group b / %d; "
+                                 "reduce_kernel adds the rows of partial sums" % (V, V))
         achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
         if mode == "persistent":
             # measured for the default command (the summary holds the warm-up launch of 200 iterations and the

@@ -70,9 +70,9 @@ struct KParams {
     // shares of the program over workgroups (multi-workgroup launches of elbo_kernel): workgroup b runs share
     // b % n_shares on sample group b / n_shares (bsvi_program_set_shares); 0 / 1 = the whole program
     uint32_t n_shares;
-    uint32_t share_n_code[3];
-    const uint4* share_code[3];
-    const uint4* share_aux[3];
+    uint32_t share_n_code[8];
+    const uint4* share_code[8];
+    const uint4* share_aux[8];
 };
 
 // ---------------------------------------------------------------------------------------
@@ -1647,7 +1647,7 @@ struct bsvi_program {
     const uint32_t* pu_idx = nullptr;
     int max_lds = 0;
     bool generic = false;   // contains instructions other than NAFF
-    const bsvi_program* shares[3] = {nullptr, nullptr, nullptr};   // bsvi_program_set_shares
+    const bsvi_program* shares[8] = {};   // bsvi_program_set_shares
     uint32_t n_shares = 0;
 };
 
@@ -1953,7 +1953,7 @@ static Geometry choose_geometry(const bsvi_program* p, uint32_t n_local, bool si
 }
 
 static size_t partial_bytes(const bsvi_program* p, const Geometry& g) {
-    return align_up(((size_t)g.n_blocks * 3 + 1) * (2 + p->d.n_uniform_grad) * 4, 256);   // x3: program shares; + the row of column sums
+    return align_up(((size_t)g.n_blocks * 8 + 1) * (2 + p->d.n_uniform_grad) * 4, 256);   // x8: program shares; + the row of column sums
 }
 
 static size_t ws_bytes(const bsvi_program* p, const Geometry& g) {
@@ -2008,7 +2008,7 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     K.seed_lo = (uint32_t)a->seed; K.seed_hi = (uint32_t)(a->seed >> 32);
     K.offset_lo = (uint32_t)a->offset; K.offset_hi = (uint32_t)(a->offset >> 32);
     K.n_shares = 0;
-    for (int v = 0; v < 3; ++v) { K.share_code[v] = nullptr; K.share_aux[v] = nullptr; K.share_n_code[v] = 0; }
+    for (int v = 0; v < 8; ++v) { K.share_code[v] = nullptr; K.share_aux[v] = nullptr; K.share_n_code[v] = 0; }
     return BSVI_OK;
 }
 
@@ -2207,7 +2207,7 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
 extern "C" int bsvi_program_set_shares(bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares) {
     if (!p) return fail(BSVI_ERR_INVALID, "null argument");
     if (!shares || n_shares < 2) { p->n_shares = 0; return BSVI_OK; }
-    if (n_shares > 3) return fail(BSVI_ERR_INVALID, "at most 3 program shares");
+    if (n_shares > 8) return fail(BSVI_ERR_INVALID, "at most 8 program shares");
     for (uint32_t v = 0; v < n_shares; ++v) {
         if (!shares[v]) return fail(BSVI_ERR_INVALID, "null program share");
         if (shares[v]->d.n_uniform != p->d.n_uniform || shares[v]->d.n_uniform_grad != p->d.n_uniform_grad ||

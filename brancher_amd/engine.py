@@ -203,6 +203,7 @@ class CompiledELBO:
         for_gradient=True + `inference.py:100`).  Returns a dict of device tensors."""
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
+        self.native.ensure_shares(n_local)
         if n_local == 0:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         if offset is None:
@@ -258,6 +259,7 @@ class CompiledELBO:
         cfg = native.make_opt_cfg(optimizer, **opt_params)
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
+        self.native.ensure_shares(n_local)
         if n_local == 0:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         dev = self.device

@@ -966,7 +966,9 @@ class _Lowering:
         prog.shares = {}
         sinks = [i for i, r in enumerate(self.records) if r[4]]
         if self.estimator == "pathwise" and len(sinks) >= 6:
-            for V in (2, 3):
+            for V in (2, 3, 4, 6, 8):
+                if len(sinks) < 2 * V:
+                    continue
                 parts = []
                 for v in range(V):
                     keep = set(sinks[v::V])

@@ -225,12 +225,9 @@ class NativeProgram:
         self.handle = handle
         self.lib = lib
         self.program = program
-        # three-way shares of the model's log-prob records for the multi-workgroup launches
-        parts = getattr(program, "shares", {}).get(3)
-        if parts:
-            self._elbo_shares = [NativeProgram(self._share_program(code, records)) for code, records in parts]
-            arr = (C.c_void_p * 3)(*[sp.handle for sp in self._elbo_shares])
-            check(lib.bsvi_program_set_shares(handle, arr, 3))
+        self._elbo_share_sets = {}      # V -> [NativeProgram]: shares of the model's log-prob records
+        self._elbo_shares_set = 0
+        self.ensure_shares(1)
 
     def workspace_bytes(self, n_local):
         return int(self.lib.bsvi_workspace_bytes(self.handle, n_local))
@@ -245,6 +242,25 @@ class NativeProgram:
 
     def persistent_supported(self, n_local):
         return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))
+
+    def ensure_shares(self, n_local):
+        """attach the widest split of the model's log-prob records for which every (sample group, share) workgroup of a
+        launch over `n_local` samples still gets a CU of its own (bsvi_program_set_shares)"""
+        available = getattr(self.program, "shares", {})
+        if not available:
+            return
+        blocks = self.geometry(n_local)["n_blocks"] if n_local > 1 else 1
+        V = max([v for v in available if v * blocks <= 256] or [0])
+        if V == self._elbo_shares_set:
+            return
+        if V >= 2 and V not in self._elbo_share_sets:
+            self._elbo_share_sets[V] = [NativeProgram(self._share_program(code, records)) for code, records in available[V]]
+        if V >= 2:
+            arr = (C.c_void_p * V)(*[sp.handle for sp in self._elbo_share_sets[V]])
+            check(self.lib.bsvi_program_set_shares(self.handle, arr, V))
+        else:
+            check(self.lib.bsvi_program_set_shares(self.handle, None, 0))
+        self._elbo_shares_set = V
 
     def _share_program(self, code, records):
         import copy

@@ -290,7 +290,7 @@ int bsvi_persistent_supported(const bsvi_program* prog, uint32_t n_samples_local
  * bsvi_train_persistent_split: shares[v] = programs created from the shares of the same lowering (identical tables,
  * own code), otherwise the arguments of bsvi_train_persistent2.  Pathwise estimator only. */
 int bsvi_persistent_split_shares(const bsvi_program* p, uint32_t n_samples_local);
-/* Attach up to 3 shares of `p` for the multi-workgroup launches of bsvi_elbo_fwd_bwd / bsvi_svi_step: when
+/* Attach up to 8 shares of `p` for the multi-workgroup launches of bsvi_elbo_fwd_bwd / bsvi_svi_step: when
  * (sample groups x shares) workgroups still get a CU each, workgroup b runs share b % n on sample group b / n and the
  * reduction adds the extra rows of partial sums.  n_shares < 2 detaches.  The shares must outlive their use. */
 int bsvi_program_set_shares(bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares);
