@@ -933,12 +933,15 @@ class _Lowering:
             """records -> (code words, record table).  own_terms=False: the posterior's sampling nodes keep sampling
             but contribute no entropy / log q term of their own (a share other than the first of a split program)."""
             words, recs_out = [], []
-            for (b, e, n_elems, n_temps, sink) in records:
+            for rec in records:
+                (b, e, n_elems, n_temps, sink), lo = rec[:5], (rec[5] if len(rec) > 5 else 0)
                 body = []
                 for ins in self.code[b:e]:
                     imm0, imm1 = ins[6], ins[7]
                     if not own_terms and (ins[0] & 0xFF) in (OP["NAFF"], OP["NODE"]) and ((ins[0] >> 8) & F_SAMPLE):
                         imm0 = imm1 = _fbits(0.0)
+                    if lo:      # an element sub-range of the record: every operand starts `lo` strides further
+                        ins = [ins[0]] + [(k, i + s * lo, s) for (k, i, s) in ins[1:6]] + [imm0, imm1]
                     body.append([ins[0] | ((R_NOALIAS << 24) if no_alias(ins, n_elems) else 0)]
                                 + [encode_operand(o, n_up, n_uni) for o in ins[1:6]] + [imm0, imm1])
                 rflag = (R_SINK if sink else 0) << 24
@@ -965,14 +968,27 @@ class _Lowering:
         # full program's.  Pathwise only: BlackBox multiplies per-sample totals.
         prog.shares = {}
         sinks = [i for i, r in enumerate(self.records) if r[4]]
-        if self.estimator == "pathwise" and len(sinks) >= 6:
+        # units of work: the elements of the sink records (a record over a datapoint / vector axis is split by elements:
+        # share v takes a contiguous sub-range, operands shifted by that many strides)
+        work = sum(self.records[i][2] for i in sinks)
+        if self.estimator == "pathwise" and work >= 6:
             for V in (2, 3, 4, 6, 8):
-                if len(sinks) < 2 * V:
+                if work < 2 * V:
                     continue
                 parts = []
                 for v in range(V):
-                    keep = set(sinks[v::V])
-                    records = [r for i, r in enumerate(self.records) if not r[4] or i in keep]
+                    records, single = [], 0
+                    for i, r in enumerate(self.records):
+                        if not r[4]:
+                            records.append(r)
+                        elif r[2] == 1:
+                            if single % V == v:
+                                records.append(r)
+                            single += 1
+                        else:
+                            lo, hi = (v * r[2]) // V, ((v + 1) * r[2]) // V
+                            if hi > lo:
+                                records.append((r[0], r[1], hi - lo, r[3], r[4], lo))
                     parts.append(assemble(records, own_terms=(v == 0)))
                 prog.shares[V] = parts
         prog.uniform, prog.records, prog.code = uni, recs, code
