@@ -1953,7 +1953,8 @@ static Geometry choose_geometry(const bsvi_program* p, uint32_t n_local, bool si
 }
 
 static size_t partial_bytes(const bsvi_program* p, const Geometry& g) {
-    return align_up(((size_t)g.n_blocks * 8 + 1) * (2 + p->d.n_uniform_grad) * 4, 256);   // x8: program shares; + the row of column sums
+    // rows: one per (wave, share) — covers the launch with one wave per workgroup (share_geometry) — + the row of column sums
+    return align_up(((size_t)g.n_blocks * g.n_waves * 8 + 1) * (2 + p->d.n_uniform_grad) * 4, 256);
 }
 
 static size_t ws_bytes(const bsvi_program* p, const Geometry& g) {
@@ -2071,16 +2072,32 @@ static int launch_reduce(const bsvi_program* p, const RParams& R, hipStream_t s)
     return BSVI_OK;
 }
 
+// With program shares attached, a small shard runs best with ONE wave per workgroup as well (every wave a CU to itself,
+// like the multi-workgroup persistent trainer): sample waves x shares workgroups, as long as each still gets a CU.
+static Geometry share_geometry(const bsvi_program* p, Geometry g, uint32_t n_local, bool diagnostic) {
+    const char* se = getenv("BSVI_ELBO_SHARES");
+    if (p->n_shares < 2 || diagnostic || (se && se[0] == '0') || g.mode != SM_LACC || g.lpw != 64 || g.n_waves < 2) return g;
+    const uint32_t waves = (n_local + 63) / 64;
+    if (waves * p->n_shares > 256) return g;
+    Geometry s = g;
+    s.n_waves = 1; s.n_blocks = waves;
+    s.stash = !p->generic && lds_need(p, 1, SM_LACC, 64, true) <= (size_t)p->max_lds;
+    s.lds_bytes = lds_need(p, 1, SM_LACC, 64, s.stash);
+    s.n_pad = waves * 64;
+    return s;
+}
+
 extern "C" int bsvi_elbo_fwd_bwd(const bsvi_program* p, const bsvi_elbo_args* a) {
     if (!p || !a) return fail(BSVI_ERR_INVALID, "null argument");
     if (!a->out_dev) return fail(BSVI_ERR_INVALID, "out_dev is null");
     Geometry g = choose_geometry(p, a->n_samples_local, false);
     if (!g.n_blocks) return fail(BSVI_ERR_RESOURCE, "program does not fit the LDS budget");
+    const char* se = getenv("BSVI_ELBO_SHARES");
+    const bool diag = a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || g_debug_stamps;
+    g = share_geometry(p, g, a->n_samples_local, diag);
     KParams K;
     int rc = fill_kparams(p, a, g, K);
     if (rc) return rc;
-    const char* se = getenv("BSVI_ELBO_SHARES");
-    const bool diag = a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || g_debug_stamps;
     const bool shares = p->n_shares > 1 && !diag && !(se && se[0] == '0');
     if (g.n_blocks == 1 && !shares) {
         K.fuse_out = a->out_dev;          // one workgroup: its epilogue writes the output block, one launch in all
@@ -2147,6 +2164,7 @@ extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, con
     if (a->n_samples_local != a->n_samples_global) return fail(BSVI_ERR_INVALID, "bsvi_svi_step is the single-GPU path");
     Geometry g = choose_geometry(p, a->n_samples_local, false);
     if (!g.n_blocks) return fail(BSVI_ERR_RESOURCE, "program does not fit the LDS budget");
+    g = share_geometry(p, g, a->n_samples_local, a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || g_debug_stamps);
     KParams K;
     bsvi_elbo_args aa = *a;
     aa.params_dev = params_dev;
