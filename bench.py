@@ -194,6 +194,8 @@ def main():
     compiled = engine.compile_model(model, None, args.estimator)
     program = compiled.program
     allow_persistent = args.mode != "stepwise"
+    if args.mode == "auto" and getattr(compiled, "prefers_stepwise", None) and compiled.prefers_stepwise(n_global):
+        allow_persistent = False      # 4+ program shares: launches per iteration beat the persistent trainer
     if args.mode == "persistent" and not (world == 1 and hasattr(compiled, "native") and compiled.native.persistent_supported(n_per_gpu)):
         raise SystemExit("persistent mode needs one GPU and a sample count that fits one workgroup")
 
@@ -252,6 +254,9 @@ def main():
             kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
             V = getattr(getattr(compiled, "native", None), "_elbo_shares_set", 0)
             if not dense and not amort and V >= 2 and os.environ.get("BSVI_ELBO_SHARES", "1") != "0":
+                waves = (n_per_gpu + 63) // 64
+                if geom.get("storage") == "lds+lane_acc" and geom.get("lanes_per_wave") == 64 and waves * V <= 256:
+                    geom = dict(geom, n_blocks=waves, n_waves=1)        # one wave per workgroup (share_geometry)
                 geom = dict(geom, n_blocks=geom["n_blocks"] * V, program_shares=V,
                             note="workgroup b runs share b %% %d of the model's log-prob records on sample group b / %d; "
                                  "reduce_kernel adds the rows of partial sums" % (V, V))

@@ -1376,9 +1376,9 @@ struct PParams {
     // shares of the program (bsvi_train_persistent_split): workgroup w runs share w % n_shares on sample wave
     // w / n_shares; every share samples the posterior but evaluates only its part of the model's log-prob records
     uint32_t n_shares;       // 0 / 1: the whole program
-    const uint4* share_code[4];
-    const uint4* share_aux[4];
-    uint32_t share_n_code[4];
+    const uint4* share_code[8];
+    const uint4* share_aux[8];
+    uint32_t share_n_code[8];
 };
 
 // Scalar-register discipline: PParams is ~90 dwords of kernel arguments.  Read as `P.x` they are all
@@ -1971,7 +1971,8 @@ static size_t base_ws_bytes(const bsvi_program* p, uint32_t n_local) {
 
 // region behind the base workspace used by persistent_multi_kernel (up to 16 workgroups):
 // [counter: 256 B][exchange: 2 x 16 x (2 + nUg) floats][parameter copies: 15 x stride][state copies: 15 x 4 x stride]
-constexpr uint32_t kMaxMultiWg = 16;
+constexpr uint32_t kMaxMultiWg = 64;     // workgroups of the persistent multi trainer (sample waves x shares)
+constexpr uint32_t kMaxMultiWaves = 16;  // sample waves it accepts
 static uint32_t mw_stride(const bsvi_program* p) { return (p->d.n_params + 63u) / 64u * 64u + 64u; }
 static size_t mw_xchg_floats(const bsvi_program* p) { return 2 * (size_t)kMaxMultiWg * (2 + p->d.n_uniform_grad); }
 static size_t mw_bytes(const bsvi_program* p) {
@@ -2186,7 +2187,7 @@ static bool multi_persistent_applies(const bsvi_program* p, uint32_t n_local) {
     const char* e = getenv("BSVI_PERSISTENT_MULTI");       // read per call: tests and tools flip it
     if (e && e[0] == '0') return false;
     const uint32_t waves = (n_local + 63) / 64;
-    return waves >= 5 && waves <= kMaxMultiWg && lds_need(p, 1, SM_LACC, 64, false) <= (size_t)p->max_lds;
+    return waves >= 5 && waves <= kMaxMultiWaves && lds_need(p, 1, SM_LACC, 64, false) <= (size_t)p->max_lds;
 }
 
 extern "C" int bsvi_persistent_supported(const bsvi_program* p, uint32_t n_local) {
@@ -2243,9 +2244,12 @@ extern "C" int bsvi_persistent_split_shares(const bsvi_program* p, uint32_t n_lo
     if (!p || !n_local || !multi_persistent_applies(p, n_local)) return 1;
     const char* e = getenv("BSVI_PERSISTENT_SHARES");
     const uint32_t waves = (n_local + 63) / 64;
-    uint32_t want = e ? (uint32_t)atoi(e) : 2u;      // two and three shares measure the same at N = 300 (10 / 15 workgroups)
-    if (want > 3) want = 3;
-    while (want > 1 && waves * want > kMaxMultiWg) --want;
+    // more shares mean more workgroups at the in-kernel exchange, which every workgroup walks in full: 2-3 shares
+    // are the optimum there (32.3 us at cfg 1; 34.9 with 6, 37.8 with 8) — the launch-per-iteration path, whose
+    // reduce_kernel adds the rows once, is the one that profits from 8 (29.0 us)
+    uint32_t want = e ? (uint32_t)atoi(e) : 2u;
+    if (want > 8) want = 8;
+    while (want > 1 && (waves * want > kMaxMultiWg || want == 5 || want == 7)) --want;      // the lowering emits 2, 3, 4, 6, 8
     return (int)(want < 1 ? 1 : want);
 }
 
@@ -2256,7 +2260,7 @@ extern "C" int bsvi_train_persistent_split(const bsvi_program* p, const bsvi_pro
                                            float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                                            const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
                                            uint32_t n_iterations, float* loss_curve_dev, float* finite_dev) {
-    if (!shares || n_shares < 2 || n_shares > 4) return fail(BSVI_ERR_INVALID, "2..4 program shares expected");
+    if (!shares || n_shares < 2 || n_shares > 8) return fail(BSVI_ERR_INVALID, "2..8 program shares expected");
     for (uint32_t v = 0; v < n_shares; ++v) {
         if (!shares[v]) return fail(BSVI_ERR_INVALID, "null program share");
         if (shares[v]->d.n_uniform != p->d.n_uniform || shares[v]->d.n_uniform_grad != p->d.n_uniform_grad ||

@@ -105,8 +105,11 @@ class ReverseKL(InferenceMethod):
             pretraining_iterations, **opt_params):
         """the loop of `inference.py:95-108`, executed by the engine"""
         compiled = engine.compile_model(joint_model, posterior_model, self.gradient_estimator)
+        extra = {}
+        if getattr(compiled, "prefers_stepwise", None) and compiled.prefers_stepwise(number_samples):
+            extra["allow_persistent"] = False
         return compiled.train(number_iterations, number_samples, optimizer,
-                              pretraining_iterations=pretraining_iterations, **opt_params)
+                              pretraining_iterations=pretraining_iterations, **extra, **opt_params)
 
 
 class MAP(ReverseKL):
