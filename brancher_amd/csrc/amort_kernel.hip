@@ -29,7 +29,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "../../include/bsvi.h"
+#include "bsvi.h"
 #include "bsvi_internal.h"
 #include "philox.h"
 

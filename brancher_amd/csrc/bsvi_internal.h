@@ -1,6 +1,70 @@
 // bsvi_internal.h — shared between the translation units of libbsvi.so (not part of the C ABI).
 #pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <string>
+#include <vector>
+
+#include "bsvi.h"
 
 // records the thread-local message returned by bsvi_last_error() and returns `code`
 int bsvi_fail(int code, const std::string& msg);
+
+namespace bsvi_spec { struct Spec; }
+
+struct bsvi_program {
+    bsvi_program_desc d;
+    void* dev_blob = nullptr;       // one allocation holding every table
+    const uint4* code = nullptr;
+    const uint4* aux = nullptr;
+    const bsvi_record* records = nullptr;
+    const bsvi_uniform_entry* uniform = nullptr;
+    const float* consts = nullptr;
+    const uint32_t* pu_ptr = nullptr;
+    const uint32_t* pu_idx = nullptr;
+    int max_lds = 0;
+    bool generic = false;   // contains instructions other than NAFF
+    const bsvi_program* shares[8] = {};   // bsvi_program_set_shares
+    uint32_t n_shares = 0;
+    bsvi_spec::Spec* spec = nullptr;      // the program-specialised kernels (specialize.cpp), or null: interpreter only
+};
+
+// ---- program specialisation (specialize.cpp): straight-line HIP generated from the instruction stream, compiled
+//      with hiprtc on first launch.  The interpreter kernels of elbo_kernel.hip remain the engine for programs the
+//      generator declines (very long unrolled streams) and when BSVI_JIT=0.
+namespace bsvi_spec {
+
+enum Mode { MODE_SUMS = 0, MODE_STEP = 1, MODE_LOOP = 2 };
+
+// Generate the sources (no compilation; host only).  `desc` must still carry its host tables.  Returns null and
+// sets `why` when the program is not specialised.
+Spec* create(const bsvi_program_desc& desc, std::string& why);
+void destroy(Spec* s);
+// device-side tables of the spec (needs a device; called from bsvi_program_create)
+int upload(Spec* s);
+// the generated translation unit of a variant (0 lean, 1 diagnostic) — tests and bsvi_program_source
+const std::string& source(const Spec* s, int variant);
+// compile a generated translation unit for gfx950 with hiprtc; `code` receives the code object
+int compile(const std::string& src, std::vector<char>& code, std::string& log);
+// bytes of workspace a launch over n_local samples needs behind the interpreter's region
+size_t workspace_bytes(const Spec* s, uint32_t n_local);
+// true when a launch in `mode` over n_local samples is served by the specialised kernel
+bool applies(const Spec* s, uint32_t n_local, int mode);
+struct Launch {
+    const bsvi_elbo_args* a = nullptr;
+    int mode = MODE_SUMS;
+    const bsvi_opt_cfg* cfg = nullptr;
+    float* params = nullptr;
+    float* state = nullptr;
+    const uint8_t* mask = nullptr;
+    const uint8_t* mask_first = nullptr;
+    uint32_t pretraining_iterations = 0, n_iterations = 1;
+    float* loss_slot = nullptr;
+    float* finite_slot = nullptr;
+    void* workspace = nullptr;      // the spec's region of the caller's workspace
+};
+int launch(Spec* s, const bsvi_program* p, const Launch& L);
+// geometry of that launch (tests / bench)
+void geometry(const Spec* s, uint32_t n_local, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes);
+
+}  // namespace bsvi_spec

@@ -9,11 +9,30 @@
 // ATen/native/Distributions.h (dirichlet_grad_one) so that parity with the PyTorch-CPU
 // reference holds to 1e-5.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include "../../include/bsvi.h"
+#else   /* hiprtc: no <math.h> */
+#ifndef INFINITY
+#define INFINITY __builtin_huge_valf()
+#endif
+#ifndef NAN
+#define NAN __builtin_nanf("")
+#endif
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#endif
+#include "bsvi.h"
 
 #define BSVI_DEV __device__ __forceinline__
+// functions that switch on the distribution id: out of line in the interpreter (the id is a run-time value there),
+// inlined into program-specialised kernels, where the id is a literal and the switch folds away
+#if defined(BSVI_SPECIALIZED)
+#define BSVI_SWITCH_FN __device__ __forceinline__
+#else
+#define BSVI_SWITCH_FN __device__ __noinline__
+#endif
 
 namespace bsvi {
 
@@ -180,7 +199,7 @@ __device__ __noinline__ float dirichlet_grad_one(float xf, float alphaf, float t
 // ---- log-probability -------------------------------------------------------------------
 __device__ __forceinline__ float lgamma_count(float a) { return (a == 1.0f || a == 2.0f) ? 0.0f : lgammaf(a); }
 
-__device__ __noinline__ float logp_generic(int dist, float x, float p0, float p1) {
+BSVI_SWITCH_FN float logp_generic(int dist, float x, float p0, float p1) {
     switch (dist) {
     case BSVI_DIST_NORMAL: {
         const float d = x - p0;
@@ -268,7 +287,7 @@ __device__ __forceinline__ void logp_bwd_impl(int dist, float x, float p0, float
 }
 
 // ---- analytic entropy ------------------------------------------------------------------
-__device__ __noinline__ float entropy_generic(int dist, float p0, float p1) {
+BSVI_SWITCH_FN float entropy_generic(int dist, float p0, float p1) {
     switch (dist) {
     case BSVI_DIST_NORMAL: return kHalfLog2PiE + logf(p1);
     case BSVI_DIST_LOGNORMAL: return (kHalfLog2PiE + logf(p1)) + p0;
@@ -310,7 +329,7 @@ __device__ __forceinline__ void entropy_bwd_impl(int dist, float p0, float p1, f
 
 // ---- reparameterised draw from supplied noise ---------------------------------------------
 // noise meaning per distribution: brancher_amd/distributions.py NOISE_*.
-__device__ __noinline__ float sample_from_noise_generic(int dist, float p0, float p1, float e) {
+BSVI_SWITCH_FN float sample_from_noise_generic(int dist, float p0, float p1, float e) {
     switch (dist) {
     case BSVI_DIST_NORMAL:
     case BSVI_DIST_CAUCHY: return p0 + e * p1;
@@ -350,22 +369,22 @@ __device__ __forceinline__ void sample_bwd_impl(int dist, float z, float p0, flo
 
 // Out-of-line entry points return their adjoints BY VALUE (in registers): reference parameters of a
 // non-inlined function live in scratch memory, one store + one flat load each per call.
-__device__ __noinline__ float4 logp_bwd_generic(int dist, float x, float p0, float p1, float g) {
+BSVI_SWITCH_FN float4 logp_bwd_generic(int dist, float x, float p0, float p1, float g) {
     float gx = 0.0f, g0 = 0.0f, g1 = 0.0f;
     logp_bwd_impl(dist, x, p0, p1, g, gx, g0, g1);
     return make_float4(gx, g0, g1, 0.0f);
 }
-__device__ __noinline__ float2 entropy_bwd_generic(int dist, float p0, float p1, float g) {
+BSVI_SWITCH_FN float2 entropy_bwd_generic(int dist, float p0, float p1, float g) {
     float g0 = 0.0f, g1 = 0.0f;
     entropy_bwd_impl(dist, p0, p1, g, g0, g1);
     return make_float2(g0, g1);
 }
-__device__ __noinline__ float2 sample_bwd_generic(int dist, float z, float p0, float p1, float e, float zb) {
+BSVI_SWITCH_FN float2 sample_bwd_generic(int dist, float z, float p0, float p1, float e, float zb) {
     float g0 = 0.0f, g1 = 0.0f;
     sample_bwd_impl(dist, z, p0, p1, e, zb, g0, g1);
     return make_float2(g0, g1);
 }
 
-__device__ __noinline__ float pow_ff(float x, float y) { return powf(x, y); }
+BSVI_SWITCH_FN float pow_ff(float x, float y) { return powf(x, y); }
 
 }  // namespace bsvi

@@ -33,9 +33,8 @@
 #include <string>
 #include <vector>
 
-#include "../../include/bsvi.h"
-#include "dist_math.h"
-#include "philox.h"
+#include "bsvi.h"
+#include "bsvi_device.h"
 #include "bsvi_internal.h"
 
 namespace bsvi {
@@ -76,52 +75,6 @@ struct KParams {
 };
 
 // ---------------------------------------------------------------------------------------
-// wave-level sum of one float per lane; result is wave-uniform (every lane gets it).
-// DPP row reduction (quad_perm, row_half_mirror, row_mirror) then 4 row totals through
-// v_readlane — fixed order, no LDS traffic.
-// ---------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);   // row_half_mirror
-    v += dpp_f<0x140>(v);   // row_mirror  -> every lane holds its 16-lane row total
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
-__device__ __forceinline__ float utransform(int t, float x) {
-    switch (t) {
-    case BSVI_UT_SOFTPLUS: return softplusf_(x);
-    case BSVI_UT_SIGMOID: return sigmoidf_(x);
-    case BSVI_UT_EXP: return expf(x);
-    case BSVI_UT_LOG: return logf(x);
-    case BSVI_UT_TANH: return tanhf(x);
-    case BSVI_UT_SQRT: return sqrtf(x);
-    case BSVI_UT_SQUARE: return x * x;
-    default: return x;
-    }
-}
-__device__ __forceinline__ float utransform_grad(int t, float x) {
-    switch (t) {
-    case BSVI_UT_SOFTPLUS: return x > 20.0f ? 1.0f : sigmoidf_(x);
-    case BSVI_UT_SIGMOID: { const float s = sigmoidf_(x); return s * (1.0f - s); }
-    case BSVI_UT_EXP: return expf(x);
-    case BSVI_UT_LOG: return 1.0f / x;
-    case BSVI_UT_TANH: { const float th = tanhf(x); return 1.0f - th * th; }
-    case BSVI_UT_SQRT: return 0.5f / sqrtf(x);
-    case BSVI_UT_SQUARE: return 2.0f * x;
-    default: return 1.0f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // dynamic LDS of every kernel in this file.  Declared at file scope and always indexed
 // directly, so that every access is a real ds_read/ds_write (a pointer that travels through
 // a struct degrades to flat loads, which cost a full memory round trip per operand).
@@ -160,21 +113,6 @@ struct Lane {
     float c0, c1, c2, c3;       // cached normals of that group
 };
 
-struct PhiloxKey { uint32_t nidx, seed_lo, seed_hi, off_lo, off_hi; };
-
-__device__ __forceinline__ u32x4 philox_raw(const PhiloxKey& k, uint32_t row, uint32_t attempt) {
-    return philox4x32_10(k.nidx, row, k.off_lo, k.off_hi ^ (attempt << 8), k.seed_lo, k.seed_hi);
-}
-// Box-Muller on the hardware transcendental units: v_sin/v_cos take revolutions, so
-// sin(2*pi*u) is one instruction and needs no range reduction
-__device__ __forceinline__ void box_muller_fast(uint32_t a, uint32_t b, float& z0, float& z1) {
-    // u01 is a normal float in (0, 1): v_log_f32 (log2) and v_sqrt_f32 need no denormal or range handling — the
-    // library logf / sqrtf spend ~20 instructions per pair on exactly that
-    const float r = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u01(a)) * -1.3862943611198906f);     // sqrt(-2 ln u)
-    const float u = u01(b);
-    z0 = r * __builtin_amdgcn_cosf(u);
-    z1 = r * __builtin_amdgcn_sinf(u);
-}
 // standard normal for noise row `row`: rows 4g..4g+3 share one Philox call (the forward sweep
 // walks the rows upwards, the reverse sweep downwards: either way 1 call per 4 draws)
 __device__ __forceinline__ float philox_normal(const KParams& K, Lane& T, uint32_t row) {
@@ -193,91 +131,6 @@ __device__ __forceinline__ float philox_normal(const KParams& K, Lane& T, uint32
     const float c0 = T.c0, c1 = T.c1, c2 = T.c2, c3 = T.c3;
     const float lo = (j & 1u) ? c1 : c0, hi = (j & 1u) ? c3 : c2;
     return (j & 2u) ? hi : lo;
-}
-
-__device__ __noinline__ float philox_gamma(PhiloxKey G, float alpha, uint32_t row, uint32_t stream) {
-    // Marsaglia & Tsang (2000), as ATen/native/Distributions.h sample_gamma
-    float scale = 1.0f;
-    uint32_t attempt = stream << 12;
-    if (alpha < 1.0f) {
-        if (alpha == 0.0f) return 0.0f;
-        const u32x4 x = philox_raw(G, row, attempt++);
-        scale *= powf(1.0f - u01(x.x), 1.0f / alpha);
-        alpha += 1.0f;
-    }
-    const float d = alpha - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
-    for (int it = 0; it < 64; ++it) {
-        const u32x4 x = philox_raw(G, row, attempt++);
-        float n0, n1;
-        box_muller(x.x, x.y, n0, n1);
-        const float y = 1.0f + c * n0;
-        if (y <= 0.0f) continue;
-        const float v = y * y * y, u = 1.0f - u01(x.z), xx = n0 * n0;
-        if (u < 1.0f - 0.0331f * xx * xx) return scale * d * v;
-        if (logf(u) < 0.5f * xx + d * (1.0f - v + logf(v))) return scale * d * v;
-    }
-    return scale * d;
-}
-
-// a fresh draw for the non-Normal distributions (out of line: cold for the AR-type models);
-// returns the draw in .x and the base noise that produced it in .y
-__device__ __noinline__ float2 philox_draw(PhiloxKey G, int dist, float p0, float p1, uint32_t row) {
-    float noise = 0.0f, v = p0;
-    switch (dist) {
-    case BSVI_DIST_LOGNORMAL: {
-        const u32x4 x = philox_raw(G, row, 0);
-        float n1;
-        box_muller(x.x, x.y, noise, n1);
-        v = expf(p0 + noise * p1);
-        break;
-    }
-    case BSVI_DIST_CAUCHY: {
-        const u32x4 x = philox_raw(G, row, 0);
-        noise = tanf(3.14159265358979323846f * (u01(x.x) - 0.5f));
-        v = p0 + noise * p1;
-        break;
-    }
-    case BSVI_DIST_LAPLACE: {
-        const u32x4 x = philox_raw(G, row, 0);
-        noise = (kFloatEps - 1.0f) + (2.0f - kFloatEps) * u01(x.x);   // torch laplace.py:83
-        v = sample_from_noise_generic(dist, p0, p1, noise);
-        break;
-    }
-    case BSVI_DIST_BETA: {
-        const float ga = philox_gamma(G, p0, row, 1), gb = philox_gamma(G, p1, row, 2);
-        v = noise = fminf(fmaxf(ga / (ga + gb), 1.17549435e-38f), 1.0f - kFloatEps);
-        break;
-    }
-    case BSVI_DIST_BERNOULLI: {
-        const u32x4 x = philox_raw(G, row, 0);
-        v = noise = u01(x.x) < sigmoidf_(p0) ? 1.0f : 0.0f;
-        break;
-    }
-    case BSVI_DIST_BINOMIAL: {
-        const float p = sigmoidf_(p1);
-        const int n = (int)p0;
-        float k = 0.0f;
-        for (int i = 0; i < n; i += 4) {
-            const u32x4 x = philox_raw(G, row, (uint32_t)(i >> 2));
-            k += (u01(x.x) < p) ? 1.0f : 0.0f;
-            if (i + 1 < n) k += (u01(x.y) < p) ? 1.0f : 0.0f;
-            if (i + 2 < n) k += (u01(x.z) < p) ? 1.0f : 0.0f;
-            if (i + 3 < n) k += (u01(x.w) < p) ? 1.0f : 0.0f;
-        }
-        v = noise = k;
-        break;
-    }
-    default: break;
-    }
-    return make_float2(v, noise);
-}
-// the base noise again, for the reverse sweep of a reparameterised non-Normal draw
-__device__ __noinline__ float philox_noise_again(PhiloxKey G, int dist, uint32_t row) {
-    const u32x4 x = philox_raw(G, row, 0);
-    if (dist == BSVI_DIST_LOGNORMAL) { float n0, n1; box_muller(x.x, x.y, n0, n1); return n0; }
-    if (dist == BSVI_DIST_CAUCHY) return tanf(3.14159265358979323846f * (u01(x.x) - 0.5f));
-    if (dist == BSVI_DIST_LAPLACE) return (kFloatEps - 1.0f) + (2.0f - kFloatEps) * u01(x.x);
-    return 0.0f;
 }
 
 // Program tables are immutable for the lifetime of a launch and are addressed with
@@ -448,75 +301,6 @@ __device__ __forceinline__ void add_adj5(const Lay& L, const Lane& T, uint32_t o
     lds_st(cb, ob + gb);
     lds_st(cc, oc + gc);
     lds_st(cs, os + gs);
-}
-
-__device__ __noinline__ float unop_rare(uint32_t sub, float x, float imm) {
-    switch (sub) {
-    case BSVI_U_SIN: return sinf(x);
-    case BSVI_U_COS: return cosf(x);
-    case BSVI_U_TANH: return tanhf(x);
-    case BSVI_U_LOG1P: return log1pf(x);
-    case BSVI_U_EXPM1: return expm1f(x);
-    case BSVI_U_P2L: { const float p = fminf(fmaxf(x, kFloatEps), 1.0f - kFloatEps); return logf(p) - log1pf(-p); }
-    case BSVI_U_POWI: return powf(x, imm);
-    default: return x;
-    }
-}
-__device__ __noinline__ float unop_rare_grad(uint32_t sub, float x, float y, float imm) {
-    switch (sub) {
-    case BSVI_U_SIN: return cosf(x);
-    case BSVI_U_COS: return -sinf(x);
-    case BSVI_U_TANH: return 1.0f - y * y;
-    case BSVI_U_LOG1P: return 1.0f / (1.0f + x);
-    case BSVI_U_EXPM1: return y + 1.0f;
-    case BSVI_U_P2L: return (x >= kFloatEps && x <= 1.0f - kFloatEps) ? (1.0f / x + 1.0f / (1.0f - x)) : 0.0f;
-    case BSVI_U_POWI: return imm * powf(x, imm - 1.0f);
-    default: return 1.0f;
-    }
-}
-template <bool GEN>
-__device__ __forceinline__ float unop(uint32_t sub, float x, float imm) {
-    switch (sub) {
-    case BSVI_U_COPY: return x;
-    case BSVI_U_NEG: return -x;
-    case BSVI_U_EXP: return expf(x);
-    case BSVI_U_LOG: return logf(x);
-    case BSVI_U_SQRT: return sqrtf(x);
-    case BSVI_U_ABS: return fabsf(x);
-    case BSVI_U_SIGMOID: return sigmoidf_(x);
-    case BSVI_U_SOFTPLUS: return softplusf_(x);
-    case BSVI_U_RELU: return fmaxf(x, 0.0f);
-    case BSVI_U_RECIP: return 1.0f / x;
-    case BSVI_U_SQUARE: return x * x;
-    case BSVI_U_POWI:
-        if (imm == 2.0f) return x * x;
-        if (imm == -1.0f) return 1.0f / x;
-        if (imm == 0.5f) return sqrtf(x);
-        return GEN ? unop_rare(sub, x, imm) : x;
-    default: return GEN ? unop_rare(sub, x, imm) : x;
-    }
-}
-template <bool GEN>
-__device__ __forceinline__ float unop_grad(uint32_t sub, float x, float y, float imm) {
-    switch (sub) {
-    case BSVI_U_COPY: return 1.0f;
-    case BSVI_U_NEG: return -1.0f;
-    case BSVI_U_EXP: return y;
-    case BSVI_U_LOG: return 1.0f / x;
-    case BSVI_U_SQRT: return 0.5f / y;
-    case BSVI_U_ABS: return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
-    case BSVI_U_SIGMOID: return y * (1.0f - y);
-    case BSVI_U_SOFTPLUS: return x > 20.0f ? 1.0f : sigmoidf_(x);
-    case BSVI_U_RELU: return (x > 0.0f) ? 1.0f : 0.0f;
-    case BSVI_U_RECIP: return -y * y;
-    case BSVI_U_SQUARE: return 2.0f * x;
-    case BSVI_U_POWI:
-        if (imm == 2.0f) return 2.0f * x;
-        if (imm == -1.0f) return -y * y;
-        if (imm == 0.5f) return 0.5f / y;
-        return GEN ? unop_rare_grad(sub, x, y, imm) : 1.0f;
-    default: return GEN ? unop_rare_grad(sub, x, y, imm) : 1.0f;
-    }
 }
 
 __device__ __forceinline__ PhiloxKey philox_key(const KParams& K, const Lane& T) {
@@ -1197,49 +981,6 @@ __global__ void __launch_bounds__(1024) elbo_kernel(const KParams K) {
     for (uint32_t k = threadIdx.x; k < K.n_uniform_grad; k += blockDim.x) part[2 + k] = g_lds[L.uadj + k * L.n_waves];
 }
 
-// ---------------------------------------------------------------------------------------
-// optimizer arithmetic shared by reduce_kernel / optimizer_kernel / persistent trainer
-//   torch.optim.SGD / torch.optim.Adam single-tensor paths, per element.
-// state layout: [4][n_params] = (momentum_buffer | exp_avg, exp_avg_sq, max_exp_avg_sq, step)
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void optimizer_update(const bsvi_opt_cfg& cfg, float* params, float* state,
-                                                 uint32_t n_params, uint32_t i, float grad) {
-    float p = params[i];
-    float* s0 = state + i;
-    float* s1 = state + n_params + i;
-    float* s2 = state + 2 * (size_t)n_params + i;
-    float* st = state + 3 * (size_t)n_params + i;
-    if (cfg.maximize) grad = -grad;
-    const float step = *st + 1.0f;
-    *st = step;
-    if (cfg.kind == BSVI_OPT_SGD) {
-        if (cfg.weight_decay != 0.0f) grad += cfg.weight_decay * p;
-        if (cfg.momentum != 0.0f) {
-            float buf = (step == 1.0f) ? grad : cfg.momentum * (*s0) + (1.0f - cfg.dampening) * grad;
-            *s0 = buf;
-            grad = cfg.nesterov ? grad + cfg.momentum * buf : buf;
-        }
-        params[i] = p - cfg.lr * grad;
-    } else {
-        if (cfg.weight_decay != 0.0f) grad += cfg.weight_decay * p;
-        const float m = *s0 + (grad - *s0) * (1.0f - cfg.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
-        const float v = cfg.beta2 * (*s1) + (1.0f - cfg.beta2) * grad * grad;
-        *s0 = m;
-        *s1 = v;
-        const double bc1 = 1.0 - pow((double)cfg.beta1, (double)step);
-        const double bc2 = 1.0 - pow((double)cfg.beta2, (double)step);
-        const float step_size = (float)((double)cfg.lr / bc1);
-        const float bc2_sqrt = (float)sqrt(bc2);
-        float vhat = v;
-        if (cfg.amsgrad) {
-            vhat = fmaxf(*s2, v);
-            *s2 = vhat;
-        }
-        const float denom = sqrtf(vhat) / bc2_sqrt + cfg.eps;
-        params[i] = p - step_size * (m / denom);
-    }
-}
-
 struct RParams {
     const bsvi_uniform_entry* uniform;
     const uint32_t* pu_ptr;
@@ -1635,22 +1376,7 @@ int bsvi_fail(int code, const std::string& msg) { return fail(code, msg); }   //
             return fail(BSVI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
     } while (0)
 
-struct bsvi_program {
-    bsvi_program_desc d;
-    void* dev_blob = nullptr;       // one allocation holding every table
-    const uint4* code = nullptr;
-    const uint4* aux = nullptr;
-    const bsvi_record* records = nullptr;
-    const bsvi_uniform_entry* uniform = nullptr;
-    const float* consts = nullptr;
-    const uint32_t* pu_ptr = nullptr;
-    const uint32_t* pu_idx = nullptr;
-    int max_lds = 0;
-    bool generic = false;   // contains instructions other than NAFF
-    const bsvi_program* shares[8] = {};   // bsvi_program_set_shares
-    uint32_t n_shares = 0;
-};
-
+static unsigned long long* g_debug_stamps = nullptr;
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 extern "C" const char* bsvi_last_error(void) { return g_last_error.c_str(); }
@@ -1809,6 +1535,13 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
     p->consts = (const float*)(base + o_con);
     p->pu_ptr = (const uint32_t*)(base + o_ptr);
     p->pu_idx = (const uint32_t*)(base + o_idx);
+    // the program-specialised kernels (specialize.cpp): sources now, hiprtc at the first launch
+    {
+        std::string why;
+        p->spec = bsvi_spec::create(*desc, why);
+        if (p->spec && bsvi_spec::upload(p->spec) != BSVI_OK) { bsvi_spec::destroy(p->spec); p->spec = nullptr; }
+        if (!p->spec && getenv("BSVI_DEBUG")) fprintf(stderr, "bsvi: program not specialised: %s\n", why.c_str());
+    }
     // host pointers of the descriptor are not kept
     p->d.code = nullptr; p->d.records = nullptr; p->d.uniform = nullptr; p->d.consts = nullptr;
     p->d.param_uniform_ptr = nullptr; p->d.param_uniform_idx = nullptr;
@@ -1868,6 +1601,7 @@ extern "C" int bsvi_program_create(const bsvi_program_desc* desc, bsvi_program**
 
 extern "C" void bsvi_program_destroy(bsvi_program* p) {
     if (!p) return;
+    if (p->spec) bsvi_spec::destroy(p->spec);
     if (p->dev_blob) hipFree(p->dev_blob);
     delete p;
 }
@@ -1981,10 +1715,31 @@ static size_t mw_bytes(const bsvi_program* p) {
 
 extern "C" size_t bsvi_workspace_bytes(const bsvi_program* p, uint32_t n_local) {
     if (!p || !n_local) return 0;
-    return base_ws_bytes(p, n_local) + mw_bytes(p);
+    return base_ws_bytes(p, n_local) + mw_bytes(p) + (p->spec ? bsvi_spec::workspace_bytes(p->spec, n_local) : 0);
 }
 
-static unsigned long long* g_debug_stamps = nullptr;
+// the specialised kernels' region of the caller's workspace: behind the interpreter's regions
+static void* spec_workspace(const bsvi_program* p, const bsvi_elbo_args* a) {
+    if (!a->workspace_dev) return nullptr;
+    return (char*)a->workspace_dev + base_ws_bytes(p, a->n_samples_local) + mw_bytes(p);
+}
+
+// Try the program-specialised kernel for this call.  Returns 1 when it was launched, 0 when the interpreter should
+// run (no specialisation, BSVI_JIT=0, the generated kernel did not compile), or a negative bsvi_status.
+static int try_spec(const bsvi_program* p, const bsvi_elbo_args* a, int mode, const bsvi_opt_cfg* cfg, float* params,
+                    float* state, const uint8_t* mask, const uint8_t* mask_first, uint32_t pretraining, uint32_t n_iterations,
+                    float* loss_slot, float* finite_slot) {
+    if (!p->spec || g_debug_stamps || !bsvi_spec::applies(p->spec, a->n_samples_local, mode)) return 0;
+    bsvi_spec::Launch L;
+    L.a = a; L.mode = mode; L.cfg = cfg; L.params = params; L.state = state; L.mask = mask; L.mask_first = mask_first;
+    L.pretraining_iterations = pretraining; L.n_iterations = n_iterations; L.loss_slot = loss_slot; L.finite_slot = finite_slot;
+    L.workspace = spec_workspace(p, a);
+    const int rc = bsvi_spec::launch(p->spec, p, L);
+    if (rc == BSVI_OK) return 1;
+    if (rc == BSVI_ERR_UNSUPPORTED) return 0;
+    return rc;
+}
+
 // diagnostic hook: device buffer of 10 uint64 receiving (s_memtime, s_memrealtime) at 5 phase
 // boundaries of workgroup 0; pass NULL to switch off.  Not part of the product path.
 extern "C" void bsvi_debug_set_stamps(unsigned long long* dev) { g_debug_stamps = dev; }
@@ -2091,6 +1846,10 @@ static Geometry share_geometry(const bsvi_program* p, Geometry g, uint32_t n_loc
 extern "C" int bsvi_elbo_fwd_bwd(const bsvi_program* p, const bsvi_elbo_args* a) {
     if (!p || !a) return fail(BSVI_ERR_INVALID, "null argument");
     if (!a->out_dev) return fail(BSVI_ERR_INVALID, "out_dev is null");
+    {
+        const int sp = try_spec(p, a, bsvi_spec::MODE_SUMS, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
+        if (sp) return sp < 0 ? sp : BSVI_OK;
+    }
     Geometry g = choose_geometry(p, a->n_samples_local, false);
     if (!g.n_blocks) return fail(BSVI_ERR_RESOURCE, "program does not fit the LDS budget");
     const char* se = getenv("BSVI_ELBO_SHARES");
@@ -2163,6 +1922,11 @@ extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, con
     if (rc) return rc;
     if (!a->out_dev || !params_dev || !state_dev || !active_mask_dev) return fail(BSVI_ERR_INVALID, "null argument");
     if (a->n_samples_local != a->n_samples_global) return fail(BSVI_ERR_INVALID, "bsvi_svi_step is the single-GPU path");
+    {
+        const int sp = try_spec(p, a, bsvi_spec::MODE_STEP, cfg, params_dev, state_dev, active_mask_dev, active_mask_dev, 0, 1,
+                                loss_slot_dev, finite_slot_dev);
+        if (sp) return sp < 0 ? sp : BSVI_OK;
+    }
     Geometry g = choose_geometry(p, a->n_samples_local, false);
     if (!g.n_blocks) return fail(BSVI_ERR_RESOURCE, "program does not fit the LDS budget");
     g = share_geometry(p, g, a->n_samples_local, a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || g_debug_stamps);
@@ -2192,6 +1956,7 @@ static bool multi_persistent_applies(const bsvi_program* p, uint32_t n_local) {
 
 extern "C" int bsvi_persistent_supported(const bsvi_program* p, uint32_t n_local) {
     if (!p || !n_local) return 0;
+    if (p->spec && bsvi_spec::applies(p->spec, n_local, bsvi_spec::MODE_LOOP)) return 1;
     if (multi_persistent_applies(p, n_local)) return 1;
     // One launch for the whole loop pays when the single workgroup runs the fast layout, or when several
     // workgroups would not run it either; a spilled (global-slot) workgroup is always slower than many LDS ones.
@@ -2242,6 +2007,7 @@ extern "C" int bsvi_program_set_shares(bsvi_program* p, const bsvi_program* cons
 // how many shares of the program (2, 3 or 1 = none) the multi-workgroup trainer would run for this sample count
 extern "C" int bsvi_persistent_split_shares(const bsvi_program* p, uint32_t n_local) {
     if (!p || !n_local || !multi_persistent_applies(p, n_local)) return 1;
+    if (p->spec && bsvi_spec::applies(p->spec, n_local, bsvi_spec::MODE_LOOP)) return 1;
     const char* e = getenv("BSVI_PERSISTENT_SHARES");
     const uint32_t waves = (n_local + 63) / 64;
     // more shares mean more workgroups at the in-kernel exchange, which every workgroup walks in full: 2-3 shares
@@ -2283,6 +2049,11 @@ static int train_persistent_impl(const bsvi_program* p, const bsvi_program* cons
     if (!a->out_dev || !params_dev || !state_dev || !active_mask_dev || !active_mask_first_dev || !loss_curve_dev || !finite_dev)
         return fail(BSVI_ERR_INVALID, "null argument");
     if (a->n_samples_local != a->n_samples_global) return fail(BSVI_ERR_INVALID, "persistent trainer is the single-GPU path");
+    {
+        const int sp = try_spec(p, a, bsvi_spec::MODE_LOOP, cfg, params_dev, state_dev, active_mask_dev, active_mask_first_dev,
+                                pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);
+        if (sp) return sp < 0 ? sp : BSVI_OK;
+    }
     const bool multi = multi_persistent_applies(p, a->n_samples_local);
     Geometry g = choose_geometry(p, a->n_samples_local, true);
     if (multi && g.n_blocks != 1) {      // does not fit ONE workgroup, but one wave per workgroup does
@@ -2344,6 +2115,37 @@ static int train_persistent_impl(const bsvi_program* p, const bsvi_program* cons
 #undef BSVI_LAUNCH_P
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
+}
+
+// ---- program specialisation: introspection (tests, bench) -------------------------------------------
+extern "C" size_t bsvi_program_source(const bsvi_program_desc* desc, int variant, char* buf, size_t capacity) {
+    if (validate(desc) != BSVI_OK) return 0;
+    std::string why;
+    bsvi_spec::Spec* sp = bsvi_spec::create(*desc, why);
+    if (!sp) { fail(BSVI_ERR_UNSUPPORTED, "program not specialised: " + why); return 0; }
+    const std::string& src = bsvi_spec::source(sp, variant);
+    const size_t need = src.size() + 1;
+    if (buf && capacity >= need) memcpy(buf, src.c_str(), need);
+    bsvi_spec::destroy(sp);
+    return need;
+}
+
+extern "C" int bsvi_jit_compile(const char* source, size_t* code_bytes) {
+    if (!source) return fail(BSVI_ERR_INVALID, "null source");
+    std::vector<char> code;
+    std::string log;
+    const int rc = bsvi_spec::compile(source, code, log);
+    if (rc) return fail(rc, log);
+    if (code_bytes) *code_bytes = code.size();
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_program_engine(const bsvi_program* p, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads,
+                                   uint32_t* lds_bytes) {
+    if (!p) return 0;
+    if (!p->spec || !bsvi_spec::applies(p->spec, n_local, mode)) return 0;
+    bsvi_spec::geometry(p->spec, n_local, n_blocks, n_threads, lds_bytes);
+    return 1;
 }
 
 extern "C" int bsvi_max_lds_bytes(const bsvi_program* p) { return p ? p->max_lds : 0; }

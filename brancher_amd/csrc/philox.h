@@ -6,8 +6,10 @@
 // attempt), so a Monte-Carlo shard on any GPU sees the same stream it would see on one GPU
 // and the kernel never reads noise from HBM.  Philox4x32-10 (Salmon et al., SC'11).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace bsvi {
 

@@ -1,0 +1,40 @@
+// spec_args.h — kernel argument block of the program-specialised kernels: ONE definition for the generated device code
+// (spec_prelude.h, through hiprtc) and the host launcher (specialize.cpp).
+#pragma once
+#if !defined(__HIPCC_RTC__)
+#include <stdint.h>
+#endif
+#include "bsvi.h"
+
+namespace bsvi {
+
+enum { SPEC_MODE_SUMS = 0, SPEC_MODE_STEP = 1, SPEC_MODE_LOOP = 2 };
+
+// kernel argument block (mirrored by the host in specialize.cpp; plain data, 8-byte aligned pointers first)
+struct SpecArgs {
+    const bsvi_uniform_entry* uniform;   // [SPEC_N_UNIFORM]
+    const float* consts;
+    float* params;                       // read by the prologue; written by the fused optimizer step
+    const float* obs;
+    const float* noise;                  // [n_noise][n_local] or null -> Philox (diagnostic variant only)
+    float* samples_out;                  // diagnostic variant only
+    float* noise_out;
+    float* fvalue_out;
+    float* out;                          // [BSVI_OUT_HEADER + n_params]
+    float* partials;                     // [grid][2 + SPEC_N_UGRAD]   (grid > 1)
+    unsigned int* ticket;                // arrival counter, zero between launches (grid > 1)
+    const uint32_t* pu_ptr;              // CSR theta -> uniform entries, entries given as POSITIONS in the order the
+    const uint32_t* pu_pos;              //   generated body completes them (spec_du)
+    const uint32_t* pu_idx;              //   ... and as uniform-table indices (for the transform)
+    float* state;                        // optimizer state [4][n_params]
+    const uint8_t* mask;                 // active parameters
+    const uint8_t* mask_first;           // ... while iteration <= pretraining_iterations (loop mode)
+    float* loss_slot;                    // step: one slot (or null); loop: the loss curve
+    float* finite_slot;
+    uint32_t n_local, n_global, sample_base, mode;
+    uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
+    uint32_t n_iterations, pretraining_iterations, n_params, reserved;
+    bsvi_opt_cfg cfg;
+};
+
+}  // namespace bsvi

@@ -1,0 +1,658 @@
+// specialize.cpp — program specialisation: a model program (include/bsvi.h) becomes straight-line HIP for gfx950.
+//
+// The interpreter of elbo_kernel.hip pays ~170-200 instructions per node visit for fetch, decode and the LDS round
+// trips of its memory-to-memory operands; the arithmetic of a Normal node is ~15.  A model is compiled ONCE per
+// (joint, posterior, estimator) and then evaluated thousands of times (brancher/inference.py:95-108), so the library
+// generates the per-sample body as HIP source — every slot a register, every record loop unrolled, every weight and
+// flag a literal — wraps it in the hand-written frame of spec_prelude.h / spec_main.h, and compiles it with hiprtc at
+// the first launch.  What the reference re-derives per call in Python (variables.py:486-570,718-749: graph walk,
+// name mapping, broadcasting) was already resolved by the lowering; this removes the last interpretive layer.
+//
+// Semantics are the interpreter's, instruction for instruction (elbo_kernel.hip exec_forward / exec_backward /
+// naff_sink and the two sweeps of elbo_block): the parity tests run every fixture through both engines.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "bsvi.h"
+#include "bsvi_internal.h"
+#include "spec_args.h"
+#include "jit_headers.inc"      // kJitHeaderNames / kJitHeaderTexts: the device headers, embedded by the Makefile
+
+namespace bsvi_spec {
+
+using bsvi::SpecArgs;
+
+// ---------------------------------------------------------------------------------------------------------------
+//  the generator
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Insn { uint32_t w0, dst, a, b, c, s, imm0, imm1; };
+
+constexpr size_t kMaxVisits = 12000;     // unrolled instruction visits (forward + reverse) a body may have
+constexpr uint32_t kKeepEpsRows = 64;    // up to this many noise rows stay in registers for the reverse sweep
+
+std::string fmt(const char* f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+std::string flit(uint32_t bits) {       // a float literal that round-trips
+    float x;
+    memcpy(&x, &bits, 4);
+    if (!isfinite(x)) return fmt("__uint_as_float(0x%08xu)", bits);
+    if (x == (float)(long long)x && fabsf(x) < 1e6f) return fmt("%.1ff", (double)x);
+    return fmt("%.9gf", (double)x);
+}
+
+class Emitter {
+public:
+    Emitter(const bsvi_program_desc& d, bool diag, uint32_t te) : d_(d), diag_(diag), te_(te) {
+        keep_eps_ = d.n_noise <= kKeepEpsRows;
+        du_total_.assign(d.n_uniform_grad, 0);
+        du_seen_.assign(d.n_uniform_grad, 0);
+    }
+
+    bool run(std::string& why) {
+        counting_ = true;
+        walk();
+        if (visits_ > kMaxVisits) { why = fmt("unrolled stream has %zu instruction visits (limit %zu)", visits_, kMaxVisits); return false; }
+        counting_ = false;
+        body_.clear();
+        fwd_groups_.clear(); rev_groups_.clear(); node_rows_.clear();
+        walk();
+        // entries nothing contributed to still own a position (their gradient is 0)
+        for (uint32_t k = 0; k < d_.n_uniform_grad; ++k)
+            if (!du_total_[k]) complete(k, "0.0f");
+        const uint32_t n = (uint32_t)order_.size();
+        if (n % te_) line(fmt("spec_du_flush(TRw, WSw, T.lane, %uu, %uu);", n - n % te_, n % te_));
+        return true;
+    }
+
+    const std::string& body() const { return body_; }
+    const std::vector<uint32_t>& order() const { return order_; }     // position -> uniform entry
+    std::string declarations() const {
+        std::string s;
+        for (uint32_t i = 0; i < d_.n_slots; ++i) s += fmt("    float v_%u = 0.0f, a_%u = 0.0f;\n", i, i);
+        for (uint32_t k = 0; k < d_.n_uniform_grad; ++k) if (du_total_[k]) s += fmt("    float du_%u = 0.0f;\n", k);
+        for (uint32_t g : all_groups_) s += fmt("    float pn_%u_0 = 0.0f, pn_%u_1 = 0.0f, pn_%u_2 = 0.0f, pn_%u_3 = 0.0f;\n", g, g, g, g);
+        for (uint32_t r : eps_rows_) s += fmt("    float ez_%u = 0.0f;\n", r);
+        for (uint32_t r : all_node_rows_) s += fmt("    float ns_%u = 0.0f;\n", r);
+        return s;
+    }
+
+private:
+    const bsvi_program_desc& d_;
+    bool diag_;
+    uint32_t te_;
+    bool keep_eps_ = true, counting_ = true;
+    size_t visits_ = 0;
+    std::string body_;
+    std::vector<uint32_t> du_total_, du_seen_, order_;
+    std::set<uint32_t> fwd_groups_, rev_groups_, all_groups_, eps_rows_, node_rows_, all_node_rows_;
+
+    Insn insn(uint32_t pc) const {
+        Insn I;
+        memcpy(&I, d_.code + 8 * (size_t)pc, 32);
+        return I;
+    }
+    void line(const std::string& s) { if (!counting_) { body_ += "    "; body_ += s; body_ += "\n"; } }
+
+    // ---- operands (include/bsvi.h: byte_offset | walks<<30 | per_lane<<31)
+    struct Opnd { bool lane; uint32_t idx; };
+    static Opnd resolve(uint32_t o, uint32_t e) {
+        const bool lane = o >> 31;
+        const uint32_t step = ((o >> 30) & 1u) * (lane ? 8u : 4u);
+        const uint32_t off = (o & 0x3FFFFFFFu) + e * step;
+        return Opnd{lane, lane ? off / 8u : off / 4u};
+    }
+    std::string val(uint32_t o, uint32_t e) const {
+        const Opnd p = resolve(o, e);
+        return p.lane ? fmt("v_%u", p.idx) : fmt("SPEC_U(%u)", p.idx);
+    }
+    void complete(uint32_t k, const std::string& expr) {
+        if (counting_) return;
+        const uint32_t pos = (uint32_t)order_.size();
+        order_.push_back(k);
+        line(fmt("SPEC_DU(%uu, %s);", pos, expr.c_str()));
+        if ((pos + 1) % te_ == 0) line(fmt("spec_du_flush(TRw, WSw, T.lane, %uu, %uu);", pos + 1 - te_, te_));
+    }
+    // scatter an adjoint: slots accumulate in their register; parameter-sourced uniform entries in theirs, leaving
+    // through the transpose tile at their last contribution; constants and observed data take none
+    void add_adj(uint32_t o, uint32_t e, const std::string& expr) {
+        const Opnd p = resolve(o, e);
+        if (p.lane) { line(fmt("a_%u += %s;", p.idx, expr.c_str())); return; }
+        if (p.idx >= d_.n_uniform_grad) return;
+        if (counting_) { ++du_total_[p.idx]; return; }
+        line(fmt("du_%u += %s;", p.idx, expr.c_str()));
+        if (++du_seen_[p.idx] == du_total_[p.idx]) complete(p.idx, fmt("du_%u", p.idx));
+    }
+
+    // ---- noise of a Normal draw
+    std::string normal_var(uint32_t row, bool reverse) {
+        const uint32_t g = row >> 2, j = row & 3u;
+        std::set<uint32_t>& have = (reverse && !keep_eps_) ? rev_groups_ : fwd_groups_;
+        if (!have.count(g)) {
+            have.insert(g);
+            all_groups_.insert(g);
+            if (diag_) line(fmt("if (!noise) spec_normals4(A, T, %uu, pn_%u_0, pn_%u_1, pn_%u_2, pn_%u_3);", g, g, g, g, g));
+            else line(fmt("spec_normals4(A, T, %uu, pn_%u_0, pn_%u_1, pn_%u_2, pn_%u_3);", g, g, g, g, g));
+        }
+        return fmt("pn_%u_%u", g, j);
+    }
+    std::string eps_forward(uint32_t row) {
+        const std::string pn = normal_var(row, false);
+        if (!diag_) return pn;
+        eps_rows_.insert(row);
+        line(fmt("ez_%u = noise ? noise[(size_t)%uu * A.n_local + T.nc] : %s;", row, row, pn.c_str()));
+        return fmt("ez_%u", row);
+    }
+    std::string eps_reverse(uint32_t row) {
+        if (keep_eps_) return diag_ ? fmt("ez_%u", row) : fmt("pn_%u_%u", row >> 2, row & 3u);
+        const std::string pn = normal_var(row, true);
+        if (!diag_) return pn;
+        line(fmt("ez_%u = noise ? noise[(size_t)%uu * A.n_local + T.nc] : %s;", row, row, pn.c_str()));
+        return fmt("ez_%u", row);
+    }
+    void diag_outputs(uint32_t row, const std::string& v, const std::string& noise) {
+        if (!diag_) return;
+        line(fmt("if (T.active) { if (A.samples_out) A.samples_out[(size_t)%uu * A.n_local + T.n] = %s; "
+                 "if (A.noise_out) A.noise_out[(size_t)%uu * A.n_local + T.n] = %s; }", row, v.c_str(), row, noise.c_str()));
+    }
+
+    // ---- forward of one instruction at element e (elbo_kernel.hip exec_forward)
+    void forward(const Insn& I, uint32_t e, bool nodes) {
+        const uint32_t op = I.w0 & 0xFFu, flags = (I.w0 >> 8) & 0xFFu, dist = (I.w0 >> 16) & 0xFFu;
+        if (op == BSVI_OP_NAFF) {
+            if (!nodes) return;
+            ++visits_;
+            if (counting_) return;
+            line("{");
+            line(fmt("  const float S = %s, loc = %s * %s + %s;", val(I.s, e).c_str(), val(I.a, e).c_str(), val(I.b, e).c_str(), val(I.c, e).c_str()));
+            std::string v = val(I.dst, e);
+            if (flags & BSVI_F_SAMPLE) {
+                const uint32_t row = resolve(I.dst, e).idx;
+                const std::string eps = eps_forward(row);
+                if (flags & BSVI_F_GIVEN) line(fmt("  %s = %s;", v.c_str(), eps.c_str()));
+                else line(fmt("  %s = loc + %s * S;", v.c_str(), eps.c_str()));
+                diag_outputs(row, v, eps);
+            }
+            if (flags & BSVI_F_ENT) line(fmt("  T.f += %s * (kHalfLog2PiE + spec_log(S));", flit(I.imm1).c_str()));
+            if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+                line(fmt("  const float lp = spec_naff_lp(%s, loc, S);", v.c_str()));
+                line(fmt("  T.f += %s * lp;", flit(I.imm0).c_str()));
+                if (flags & BSVI_F_WF) line("  T.lq += lp;");
+            }
+            line("}");
+        } else if (op == BSVI_OP_BIN) {
+            ++visits_;
+            if (counting_) return;
+            const std::string a = val(I.a, e), b = val(I.b, e), y = val(I.dst, e);
+            switch (flags) {
+            case BSVI_B_ADD: line(fmt("%s = %s + %s;", y.c_str(), a.c_str(), b.c_str())); break;
+            case BSVI_B_SUB: line(fmt("%s = %s - %s;", y.c_str(), a.c_str(), b.c_str())); break;
+            case BSVI_B_MUL: line(fmt("%s = %s * %s;", y.c_str(), a.c_str(), b.c_str())); break;
+            case BSVI_B_DIV: line(fmt("%s = %s / %s;", y.c_str(), a.c_str(), b.c_str())); break;
+            case BSVI_B_POW: line(fmt("%s = pow_ff(%s, %s);", y.c_str(), a.c_str(), b.c_str())); break;
+            default: line(fmt("%s = (%s == %s) ? 1.0f : 0.0f;", y.c_str(), a.c_str(), b.c_str())); break;
+            }
+        } else if (op == BSVI_OP_UN) {
+            ++visits_;
+            if (counting_) return;
+            line(fmt("%s = unop<true>(%uu, %s, %s);", val(I.dst, e).c_str(), flags, val(I.a, e).c_str(), flit(I.imm0).c_str()));
+        } else if (op == BSVI_OP_NODE) {
+            if (!nodes) return;
+            ++visits_;
+            if (counting_) return;
+            line("{");
+            line(fmt("  const float p0 = %s, p1 = %s;", val(I.a, e).c_str(), val(I.b, e).c_str()));
+            const std::string v = val(I.dst, e);
+            if (flags & BSVI_F_SAMPLE) {
+                const uint32_t row = resolve(I.dst, e).idx;
+                node_rows_.insert(row);
+                all_node_rows_.insert(row);
+                const std::string draw = fmt("{ const float2 dr = philox_draw(spec_key(A, T), %u, p0, p1, %uu); %s = dr.x; ns_%u = dr.y; }",
+                                             dist, row, v.c_str(), row);
+                if (diag_) {
+                    const std::string given = (flags & BSVI_F_GIVEN) ? fmt("ns_%u", row) : fmt("sample_from_noise_generic(%u, p0, p1, ns_%u)", dist, row);
+                    line(fmt("  if (noise) { ns_%u = noise[(size_t)%uu * A.n_local + T.nc]; %s = %s; } else %s", row, row, v.c_str(), given.c_str(), draw.c_str()));
+                } else {
+                    line("  " + draw);
+                }
+                diag_outputs(row, v, fmt("ns_%u", row));
+            }
+            if (flags & BSVI_F_ENT) line(fmt("  T.f += %s * entropy_generic(%u, p0, p1);", flit(I.imm1).c_str(), dist));
+            if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+                line(fmt("  const float lp = logp_generic(%u, %s, p0, p1);", dist, v.c_str()));
+                line(fmt("  T.f += %s * lp;", flit(I.imm0).c_str()));
+                if (flags & BSVI_F_WF) line("  T.lq += lp;");
+            }
+            line("}");
+        }
+    }
+
+    // ---- a model log-prob term N(value | A*B + C, S) finished in the forward sweep (elbo_kernel.hip naff_sink)
+    void naff_sink(const Insn& I, uint32_t e) {
+        ++visits_;
+        const std::string A = val(I.a, e), B = val(I.b, e);
+        if (!counting_) {
+            line("{");
+            line(fmt("  float gl, gs; spec_naff_sink(%s, %s, %s * %s + %s, %s, T.f, gl, gs);", flit(I.imm0).c_str(), val(I.dst, e).c_str(),
+                     A.c_str(), B.c_str(), val(I.c, e).c_str(), val(I.s, e).c_str()));
+        }
+        add_adj(I.dst, e, "-gl");
+        add_adj(I.a, e, "gl * " + B);
+        add_adj(I.b, e, "gl * " + A);
+        add_adj(I.c, e, "gl");
+        add_adj(I.s, e, "gs");
+        line("}");
+    }
+
+    // ---- reverse of one instruction at element e (elbo_kernel.hip exec_backward)
+    void backward(const Insn& I, uint32_t e) {
+        const uint32_t op = I.w0 & 0xFFu, flags = (I.w0 >> 8) & 0xFFu, dist = (I.w0 >> 16) & 0xFFu;
+        ++visits_;
+        if (op == BSVI_OP_NAFF) {
+            const std::string A = val(I.a, e), B = val(I.b, e), v = val(I.dst, e);
+            if (!counting_) {
+                line("{");
+                line(fmt("  const float S = %s, loc = %s * %s + %s;", val(I.s, e).c_str(), A.c_str(), B.c_str(), val(I.c, e).c_str()));
+                line("  float gv = 0.0f, gl = 0.0f, gs = 0.0f;");
+                if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+                    const std::string gw = (flags & BSVI_F_WF) ? fmt("(%s + fweight)", flit(I.imm0).c_str()) : flit(I.imm0);
+                    line(fmt("  spec_naff_lp_bwd(%s, %s, loc, S, gv, gl, gs);", gw.c_str(), v.c_str()));
+                }
+                if (flags & BSVI_F_ENT) line(fmt("  gs += %s * spec_rcp(S);", flit(I.imm1).c_str()));
+            }
+            if (flags & BSVI_F_SAMPLE) {
+                // a sampled latent's own adjoint is its incoming gradient: folded into loc / scale, left unchanged
+                if (!counting_) {
+                    const Opnd dst = resolve(I.dst, e);
+                    const std::string eps = eps_reverse(dst.idx);
+                    line(fmt("  const float zb = a_%u + gv;", dst.idx));
+                    line("  gl += zb;");
+                    line(fmt("  gs += zb * %s;", eps.c_str()));
+                }
+            } else {
+                add_adj(I.dst, e, "gv");
+            }
+            add_adj(I.a, e, "gl * " + B);
+            add_adj(I.b, e, "gl * " + A);
+            add_adj(I.c, e, "gl");
+            add_adj(I.s, e, "gs");
+            line("}");
+        } else if (op == BSVI_OP_BIN) {
+            const std::string a = val(I.a, e), b = val(I.b, e);
+            const Opnd dst = resolve(I.dst, e);
+            const std::string g = fmt("a_%u", dst.idx), y = fmt("v_%u", dst.idx);
+            switch (flags) {
+            case BSVI_B_ADD: add_adj(I.a, e, g); add_adj(I.b, e, g); break;
+            case BSVI_B_SUB: add_adj(I.a, e, g); add_adj(I.b, e, "-" + g); break;
+            case BSVI_B_MUL: add_adj(I.a, e, g + " * " + b); add_adj(I.b, e, g + " * " + a); break;
+            case BSVI_B_DIV:
+                line(fmt("{ const float ga = %s / %s;", g.c_str(), b.c_str()));
+                add_adj(I.a, e, "ga");
+                add_adj(I.b, e, "-ga * " + y);
+                line("}");
+                break;
+            case BSVI_B_POW:
+                line(fmt("{ const float g = %s, pa = %s, pb = %s;", g.c_str(), a.c_str(), b.c_str()));
+                add_adj(I.a, e, "g * pb * pow_ff(pa, pb - 1.0f)");
+                add_adj(I.b, e, "((g == 0.0f) ? 0.0f : g * " + y + " * logf(pa))");
+                line("}");
+                break;
+            default: break;
+            }
+        } else if (op == BSVI_OP_UN) {
+            const Opnd dst = resolve(I.dst, e);
+            const std::string a = val(I.a, e);
+            add_adj(I.a, e, fmt("a_%u * unop_grad<true>(%uu, %s, v_%u, %s)", dst.idx, flags, a.c_str(), dst.idx, flit(I.imm0).c_str()));
+        } else if (op == BSVI_OP_NODE) {
+            const std::string v = val(I.dst, e);
+            if (!counting_) {
+                line("{");
+                line(fmt("  const float p0 = %s, p1 = %s;", val(I.a, e).c_str(), val(I.b, e).c_str()));
+                line("  float gv = 0.0f, g0 = 0.0f, g1 = 0.0f;");
+                if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
+                    const std::string gw = (flags & BSVI_F_WF) ? fmt("(%s + fweight)", flit(I.imm0).c_str()) : flit(I.imm0);
+                    line(fmt("  { const float4 r = logp_bwd_generic(%u, %s, p0, p1, %s); gv += r.x; g0 += r.y; g1 += r.z; }", dist, v.c_str(), gw.c_str()));
+                }
+                if (flags & BSVI_F_ENT)
+                    line(fmt("  { const float2 r = entropy_bwd_generic(%u, p0, p1, %s); g0 += r.x; g1 += r.y; }", dist, flit(I.imm1).c_str()));
+            }
+            if (flags & BSVI_F_SAMPLE) {
+                if (!counting_) {
+                    const Opnd dst = resolve(I.dst, e);
+                    const bool base = dist == BSVI_DIST_LOGNORMAL || dist == BSVI_DIST_CAUCHY || dist == BSVI_DIST_LAPLACE;
+                    const std::string noise = base ? fmt("ns_%u", dst.idx) : v;
+                    line(fmt("  { const float2 r = sample_bwd_generic(%u, %s, p0, p1, %s, a_%u + gv); g0 += r.x; g1 += r.y; }",
+                             dist, v.c_str(), noise.c_str(), dst.idx));
+                }
+            } else {
+                add_adj(I.dst, e, "gv");
+            }
+            add_adj(I.a, e, "g0");
+            add_adj(I.b, e, "g1");
+            line("}");
+        }
+    }
+
+    void zero_temps(uint32_t base, uint32_t n) {
+        for (uint32_t t = 0; t < n; ++t) line(fmt("a_%u = 0.0f;", base + t));
+    }
+
+    // ---- the two sweeps of elbo_block
+    void walk() {
+        visits_ = 0;
+        for (uint32_t pc = 0; pc < d_.n_code;) {
+            const Insn I = insn(pc);
+            const uint32_t op = I.w0 & 0xFFu;
+            const bool sink = (I.w0 >> 24) & BSVI_R_SINK;
+            if (op == BSVI_OP_REC_BEGIN) {
+                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                for (uint32_t e = 0; e < n_elems && visits_ <= kMaxVisits; ++e) {
+                    for (uint32_t j = 1; j <= n; ++j) forward(insn(pc + j), e, true);
+                    if (sink) {
+                        zero_temps(temp_base, n_temps);
+                        for (uint32_t j = n; j >= 1; --j) backward(insn(pc + j), e);
+                    }
+                }
+                pc += n + 2;
+            } else {
+                if (sink && op == BSVI_OP_NAFF) {
+                    naff_sink(I, 0);
+                } else {
+                    forward(I, 0, true);
+                    if (sink) backward(I, 0);
+                }
+                pc += 1;
+            }
+            if (visits_ > kMaxVisits) return;
+        }
+        line("const float fweight = T.f; (void)fweight;");
+        if (diag_) line("if (A.fvalue_out && T.active) { A.fvalue_out[T.n] = T.f; A.fvalue_out[(size_t)A.n_local + T.n] = T.lq; }");
+        for (uint32_t pc = d_.n_code; pc > 0;) {
+            const Insn I = insn(pc - 1);
+            const uint32_t op = I.w0 & 0xFFu;
+            const bool sink = (I.w0 >> 24) & BSVI_R_SINK;
+            if (op == BSVI_OP_REC_END) {
+                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
+                const uint32_t first = pc - 1 - n;
+                if (!sink) {
+                    for (uint32_t e = n_elems; e-- > 0 && visits_ <= kMaxVisits;) {
+                        for (uint32_t j = 0; j < n; ++j) forward(insn(first + j), e, false);     // re-materialise the temps
+                        zero_temps(temp_base, n_temps);
+                        for (uint32_t j = n; j-- > 0;) backward(insn(first + j), e);
+                    }
+                }
+                pc = first - 1;
+            } else {
+                if (!sink) backward(I, 0);
+                pc -= 1;
+            }
+            if (visits_ > kMaxVisits) return;
+        }
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+//  a program's specialisation: sources, compiled modules, device tables
+// ---------------------------------------------------------------------------------------------------------------
+struct Variant {
+    std::string src;
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    bool failed = false;
+};
+
+struct Spec {
+    uint32_t n_params = 0, n_uniform = 0, n_ugrad = 0, n_obs = 0, n_noise = 0;
+    uint32_t max_threads = 512, te = 64;
+    uint32_t lds_bytes = 0;
+    std::vector<uint32_t> pu_ptr_host, pu_pos_host;       // CSR in positions
+    Variant variant[2];                                   // 0 lean, 1 diagnostic
+    void* dev = nullptr;                                  // [tickets: 256 B][pu_pos]
+    unsigned int* tickets = nullptr;
+    const uint32_t* pu_pos = nullptr;
+    uint32_t launch_seq = 0;
+    std::mutex mu;
+};
+
+static uint32_t lds_floats(uint32_t n_uniform, uint32_t n_obs, uint32_t n_ugrad, uint32_t max_threads, uint32_t te) {
+    const uint32_t W = max_threads / 64;
+    const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nug_pad = (n_ugrad + te + 3) / 4 * 4;
+    return u_pad + W * nug_pad + (2 * W + 8) + W * te * 65;
+}
+
+Spec* create(const bsvi_program_desc& d, std::string& why) {
+    if (!d.n_code) { why = "empty program"; return nullptr; }
+    // launch bounds: a sample keeps 2 registers per slot (value, adjoint) plus its noise; 512 threads leave 256
+    // registers per lane, 256 threads the whole 512-entry file (MI355X_MICROARCH.md, register files)
+    uint32_t max_threads = 512;
+    const uint32_t live = 2 * d.n_slots + (d.n_noise <= kKeepEpsRows ? d.n_noise : 0) + 48;
+    if (live > 232) max_threads = 256;
+    uint32_t te = 64;
+    while (te > 8 && lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
+    if (lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
+        max_threads = 256;
+        te = 64;
+        while (te > 8 && lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
+        if (lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
+            why = "uniform table does not fit LDS";
+            return nullptr;
+        }
+    }
+    Spec* s = new Spec();
+    s->n_params = d.n_params; s->n_uniform = d.n_uniform; s->n_ugrad = d.n_uniform_grad; s->n_obs = d.n_obs; s->n_noise = d.n_noise;
+    s->max_threads = max_threads; s->te = te;
+    s->lds_bytes = lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u;
+    std::vector<uint32_t> order;
+    for (int v = 0; v < 2; ++v) {
+        Emitter E(d, v == 1, te);
+        if (!E.run(why)) { delete s; return nullptr; }
+        if (v == 0) order = E.order();
+        else if (order != E.order()) { why = "internal: variants disagree on the completion order"; delete s; return nullptr; }
+        std::string src;
+        src += "// generated by libbsvi (specialize.cpp) from a model program: do not edit\n";
+        src += "#define BSVI_SPECIALIZED 1\n";
+        src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
+                   d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
+        src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_TE %u\n#define SPEC_DIAG %d\n", d.estimator, max_threads, te, v);
+        src += "#include \"spec_prelude.h\"\n";
+        src += "namespace bsvi {\n";
+        src += "__device__ __forceinline__ void spec_body(const SpecBody& A, SpecLane& T, float* TRw, float* WSw) {\n";
+        if (v == 1) src += "    const float* const noise = A.noise;\n";
+        src += E.declarations();
+        src += E.body();
+        src += "}\n}  // namespace bsvi\n";
+        src += "#include \"spec_main.h\"\n";
+        s->variant[v].src = std::move(src);
+    }
+    // CSR theta -> positions
+    std::vector<uint32_t> pos_of(d.n_uniform_grad, 0);
+    for (uint32_t p = 0; p < order.size(); ++p) pos_of[order[p]] = p;
+    s->pu_ptr_host.assign(d.param_uniform_ptr, d.param_uniform_ptr + (d.n_params ? d.n_params + 1 : 0));
+    s->pu_pos_host.resize(d.n_uniform_grad);
+    for (uint32_t j = 0; j < d.n_uniform_grad; ++j) s->pu_pos_host[j] = pos_of[d.param_uniform_idx[j]];
+    return s;
+}
+
+void destroy(Spec* s) {
+    if (!s) return;
+    for (Variant& v : s->variant) if (v.module) (void)hipModuleUnload(v.module);
+    if (s->dev) (void)hipFree(s->dev);
+    delete s;
+}
+
+int upload(Spec* s) {
+    const size_t bytes = 256 + (size_t)s->pu_pos_host.size() * 4 + 256;
+    hipError_t e = hipMalloc(&s->dev, bytes);
+    if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("hipMalloc (specialiser tables): ") + hipGetErrorString(e));
+    e = hipMemset(s->dev, 0, bytes);
+    if (e == hipSuccess && !s->pu_pos_host.empty())
+        e = hipMemcpy((char*)s->dev + 256, s->pu_pos_host.data(), s->pu_pos_host.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("specialiser tables: ") + hipGetErrorString(e));
+    s->tickets = (unsigned int*)s->dev;
+    s->pu_pos = (const uint32_t*)((char*)s->dev + 256);
+    return BSVI_OK;
+}
+
+const std::string& source(const Spec* s, int variant) { return s->variant[variant ? 1 : 0].src; }
+
+// ---------------------------------------------------------------------------------------------------------------
+//  hiprtc
+// ---------------------------------------------------------------------------------------------------------------
+int compile(const std::string& src, std::vector<char>& code, std::string& log) {
+    hiprtcProgram prog = nullptr;
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "bsvi_spec.hip", kJitHeaderCount, kJitHeaderTexts, kJitHeaderNames);
+    if (r != HIPRTC_SUCCESS) { log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r); return BSVI_ERR_HIP; }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    r = hiprtcCompileProgram(prog, 3, opts);
+    size_t n = 0;
+    if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
+        log.resize(n);
+        (void)hiprtcGetProgramLog(prog, &log[0]);
+    }
+    if (r != HIPRTC_SUCCESS) {
+        log = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log;
+        (void)hiprtcDestroyProgram(&prog);
+        return BSVI_ERR_HIP;
+    }
+    size_t cs = 0;
+    r = hiprtcGetCodeSize(prog, &cs);
+    if (r == HIPRTC_SUCCESS) { code.resize(cs); r = hiprtcGetCode(prog, code.data()); }
+    (void)hiprtcDestroyProgram(&prog);
+    if (r != HIPRTC_SUCCESS) { log = std::string("hiprtcGetCode: ") + hiprtcGetErrorString(r); return BSVI_ERR_HIP; }
+    if (const char* dump = getenv("BSVI_JIT_DUMP")) {       // tools: keep the code object for llvm-objdump / llvm-readelf
+        if (FILE* f = fopen(dump, "wb")) { fwrite(code.data(), 1, code.size(), f); fclose(f); }
+    }
+    return BSVI_OK;
+}
+
+// code objects of this process, by source text: programs lowered twice (tests, estimator siblings) compile once
+static std::mutex g_cache_mu;
+static std::map<std::string, std::vector<char>> g_code_cache;
+
+static int ensure_compiled(Spec* s, int v) {
+    Variant& V = s->variant[v];
+    if (V.fn) return BSVI_OK;
+    if (V.failed) return BSVI_ERR_UNSUPPORTED;
+    std::vector<char> code;
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        auto it = g_code_cache.find(V.src);
+        if (it != g_code_cache.end()) code = it->second;
+    }
+    if (code.empty()) {
+        std::string log;
+        const int rc = compile(V.src, code, log);
+        if (rc) {
+            V.failed = true;
+            if (getenv("BSVI_DEBUG")) fprintf(stderr, "bsvi: specialised kernel did not compile:\n%s\n", log.c_str());
+            return bsvi_fail(BSVI_ERR_UNSUPPORTED, "specialised kernel did not compile: " + log.substr(0, 400));
+        }
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        g_code_cache[V.src] = code;
+    }
+    hipError_t e = hipModuleLoadData(&V.module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&V.fn, V.module, "bsvi_spec_kernel");
+    if (e != hipSuccess) {
+        V.failed = true;
+        V.fn = nullptr;
+        return bsvi_fail(BSVI_ERR_HIP, std::string("loading the specialised kernel: ") + hipGetErrorString(e));
+    }
+    return BSVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  launch
+// ---------------------------------------------------------------------------------------------------------------
+struct Geo { uint32_t blocks, threads; };
+static Geo geo(const Spec* s, uint32_t n_local) {
+    const uint32_t waves = (n_local + 63) / 64, max_waves = s->max_threads / 64;
+    if (waves <= max_waves) return Geo{1, waves * 64};
+    // many samples: 256-thread workgroups (one wave per SIMD), every one of them full but the last
+    const uint32_t threads = s->max_threads < 256 ? s->max_threads : 256;
+    return Geo{(n_local + threads - 1) / threads, threads};
+}
+
+void geometry(const Spec* s, uint32_t n_local, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes) {
+    const Geo g = geo(s, n_local);
+    if (n_blocks) *n_blocks = g.blocks;
+    if (n_threads) *n_threads = g.threads;
+    if (lds_bytes) *lds_bytes = s->lds_bytes;
+}
+
+size_t workspace_bytes(const Spec* s, uint32_t n_local) {
+    const Geo g = geo(s, n_local);
+    return ((size_t)g.blocks * (2 + s->n_ugrad) * 4 + 255) / 256 * 256 + 256;
+}
+
+bool applies(const Spec* s, uint32_t n_local, int mode) {
+    if (!s || !n_local) return false;
+    const char* e = getenv("BSVI_JIT");
+    if (e && e[0] == '0') return false;
+    if (s->variant[0].failed || s->variant[1].failed) return false;
+    if (mode == MODE_LOOP && geo(s, n_local).blocks != 1) return false;
+    return true;
+}
+
+int launch(Spec* s, const bsvi_program* p, const Launch& L) {
+    const bsvi_elbo_args* a = L.a;
+    if (!a->params_dev && s->n_params) return bsvi_fail(BSVI_ERR_INVALID, "params_dev is null");
+    if (!a->obs_dev && s->n_obs) return bsvi_fail(BSVI_ERR_INVALID, "obs_dev is null");
+    if (!a->out_dev) return bsvi_fail(BSVI_ERR_INVALID, "out_dev is null");
+    if (!a->n_samples_local || !a->n_samples_global) return bsvi_fail(BSVI_ERR_INVALID, "zero samples");
+    const int v = (a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev) ? 1 : 0;
+    uint32_t seq;
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        const int rc = ensure_compiled(s, v);
+        if (rc) return rc;
+        seq = s->launch_seq++;
+    }
+    const Geo g = geo(s, a->n_samples_local);
+    if (g.blocks > 1 && !L.workspace) return bsvi_fail(BSVI_ERR_INVALID, "workspace_dev is null");
+    SpecArgs A;
+    memset(&A, 0, sizeof A);
+    A.uniform = p->uniform; A.consts = p->consts;
+    A.params = L.params ? L.params : const_cast<float*>(a->params_dev);
+    A.obs = a->obs_dev; A.noise = a->noise_dev;
+    A.samples_out = a->samples_out_dev; A.noise_out = a->noise_out_dev; A.fvalue_out = a->fvalue_out_dev;
+    A.out = a->out_dev;
+    A.partials = (float*)L.workspace;
+    A.ticket = s->tickets + (seq % 64u);     // library-owned, zero between launches
+    A.pu_ptr = p->pu_ptr; A.pu_pos = s->pu_pos; A.pu_idx = p->pu_idx;
+    A.state = L.state; A.mask = L.mask; A.mask_first = L.mask_first ? L.mask_first : L.mask;
+    A.loss_slot = L.loss_slot; A.finite_slot = L.finite_slot;
+    A.n_local = a->n_samples_local; A.n_global = a->n_samples_global; A.sample_base = a->sample_base;
+    A.mode = (uint32_t)L.mode;
+    A.seed_lo = (uint32_t)a->seed; A.seed_hi = (uint32_t)(a->seed >> 32);
+    A.offset_lo = (uint32_t)a->offset; A.offset_hi = (uint32_t)(a->offset >> 32);
+    A.n_iterations = L.n_iterations; A.pretraining_iterations = L.pretraining_iterations; A.n_params = s->n_params;
+    if (L.cfg) A.cfg = *L.cfg;
+    size_t size = sizeof A;
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    const hipError_t e = hipModuleLaunchKernel(s->variant[v].fn, g.blocks, 1, 1, g.threads, 1, 1, 0, (hipStream_t)a->stream, nullptr, config);
+    if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("hipModuleLaunchKernel (specialised kernel): ") + hipGetErrorString(e));
+    return BSVI_OK;
+}
+
+}  // namespace bsvi_spec

@@ -259,6 +259,8 @@ class CompiledELBO:
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
         self.native.ensure_shares(n_local)
+        if self.native.engine(n_local, 2)["engine"] == "specialised":
+            return False        # the program-specialised kernel keeps the whole loop in one launch
         return world == 1 and getattr(self.native, "_elbo_shares_set", 0) >= 4 \
             and os.environ.get("BSVI_ELBO_SHARES", "1") != "0"
 

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 OUT_HEADER = 4
 
 
@@ -109,6 +109,10 @@ EXPORTS = {
     "bsvi_train_persistent_split": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(ElboArgs),
                                               C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bsvi_program_source": (C.c_size_t, [C.POINTER(ProgramDesc), C.c_int, C.c_char_p, C.c_size_t]),
+    "bsvi_jit_compile": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t)]),
+    "bsvi_program_engine": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32)]),
     "bsvi_max_lds_bytes": (C.c_int, [C.c_void_p]),
     "bsvi_query_geometry": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
@@ -197,29 +201,55 @@ def _ptr(arr):
     return arr.ctypes.data_as(C.c_void_p) if arr is not None and arr.size else None
 
 
+def program_desc(program):
+    """lowered ``Program`` -> (bsvi_program_desc, the arrays it points into)"""
+    from brancher_amd.lowering import EST
+    k = dict(
+        uniform=np.ascontiguousarray(program.uniform), records=np.ascontiguousarray(program.records),
+        code=np.ascontiguousarray(program.code, dtype=np.uint32),
+        consts=np.ascontiguousarray(program.consts, dtype=np.float32),
+        ptr=np.ascontiguousarray(program.param_uniform_ptr, dtype=np.uint32),
+        idx=np.ascontiguousarray(program.param_uniform_idx, dtype=np.uint32))
+    assert k["uniform"].dtype.itemsize == C.sizeof(UniformEntry)
+    assert k["records"].dtype.itemsize == C.sizeof(Record)
+    d = ProgramDesc(abi_version=ABI_VERSION, n_params=program.n_params, n_consts=k["consts"].size,
+                    n_obs=program.obs.size, n_slots=program.n_slots, n_noise=program.n_noise,
+                    n_uniform=len(k["uniform"]), n_uniform_grad=program.n_uniform_grad,
+                    n_records=len(k["records"]), n_code=len(k["code"]), estimator=EST[program.estimator],
+                    uniform=_ptr(k["uniform"]), records=_ptr(k["records"]), code=_ptr(k["code"]),
+                    consts=_ptr(k["consts"]), param_uniform_ptr=_ptr(k["ptr"]), param_uniform_idx=_ptr(k["idx"]))
+    return d, k
+
+
+def specialised_source(program, variant=0):
+    """The HIP translation unit libbsvi generates for a lowered program (bsvi_program_source): variant 0 is the
+    training kernel, 1 the diagnostic one.  Host only — no device needed.  None when the program is left to the
+    interpreter kernels."""
+    lib = load()
+    d, keep = program_desc(program)
+    need = lib.bsvi_program_source(C.byref(d), variant, None, 0)
+    if need == 0:
+        return None
+    buf = C.create_string_buffer(need)
+    lib.bsvi_program_source(C.byref(d), variant, buf, need)
+    return buf.value.decode()
+
+
+def jit_compile(source):
+    """hiprtc-compile a generated translation unit for gfx950 (no device needed); returns the code-object size."""
+    n = C.c_size_t()
+    check(load().bsvi_jit_compile(source.encode(), C.byref(n)))
+    return n.value
+
+
 class NativeProgram:
     """Owns a ``bsvi_program*`` created from a lowered ``Program``."""
 
     def __init__(self, program):
-        from brancher_amd.lowering import EST
         lib = load()
         if lib.bsvi_device_count() < 1:
             raise NativeError("no MI355X / HIP device visible: the engine cannot run (no CPU fallback)")
-        self._keep = dict(
-            uniform=np.ascontiguousarray(program.uniform), records=np.ascontiguousarray(program.records),
-            code=np.ascontiguousarray(program.code, dtype=np.uint32),
-            consts=np.ascontiguousarray(program.consts, dtype=np.float32),
-            ptr=np.ascontiguousarray(program.param_uniform_ptr, dtype=np.uint32),
-            idx=np.ascontiguousarray(program.param_uniform_idx, dtype=np.uint32))
-        k = self._keep
-        assert k["uniform"].dtype.itemsize == C.sizeof(UniformEntry)
-        assert k["records"].dtype.itemsize == C.sizeof(Record)
-        d = ProgramDesc(abi_version=ABI_VERSION, n_params=program.n_params, n_consts=k["consts"].size,
-                        n_obs=program.obs.size, n_slots=program.n_slots, n_noise=program.n_noise,
-                        n_uniform=len(k["uniform"]), n_uniform_grad=program.n_uniform_grad,
-                        n_records=len(k["records"]), n_code=len(k["code"]), estimator=EST[program.estimator],
-                        uniform=_ptr(k["uniform"]), records=_ptr(k["records"]), code=_ptr(k["code"]),
-                        consts=_ptr(k["consts"]), param_uniform_ptr=_ptr(k["ptr"]), param_uniform_idx=_ptr(k["idx"]))
+        d, self._keep = program_desc(program)
         handle = C.c_void_p()
         check(lib.bsvi_program_create(C.byref(d), C.byref(handle)))
         self.handle = handle
@@ -239,6 +269,14 @@ class NativeProgram:
         return dict(n_blocks=nb.value, n_waves=nw.value, zglobal=mode == 2,
                     storage=("lds+wave_sum", "lds+lane_acc", "global")[mode], lanes_per_wave=lanes or 64,
                     lds_bytes=lds.value)
+
+    def engine(self, n_local, mode=0):
+        """which kernels serve a call over n_local samples (mode 0 fwd_bwd, 1 svi_step, 2 persistent loop):
+        dict(engine="specialised", n_blocks, n_threads, lds_bytes) or dict(engine="interpreter")"""
+        nb, nt, lds = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        if self.lib.bsvi_program_engine(self.handle, n_local, mode, C.byref(nb), C.byref(nt), C.byref(lds)):
+            return dict(engine="specialised", n_blocks=nb.value, n_threads=nt.value, lds_bytes=lds.value)
+        return dict(engine="interpreter")
 
     def persistent_supported(self, n_local):
         return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))

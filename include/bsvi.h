@@ -25,14 +25,23 @@
 #ifndef BSVI_H
 #define BSVI_H
 
+#if !defined(__HIPCC_RTC__)
 #include <stddef.h>
 #include <stdint.h>
+#else   /* hiprtc (the library's run-time specialiser) has no system headers */
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 4
+#define BSVI_ABI_VERSION 5
 
 typedef enum bsvi_status {
     BSVI_OK = 0,
@@ -306,6 +315,26 @@ int bsvi_train_persistent_split(const bsvi_program* p, const bsvi_program* const
 int bsvi_svi_step(const bsvi_program* prog, const bsvi_elbo_args* args, const bsvi_opt_cfg* cfg,
                   float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                   float* loss_slot_dev, float* finite_slot_dev);
+
+/* ---- program specialisation -----------------------------------------------------------------------------------
+ * bsvi_program_create also turns the instruction stream into straight-line HIP (every slot a register, every record
+ * loop unrolled, weights and flags literals) inside a hand-written kernel frame; hiprtc compiles it for gfx950 at the
+ * program's first launch, and bsvi_elbo_fwd_bwd / bsvi_svi_step / bsvi_train_persistent* run it in place of the
+ * interpreter kernels (one launch per call: the reductions, the chain rule to theta, finalize and the optimizer step
+ * are its epilogue).  The interpreter serves programs whose unrolled stream is too long, and everything when the
+ * environment has BSVI_JIT=0.  Replaces the same reference code as bsvi_elbo_fwd_bwd.
+ *
+ * bsvi_program_source: the generated translation unit of a program (variant 0: training kernel, in-kernel Philox
+ *   noise only; 1: diagnostic kernel with noise in / samples, noise and per-sample values out).  Host only — needs no
+ *   device.  Returns the byte count including the terminator (0: not specialised, see bsvi_last_error) and copies
+ *   when `capacity` suffices.
+ * bsvi_jit_compile: compile such a translation unit for gfx950 (hiprtc; needs no device).
+ * bsvi_program_engine: 1 when a call in `mode` (0 bsvi_elbo_fwd_bwd, 1 bsvi_svi_step, 2 bsvi_train_persistent*) over
+ *   n_local samples is served by the specialised kernel (and its launch geometry), 0 when by the interpreter. */
+size_t bsvi_program_source(const bsvi_program_desc* desc, int variant, char* buf, size_t capacity);
+int bsvi_jit_compile(const char* source, size_t* code_bytes);
+int bsvi_program_engine(const bsvi_program* prog, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads,
+                        uint32_t* lds_bytes);
 
 /* LDS bytes per workgroup the runtime granted to this program's kernels (160 KiB on gfx950). */
 int bsvi_max_lds_bytes(const bsvi_program* prog);

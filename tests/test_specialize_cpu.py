@@ -1,0 +1,67 @@
+"""Host side of the program specialiser (brancher_amd/csrc/specialize.cpp): the library turns a lowered program into a
+HIP translation unit and compiles it for gfx950 with hiprtc — neither step needs a GPU, so both are checked here for
+every scalar golden workload and for the BASELINE configurations.  What the generated kernels compute is checked on
+the GPU (tests/test_gpu_parity.py runs every fixture through the specialised kernels AND the interpreter)."""
+import re
+
+import numpy as np
+import pytest
+
+from conftest import Golden, golden_cases
+from brancher_amd import lowering, native, workloads as W
+
+SCALAR = [c for c in golden_cases() if not c.startswith("logreg")]
+
+
+def lowered(case, estimator="pathwise"):
+    model = Golden(case).build()
+    return lowering.lower(model, model.posterior_model, estimator)
+
+
+@pytest.mark.parametrize("case", SCALAR)
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_generated_kernels_compile_for_gfx950(case, estimator):
+    program = lowered(case, estimator)
+    for variant in (0, 1):
+        src = native.specialised_source(program, variant)
+        assert src is not None, native.load().bsvi_last_error()
+        assert "#define SPEC_ESTIMATOR %d" % lowering.EST[estimator] in src
+        assert native.jit_compile(src) > 0
+
+
+def test_source_structure_config1():
+    """README AR T=20 (BASELINE config 1): 63 instructions -> one straight-line body; every parameter-sourced uniform
+    entry leaves through exactly one SPEC_DU position; the lean variant never touches a noise tensor."""
+    model = W.build_readme_ar(W.native_api(), T=20)
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    lean, diag = native.specialised_source(program, 0), native.specialised_source(program, 1)
+    positions = [int(m) for m in re.findall(r"SPEC_DU\((\d+)u,", lean)]
+    assert sorted(positions) == list(range(program.n_uniform_grad))
+    assert positions == [int(m) for m in re.findall(r"SPEC_DU\((\d+)u,", diag)]      # same completion order: one CSR table
+    assert "noise[" not in lean and "noise[" in diag
+    assert lean.count("spec_normals4(") == (program.n_noise + 3) // 4                  # one Philox call per 4 rows
+    assert lean.count("spec_naff_sink(") == 41                                          # the model's log-prob terms
+    assert "for (" not in lean.split("spec_body")[1].split('#include "spec_main.h"')[0]  # no loops: fully unrolled
+
+
+def test_long_chain_keeps_fewer_registers():
+    """T=200 (BASELINE config 3): 201 noise rows are not kept for the reverse sweep (regenerated group by group), and the
+    launch bounds drop to 256 threads so that a lane may use the whole register file"""
+    model = W.build_readme_ar(W.native_api(), T=200)
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    src = native.specialised_source(program, 0)
+    assert "#define SPEC_MAX_THREADS 256" in src
+    assert src.count("spec_normals4(") == 2 * ((program.n_noise + 3) // 4)
+
+
+def test_unrolling_limit_declines():
+    """a program whose unrolled stream exceeds the generator's limit is left to the interpreter (not an error)"""
+    api = W.native_api()
+    model = W.build_multivariate_regression(api, n=100) if hasattr(W, "build_multivariate_regression") else None
+    if model is None:
+        pytest.skip("no wide workload builder")
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    src = native.specialised_source(program, 0)
+    # either outcome is legal; when declined the reason is reported
+    if src is None:
+        assert b"instruction visits" in native.load().bsvi_last_error()
