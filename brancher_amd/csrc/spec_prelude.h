@@ -5,9 +5,10 @@
 // few lines of arithmetic, the record loops are unrolled (specialize.cpp).  The generated translation unit is
 //
 //     #define SPEC_* ...            sizes of the program, launch bounds, variant
-//     #include "spec_prelude.h"     this file: argument block, per-lane state, node arithmetic, noise
-//     spec_body(...)                GENERATED: forward sweep, turn, reverse sweep of ONE Monte-Carlo sample
-//     #include "spec_main.h"        the kernel: uniform-table prologue, spec_body, fixed-order reductions,
+//     #include "spec_prelude.h"     this file: argument block, per-lane state, node arithmetic, noise, LDS image
+//     spec_draw(...)                GENERATED: the standard normals of one Monte-Carlo sample (Philox, or the caller's)
+//     spec_body(...)                GENERATED: forward sweep, turn, reverse sweep of that sample
+//     #include "spec_main.h"        the kernel: uniform-table prologue, spec_draw + spec_body, fixed-order reductions,
 //                                   chain rule to theta, finalize, optimizer step, in-kernel training loop
 //
 // and is compiled for gfx950 with hiprtc when the program is first launched.  One lane = one Monte-Carlo sample,
@@ -40,25 +41,33 @@ struct SpecLane {
     bool active;
 };
 
+// the standard normals of a sample, drawn BEFORE the barrier that publishes the uniform table (they do not depend on
+// it): registers after inlining.  Programs with more noise rows than the generator keeps draw inside the body instead.
+#ifndef SPEC_KEEP_NOISE
+#define SPEC_KEEP_NOISE 0
+#endif
+struct SpecNoise { float z[SPEC_KEEP_NOISE ? SPEC_KEEP_NOISE : 1]; };
+
 __device__ __forceinline__ float spec_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float spec_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // ---- Normal node with affine location, NormalVariable(loc = A*B + C, scale = S): BSVI_OP_NAFF -----------------
-__device__ __forceinline__ float spec_naff_lp(float v, float loc, float S) {
-    const float u = (v - loc) * spec_rcp(S);
-    return -0.5f * (u * u) - spec_log(S) - kLogSqrt2Pi;
+// rS = 1/S and lS = log S come from the caller: for a lane-uniform scale (the usual case: a transformed parameter)
+// they are entries of the uniform table's companions, computed once per iteration by the thread that owns the
+// parameter; for a per-sample scale they are v_rcp_f32 / v_log_f32 of it.
+__device__ __forceinline__ float spec_naff_lp(float v, float loc, float rS, float lS) {
+    const float u = (v - loc) * rS;
+    return -0.5f * (u * u) - lS - kLogSqrt2Pi;
 }
 // a model log-probability term with constant weight w: value into f, adjoints of loc and S out
-__device__ __forceinline__ void spec_naff_sink(float w, float v, float loc, float S, float& f, float& gloc, float& gS) {
-    const float rS = spec_rcp(S);
+__device__ __forceinline__ void spec_naff_sink(float w, float v, float loc, float rS, float lS, float& f, float& gloc, float& gS) {
     const float u = (v - loc) * rS;
-    f += w * (-0.5f * (u * u) - spec_log(S) - kLogSqrt2Pi);
+    f += w * (-0.5f * (u * u) - lS - kLogSqrt2Pi);
     gloc = w * u * rS;                   // d lp / d loc = (v - loc) / S^2
     gS = w * (u * u - 1.0f) * rS;
 }
 // reverse of the log-prob part of a posterior node: weight gw on log N(v | loc, S)
-__device__ __forceinline__ void spec_naff_lp_bwd(float gw, float v, float loc, float S, float& gv, float& gloc, float& gS) {
-    const float rS = spec_rcp(S);
+__device__ __forceinline__ void spec_naff_lp_bwd(float gw, float v, float loc, float rS, float& gv, float& gloc, float& gS) {
     const float d = v - loc, t = d * (rS * rS);
     gv = -gw * t;
     gloc = gw * t;
@@ -78,45 +87,61 @@ __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane&
     return PhiloxKey{T.nidx, A.seed_lo, A.seed_hi, T.off_lo, T.off_hi};
 }
 
-// ---- the uniform table and the per-lane gradient contributions -----------------------------------------------
-// LDS image of a workgroup (floats):
-//   [0, SPEC_U_PAD)                      uniform table U, then the observed data
-//   WS  [W][SPEC_NUG_PAD]                per-wave sums of d f / d U, in completion order ("positions")
-//   RED [SPEC_RED_FLOATS]                value / non-finite sums per wave, block totals, flags
-//   TR  [W][SPEC_TE * 65]                per-wave transpose tile: the lanes of a wave store their contribution to
-//                                        position p at TR[(p % TE) * 65 + lane]; every TE positions lane j adds up
-//                                        row j (64 conflict-free reads, fixed order) — ~3 instructions per entry and
-//                                        lane instead of a 10-instruction DPP reduction per entry
+// ---- LDS image of a workgroup (floats) -----------------------------------------------------------------------
+//   U    [SPEC_U_PAD]                   uniform table U, then the observed data
+//   UR   [SPEC_NU_PAD]                  1 / U[k]      } companions of the uniform table: what a Normal node needs
+//   UL   [SPEC_NU_PAD]                  log U[k]      } of a lane-uniform scale
+//   WS   [W][SPEC_NUG_PAD]              per-wave sums of d f / d U, in completion order ("positions")
+//   RED  [SPEC_RED_FLOATS]              value / non-finite sums per wave, block totals, flags
+//   PS   [5][SPEC_NP_PAD]               theta and the optimizer state [4][n_params]: the working copy of a launch
+//   TAB                                 uniform entries (4 words each), CSR theta -> positions / uniform indices, masks
+//   TR   [W][SPEC_TE * SPEC_TR_STRIDE]  per-wave transpose tile: the lanes of a wave store their contribution to
+//                                       position p at TR[(p % TE) * 68 + lane]; every TE positions lane j adds up
+//                                       row j with 16 conflict-free ds_read_b128, fixed order — ~2 instructions per
+//                                       entry and lane instead of a 10-instruction DPP reduction per entry
 #ifndef SPEC_TE
 #define SPEC_TE 64
 #endif
+#define SPEC_TR_STRIDE 68      /* 16-byte aligned rows; 16 lanes x 4 consecutive banks tile the 64 banks exactly */
 #define SPEC_MAX_WAVES (SPEC_MAX_THREADS / 64)
 #define SPEC_U_PAD ((SPEC_N_UNIFORM + SPEC_N_OBS + 3) / 4 * 4)
-#define SPEC_NUG_PAD ((SPEC_N_UGRAD + SPEC_TE + 3) / 4 * 4)      /* flushes write whole tiles: room for the last one */
+#define SPEC_NU_PAD ((SPEC_N_UNIFORM + 3) / 4 * 4)
+#define SPEC_NUG_PAD ((SPEC_N_UGRAD + 3) / 4 * 4 + 4)
 #define SPEC_RED_FLOATS (2 * SPEC_MAX_WAVES + 8)
-#define SPEC_TR_FLOATS (SPEC_TE * 65)
-#define SPEC_LDS_FLOATS (SPEC_U_PAD + SPEC_MAX_WAVES * SPEC_NUG_PAD + SPEC_RED_FLOATS + SPEC_MAX_WAVES * SPEC_TR_FLOATS)
+#define SPEC_NP_PAD ((SPEC_N_PARAMS + 3) / 4 * 4 + 4)
+#define SPEC_TAB_WORDS ((4 * SPEC_N_UNIFORM + (2 * SPEC_N_PARAMS + 1) + 2 * SPEC_N_UGRAD + 3) / 4 * 4 + 4)
+#define SPEC_TR_FLOATS (SPEC_TE * SPEC_TR_STRIDE)
+#define SPEC_OFF_UR SPEC_U_PAD
+#define SPEC_OFF_UL (SPEC_OFF_UR + SPEC_NU_PAD)
+#define SPEC_OFF_WS (SPEC_OFF_UL + SPEC_NU_PAD)
+#define SPEC_OFF_RED (SPEC_OFF_WS + SPEC_MAX_WAVES * SPEC_NUG_PAD)
+#define SPEC_OFF_PS (SPEC_OFF_RED + SPEC_RED_FLOATS)
+#define SPEC_OFF_TAB (SPEC_OFF_PS + 5 * SPEC_NP_PAD)
+#define SPEC_OFF_TR (SPEC_OFF_TAB + SPEC_TAB_WORDS)
+#define SPEC_LDS_FLOATS (SPEC_OFF_TR + SPEC_MAX_WAVES * SPEC_TR_FLOATS)
 __shared__ __attribute__((aligned(16))) float spec_lds[SPEC_LDS_FLOATS];
 
 // A uniform-table read.  The address is lane-uniform, and left provably so the compiler moves every entry into a
 // scalar register (ds_read + v_readfirstlane): ~90 of them on top of the argument block overflow the 102 SGPRs and
-// spill through v_writelane / v_readlane (800 instructions of a 4 300-instruction kernel at BASELINE config 1).
-// Adding the per-lane zero keeps the entries in vector registers; the reads still broadcast, and adjacent entries
-// still merge into ds_read2 / ds_read_b128.
+// spill through v_writelane / v_readlane.  Adding the per-lane zero keeps the entries in vector registers; the reads
+// still broadcast, and adjacent entries still merge into ds_read2 / ds_read_b128.
 #define SPEC_U(k) spec_lds[(k) + T.vz]
+#define SPEC_UR(k) spec_lds[SPEC_OFF_UR + (k) + T.vz]
+#define SPEC_UL(k) spec_lds[SPEC_OFF_UL + (k) + T.vz]
 
 // contribution of this lane to position `pos` (a literal)
-#define SPEC_DU(pos, val) TRw[((pos) % SPEC_TE) * 65u + T.lane] = T.active ? (val) : 0.0f
+#define SPEC_DU(pos, val) TRw[((pos) % SPEC_TE) * SPEC_TR_STRIDE + T.lane] = T.active ? (val) : 0.0f
 
+typedef float spec_f4 __attribute__((ext_vector_type(4)));
 // positions [base, base + count) are complete: lane j < count adds the 64 lane contributions of position base + j
 __device__ __forceinline__ void spec_du_flush(float* TRw, float* WSw, uint32_t lane, uint32_t base, uint32_t count) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's tile stores have landed (LDS is in order)
     if (lane < count) {
-        const float* row = TRw + lane * 65u;
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        const spec_f4* row = reinterpret_cast<const spec_f4*>(TRw + lane * SPEC_TR_STRIDE);
+        spec_f4 s = row[0];
 #pragma unroll
-        for (uint32_t l = 0; l < 64u; l += 4u) { s0 += row[l]; s1 += row[l + 1u]; s2 += row[l + 2u]; s3 += row[l + 3u]; }
-        WSw[base + lane] = (s0 + s1) + (s2 + s3);
+        for (uint32_t q = 1; q < 16u; ++q) s += row[q];
+        WSw[base + lane] = (s.x + s.y) + (s.z + s.w);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next tile overwrites the rows
 }

@@ -85,6 +85,26 @@ public:
     }
 
     const std::string& body() const { return body_; }
+    bool keeps_noise() const { return keep_eps_; }
+    // body of spec_draw(): the standard normals of the sample's Normal nodes, one Philox call per group of 4 rows
+    std::string draw() const {
+        std::string s;
+        if (!keep_eps_) return s;
+        std::set<uint32_t> groups;
+        for (uint32_t r : normal_rows_) groups.insert(r >> 2);
+        std::string philox;
+        for (uint32_t g : groups) {
+            philox += fmt("        { float z0, z1, z2, z3; spec_normals4(A, T, %uu, z0, z1, z2, z3);", g);
+            for (uint32_t j = 0; j < 4; ++j)
+                if (normal_rows_.count(4 * g + j)) philox += fmt(" Z.z[%u] = z%u;", 4 * g + j, j);
+            philox += " }\n";
+        }
+        if (!diag_) return "    {\n" + philox + "    }\n";
+        s += "    if (A.noise) {\n";
+        for (uint32_t r : normal_rows_) s += fmt("        Z.z[%u] = A.noise[(size_t)%uu * A.n_local + T.nc];\n", r, r);
+        s += "    } else {\n" + philox + "    }\n";
+        return s;
+    }
     const std::vector<uint32_t>& order() const { return order_; }     // position -> uniform entry
     std::string declarations() const {
         std::string s;
@@ -104,7 +124,7 @@ private:
     size_t visits_ = 0;
     std::string body_;
     std::vector<uint32_t> du_total_, du_seen_, order_;
-    std::set<uint32_t> fwd_groups_, rev_groups_, all_groups_, eps_rows_, node_rows_, all_node_rows_;
+    std::set<uint32_t> fwd_groups_, rev_groups_, all_groups_, eps_rows_, node_rows_, all_node_rows_, normal_rows_;
 
     Insn insn(uint32_t pc) const {
         Insn I;
@@ -143,7 +163,18 @@ private:
         if (++du_seen_[p.idx] == du_total_[p.idx]) complete(p.idx, fmt("du_%u", p.idx));
     }
 
-    // ---- noise of a Normal draw
+    // 1/S and log S of a Normal node's scale: companions of the uniform table when S is lane-uniform
+    std::string rcp_of(uint32_t o, uint32_t e) const {
+        const Opnd p = resolve(o, e);
+        return p.lane ? fmt("spec_rcp(v_%u)", p.idx) : fmt("SPEC_UR(%u)", p.idx);
+    }
+    std::string log_of(uint32_t o, uint32_t e) const {
+        const Opnd p = resolve(o, e);
+        return p.lane ? fmt("spec_log(v_%u)", p.idx) : fmt("SPEC_UL(%u)", p.idx);
+    }
+
+    // ---- noise of a Normal draw.  Programs that keep their noise (keep_eps_) take it from spec_draw's SpecNoise,
+    //      drawn ahead of the barrier; longer ones draw group by group inside the sweeps.
     std::string normal_var(uint32_t row, bool reverse) {
         const uint32_t g = row >> 2, j = row & 3u;
         std::set<uint32_t>& have = (reverse && !keep_eps_) ? rev_groups_ : fwd_groups_;
@@ -156,6 +187,7 @@ private:
         return fmt("pn_%u_%u", g, j);
     }
     std::string eps_forward(uint32_t row) {
+        if (keep_eps_) { normal_rows_.insert(row); return fmt("Z.z[%u]", row); }
         const std::string pn = normal_var(row, false);
         if (!diag_) return pn;
         eps_rows_.insert(row);
@@ -163,7 +195,7 @@ private:
         return fmt("ez_%u", row);
     }
     std::string eps_reverse(uint32_t row) {
-        if (keep_eps_) return diag_ ? fmt("ez_%u", row) : fmt("pn_%u_%u", row >> 2, row & 3u);
+        if (keep_eps_) return fmt("Z.z[%u]", row);
         const std::string pn = normal_var(row, true);
         if (!diag_) return pn;
         line(fmt("ez_%u = noise ? noise[(size_t)%uu * A.n_local + T.nc] : %s;", row, row, pn.c_str()));
@@ -183,18 +215,19 @@ private:
             ++visits_;
             if (counting_) return;
             line("{");
-            line(fmt("  const float S = %s, loc = %s * %s + %s;", val(I.s, e).c_str(), val(I.a, e).c_str(), val(I.b, e).c_str(), val(I.c, e).c_str()));
+            line(fmt("  const float loc = %s * %s + %s;", val(I.a, e).c_str(), val(I.b, e).c_str(), val(I.c, e).c_str()));
             std::string v = val(I.dst, e);
             if (flags & BSVI_F_SAMPLE) {
                 const uint32_t row = resolve(I.dst, e).idx;
                 const std::string eps = eps_forward(row);
                 if (flags & BSVI_F_GIVEN) line(fmt("  %s = %s;", v.c_str(), eps.c_str()));
-                else line(fmt("  %s = loc + %s * S;", v.c_str(), eps.c_str()));
+                else line(fmt("  %s = loc + %s * %s;", v.c_str(), eps.c_str(), val(I.s, e).c_str()));
                 diag_outputs(row, v, eps);
             }
-            if (flags & BSVI_F_ENT) line(fmt("  T.f += %s * (kHalfLog2PiE + spec_log(S));", flit(I.imm1).c_str()));
+            if (flags & (BSVI_F_ENT | BSVI_F_LOGP | BSVI_F_WF)) line(fmt("  const float lS = %s;", log_of(I.s, e).c_str()));
+            if (flags & BSVI_F_ENT) line(fmt("  T.f += %s * (kHalfLog2PiE + lS);", flit(I.imm1).c_str()));
             if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
-                line(fmt("  const float lp = spec_naff_lp(%s, loc, S);", v.c_str()));
+                line(fmt("  const float lp = spec_naff_lp(%s, loc, %s, lS);", v.c_str(), rcp_of(I.s, e).c_str()));
                 line(fmt("  T.f += %s * lp;", flit(I.imm0).c_str()));
                 if (flags & BSVI_F_WF) line("  T.lq += lp;");
             }
@@ -252,8 +285,8 @@ private:
         const std::string A = val(I.a, e), B = val(I.b, e);
         if (!counting_) {
             line("{");
-            line(fmt("  float gl, gs; spec_naff_sink(%s, %s, %s * %s + %s, %s, T.f, gl, gs);", flit(I.imm0).c_str(), val(I.dst, e).c_str(),
-                     A.c_str(), B.c_str(), val(I.c, e).c_str(), val(I.s, e).c_str()));
+            line(fmt("  float gl, gs; spec_naff_sink(%s, %s, %s * %s + %s, %s, %s, T.f, gl, gs);", flit(I.imm0).c_str(), val(I.dst, e).c_str(),
+                     A.c_str(), B.c_str(), val(I.c, e).c_str(), rcp_of(I.s, e).c_str(), log_of(I.s, e).c_str()));
         }
         add_adj(I.dst, e, "-gl");
         add_adj(I.a, e, "gl * " + B);
@@ -271,13 +304,13 @@ private:
             const std::string A = val(I.a, e), B = val(I.b, e), v = val(I.dst, e);
             if (!counting_) {
                 line("{");
-                line(fmt("  const float S = %s, loc = %s * %s + %s;", val(I.s, e).c_str(), A.c_str(), B.c_str(), val(I.c, e).c_str()));
+                line(fmt("  const float rS = %s, loc = %s * %s + %s;", rcp_of(I.s, e).c_str(), A.c_str(), B.c_str(), val(I.c, e).c_str()));
                 line("  float gv = 0.0f, gl = 0.0f, gs = 0.0f;");
                 if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
                     const std::string gw = (flags & BSVI_F_WF) ? fmt("(%s + fweight)", flit(I.imm0).c_str()) : flit(I.imm0);
-                    line(fmt("  spec_naff_lp_bwd(%s, %s, loc, S, gv, gl, gs);", gw.c_str(), v.c_str()));
+                    line(fmt("  spec_naff_lp_bwd(%s, %s, loc, rS, gv, gl, gs);", gw.c_str(), v.c_str()));
                 }
-                if (flags & BSVI_F_ENT) line(fmt("  gs += %s * spec_rcp(S);", flit(I.imm1).c_str()));
+                if (flags & BSVI_F_ENT) line(fmt("  gs += %s * rS;", flit(I.imm1).c_str()));
             }
             if (flags & BSVI_F_SAMPLE) {
                 // a sampled latent's own adjoint is its incoming gradient: folded into loc / scale, left unchanged
@@ -435,10 +468,12 @@ struct Spec {
     std::mutex mu;
 };
 
-static uint32_t lds_floats(uint32_t n_uniform, uint32_t n_obs, uint32_t n_ugrad, uint32_t max_threads, uint32_t te) {
+static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs, uint32_t n_ugrad, uint32_t max_threads, uint32_t te) {
+    // mirrors the SPEC_OFF_* layout of spec_prelude.h
     const uint32_t W = max_threads / 64;
-    const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nug_pad = (n_ugrad + te + 3) / 4 * 4;
-    return u_pad + W * nug_pad + (2 * W + 8) + W * te * 65;
+    const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4, nug_pad = (n_ugrad + 3) / 4 * 4 + 4;
+    const uint32_t np_pad = (n_params + 3) / 4 * 4 + 4, tab = (4 * n_uniform + (2 * n_params + 1) + 2 * n_ugrad + 3) / 4 * 4 + 4;
+    return u_pad + 2 * nu_pad + W * nug_pad + (2 * W + 8) + 5 * np_pad + tab + W * te * 68;
 }
 
 Spec* create(const bsvi_program_desc& d, std::string& why) {
@@ -449,12 +484,12 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     const uint32_t live = 2 * d.n_slots + (d.n_noise <= kKeepEpsRows ? d.n_noise : 0) + 48;
     if (live > 232) max_threads = 256;
     uint32_t te = 64;
-    while (te > 8 && lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
-    if (lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
+    while (te > 8 && lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
+    if (lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
         max_threads = 256;
         te = 64;
-        while (te > 8 && lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
-        if (lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
+        while (te > 8 && lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
+        if (lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
             why = "uniform table does not fit LDS";
             return nullptr;
         }
@@ -462,7 +497,7 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     Spec* s = new Spec();
     s->n_params = d.n_params; s->n_uniform = d.n_uniform; s->n_ugrad = d.n_uniform_grad; s->n_obs = d.n_obs; s->n_noise = d.n_noise;
     s->max_threads = max_threads; s->te = te;
-    s->lds_bytes = lds_floats(d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u;
+    s->lds_bytes = lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u;
     std::vector<uint32_t> order;
     for (int v = 0; v < 2; ++v) {
         Emitter E(d, v == 1, te);
@@ -475,9 +510,15 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
         src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
                    d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
         src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_TE %u\n#define SPEC_DIAG %d\n", d.estimator, max_threads, te, v);
+        src += fmt("#define SPEC_KEEP_NOISE %u\n", E.keeps_noise() ? d.n_noise : 0u);
         src += "#include \"spec_prelude.h\"\n";
         src += "namespace bsvi {\n";
-        src += "__device__ __forceinline__ void spec_body(const SpecBody& A, SpecLane& T, float* TRw, float* WSw) {\n";
+        src += "__device__ __forceinline__ void spec_draw(const SpecBody& A, const SpecLane& T, SpecNoise& Z) {\n";
+        src += "    (void)A; (void)T; (void)Z;\n";
+        src += E.draw();
+        src += "}\n";
+        src += "__device__ __forceinline__ void spec_body(const SpecBody& A, SpecLane& T, const SpecNoise& Z, float* TRw, float* WSw) {\n";
+        src += "    (void)Z;\n";
         if (v == 1) src += "    const float* const noise = A.noise;\n";
         src += E.declarations();
         src += E.body();
