@@ -47,7 +47,7 @@ WORKLOADS = {
                  "README AR T=20 at number_samples=262144 (throughput regime of the same kernel)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r1")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
 
 
 def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False, column="mean_KB_per_dispatch"):
@@ -155,6 +155,22 @@ def cpu_baseline(builder, kwargs, n_samples, optimizer, opt_kwargs, dense=False,
                 iters_per_sec=iters / dt, number_samples=n_cpu)
 
 
+def self_launch(n_gpus, argv=None, port=None):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child (one rank per GPU, rendezvous on 127.0.0.1) and pass its output and exit code on."""
+    import socket
+    import subprocess
+    if port is None:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,9 +181,16 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "persistent", "stepwise"])
     ap.add_argument("--samples", type=int, default=0, help="override number_samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup-ms", type=float, default=300.0,
+                    help="untimed iterations of the timed path after the W warm-up steps, to let the clocks ramp (0: off)")
     ap.add_argument("--estimator", default="pathwise", choices=["pathwise", "blackbox", "taylor1"],
                     help="gradient estimator (BASELINE config 5 names both Pathwise and BlackBox)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as a plain `python bench.py --gpus N`: become the launcher.  The ranks are CHILD processes started
+        # before this process has touched the GPU (nothing here has initialised HIP yet); their output is relayed.
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -175,8 +198,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -204,8 +226,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up (untimed): W steps through exactly the path that is timed
+    # ---- warm-up (untimed): W steps through exactly the path that is timed (this is also where hiprtc compiles the
+    #      program-specialised kernel), then — still untimed — the same path for --spinup-ms so that a short timed region
+    #      (the driver runs K = 20) is not measured on a GPU whose clocks have not ramped yet
     compiled.train(max(args.warmup, 1), n_global, optimizer, seed=0, allow_persistent=allow_persistent, **opt_kwargs)
+    barrier()
+    spun = 0
+    if args.spinup_ms > 0:
+        chunk = max(args.steps, 200)
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            compiled.train(chunk, n_global, optimizer, seed=0, allow_persistent=allow_persistent, **opt_kwargs)
+            torch.cuda.synchronize()
+            spun += chunk
     barrier()
 
     # ---- timed region: exactly K steps
@@ -233,10 +266,21 @@ def main():
         dense = hasattr(program, "n_classes")
         amort = hasattr(program, "enc_layers")
         geom = dict(kind="dense") if dense else dict(kind="amortized") if amort else compiled.native.geometry(n_per_gpu)
+        spec = None
+        if not dense and not amort:
+            spec = compiled.native.engine(n_per_gpu, 2 if mode == "persistent" else 1 if mode == "stepwise" else 0)
+            spec = spec if spec["engine"] == "specialised" else None
         # roofline of the dominant kernel (the fused ELBO kernel; in persistent mode one launch
         # covers all K iterations).  Launch duration from HIP events on the launch stream.
         alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu * (program.batch_size if amort else 1))
-        if mode == "persistent":
+        if spec is not None:
+            # the program-specialised kernel: ONE launch per bsvi_* call — the whole loop in persistent mode
+            units_per_launch = args.steps if mode == "persistent" else 1
+            launch_ms = dev_ms / (1 if mode == "persistent" else args.steps)
+            kernel = "bsvi_spec_kernel (straight-line HIP generated from the model program, hiprtc)"
+            geom = dict(engine="specialised", n_blocks=spec["n_blocks"], n_threads=spec["n_threads"],
+                        lds_bytes=spec["lds_bytes"], storage="registers")
+        elif mode == "persistent":
             launch_ms, launches, units_per_launch = dev_ms, 1, args.steps
             # five or more waves run as one wave per workgroup (persistent_multi_kernel)
             multi = (n_per_gpu + 63) // 64 >= 5 and os.environ.get("BSVI_PERSISTENT_MULTI", "1") != "0"
@@ -261,12 +305,13 @@ def main():
                             note="workgroup b runs share b %% %d of the model's log-prob records on sample group b / %d; "
                                  "reduce_kernel adds the rows of partial sums" % (V, V))
         achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
-        if mode == "persistent":
-            # measured for the default command (the summary holds the warm-up launch of 200 iterations and the
-            # timed one of 20000: the larger is the timed launch — parameters/observations read, loss and
-            # finite curves written)
-            traffic = pmc_traffic_bytes("cfg1_persistent_pmc_hbm_traffic.csv", ["persistent_kernel", "persistent_multi_kernel"], column="max_KB") \
-                if args.workload == "cfg1" and not args.samples and args.steps == 20000 else None
+        if spec is not None:
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_hbm.sh), committed per round:
+            # the timed launch is the larger of the two launches in the summary (the other is the warm-up)
+            traffic = pmc_traffic_bytes("cfg1_spec_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"], column="max_KB") \
+                if args.workload == "cfg1" and not args.samples and args.steps == 20000 and mode == "persistent" else None
+        elif mode == "persistent":
+            traffic = None
         else:
             traffic = pmc_traffic_bytes("pmc_hbm_traffic.csv", ["elbo_kernel"]) \
                 if args.workload == "cfg1" and not args.samples else None
@@ -313,7 +358,7 @@ def main():
                     config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
                                 optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
                                 estimator=args.estimator, mode=mode, parallelism="sample-shard x%d" % world,
-                                grid=geom),
+                                grid=geom, untimed_spinup_iterations=spun),
                     iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
                     device_ms_per_step=dev_ms / args.steps, all_finite=ok,
                     final_loss=float(losses[-1].item()), roofline=roofline)

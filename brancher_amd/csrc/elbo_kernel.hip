@@ -66,6 +66,7 @@ struct KParams {
     uint32_t stash;         // lds+lane_acc: rows carry one cell per noise row; the reverse sweep reads eps back
                             // instead of regenerating it (Philox + Box-Muller are ~8 % of a wave's instructions)
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
+    const unsigned long long* offset_dev;   // added to the offset when non-null (graph-replayed multi-GPU step)
     // shares of the program over workgroups (multi-workgroup launches of elbo_kernel): workgroup b runs share
     // b % n_shares on sample group b / n_shares (bsvi_program_set_shares); 0 / 1 = the whole program
     uint32_t n_shares;
@@ -942,7 +943,13 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
 }
 
 template <int SM, bool OUT, bool GEN>
-__global__ void __launch_bounds__(1024) elbo_kernel(const KParams K) {
+__global__ void __launch_bounds__(1024) elbo_kernel(const KParams K_in) {
+    KParams K = K_in;
+    if (K.offset_dev) {
+        const unsigned long long o = *K.offset_dev + (((unsigned long long)K.offset_hi << 32) | K.offset_lo);
+        K.offset_lo = (uint32_t)o;
+        K.offset_hi = (uint32_t)(o >> 32);
+    }
     if (K.n_shares > 1) {
         // every share samples the posterior but evaluates only its part of the model's log-prob records: value and
         // adjoints are linear in them, so the rows of partial sums add up in reduce_kernel like those of sample groups
@@ -1092,6 +1099,38 @@ __global__ void finalize_step_kernel(const bsvi_opt_cfg cfg, float* params, floa
         out[3] = finite;
         if (loss_slot) *loss_slot = loss;
         if (finite_slot) *finite_slot = finite;
+    }
+}
+
+// The same for a step sequence that is captured once in a HIP graph and replayed: nothing in the launch may change
+// between replays, so the iteration number lives in device memory.  counters[0] = Philox offset of the iteration
+// (read by bsvi_elbo_fwd_bwd through bsvi_elbo_args::offset_dev), counters[1] = index of the iteration within the run:
+// picks the loss / finite slot and, with pretraining_iterations, the mask; both are advanced here.
+__global__ void finalize_step_counted_kernel(const bsvi_opt_cfg cfg, float* params, float* out, float* state,
+                                             const uint8_t* mask_all, const uint8_t* mask_first, uint32_t pretraining,
+                                             uint32_t n_params, uint32_t n_global, float* loss_curve, float* finite_curve,
+                                             unsigned long long* counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long it = counters[1];
+    const float scale = -1.0f / (float)n_global;
+    const float loss = out[0] * scale;
+    const float finite = isfinite(loss) ? 1.0f : 0.0f;
+    const uint8_t* mask = (it > pretraining) ? mask_all : mask_first;
+    if (i < n_params) {
+        const float grad = out[BSVI_OUT_HEADER + i] * scale;
+        out[BSVI_OUT_HEADER + i] = grad;
+        if (finite != 0.0f && mask[i]) optimizer_update(cfg, params, state, n_params, i, grad);
+    }
+    // one workgroup covers every parameter of the launch (checked by the host): the barrier orders every thread's
+    // reads of out[0] and counters[1] before thread 0 rewrites them
+    __syncthreads();
+    if (i == 0) {
+        out[2] = loss;
+        out[3] = finite;
+        if (loss_curve) loss_curve[it] = loss;
+        if (finite_curve) finite_curve[it] = finite;
+        counters[0] += 1ull;
+        counters[1] = it + 1ull;
     }
 }
 
@@ -1764,6 +1803,7 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     K.stash = g.stash ? 1u : 0u;
     K.seed_lo = (uint32_t)a->seed; K.seed_hi = (uint32_t)(a->seed >> 32);
     K.offset_lo = (uint32_t)a->offset; K.offset_hi = (uint32_t)(a->offset >> 32);
+    K.offset_dev = (const unsigned long long*)a->offset_dev;
     K.n_shares = 0;
     for (int v = 0; v < 8; ++v) { K.share_code[v] = nullptr; K.share_aux[v] = nullptr; K.share_n_code[v] = 0; }
     return BSVI_OK;
@@ -1914,6 +1954,25 @@ extern "C" int bsvi_finalize_step(const bsvi_opt_cfg* cfg, float* params_dev, fl
     return BSVI_OK;
 }
 
+extern "C" int bsvi_finalize_step_counted(const bsvi_opt_cfg* cfg, float* params_dev, float* out_dev, float* state_dev,
+                                          const uint8_t* active_mask_dev, const uint8_t* active_mask_first_dev,
+                                          uint32_t pretraining_iterations, uint32_t n_params, uint32_t n_samples_global,
+                                          float* loss_curve_dev, float* finite_curve_dev, uint64_t* counters_dev,
+                                          void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!out_dev || !n_samples_global || !counters_dev) return fail(BSVI_ERR_INVALID, "null argument");
+    if (n_params && (!params_dev || !state_dev || !active_mask_dev || !active_mask_first_dev))
+        return fail(BSVI_ERR_INVALID, "null argument");
+    if (n_params > 1024) return fail(BSVI_ERR_UNSUPPORTED, "bsvi_finalize_step_counted: at most 1024 parameters (one workgroup)");
+    const uint32_t threads = n_params <= 64 ? 64 : (n_params + 63) / 64 * 64;
+    hipLaunchKernelGGL(finalize_step_counted_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, *cfg, params_dev, out_dev,
+                       state_dev, active_mask_dev, active_mask_first_dev, pretraining_iterations, n_params, n_samples_global,
+                       loss_curve_dev, finite_curve_dev, (unsigned long long*)counters_dev);
+    HIP_TRY(hipGetLastError());
+    return BSVI_OK;
+}
+
 extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
                              float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                              float* loss_slot_dev, float* finite_slot_dev) {
@@ -2049,6 +2108,7 @@ static int train_persistent_impl(const bsvi_program* p, const bsvi_program* cons
     if (!a->out_dev || !params_dev || !state_dev || !active_mask_dev || !active_mask_first_dev || !loss_curve_dev || !finite_dev)
         return fail(BSVI_ERR_INVALID, "null argument");
     if (a->n_samples_local != a->n_samples_global) return fail(BSVI_ERR_INVALID, "persistent trainer is the single-GPU path");
+    if (a->offset_dev) return fail(BSVI_ERR_INVALID, "the in-kernel training loop counts its own iterations: offset_dev must be null");
     {
         const int sp = try_spec(p, a, bsvi_spec::MODE_LOOP, cfg, params_dev, state_dev, active_mask_dev, active_mask_first_dev,
                                 pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);

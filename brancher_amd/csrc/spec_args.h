@@ -31,6 +31,7 @@ struct SpecArgs {
     const uint8_t* mask_first;           // ... while iteration <= pretraining_iterations (loop mode)
     float* loss_slot;                    // step: one slot (or null); loop: the loss curve
     float* finite_slot;
+    const unsigned long long* offset_dev;   // added to the Philox offset when non-null (bsvi_elbo_args::offset_dev)
     uint32_t n_local, n_global, sample_base, mode;
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
     uint32_t n_iterations, pretraining_iterations, n_params, reserved;

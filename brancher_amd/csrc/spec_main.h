@@ -119,11 +119,13 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) bsvi_spec_kernel(
 #else
             B.noise = nullptr; B.samples_out = nullptr; B.noise_out = nullptr; B.fvalue_out = nullptr;
 #endif
-            const uint32_t off_lo = SPEC_A->offset_lo;
+            unsigned long long off = (((unsigned long long)SPEC_A->offset_hi << 32) | SPEC_A->offset_lo) + it;
+            const unsigned long long* const offset_dev = SPEC_A->offset_dev;
+            if (offset_dev) off += *offset_dev;
             T.f = 0.0f;
             T.lq = 0.0f;
-            T.off_lo = off_lo + it;
-            T.off_hi = SPEC_A->offset_hi + ((T.off_lo < off_lo) ? 1u : 0u);
+            T.off_lo = (uint32_t)off;
+            T.off_hi = (uint32_t)(off >> 32);
             SpecNoise Z;
             spec_draw(B, T, Z);
             __syncthreads();                                   // the uniform table of this iteration is complete

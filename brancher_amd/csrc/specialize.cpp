@@ -687,6 +687,7 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     A.mode = (uint32_t)L.mode;
     A.seed_lo = (uint32_t)a->seed; A.seed_hi = (uint32_t)(a->seed >> 32);
     A.offset_lo = (uint32_t)a->offset; A.offset_hi = (uint32_t)(a->offset >> 32);
+    A.offset_dev = (const unsigned long long*)a->offset_dev;
     A.n_iterations = L.n_iterations; A.pretraining_iterations = L.pretraining_iterations; A.n_params = s->n_params;
     if (L.cfg) A.cfg = *L.cfg;
     size_t size = sizeof A;

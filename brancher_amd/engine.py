@@ -264,6 +264,41 @@ class CompiledELBO:
         return world == 1 and getattr(self.native, "_elbo_shares_set", 0) >= 4 \
             and os.environ.get("BSVI_ELBO_SHARES", "1") != "0"
 
+    def _train_graph(self, K, n_local, n_global, base, cfg, state, loss_curve, finite, seed, offset0, pretraining):
+        """The sharded iteration — `bsvi_elbo_fwd_bwd` (this rank's samples), ONE all-reduce of the [4+P] sums over the
+        ranks (RCCL), `bsvi_finalize_step_counted` (loss, finite flag, replicated optimizer step) — captured in a HIP
+        graph, `BSVI_GRAPH_UNROLL` iterations per graph, and replayed.  The iteration number (Philox offset, loss slot,
+        pretraining mask) lives in device memory, so the replays are identical launches; the host only enqueues graphs."""
+        dev, p = self.device, self.program
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        counters = torch.tensor([int(offset0), 0], dtype=torch.int64, device=dev)
+        # hiprtc / module loading and RCCL's first-call set-up cannot happen inside a capture: one untimed launch of each
+        warm = self._elbo_args(n_local, n_global, base, None, seed, int(offset0))
+        native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(warm)))
+        allreduce_sums(torch.zeros_like(self.out))
+        torch.cuda.synchronize(dev)
+
+        def capture(n_steps):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                args = self._elbo_args(n_local, n_global, base, None, seed, 0)        # on the capturing stream
+                args.offset_dev = counters.data_ptr()
+                for _ in range(n_steps):
+                    native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
+                    allreduce_sums(self.out)
+                    native.check(self.lib.bsvi_finalize_step_counted(
+                        C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(self.mask_all), ptr(self.mask_first),
+                        pretraining, p.n_params, n_global, ptr(loss_curve), ptr(finite), ptr(counters), self._stream()))
+            return graph
+
+        unroll = min(K, _graph_unroll())
+        main = capture(unroll)
+        for _ in range(K // unroll):
+            main.replay()
+        if K % unroll:
+            capture(K % unroll).replay()
+        self._graphs = getattr(self, "_graphs", [])[-3:] + [main]      # keep the executables alive while they run
+
     def train(self, number_iterations, number_samples, optimizer="Adam", noise_seq=None, seed=None,
               pretraining_iterations=0, allow_persistent=True, minibatch_seq=None, _force_sharded_path=False,
               **opt_params):
@@ -313,6 +348,17 @@ class CompiledELBO:
             self.last_mode = "persistent"
             return loss_curve, finite
 
+        sharded = world > 1 or _force_sharded_path
+        if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0" and p.n_params <= 1024:
+            # multi-GPU: the step sequence is captured once in a HIP graph and replayed — no Python between the launches
+            try:
+                self._train_graph(K, n_local, number_samples, base, cfg, state, loss_curve, finite, seed, offset0,
+                                  int(pretraining_iterations))
+                self.last_mode = "graph" if world == 1 else "graph+allreduce"
+                return loss_curve, finite
+            except (RuntimeError, native.NativeError) as err:      # capture refused: launch by launch below
+                warnings.warn("HIP-graph capture of the sharded step failed ({}); stepping eagerly".format(err))
+                loss_curve.zero_()
         for it in range(K):
             nz = None if noise_t is None else noise_t[it]
             args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
@@ -329,6 +375,10 @@ class CompiledELBO:
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         return loss_curve, finite
+
+
+def _graph_unroll():
+    return max(1, int(os.environ.get("BSVI_GRAPH_UNROLL", "32")))
 
 
 def compile_model(joint_model, posterior_model=None, gradient_estimator=None):

@@ -43,7 +43,8 @@ class ElboArgs(C.Structure):
                 ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
                 ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
                 ("out_dev", C.c_void_p), ("samples_out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p),
-                ("fvalue_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p)]
+                ("fvalue_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p),
+                ("offset_dev", C.c_void_p)]
 
 
 class OptCfg(C.Structure):
@@ -97,6 +98,9 @@ EXPORTS = {
                                       C.c_uint32, C.c_void_p]),
     "bsvi_finalize_step": (C.c_int, [C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsvi_finalize_step_counted": (C.c_int, [C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
     "bsvi_svi_step": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsvi_train_persistent": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,

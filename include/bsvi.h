@@ -229,6 +229,9 @@ typedef struct bsvi_elbo_args {
     float* fvalue_out_dev;        /* [2][n_samples_local] or NULL: per-sample f and log q   */
     void* workspace_dev;          /* bsvi_workspace_bytes(...)                              */
     void* stream;
+    const uint64_t* offset_dev;   /* NULL, or a device word added to `offset` when the launch executes: a step
+                                     sequence captured in a HIP graph advances it on the device
+                                     (bsvi_finalize_step_counted) and is replayed unchanged            */
 } bsvi_elbo_args;
 
 /* One ELBO forward+backward over this GPU's sample shard: q-sampling, p log-prob, q entropy
@@ -270,6 +273,16 @@ int bsvi_optimizer_step(const bsvi_opt_cfg* cfg, float* params_dev, const float*
 int bsvi_finalize_step(const bsvi_opt_cfg* cfg, float* params_dev, float* out_dev, float* state_dev,
                        const uint8_t* active_mask_dev, uint32_t n_params, uint32_t n_samples_global,
                        float* loss_slot_dev, float* finite_slot_dev, void* stream);
+
+/* bsvi_finalize_step for a step sequence captured ONCE in a HIP graph and replayed (the multi-GPU loop: fwd_bwd,
+ * all-reduce, this): the iteration number lives on the device.  counters_dev[0] = Philox offset of the iteration (give
+ * it to bsvi_elbo_fwd_bwd as bsvi_elbo_args::offset_dev), counters_dev[1] = index of the iteration within the run: it
+ * selects loss_curve_dev[it] / finite_curve_dev[it] and the mask (active_mask_first_dev while it <=
+ * pretraining_iterations, inference.py:102-104).  Both counters are advanced by the launch.  n_params <= 1024. */
+int bsvi_finalize_step_counted(const bsvi_opt_cfg* cfg, float* params_dev, float* out_dev, float* state_dev,
+                               const uint8_t* active_mask_dev, const uint8_t* active_mask_first_dev,
+                               uint32_t pretraining_iterations, uint32_t n_params, uint32_t n_samples_global,
+                               float* loss_curve_dev, float* finite_curve_dev, uint64_t* counters_dev, void* stream);
 
 /* Run `n_iterations` complete SVI iterations (ELBO fwd+bwd, finalize, optimizer step, loss
  * log) inside one kernel launch when the local sample count fits one workgroup; the whole
