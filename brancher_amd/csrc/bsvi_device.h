@@ -163,42 +163,50 @@ BSVI_SWITCH_FN float philox_noise_again(PhiloxKey G, int dist, uint32_t row) {
 //   torch.optim.SGD / torch.optim.Adam single-tensor paths, per element.
 // state layout: [4][n_params] = (momentum_buffer | exp_avg, exp_avg_sq, max_exp_avg_sq, step)
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void optimizer_update(const bsvi_opt_cfg& cfg, float* params, float* state,
-                                                 uint32_t n_params, uint32_t i, float grad) {
-    float p = params[i];
-    float* s0 = state + i;
-    float* s1 = state + n_params + i;
-    float* s2 = state + 2 * (size_t)n_params + i;
-    float* st = state + 3 * (size_t)n_params + i;
+// on values (registers): p = parameter, (s0, s1, s2, st) = its four state words
+__device__ __forceinline__ void optimizer_apply(const bsvi_opt_cfg& cfg, float& p, float& s0, float& s1, float& s2, float& st,
+                                                float grad) {
     if (cfg.maximize) grad = -grad;
-    const float step = *st + 1.0f;
-    *st = step;
+    const float step = st + 1.0f;
+    st = step;
     if (cfg.kind == BSVI_OPT_SGD) {
         if (cfg.weight_decay != 0.0f) grad += cfg.weight_decay * p;
         if (cfg.momentum != 0.0f) {
-            float buf = (step == 1.0f) ? grad : cfg.momentum * (*s0) + (1.0f - cfg.dampening) * grad;
-            *s0 = buf;
+            const float buf = (step == 1.0f) ? grad : cfg.momentum * s0 + (1.0f - cfg.dampening) * grad;
+            s0 = buf;
             grad = cfg.nesterov ? grad + cfg.momentum * buf : buf;
         }
-        params[i] = p - cfg.lr * grad;
+        p = p - cfg.lr * grad;
     } else {
         if (cfg.weight_decay != 0.0f) grad += cfg.weight_decay * p;
-        const float m = *s0 + (grad - *s0) * (1.0f - cfg.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
-        const float v = cfg.beta2 * (*s1) + (1.0f - cfg.beta2) * grad * grad;
-        *s0 = m;
-        *s1 = v;
+        const float m = s0 + (grad - s0) * (1.0f - cfg.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
+        const float v = cfg.beta2 * s1 + (1.0f - cfg.beta2) * grad * grad;
+        s0 = m;
+        s1 = v;
         const double bc1 = 1.0 - pow((double)cfg.beta1, (double)step);
         const double bc2 = 1.0 - pow((double)cfg.beta2, (double)step);
         const float step_size = (float)((double)cfg.lr / bc1);
         const float bc2_sqrt = (float)sqrt(bc2);
         float vhat = v;
         if (cfg.amsgrad) {
-            vhat = fmaxf(*s2, v);
-            *s2 = vhat;
+            vhat = fmaxf(s2, v);
+            s2 = vhat;
         }
         const float denom = sqrtf(vhat) / bc2_sqrt + cfg.eps;
-        params[i] = p - step_size * (m / denom);
+        p = p - step_size * (m / denom);
     }
+}
+// on memory: state planes `n_params` words apart
+__device__ __forceinline__ void optimizer_update(const bsvi_opt_cfg& cfg, float* params, float* state,
+                                                 uint32_t n_params, uint32_t i, float grad) {
+    float p = params[i], s0 = state[i], s1 = state[n_params + i], s2 = state[2 * (size_t)n_params + i];
+    float st = state[3 * (size_t)n_params + i];
+    optimizer_apply(cfg, p, s0, s1, s2, st, grad);
+    params[i] = p;
+    state[i] = s0;
+    state[n_params + i] = s1;
+    state[2 * (size_t)n_params + i] = s2;
+    state[3 * (size_t)n_params + i] = st;
 }
 
 // ---- unary link functions (brancher/functions.py:28-41) and their derivatives; GEN=false compiles the rare ones out

@@ -33,16 +33,88 @@ namespace bsvi {
 #define SPEC_TAB_IDX (SPEC_TAB_POS + SPEC_N_UGRAD)
 #define SPEC_TAB_MASK (SPEC_TAB_IDX + SPEC_N_UGRAD)
 
-// U[k] = a + b * g(x) and its companions, from the LDS copy of entry k
-__device__ __forceinline__ void spec_publish_uniform(const uint32_t* TAB, uint32_t k, float x) {
-    const uint32_t w1 = TAB[4 * k + 1];
-    const float u = __uint_as_float(TAB[4 * k + 2]) + __uint_as_float(TAB[4 * k + 3]) * utransform((int)(w1 & 0xFFu), x);
-    spec_lds[k] = u;
-    spec_lds[SPEC_OFF_UR + k] = 1.0f / u;
-    spec_lds[SPEC_OFF_UL + k] = logf(u);
+// The barriers of the iteration loop order LDS traffic only (sums, uniform table, theta all live in LDS), so they wait
+// for the LDS counter and not for global memory: __syncthreads() also drains vmcnt, i.e. every iteration would wait
+// for the write acknowledgements of its loss / gradient stores — 1.3 of 6.3 us per iteration at BASELINE config 1.
+__device__ __forceinline__ void spec_lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
-extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) bsvi_spec_kernel(const SpecArgs A_unused) {
+// U[k] = a + b * g(x) and its companions, from the LDS copy of entry k
+// The transforms of the uniform table on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp):
+// they sit on the critical path of every in-kernel iteration (between the barrier after the body and the one before the
+// next), where the library forms (range reduction, denormal handling) cost ~10x the instructions.
+__device__ __forceinline__ float spec_softplus(float x) {
+    if (x > 20.0f) return x;                                   // torch.nn.functional.softplus threshold
+    const float e = __expf(x);
+    // log1p(e): below 2^-6 the series keeps the relative accuracy that log(1 + e) loses to the rounding of 1 + e
+    return e < 0.015625f ? e * (1.0f - e * (0.5f - e * (0.33333334f - 0.25f * e))) : spec_log(1.0f + e);
+}
+__device__ __forceinline__ float spec_sigmoid(float x) { return spec_rcp(1.0f + __expf(-x)); }
+// (the transform id is data: written as one switch the compiler evaluates EVERY case and selects — tanh polynomial,
+//  sqrt refinement and all; the rare ones stay out of line behind a real branch)
+__device__ __noinline__ float spec_utransform_rare(uint32_t t, float x) { return utransform((int)t, x); }
+__device__ __noinline__ float spec_utransform_grad_rare(uint32_t t, float x) { return utransform_grad((int)t, x); }
+// The VALUES of the uniform table use the library forms of the interpreter (softplusf_ = log1pf(expf(x)), sigmoidf_):
+// a draw can depend on a parameter discontinuously (the gamma sampler behind a Beta node branches on alpha < 1), so an
+// entry that is one ulp off draws a different — equally valid — sample than the other engine, and the two stop being
+// comparable.  Only the derivative below, whose rounding moves a gradient by 1e-7, uses the hardware units.
+__device__ __forceinline__ float utransform_common(uint32_t t, float x) {
+    if (t > BSVI_UT_SIGMOID) return spec_utransform_rare(t, x);
+    const float e = expf(t == BSVI_UT_SIGMOID ? -x : x);
+    const float soft = x > 20.0f ? x : log1pf(e), sig = 1.0f / (1.0f + e);
+    return t == BSVI_UT_IDENTITY ? x : (t == BSVI_UT_SOFTPLUS ? soft : sig);
+}
+__device__ __forceinline__ float spec_utransform_grad(uint32_t t, float x) {
+    if (t > BSVI_UT_SIGMOID) return spec_utransform_grad_rare(t, x);
+    const float s = spec_rcp(1.0f + __expf(-x));               // sigmoid(x) = softplus'(x)
+    const float soft = x > 20.0f ? 1.0f : s;
+    return t == BSVI_UT_IDENTITY ? 1.0f : (t == BSVI_UT_SOFTPLUS ? soft : s * (1.0f - s));
+}
+__device__ __forceinline__ void spec_store_uniform(uint32_t k, float u) {
+    spec_lds[k] = u;
+    spec_lds[SPEC_OFF_UR + k] = spec_rcp(u);
+    spec_lds[SPEC_OFF_UL + k] = spec_log(u);
+}
+__device__ __forceinline__ void spec_publish_uniform(const uint32_t* TAB, uint32_t k, float x) {
+    const uint32_t w1 = TAB[4 * k + 1];
+    spec_store_uniform(k, __uint_as_float(TAB[4 * k + 2]) + __uint_as_float(TAB[4 * k + 3]) * utransform_common(w1 & 0xFFu, x));
+}
+
+// What the thread that owns parameter `tid` keeps in registers across the iterations of a launch (parameters beyond
+// the workgroup size, or with more than two uniform entries, go through the LDS working copy instead)
+struct SpecOwn {
+    float theta, s0, s1, s2, st;     // parameter and optimizer state
+    float a[2], b[2];                // its uniform entries: U = a + b * g(theta)
+    uint32_t pos[2], k[2], tr[2];
+    uint32_t n, mask;                // entries (0..2); mask bits (SPEC_TAB_MASK)
+};
+__device__ __forceinline__ void spec_own_store(spec_f4* row, const SpecOwn& o) {
+    row[0] = spec_f4{o.theta, o.s0, o.s1, o.s2};
+    row[1] = spec_f4{o.st, o.a[0], o.b[0], o.a[1]};
+    row[2] = spec_f4{o.b[1], __uint_as_float(o.pos[0]), __uint_as_float(o.pos[1]), __uint_as_float(o.k[0])};
+    row[3] = spec_f4{__uint_as_float(o.k[1]), __uint_as_float(o.tr[0] | (o.tr[1] << 8) | (o.n << 16) | (o.mask << 24)), 0.0f, 0.0f};
+}
+__device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
+    const spec_f4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+    SpecOwn o;
+    o.theta = q0.x; o.s0 = q0.y; o.s1 = q0.z; o.s2 = q0.w;
+    o.st = q1.x; o.a[0] = q1.y; o.b[0] = q1.z; o.a[1] = q1.w;
+    o.b[1] = q2.x; o.pos[0] = __float_as_uint(q2.y); o.pos[1] = __float_as_uint(q2.z); o.k[0] = __float_as_uint(q2.w);
+    o.k[1] = __float_as_uint(q3.x);
+    const uint32_t meta = __float_as_uint(q3.y);
+    o.tr[0] = meta & 0xFFu; o.tr[1] = (meta >> 8) & 0xFFu; o.n = (meta >> 16) & 0xFFu; o.mask = meta >> 24;
+    return o;
+}
+
+#ifdef SPEC_NUM_VGPR
+#define SPEC_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SPEC_NUM_VGPR)))
+#else
+#define SPEC_VGPR_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bsvi_spec_kernel(const SpecArgs A_unused) {
     (void)A_unused;
     const SPEC_CONST_AS char* ka = (const SPEC_CONST_AS char*)__builtin_amdgcn_kernarg_segment_ptr();
 #define SPEC_A ((const SPEC_CONST_AS SpecArgs*)ka)
@@ -101,41 +173,103 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) bsvi_spec_kernel(
         }
     }
 
+    // the owner rows: built once, read back with four 16-byte LDS loads per iteration (kept in registers across the body
+    // they are the first values the allocator spills to scratch: 2.2 us of scratch round trips per iteration)
+    spec_f4* const OWN = reinterpret_cast<spec_f4*>(spec_lds + SPEC_OFF_OWN);
+    bool own_fast = false;
+    if (tid < SPEC_N_PARAMS) {
+        const uint32_t j0 = TAB[SPEC_TAB_PTR + tid], j1 = TAB[SPEC_TAB_PTR + tid + 1];
+        if (j1 - j0 <= 2u) {
+            own_fast = true;
+            SpecOwn own;
+            own.n = j1 - j0;
+            own.mask = 0;
+            own.theta = PS[tid];
+            own.s0 = own.s1 = own.s2 = own.st = 0.0f;
+            own.a[0] = own.a[1] = own.b[0] = own.b[1] = 0.0f;
+            own.pos[0] = own.pos[1] = own.k[0] = own.k[1] = own.tr[0] = own.tr[1] = 0;
+            if (step) {
+                own.s0 = PS[SPEC_NP_PAD + tid]; own.s1 = PS[2 * SPEC_NP_PAD + tid];
+                own.s2 = PS[3 * SPEC_NP_PAD + tid]; own.st = PS[4 * SPEC_NP_PAD + tid];
+                own.mask = TAB[SPEC_TAB_MASK + tid];
+            }
+#pragma unroll
+            for (uint32_t e = 0; e < 2u; ++e) {
+                if (e < own.n) {
+                    const uint32_t k = TAB[SPEC_TAB_IDX + j0 + e];
+                    own.pos[e] = TAB[SPEC_TAB_POS + j0 + e];
+                    own.k[e] = k;
+                    own.tr[e] = TAB[4 * k + 1] & 0xFFu;
+                    own.a[e] = __uint_as_float(TAB[4 * k + 2]);
+                    own.b[e] = __uint_as_float(TAB[4 * k + 3]);
+                }
+            }
+            spec_own_store(OWN + 4 * tid, own);
+        }
+    }
+
+    // ---- what the iterations read of the argument block, once: a scalar load per iteration and phase is a round trip
+    //      to the scalar cache on the critical path of a ~5 us iteration
+    SPEC_RELOAD_ARGS();
+    SpecBody B0;
+    B0.n_local = SPEC_A->n_local;
+    B0.seed_lo = SPEC_A->seed_lo;
+    B0.seed_hi = SPEC_A->seed_hi;
+#if SPEC_DIAG
+    B0.noise = SPEC_A->noise;
+    B0.samples_out = SPEC_A->samples_out;
+    B0.noise_out = SPEC_A->noise_out;
+    B0.fvalue_out = SPEC_A->fvalue_out;
+#else
+    B0.noise = nullptr; B0.samples_out = nullptr; B0.noise_out = nullptr; B0.fvalue_out = nullptr;
+#endif
+    unsigned long long off0 = ((unsigned long long)SPEC_A->offset_hi << 32) | SPEC_A->offset_lo;
+    if (const unsigned long long* const offset_dev = SPEC_A->offset_dev) off0 += *offset_dev;
+    const uint32_t n_global = SPEC_A->n_global;
+    const uint32_t pretraining = SPEC_A->pretraining_iterations;
+
+#if defined(SPEC_DEBUG_STAMPS)        // timing experiment (tools/spec_stamps.py): s_memtime at the phase boundaries of one iteration
+    unsigned long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SPEC_STAMP(i) if (it == n_it / 2) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define SPEC_STAMP(i)
+#endif
     for (uint32_t it = 0; it < n_it; ++it) {
+        SPEC_STAMP(0);
         // ---- one Monte-Carlo sample per lane.  Its standard normals do not depend on the uniform table: they are drawn
         //      ahead of the barrier that publishes it.
         {
-            SPEC_RELOAD_ARGS();
-            SpecBody B;
-            B.n_local = SPEC_A->n_local;
-            B.seed_lo = SPEC_A->seed_lo;
-            B.seed_hi = SPEC_A->seed_hi;
+            SpecBody B = B0;
 #if SPEC_DIAG
             // a given-noise sequence is laid out [iteration][row][n_local]
-            B.noise = SPEC_A->noise ? SPEC_A->noise + (size_t)it * SPEC_N_NOISE * B.n_local : nullptr;
-            B.samples_out = SPEC_A->samples_out;
-            B.noise_out = SPEC_A->noise_out;
-            B.fvalue_out = SPEC_A->fvalue_out;
-#else
-            B.noise = nullptr; B.samples_out = nullptr; B.noise_out = nullptr; B.fvalue_out = nullptr;
+            if (B.noise) B.noise += (size_t)it * SPEC_N_NOISE * B.n_local;
 #endif
-            unsigned long long off = (((unsigned long long)SPEC_A->offset_hi << 32) | SPEC_A->offset_lo) + it;
-            const unsigned long long* const offset_dev = SPEC_A->offset_dev;
-            if (offset_dev) off += *offset_dev;
+            const unsigned long long off = off0 + it;
             T.f = 0.0f;
             T.lq = 0.0f;
             T.off_lo = (uint32_t)off;
             T.off_hi = (uint32_t)(off >> 32);
             SpecNoise Z;
+#if defined(SPEC_DEBUG_NO_DRAW)                                // timing experiment (BSVI_SPEC_DEFINES): what the noise costs
+            for (uint32_t r = 0; r < (SPEC_KEEP_NOISE ? SPEC_KEEP_NOISE : 1); ++r) Z.z[r] = 0.25f;
+#else
             spec_draw(B, T, Z);
-            __syncthreads();                                   // the uniform table of this iteration is complete
+#endif
+            SPEC_STAMP(1);
+            spec_lds_barrier();                                // the uniform table of this iteration is complete
+            SPEC_STAMP(2);
+#if !defined(SPEC_DEBUG_NO_BODY)
             spec_body(B, T, Z, TRw, WSw);
+#endif
         }
+        SPEC_STAMP(3);
         const float value = (SPEC_ESTIMATOR == BSVI_EST_BLACKBOX) ? (T.lq * T.f + T.f) : T.f;
         const float vsum = wave_sum(T.active ? value : 0.0f);
         const float bad = wave_sum((T.active && !isfinite(value)) ? 1.0f : 0.0f);
         if (lane == 0) { RED[8 + 2 * wave] = vsum; RED[9 + 2 * wave] = bad; }
-        __syncthreads();                                       // every wave's sums are in WS / RED
+        SPEC_STAMP(4);
+        spec_lds_barrier();                                    // every wave's sums are in WS / RED
+        SPEC_STAMP(5);
 
         // ---- several workgroups: every one publishes its row of sums, the last to arrive adds the rows in order
         uint32_t rows = W;                                     // rows of WS / RED that hold sums
@@ -190,29 +324,76 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) bsvi_spec_kernel(
         //      its uniform entries, applies the chain rule, the optimizer step on the LDS working copy, and publishes
         //      the entries' new values for the next iteration — so an iteration of the in-kernel loop has two
         //      barriers: after the body, and before the next one.
+        // (the epilogue's own words of the argument block: requested here, they arrive while the LDS reads below are in flight)
         SPEC_RELOAD_ARGS();
-        const uint32_t n_global = SPEC_A->n_global;
+        float* const out = SPEC_A->out;
+        float* const loss_slot = SPEC_A->loss_slot;
+        float* const finite_slot = SPEC_A->finite_slot;
+        const bsvi_opt_cfg cfg = SPEC_A->cfg;
+        // (literal trip counts and clamped addresses: the LDS reads issue back to back instead of one round trip per wave)
         float vs = 0.0f, vb = 0.0f;
-        for (uint32_t w = 0; w < rows; ++w) { vs += RED[8 + 2 * w]; vb += RED[9 + 2 * w]; }
+#pragma unroll
+        for (uint32_t w = 0; w < SPEC_MAX_WAVES; ++w) {
+            const uint32_t ww = w < rows ? w : 0u;
+            const float a = RED[8 + 2 * ww], b = RED[9 + 2 * ww];
+            vs += w < rows ? a : 0.0f;
+            vb += w < rows ? b : 0.0f;
+        }
         const float loss = -vs / (float)n_global;
         const float finite = isfinite(loss) ? 1.0f : 0.0f;
-        float* const out = SPEC_A->out;
+        SPEC_STAMP(7);
         if (tid == 0) {
-            out[0] = vs;
-            out[1] = vb;
+            if (it + 1u == n_it) { out[0] = vs; out[1] = vb; }     // (the output block of the launch's last iteration)
             if (step) {
-                out[2] = loss;
-                out[3] = finite;
-                float* const loss_slot = SPEC_A->loss_slot;
-                float* const finite_slot = SPEC_A->finite_slot;
+                if (it + 1u == n_it) { out[2] = loss; out[3] = finite; }
                 if (loss_slot) loss_slot[it] = loss;
                 if (finite_slot) finite_slot[it] = finite;
             }
         }
         const float scale = step ? -1.0f / (float)n_global : 1.0f;
         const bool last = it + 1u == n_it;
-        const uint32_t mask_bit = (mode == SPEC_MODE_LOOP && it <= SPEC_A->pretraining_iterations) ? 2u : 1u;
+        const uint32_t mask_bit = (mode == SPEC_MODE_LOOP && it <= pretraining) ? 2u : 1u;
+        if (own_fast) {
+            SpecOwn own = spec_own_load(OWN + 4 * tid);
+            float gsum = 0.0f;
+#pragma unroll
+            for (uint32_t e = 0; e < 2u; ++e) {
+                if (e < own.n) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (uint32_t w = 0; w < SPEC_MAX_WAVES; ++w) {
+                        const float x = WS[(w < rows ? w : 0u) * SPEC_NUG_PAD + own.pos[e]];
+                        s += w < rows ? x : 0.0f;
+                    }
+                    gsum += s * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
+                }
+            }
+            const float grad = gsum * scale;
+            SPEC_STAMP(8);
+            if (last || !step) out[BSVI_OUT_HEADER + tid] = grad;
+            if (step) {
+                if (finite != 0.0f && (own.mask & mask_bit)) optimizer_apply(cfg, own.theta, own.s0, own.s1, own.s2, own.st, grad);
+                SPEC_STAMP(9);
+                if (last) {
+                    float* const params = SPEC_A->params;
+                    float* const state = SPEC_A->state;
+                    params[tid] = own.theta;
+                    state[tid] = own.s0;
+                    state[(size_t)SPEC_N_PARAMS + tid] = own.s1;
+                    state[2 * (size_t)SPEC_N_PARAMS + tid] = own.s2;
+                    state[3 * (size_t)SPEC_N_PARAMS + tid] = own.st;
+                } else {
+#pragma unroll
+                    for (uint32_t e = 0; e < 2u; ++e)
+                        if (e < own.n) spec_store_uniform(own.k[e], own.a[e] + own.b[e] * utransform_common(own.tr[e], own.theta));
+                    OWN[4 * tid] = spec_f4{own.theta, own.s0, own.s1, own.s2};
+                    spec_lds[SPEC_OFF_OWN + 16 * tid + 4] = own.st;
+                }
+            }
+        }
+#if SPEC_GENERIC_OWNERS      // parameters beyond the workgroup size or with more than two uniform entries: the LDS working copy
         for (uint32_t i = tid; i < SPEC_N_PARAMS; i += nthreads) {
+            if (i == tid && own_fast) continue;
             const float theta = PS[i];
             const uint32_t j0 = TAB[SPEC_TAB_PTR + i], j1 = TAB[SPEC_TAB_PTR + i + 1];
             float gsum = 0.0f;
@@ -220,14 +401,12 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) bsvi_spec_kernel(
                 const uint32_t pos = TAB[SPEC_TAB_POS + j], k = TAB[SPEC_TAB_IDX + j];
                 float s = WS[pos];
                 for (uint32_t w = 1; w < rows; ++w) s += WS[w * SPEC_NUG_PAD + pos];
-                gsum += s * (__uint_as_float(TAB[4 * k + 3]) * utransform_grad((int)(TAB[4 * k + 1] & 0xFFu), theta));
+                gsum += s * (__uint_as_float(TAB[4 * k + 3]) * spec_utransform_grad(TAB[4 * k + 1] & 0xFFu, theta));
             }
             const float grad = gsum * scale;
-            out[BSVI_OUT_HEADER + i] = grad;
-            if (step && finite != 0.0f && (TAB[SPEC_TAB_MASK + i] & mask_bit)) {
-                const bsvi_opt_cfg cfg = SPEC_A->cfg;
+            if (last || !step) out[BSVI_OUT_HEADER + i] = grad;
+            if (step && finite != 0.0f && (TAB[SPEC_TAB_MASK + i] & mask_bit))
                 optimizer_update(cfg, PS, PS + SPEC_NP_PAD, SPEC_NP_PAD, i, grad);
-            }
             if (!step) continue;
             if (last) {
                 float* const params = SPEC_A->params;
@@ -240,7 +419,16 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) bsvi_spec_kernel(
                 for (uint32_t j = j0; j < j1; ++j) spec_publish_uniform(TAB, TAB[SPEC_TAB_IDX + j], theta2);
             }
         }
+#endif
+        SPEC_STAMP(6);
     }
+#if defined(SPEC_DEBUG_STAMPS)
+    float* const loss_slot = SPEC_A->loss_slot;
+    if (tid == 0 && loss_slot && n_it > 16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int i = 1; i < 12; ++i) loss_slot[i] = (float)(stamp[i] - stamp[0]);
+    }
+#endif
 #undef SPEC_A
 }
 

@@ -95,12 +95,17 @@ __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane&
 //   RED  [SPEC_RED_FLOATS]              value / non-finite sums per wave, block totals, flags
 //   PS   [5][SPEC_NP_PAD]               theta and the optimizer state [4][n_params]: the working copy of a launch
 //   TAB                                 uniform entries (4 words each), CSR theta -> positions / uniform indices, masks
+//   OWN  [min(NP, threads)][16]         what the thread that owns a parameter needs per iteration, packed for four
+//                                       ds_read_b128: theta, optimizer state, its (<= 2) uniform entries
 //   TR   [W][SPEC_TE * SPEC_TR_STRIDE]  per-wave transpose tile: the lanes of a wave store their contribution to
 //                                       position p at TR[(p % TE) * 68 + lane]; every TE positions lane j adds up
 //                                       row j with 16 conflict-free ds_read_b128, fixed order — ~2 instructions per
 //                                       entry and lane instead of a 10-instruction DPP reduction per entry
 #ifndef SPEC_TE
 #define SPEC_TE 64
+#endif
+#ifndef SPEC_GENERIC_OWNERS
+#define SPEC_GENERIC_OWNERS 1
 #endif
 #define SPEC_TR_STRIDE 68      /* 16-byte aligned rows; 16 lanes x 4 consecutive banks tile the 64 banks exactly */
 #define SPEC_MAX_WAVES (SPEC_MAX_THREADS / 64)
@@ -117,7 +122,9 @@ __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane&
 #define SPEC_OFF_RED (SPEC_OFF_WS + SPEC_MAX_WAVES * SPEC_NUG_PAD)
 #define SPEC_OFF_PS (SPEC_OFF_RED + SPEC_RED_FLOATS)
 #define SPEC_OFF_TAB (SPEC_OFF_PS + 5 * SPEC_NP_PAD)
-#define SPEC_OFF_TR (SPEC_OFF_TAB + SPEC_TAB_WORDS)
+#define SPEC_OWN_ROWS (SPEC_N_PARAMS < SPEC_MAX_THREADS ? SPEC_N_PARAMS : SPEC_MAX_THREADS)
+#define SPEC_OFF_OWN (SPEC_OFF_TAB + SPEC_TAB_WORDS)
+#define SPEC_OFF_TR (SPEC_OFF_OWN + 16 * SPEC_OWN_ROWS)
 #define SPEC_LDS_FLOATS (SPEC_OFF_TR + SPEC_MAX_WAVES * SPEC_TR_FLOATS)
 __shared__ __attribute__((aligned(16))) float spec_lds[SPEC_LDS_FLOATS];
 

@@ -473,7 +473,8 @@ static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs
     const uint32_t W = max_threads / 64;
     const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4, nug_pad = (n_ugrad + 3) / 4 * 4 + 4;
     const uint32_t np_pad = (n_params + 3) / 4 * 4 + 4, tab = (4 * n_uniform + (2 * n_params + 1) + 2 * n_ugrad + 3) / 4 * 4 + 4;
-    return u_pad + 2 * nu_pad + W * nug_pad + (2 * W + 8) + 5 * np_pad + tab + W * te * 68;
+    const uint32_t own = 16 * (n_params < max_threads ? n_params : max_threads);
+    return u_pad + 2 * nu_pad + W * nug_pad + (2 * W + 8) + 5 * np_pad + tab + own + W * te * 68;
 }
 
 Spec* create(const bsvi_program_desc& d, std::string& why) {
@@ -511,6 +512,14 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
                    d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
         src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_TE %u\n#define SPEC_DIAG %d\n", d.estimator, max_threads, te, v);
         src += fmt("#define SPEC_KEEP_NOISE %u\n", E.keeps_noise() ? d.n_noise : 0u);
+        {
+            // every parameter owned by a thread of the smallest workgroup (one wave) with at most two uniform entries:
+            // the epilogue's generic loop over the LDS working copy is compiled out
+            bool all_fast = d.n_params <= 64;
+            for (uint32_t i = 0; i < d.n_params && all_fast; ++i)
+                all_fast = d.param_uniform_ptr[i + 1] - d.param_uniform_ptr[i] <= 2;
+            src += fmt("#define SPEC_GENERIC_OWNERS %d\n", all_fast ? 0 : 1);
+        }
         src += "#include \"spec_prelude.h\"\n";
         src += "namespace bsvi {\n";
         src += "__device__ __forceinline__ void spec_draw(const SpecBody& A, const SpecLane& T, SpecNoise& Z) {\n";
@@ -603,14 +612,16 @@ static int ensure_compiled(Spec* s, int v) {
     }
     if (code.empty()) {
         std::string log;
-        const int rc = compile(V.src, code, log);
+        std::string src = V.src;
+        if (const char* defs = getenv("BSVI_SPEC_DEFINES")) src = std::string(defs) + "\n" + src;     // tools: timing experiments
+        const int rc = compile(src, code, log);
         if (rc) {
             V.failed = true;
             if (getenv("BSVI_DEBUG")) fprintf(stderr, "bsvi: specialised kernel did not compile:\n%s\n", log.c_str());
             return bsvi_fail(BSVI_ERR_UNSUPPORTED, "specialised kernel did not compile: " + log.substr(0, 400));
         }
         std::lock_guard<std::mutex> g(g_cache_mu);
-        g_code_cache[V.src] = code;
+        if (!getenv("BSVI_SPEC_DEFINES")) g_code_cache[V.src] = code;
     }
     hipError_t e = hipModuleLoadData(&V.module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&V.fn, V.module, "bsvi_spec_kernel");
