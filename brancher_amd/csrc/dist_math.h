@@ -43,6 +43,11 @@ constexpr float kLog4Pi = 2.53102424696929079309f;
 constexpr float kLog2 = 0.69314718055994530942f;
 constexpr float kFloatEps = 1.1920928955078125e-07f;
 
+// The library forms on purpose (log1pf(expf(x)), IEEE division): they reproduce torch's values of the
+// geometric_ranges.py transforms to the last bit in the cases probed (softplus(inverse_softplus(1)) == 1 exactly), and a
+// model can depend on a transformed parameter discontinuously or degenerately — the gamma sampler behind a Beta node
+// branches on alpha < 1; log Beta(x | 1, 1) is identically 0 and becomes rounding noise for alpha one ulp off
+// (tests/golden/beta_binomial_N512).  The hardware-transcendental forms below are for derivatives and likelihood terms.
 BSVI_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // torch.nn.functional.softplus(beta=1, threshold=20)
 BSVI_DEV float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }

@@ -30,8 +30,8 @@ namespace bsvi {
 //              per parameter: bit 0 active, bit 1 active while iteration <= pretraining_iterations [NP]
 #define SPEC_TAB_PTR (4 * SPEC_N_UNIFORM)
 #define SPEC_TAB_POS (SPEC_TAB_PTR + SPEC_N_PARAMS + 1)
-#define SPEC_TAB_IDX (SPEC_TAB_POS + SPEC_N_UGRAD)
-#define SPEC_TAB_MASK (SPEC_TAB_IDX + SPEC_N_UGRAD)
+#define SPEC_TAB_IDX (SPEC_TAB_POS + SPEC_N_POS)
+#define SPEC_TAB_MASK (SPEC_TAB_IDX + SPEC_N_POS)
 
 // The barriers of the iteration loop order LDS traffic only (sums, uniform table, theta all live in LDS), so they wait
 // for the LDS counter and not for global memory: __syncthreads() also drains vmcnt, i.e. every iteration would wait
@@ -43,28 +43,15 @@ __device__ __forceinline__ void spec_lds_barrier() {
 }
 
 // U[k] = a + b * g(x) and its companions, from the LDS copy of entry k
-// The transforms of the uniform table on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp):
-// they sit on the critical path of every in-kernel iteration (between the barrier after the body and the one before the
-// next), where the library forms (range reduction, denormal handling) cost ~10x the instructions.
-__device__ __forceinline__ float spec_softplus(float x) {
-    if (x > 20.0f) return x;                                   // torch.nn.functional.softplus threshold
-    const float e = __expf(x);
-    // log1p(e): below 2^-6 the series keeps the relative accuracy that log(1 + e) loses to the rounding of 1 + e
-    return e < 0.015625f ? e * (1.0f - e * (0.5f - e * (0.33333334f - 0.25f * e))) : spec_log(1.0f + e);
-}
-__device__ __forceinline__ float spec_sigmoid(float x) { return spec_rcp(1.0f + __expf(-x)); }
-// (the transform id is data: written as one switch the compiler evaluates EVERY case and selects — tanh polynomial,
-//  sqrt refinement and all; the rare ones stay out of line behind a real branch)
+// The transforms of the uniform table: values through the library forms of dist_math.h (softplusf_ / sigmoidf_, see
+// there), derivatives on the hardware transcendental units (their rounding moves a gradient by 1e-7).  The transform id is
+// data: written as one switch the compiler evaluates EVERY case and selects — tanh polynomial, sqrt refinement and all;
+// the rare ones stay out of line behind a real branch.
 __device__ __noinline__ float spec_utransform_rare(uint32_t t, float x) { return utransform((int)t, x); }
 __device__ __noinline__ float spec_utransform_grad_rare(uint32_t t, float x) { return utransform_grad((int)t, x); }
-// The VALUES of the uniform table use the library forms of the interpreter (softplusf_ = log1pf(expf(x)), sigmoidf_):
-// a draw can depend on a parameter discontinuously (the gamma sampler behind a Beta node branches on alpha < 1), so an
-// entry that is one ulp off draws a different — equally valid — sample than the other engine, and the two stop being
-// comparable.  Only the derivative below, whose rounding moves a gradient by 1e-7, uses the hardware units.
 __device__ __forceinline__ float utransform_common(uint32_t t, float x) {
     if (t > BSVI_UT_SIGMOID) return spec_utransform_rare(t, x);
-    const float e = expf(t == BSVI_UT_SIGMOID ? -x : x);
-    const float soft = x > 20.0f ? x : log1pf(e), sig = 1.0f / (1.0f + e);
+    const float soft = softplusf_(x), sig = sigmoidf_(x);
     return t == BSVI_UT_IDENTITY ? x : (t == BSVI_UT_SOFTPLUS ? soft : sig);
 }
 __device__ __forceinline__ float spec_utransform_grad(uint32_t t, float x) {
@@ -131,13 +118,10 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
     SpecLane T;
     T.lane = lane;
     T.n = blockIdx.x * nthreads + tid;
-    {
-        const uint32_t n_local = SPEC_A->n_local;
-        T.active = T.n < n_local;
-        T.nc = T.active ? T.n : (n_local - 1u);
-        T.nidx = SPEC_A->sample_base + T.nc;
-    }
+    T.active = false; T.nc = 0; T.nidx = 0;
     T.vz = T.n >> 31;
+    const uint32_t sample_base = SPEC_A->sample_base;
+    const uint32_t n_chunks = (SPEC_A->n_local + G * nthreads - 1u) / (G * nthreads);
     const uint32_t mode = SPEC_A->mode;
     const bool step = mode != SPEC_MODE_SUMS;
     const uint32_t n_it = (mode == SPEC_MODE_LOOP) ? SPEC_A->n_iterations : 1u;
@@ -153,7 +137,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
         const float* state = SPEC_A->state;
         for (uint32_t i = tid; i < 4u * SPEC_N_UNIFORM; i += nthreads) TAB[i] = uniform[i];
         for (uint32_t i = tid; i < SPEC_N_PARAMS + 1u; i += nthreads) TAB[SPEC_TAB_PTR + i] = pu_ptr[i];
-        for (uint32_t j = tid; j < SPEC_N_UGRAD; j += nthreads) { TAB[SPEC_TAB_POS + j] = pu_pos[j]; TAB[SPEC_TAB_IDX + j] = pu_idx[j]; }
+        for (uint32_t j = tid; j < SPEC_N_POS; j += nthreads) { TAB[SPEC_TAB_POS + j] = pu_pos[j]; TAB[SPEC_TAB_IDX + j] = pu_idx[j]; }
         for (uint32_t i = tid; i < SPEC_N_OBS; i += nthreads) spec_lds[SPEC_N_UNIFORM + i] = obs[i];
         const uint8_t* mask = SPEC_A->mask;
         const uint8_t* mask_first = SPEC_A->mask_first;
@@ -236,14 +220,21 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
 #endif
     for (uint32_t it = 0; it < n_it; ++it) {
         SPEC_STAMP(0);
-        // ---- one Monte-Carlo sample per lane.  Its standard normals do not depend on the uniform table: they are drawn
+        // ---- one Monte-Carlo sample per lane and chunk (a workgroup of a large shard walks several chunks of samples, so
+        //      that the launch's fixed costs — tables, prologue, the row of sums — are paid once per workgroup, not once
+        //      per 256 samples).  The standard normals do not depend on the uniform table: the first chunk's are drawn
         //      ahead of the barrier that publishes it.
-        {
+        float lane_value = 0.0f, lane_bad = 0.0f;
+        for (uint32_t chunk = 0; chunk < n_chunks; ++chunk) {
             SpecBody B = B0;
 #if SPEC_DIAG
             // a given-noise sequence is laid out [iteration][row][n_local]
             if (B.noise) B.noise += (size_t)it * SPEC_N_NOISE * B.n_local;
 #endif
+            T.n = (chunk * G + blockIdx.x) * nthreads + tid;
+            T.active = T.n < B.n_local;
+            T.nc = T.active ? T.n : (B.n_local - 1u);
+            T.nidx = sample_base + T.nc;
             const unsigned long long off = off0 + it;
             T.f = 0.0f;
             T.lq = 0.0f;
@@ -256,16 +247,21 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             spec_draw(B, T, Z);
 #endif
             SPEC_STAMP(1);
-            spec_lds_barrier();                                // the uniform table of this iteration is complete
+            if (chunk == 0) {
+                spec_lds_barrier();                            // the uniform table of this iteration is complete ...
+                for (uint32_t k = lane; k < SPEC_N_POS; k += 64u) WSw[k] = 0.0f;     // ... and the last one's sums are consumed
+            }
             SPEC_STAMP(2);
 #if !defined(SPEC_DEBUG_NO_BODY)
             spec_body(B, T, Z, TRw, WSw);
 #endif
+            SPEC_STAMP(3);
+            const float value = (SPEC_ESTIMATOR == BSVI_EST_BLACKBOX) ? (T.lq * T.f + T.f) : T.f;
+            lane_value += T.active ? value : 0.0f;
+            lane_bad += (T.active && !isfinite(value)) ? 1.0f : 0.0f;
         }
-        SPEC_STAMP(3);
-        const float value = (SPEC_ESTIMATOR == BSVI_EST_BLACKBOX) ? (T.lq * T.f + T.f) : T.f;
-        const float vsum = wave_sum(T.active ? value : 0.0f);
-        const float bad = wave_sum((T.active && !isfinite(value)) ? 1.0f : 0.0f);
+        const float vsum = wave_sum(lane_value);
+        const float bad = wave_sum(lane_bad);
         if (lane == 0) { RED[8 + 2 * wave] = vsum; RED[9 + 2 * wave] = bad; }
         SPEC_STAMP(4);
         spec_lds_barrier();                                    // every wave's sums are in WS / RED
@@ -277,9 +273,9 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             SPEC_RELOAD_ARGS();
             float* const partials = SPEC_A->partials;
             unsigned int* const ticket = SPEC_A->ticket;
-            const uint32_t stride = 2u + SPEC_N_UGRAD;
+            const uint32_t stride = 2u + SPEC_N_POS;
             float* mine = partials + (size_t)blockIdx.x * stride;
-            for (uint32_t k = tid; k < SPEC_N_UGRAD; k += nthreads) {
+            for (uint32_t k = tid; k < SPEC_N_POS; k += nthreads) {
                 float s = WS[k];
                 for (uint32_t w = 1; w < W; ++w) s += WS[w * SPEC_NUG_PAD + k];
                 mine[2 + k] = s;

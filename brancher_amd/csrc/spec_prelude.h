@@ -83,6 +83,13 @@ __device__ __forceinline__ void spec_normals4(const SpecBody& A, const SpecLane&
     box_muller_fast(x.x, x.y, z0, z1);
     box_muller_fast(x.z, x.w, z2, z3);
 }
+// a value the optimiser cannot see through
+__device__ __forceinline__ uint32_t spec_opaque(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(x));
+#endif
+    return x;
+}
 __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane& T) {
     return PhiloxKey{T.nidx, A.seed_lo, A.seed_hi, T.off_lo, T.off_hi};
 }
@@ -104,6 +111,9 @@ __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane&
 #ifndef SPEC_TE
 #define SPEC_TE 64
 #endif
+#ifndef SPEC_FLUSH_OUT_OF_LINE
+#define SPEC_FLUSH_OUT_OF_LINE 0
+#endif
 #ifndef SPEC_GENERIC_OWNERS
 #define SPEC_GENERIC_OWNERS 1
 #endif
@@ -111,10 +121,10 @@ __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane&
 #define SPEC_MAX_WAVES (SPEC_MAX_THREADS / 64)
 #define SPEC_U_PAD ((SPEC_N_UNIFORM + SPEC_N_OBS + 3) / 4 * 4)
 #define SPEC_NU_PAD ((SPEC_N_UNIFORM + 3) / 4 * 4)
-#define SPEC_NUG_PAD ((SPEC_N_UGRAD + 3) / 4 * 4 + 4)
+#define SPEC_NUG_PAD ((SPEC_N_POS + 3) / 4 * 4 + 4)
 #define SPEC_RED_FLOATS (2 * SPEC_MAX_WAVES + 8)
 #define SPEC_NP_PAD ((SPEC_N_PARAMS + 3) / 4 * 4 + 4)
-#define SPEC_TAB_WORDS ((4 * SPEC_N_UNIFORM + (2 * SPEC_N_PARAMS + 1) + 2 * SPEC_N_UGRAD + 3) / 4 * 4 + 4)
+#define SPEC_TAB_WORDS ((4 * SPEC_N_UNIFORM + (2 * SPEC_N_PARAMS + 1) + 2 * SPEC_N_POS + 3) / 4 * 4 + 4)
 #define SPEC_TR_FLOATS (SPEC_TE * SPEC_TR_STRIDE)
 #define SPEC_OFF_UR SPEC_U_PAD
 #define SPEC_OFF_UL (SPEC_OFF_UR + SPEC_NU_PAD)
@@ -140,15 +150,23 @@ __shared__ __attribute__((aligned(16))) float spec_lds[SPEC_LDS_FLOATS];
 #define SPEC_DU(pos, val) TRw[((pos) % SPEC_TE) * SPEC_TR_STRIDE + T.lane] = T.active ? (val) : 0.0f
 
 typedef float spec_f4 __attribute__((ext_vector_type(4)));
-// positions [base, base + count) are complete: lane j < count adds the 64 lane contributions of position base + j
-__device__ __forceinline__ void spec_du_flush(float* TRw, float* WSw, uint32_t lane, uint32_t base, uint32_t count) {
+// positions [base, base + count) are complete: lane j < count adds the 64 lane contributions of position base + j.
+// Out of line in long programs (several flushes per body): inlined, every flush — 64 registers of reads in flight between
+// two memory-clobbering waits — makes the register allocator spill hundreds of the body's long-lived values (T = 60:
+// 206 spilled registers inlined, none as a call).
+#if SPEC_FLUSH_OUT_OF_LINE
+#define SPEC_FLUSH_FN __device__ __noinline__
+#else
+#define SPEC_FLUSH_FN __device__ __forceinline__
+#endif
+SPEC_FLUSH_FN void spec_du_flush(float* TRw, float* WSw, uint32_t lane, uint32_t base, uint32_t count) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's tile stores have landed (LDS is in order)
     if (lane < count) {
         const spec_f4* row = reinterpret_cast<const spec_f4*>(TRw + lane * SPEC_TR_STRIDE);
         spec_f4 s = row[0];
 #pragma unroll
         for (uint32_t q = 1; q < 16u; ++q) s += row[q];
-        WSw[base + lane] = (s.x + s.y) + (s.z + s.w);
+        WSw[base + lane] += (s.x + s.y) + (s.z + s.w);      // (zeroed at the top of the iteration: a wave may run several sample chunks)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next tile overwrites the rows
 }

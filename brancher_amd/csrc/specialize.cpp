@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <set>
@@ -42,6 +43,10 @@ struct Insn { uint32_t w0, dst, a, b, c, s, imm0, imm1; };
 
 constexpr size_t kMaxVisits = 12000;     // unrolled instruction visits (forward + reverse) a body may have
 constexpr uint32_t kKeepEpsRows = 64;    // up to this many noise rows stay in registers for the reverse sweep
+constexpr uint32_t kRescheduleAboveSlots = 40; // programs with more per-sample slots defer their sinks (register pressure)
+constexpr uint32_t kFenceAboveCode = 160;     // programs longer than this get scheduling fences ...
+constexpr uint32_t kFenceEvery = 4;           // ... every this many records
+constexpr uint32_t kAccumulateEntries = 96;   // up to this many gradient-carrying uniform entries accumulate in registers
 
 std::string fmt(const char* f, ...) {
     char buf[512];
@@ -64,6 +69,18 @@ class Emitter {
 public:
     Emitter(const bsvi_program_desc& d, bool diag, uint32_t te) : d_(d), diag_(diag), te_(te) {
         keep_eps_ = d.n_noise <= kKeepEpsRows;
+        // long programs: a gradient contribution leaves through its own position of the transpose tile instead of
+        // waiting in an accumulator register for the entry's last contribution
+        direct_du_ = d.n_uniform_grad > kAccumulateEntries;
+        // (short programs have the registers to spare and run a little faster with every sink in the forward sweep,
+        //  where the scheduler finds more independent work: 6.75 vs 7.7 kcycles per body at BASELINE config 1)
+        reschedule_ = d.n_slots > kRescheduleAboveSlots;
+        for (uint32_t pc = 0; pc < d.n_code; ++pc) {
+            const Insn I = insn(pc);
+            const uint32_t op = I.w0 & 0xFFu;
+            if ((op == BSVI_OP_NAFF || op == BSVI_OP_NODE) && (((I.w0 >> 8) & 0xFFu) & BSVI_F_WF)) reschedule_ = false;
+        }
+        if (d.estimator == BSVI_EST_BLACKBOX) reschedule_ = false;
         du_total_.assign(d.n_uniform_grad, 0);
         du_seen_.assign(d.n_uniform_grad, 0);
     }
@@ -109,7 +126,7 @@ public:
     std::string declarations() const {
         std::string s;
         for (uint32_t i = 0; i < d_.n_slots; ++i) s += fmt("    float v_%u = 0.0f, a_%u = 0.0f;\n", i, i);
-        for (uint32_t k = 0; k < d_.n_uniform_grad; ++k) if (du_total_[k]) s += fmt("    float du_%u = 0.0f;\n", k);
+        if (!direct_du_) for (uint32_t k = 0; k < d_.n_uniform_grad; ++k) if (du_total_[k]) s += fmt("    float du_%u = 0.0f;\n", k);
         for (uint32_t g : all_groups_) s += fmt("    float pn_%u_0 = 0.0f, pn_%u_1 = 0.0f, pn_%u_2 = 0.0f, pn_%u_3 = 0.0f;\n", g, g, g, g);
         for (uint32_t r : eps_rows_) s += fmt("    float ez_%u = 0.0f;\n", r);
         for (uint32_t r : all_node_rows_) s += fmt("    float ns_%u = 0.0f;\n", r);
@@ -120,7 +137,7 @@ private:
     const bsvi_program_desc& d_;
     bool diag_;
     uint32_t te_;
-    bool keep_eps_ = true, counting_ = true;
+    bool keep_eps_ = true, counting_ = true, direct_du_ = false, reschedule_ = true;
     size_t visits_ = 0;
     std::string body_;
     std::vector<uint32_t> du_total_, du_seen_, order_;
@@ -159,6 +176,7 @@ private:
         if (p.lane) { line(fmt("a_%u += %s;", p.idx, expr.c_str())); return; }
         if (p.idx >= d_.n_uniform_grad) return;
         if (counting_) { ++du_total_[p.idx]; return; }
+        if (direct_du_) { complete(p.idx, expr); return; }
         line(fmt("du_%u += %s;", p.idx, expr.c_str()));
         if (++du_seen_[p.idx] == du_total_[p.idx]) complete(p.idx, fmt("du_%u", p.idx));
     }
@@ -181,8 +199,12 @@ private:
         if (!have.count(g)) {
             have.insert(g);
             all_groups_.insert(g);
-            if (diag_) line(fmt("if (!noise) spec_normals4(A, T, %uu, pn_%u_0, pn_%u_1, pn_%u_2, pn_%u_3);", g, g, g, g, g));
-            else line(fmt("spec_normals4(A, T, %uu, pn_%u_0, pn_%u_1, pn_%u_2, pn_%u_3);", g, g, g, g, g));
+            // (the reverse sweep's second draw of a group goes through an opaque copy of the group number: the same call
+            //  on the same literal is a common subexpression of the forward sweep's, and the optimiser would keep that
+            //  one's four normals in registers across the whole body instead of drawing again)
+            const std::string gs = (reverse && !keep_eps_) ? std::string("spec_opaque(") + fmt("%uu", g) + ")" : fmt("%uu", g);
+            if (diag_) line(fmt("if (!noise) spec_normals4(A, T, %s, pn_%u_0, pn_%u_1, pn_%u_2, pn_%u_3);", gs.c_str(), g, g, g, g));
+            else line(fmt("spec_normals4(A, T, %s, pn_%u_0, pn_%u_1, pn_%u_2, pn_%u_3);", gs.c_str(), g, g, g, g));
         }
         return fmt("pn_%u_%u", g, j);
     }
@@ -389,57 +411,154 @@ private:
         for (uint32_t t = 0; t < n; ++t) line(fmt("a_%u = 0.0f;", base + t));
     }
 
-    // ---- the two sweeps of elbo_block
-    void walk() {
-        visits_ = 0;
+    // ---- the records of the stream
+    struct Item { uint32_t first, n, n_elems, temp_base, n_temps; bool bracket, sink; };
+    std::vector<Item> items() const {
+        std::vector<Item> v;
         for (uint32_t pc = 0; pc < d_.n_code;) {
             const Insn I = insn(pc);
-            const uint32_t op = I.w0 & 0xFFu;
             const bool sink = (I.w0 >> 24) & BSVI_R_SINK;
-            if (op == BSVI_OP_REC_BEGIN) {
-                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
-                for (uint32_t e = 0; e < n_elems && visits_ <= kMaxVisits; ++e) {
-                    for (uint32_t j = 1; j <= n; ++j) forward(insn(pc + j), e, true);
-                    if (sink) {
-                        zero_temps(temp_base, n_temps);
-                        for (uint32_t j = n; j >= 1; --j) backward(insn(pc + j), e);
-                    }
-                }
-                pc += n + 2;
+            if ((I.w0 & 0xFFu) == BSVI_OP_REC_BEGIN) {
+                v.push_back(Item{pc + 1, I.dst, I.a, I.b, I.c, true, sink});
+                pc += I.dst + 2;
             } else {
-                if (sink && op == BSVI_OP_NAFF) {
-                    naff_sink(I, 0);
-                } else {
-                    forward(I, 0, true);
-                    if (sink) backward(I, 0);
-                }
+                v.push_back(Item{pc, 1, 1, 0, 0, false, sink});
                 pc += 1;
             }
+        }
+        return v;
+    }
+    void emit_forward(const Item& R) {          // forward sweep of a record; a sink also runs its reverse step here
+        if (!R.bracket) {
+            const Insn I = insn(R.first);
+            if (R.sink && (I.w0 & 0xFFu) == BSVI_OP_NAFF) { naff_sink(I, 0); return; }
+            forward(I, 0, true);
+            if (R.sink) backward(I, 0);
+            return;
+        }
+        for (uint32_t e = 0; e < R.n_elems && visits_ <= kMaxVisits; ++e) {
+            for (uint32_t j = 0; j < R.n; ++j) forward(insn(R.first + j), e, true);
+            if (R.sink) {
+                zero_temps(R.temp_base, R.n_temps);
+                for (uint32_t j = R.n; j-- > 0;) backward(insn(R.first + j), e);
+            }
+        }
+    }
+    void emit_reverse(const Item& R) {          // reverse sweep of a (non-sink) record
+        if (!R.bracket) { backward(insn(R.first), 0); return; }
+        for (uint32_t e = R.n_elems; e-- > 0 && visits_ <= kMaxVisits;) {
+            for (uint32_t j = 0; j < R.n; ++j) forward(insn(R.first + j), e, false);      // re-materialise the temps
+            zero_temps(R.temp_base, R.n_temps);
+            for (uint32_t j = R.n; j-- > 0;) backward(insn(R.first + j), e);
+        }
+    }
+    // slots an instruction reads or scatters adjoints to / the slot it defines, over the record's elements
+    void slots_of(const Item& R, std::set<uint32_t>& reads, std::set<uint32_t>& writes) const {
+        for (uint32_t j = 0; j < R.n; ++j) {
+            const Insn I = insn(R.first + j);
+            const uint32_t op = I.w0 & 0xFFu, flags = (I.w0 >> 8) & 0xFFu;
+            const uint32_t ops[5] = {I.dst, I.a, I.b, I.c, I.s};
+            const int n_opnd = (op == BSVI_OP_NAFF) ? 5 : ((op == BSVI_OP_UN) ? 2 : 3);
+            const bool defines = op == BSVI_OP_BIN || op == BSVI_OP_UN || (flags & BSVI_F_SAMPLE);
+            for (uint32_t e = 0; e < R.n_elems; ++e)
+                for (int k = 0; k < n_opnd; ++k) {
+                    const Opnd p = resolve(ops[k], e);
+                    if (!p.lane) continue;
+                    if (k == 0 && defines) writes.insert(p.idx); else reads.insert(p.idx);
+                }
+        }
+    }
+
+    // ---- the two sweeps of elbo_block.  The interpreter runs every sink record (a model log-prob term: value AND
+    //      adjoints in one visit) in the forward sweep, so the adjoint of every latent stays live from there to the
+    //      latent's turn in the reverse sweep — 2 registers per latent across the whole body.  Here a sink is deferred to
+    //      just before the reverse step of the LAST-defined slot it touches (the first of them the reverse sweep
+    //      consumes): adjoints live for a few instructions.  Not with a score term in the program (BlackBox: the reverse
+    //      steps weight log q with the COMPLETE f).
+    void walk() {
+        visits_ = 0;
+        const std::vector<Item> recs = items();
+        // Reverse order of the non-sink records.  Reverse stream order is one valid order; any order works in which a
+        // record's reverse step comes after the reverse steps of the records that read what it defines.  A DERIVED value
+        // (an arithmetic record, e.g. the sigmoid(b) that every transition prior of an AR chain reads) is defined late
+        // in the stream, so in reverse stream order it would come first and pull every sink that reads it to the front.
+        // It is anchored instead to the latest-defined latent among its inputs: its reverse step runs just before that
+        // latent's.  key = (anchor, index), visited in descending order.
+        std::vector<std::pair<int, int>> key(recs.size(), std::make_pair(-1, -1));
+        std::vector<int> def_of(d_.n_slots, -1);
+        std::vector<uint32_t> rorder;                     // non-sink records in reverse-sweep order
+        for (uint32_t r = 0; r < recs.size(); ++r) {
+            if (recs[r].sink) continue;
+            std::set<uint32_t> rd, wr;
+            slots_of(recs[r], rd, wr);
+            bool samples = false;
+            for (uint32_t j = 0; j < recs[r].n; ++j) {
+                const Insn I = insn(recs[r].first + j);
+                const uint32_t op = I.w0 & 0xFFu;
+                if ((op == BSVI_OP_NAFF || op == BSVI_OP_NODE) && (((I.w0 >> 8) & 0xFFu) & BSVI_F_SAMPLE)) samples = true;
+            }
+            int anchor = (int)r;
+            if (!samples && reschedule_) {
+                int a = -1;
+                for (uint32_t sl : rd) {
+                    if (sl >= recs[r].temp_base && sl < recs[r].temp_base + recs[r].n_temps) continue;
+                    if (def_of[sl] >= 0 && key[def_of[sl]].first > a) a = key[def_of[sl]].first;
+                }
+                if (a >= 0) anchor = a;
+            }
+            key[r] = std::make_pair(anchor, (int)r);
+            for (uint32_t sl : wr) def_of[sl] = (int)r;
+            rorder.push_back(r);
+        }
+        std::sort(rorder.begin(), rorder.end(), [&](uint32_t x, uint32_t y) { return key[x] > key[y]; });
+        std::vector<std::vector<uint32_t>> deferred(recs.size());
+        std::vector<int> home(recs.size(), -1);
+        if (reschedule_) {
+            for (uint32_t r = 0; r < recs.size(); ++r) {
+                if (!recs[r].sink) continue;
+                std::set<uint32_t> rd, wr;
+                slots_of(recs[r], rd, wr);
+                int first = -1;                           // the definer of its slots that the reverse sweep visits first
+                for (uint32_t sl : rd) {
+                    if (sl >= recs[r].temp_base && sl < recs[r].temp_base + recs[r].n_temps) continue;     // its own temps
+                    const int dr = def_of[sl];         // (latents and derived values are defined once)
+                    if (dr >= 0 && (uint32_t)dr < r && (first < 0 || key[dr] > key[first])) first = dr;
+                }
+                if (first >= 0) { home[r] = first; deferred[first].push_back(r); }
+            }
+        }
+        // long programs: a compiler fence every few records.  A node's uniform entries (scale, 1/scale, log scale) are read
+        // in the forward sweep and again in the reverse sweep; with no store in between that provably aliases them the
+        // optimiser keeps the first read's value instead of reading LDS again — three registers per node held across
+        // the whole body (T = 200: 600 registers, spilled to scratch).  The fence makes it read again.
+        const bool fence = d_.n_code > kFenceAboveCode;
+        uint32_t since = 0;
+        auto maybe_fence = [&]() { if (fence && ++since >= kFenceEvery) { since = 0; line("asm volatile(\"\" ::: \"memory\"); __builtin_amdgcn_sched_barrier(0);"); } };
+        for (uint32_t r = 0; r < recs.size(); ++r) {
+            if (home[r] >= 0) continue;
+            emit_forward(recs[r]);
+            maybe_fence();
             if (visits_ > kMaxVisits) return;
         }
         line("const float fweight = T.f; (void)fweight;");
-        if (diag_) line("if (A.fvalue_out && T.active) { A.fvalue_out[T.n] = T.f; A.fvalue_out[(size_t)A.n_local + T.n] = T.lq; }");
-        for (uint32_t pc = d_.n_code; pc > 0;) {
-            const Insn I = insn(pc - 1);
-            const uint32_t op = I.w0 & 0xFFu;
-            const bool sink = (I.w0 >> 24) & BSVI_R_SINK;
-            if (op == BSVI_OP_REC_END) {
-                const uint32_t n = I.dst, n_elems = I.a, temp_base = I.b, n_temps = I.c;
-                const uint32_t first = pc - 1 - n;
-                if (!sink) {
-                    for (uint32_t e = n_elems; e-- > 0 && visits_ <= kMaxVisits;) {
-                        for (uint32_t j = 0; j < n; ++j) forward(insn(first + j), e, false);     // re-materialise the temps
-                        zero_temps(temp_base, n_temps);
-                        for (uint32_t j = n; j-- > 0;) backward(insn(first + j), e);
-                    }
-                }
-                pc = first - 1;
-            } else {
-                if (!sink) backward(I, 0);
-                pc -= 1;
+        if (fence) {
+            // long programs: the reverse sweep recomputes a node's location from its parents' values; as a common
+            // subexpression of the forward sweep's the optimiser would instead keep all of them (one register per node
+            // across the body).  Passing the slot values through an empty asm makes them new values to it.
+            line("asm volatile(\"\" ::: \"memory\");");
+            for (uint32_t s0 = 0; s0 < d_.n_slots; s0 += 16) {
+                std::string ops;
+                for (uint32_t sl = s0; sl < d_.n_slots && sl < s0 + 16; ++sl) ops += fmt("%s\"+v\"(v_%u)", sl == s0 ? "" : ", ", sl);
+                line("asm volatile(\"\" : " + ops + ");");
             }
+        }
+        for (uint32_t r : rorder) {
+            for (uint32_t sidx : deferred[r]) emit_forward(recs[sidx]);
+            emit_reverse(recs[r]);
+            maybe_fence();
             if (visits_ > kMaxVisits) return;
         }
+        if (diag_) line("if (A.fvalue_out && T.active) { A.fvalue_out[T.n] = T.f; A.fvalue_out[(size_t)A.n_local + T.n] = T.lq; }");
     }
 };
 
@@ -455,92 +574,105 @@ struct Variant {
     bool failed = false;
 };
 
+// two launch geometries, each with its own compiled kernels (the transpose-tile size is part of the generated body):
+//   ONE  a shard of up to max_threads / 64 waves runs as ONE workgroup — no grid reduction, the training loop can stay
+//        in the kernel;
+//   MANY larger shards: 256-thread workgroups, sized so that two fit a CU's LDS, each walking several sample chunks.
+enum { GEOM_ONE = 0, GEOM_MANY = 1 };
+struct Geom { uint32_t max_threads = 0, te = 0, lds_bytes = 0; };
+
 struct Spec {
     uint32_t n_params = 0, n_uniform = 0, n_ugrad = 0, n_obs = 0, n_noise = 0;
-    uint32_t max_threads = 512, te = 64;
-    uint32_t lds_bytes = 0;
-    std::vector<uint32_t> pu_ptr_host, pu_pos_host;       // CSR in positions
-    Variant variant[2];                                   // 0 lean, 1 diagnostic
-    void* dev = nullptr;                                  // [tickets: 256 B][pu_pos]
+    uint32_t n_pos = 0;                                   // positions of the transpose tile (>= n_ugrad)
+    Geom geom[2];
+    std::vector<uint32_t> pu_ptr_host, pu_pos_host, pu_idx_host;   // CSR theta -> (position, uniform entry)
+    Variant variant[4];                                   // [geometry][0 lean, 1 diagnostic]
+    void* dev = nullptr;                                  // [tickets: 256 B][pu_ptr][pu_pos][pu_idx]
     unsigned int* tickets = nullptr;
+    const uint32_t* pu_ptr = nullptr;
     const uint32_t* pu_pos = nullptr;
+    const uint32_t* pu_idx = nullptr;
+    uint32_t n_cus = 256;
     uint32_t launch_seq = 0;
     std::mutex mu;
 };
 
-static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs, uint32_t n_ugrad, uint32_t max_threads, uint32_t te) {
+static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs, uint32_t n_pos, uint32_t max_threads, uint32_t te) {
     // mirrors the SPEC_OFF_* layout of spec_prelude.h
     const uint32_t W = max_threads / 64;
-    const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4, nug_pad = (n_ugrad + 3) / 4 * 4 + 4;
-    const uint32_t np_pad = (n_params + 3) / 4 * 4 + 4, tab = (4 * n_uniform + (2 * n_params + 1) + 2 * n_ugrad + 3) / 4 * 4 + 4;
+    const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4, nug_pad = (n_pos + 3) / 4 * 4 + 4;
+    const uint32_t np_pad = (n_params + 3) / 4 * 4 + 4, tab = (4 * n_uniform + (2 * n_params + 1) + 2 * n_pos + 3) / 4 * 4 + 4;
     const uint32_t own = 16 * (n_params < max_threads ? n_params : max_threads);
     return u_pad + 2 * nu_pad + W * nug_pad + (2 * W + 8) + 5 * np_pad + tab + own + W * te * 68;
 }
 
 Spec* create(const bsvi_program_desc& d, std::string& why) {
     if (!d.n_code) { why = "empty program"; return nullptr; }
-    // launch bounds: a sample keeps 2 registers per slot (value, adjoint) plus its noise; 512 threads leave 256
-    // registers per lane, 256 threads the whole 512-entry file (MI355X_MICROARCH.md, register files)
-    uint32_t max_threads = 512;
-    const uint32_t live = 2 * d.n_slots + (d.n_noise <= kKeepEpsRows ? d.n_noise : 0) + 48;
-    if (live > 232) max_threads = 256;
-    uint32_t te = 64;
-    while (te > 8 && lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
-    if (lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
-        max_threads = 256;
-        te = 64;
-        while (te > 8 && lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) te >>= 1;
-        if (lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u > 160u * 1024u) {
-            why = "uniform table does not fit LDS";
-            return nullptr;
-        }
-    }
     Spec* s = new Spec();
     s->n_params = d.n_params; s->n_uniform = d.n_uniform; s->n_ugrad = d.n_uniform_grad; s->n_obs = d.n_obs; s->n_noise = d.n_noise;
-    s->max_threads = max_threads; s->te = te;
-    s->lds_bytes = lds_floats(d.n_params, d.n_uniform, d.n_obs, d.n_uniform_grad, max_threads, te) * 4u;
-    std::vector<uint32_t> order;
-    for (int v = 0; v < 2; ++v) {
-        Emitter E(d, v == 1, te);
+    {
+        // the positions (and with them the CSR map theta -> positions) do not depend on the geometry
+        Emitter E(d, false, 64);
         if (!E.run(why)) { delete s; return nullptr; }
-        if (v == 0) order = E.order();
-        else if (order != E.order()) { why = "internal: variants disagree on the completion order"; delete s; return nullptr; }
-        std::string src;
-        src += "// generated by libbsvi (specialize.cpp) from a model program: do not edit\n";
-        src += "#define BSVI_SPECIALIZED 1\n";
-        src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
-                   d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
-        src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_TE %u\n#define SPEC_DIAG %d\n", d.estimator, max_threads, te, v);
-        src += fmt("#define SPEC_KEEP_NOISE %u\n", E.keeps_noise() ? d.n_noise : 0u);
-        {
-            // every parameter owned by a thread of the smallest workgroup (one wave) with at most two uniform entries:
-            // the epilogue's generic loop over the LDS working copy is compiled out
-            bool all_fast = d.n_params <= 64;
-            for (uint32_t i = 0; i < d.n_params && all_fast; ++i)
-                all_fast = d.param_uniform_ptr[i + 1] - d.param_uniform_ptr[i] <= 2;
-            src += fmt("#define SPEC_GENERIC_OWNERS %d\n", all_fast ? 0 : 1);
+        const std::vector<uint32_t>& order = E.order();
+        s->n_pos = (uint32_t)order.size();
+        std::vector<std::vector<uint32_t>> pos_of(d.n_uniform_grad);
+        for (uint32_t p = 0; p < order.size(); ++p) pos_of[order[p]].push_back(p);
+        s->pu_ptr_host.assign(1, 0u);
+        for (uint32_t i = 0; i < d.n_params; ++i) {
+            for (uint32_t j = d.param_uniform_ptr[i]; j < d.param_uniform_ptr[i + 1]; ++j)
+                for (uint32_t p : pos_of[d.param_uniform_idx[j]]) { s->pu_pos_host.push_back(p); s->pu_idx_host.push_back(d.param_uniform_idx[j]); }
+            s->pu_ptr_host.push_back((uint32_t)s->pu_pos_host.size());
         }
-        src += "#include \"spec_prelude.h\"\n";
-        src += "namespace bsvi {\n";
-        src += "__device__ __forceinline__ void spec_draw(const SpecBody& A, const SpecLane& T, SpecNoise& Z) {\n";
-        src += "    (void)A; (void)T; (void)Z;\n";
-        src += E.draw();
-        src += "}\n";
-        src += "__device__ __forceinline__ void spec_body(const SpecBody& A, SpecLane& T, const SpecNoise& Z, float* TRw, float* WSw) {\n";
-        src += "    (void)Z;\n";
-        if (v == 1) src += "    const float* const noise = A.noise;\n";
-        src += E.declarations();
-        src += E.body();
-        src += "}\n}  // namespace bsvi\n";
-        src += "#include \"spec_main.h\"\n";
-        s->variant[v].src = std::move(src);
     }
-    // CSR theta -> positions
-    std::vector<uint32_t> pos_of(d.n_uniform_grad, 0);
-    for (uint32_t p = 0; p < order.size(); ++p) pos_of[order[p]] = p;
-    s->pu_ptr_host.assign(d.param_uniform_ptr, d.param_uniform_ptr + (d.n_params ? d.n_params + 1 : 0));
-    s->pu_pos_host.resize(d.n_uniform_grad);
-    for (uint32_t j = 0; j < d.n_uniform_grad; ++j) s->pu_pos_host[j] = pos_of[d.param_uniform_idx[j]];
+    // launch bounds: a sample keeps its slot values and its noise in registers; 512 threads leave 256 registers per
+    // lane, 256 threads the whole 512-entry file (MI355X_MICROARCH.md, register files)
+    const uint32_t live = 2 * d.n_slots + (d.n_noise <= kKeepEpsRows ? d.n_noise : 0) + (d.n_uniform_grad <= kAccumulateEntries ? d.n_uniform_grad : 0) + 40;
+    auto fit = [&](uint32_t threads, uint32_t budget_bytes, Geom& g) {
+        for (uint32_t te = 64; te >= 8; te >>= 1) {
+            const uint32_t bytes = lds_floats(d.n_params, d.n_uniform, d.n_obs, s->n_pos, threads, te) * 4u;
+            if (bytes <= budget_bytes) { g.max_threads = threads; g.te = te; g.lds_bytes = bytes; return true; }
+        }
+        return false;
+    };
+    const uint32_t kLds = 160u * 1024u;
+    bool ok = (live <= 232 && fit(512, kLds, s->geom[GEOM_ONE])) || fit(256, kLds, s->geom[GEOM_ONE]);
+    ok = ok && (fit(256, kLds / 2 - 1024, s->geom[GEOM_MANY]) || fit(256, kLds, s->geom[GEOM_MANY]));
+    if (!ok) { why = "the program's tables do not fit LDS"; delete s; return nullptr; }
+    bool all_fast = d.n_params <= 64;      // every parameter owned by a thread of the smallest workgroup, <= 2 positions
+    for (uint32_t i = 0; i < d.n_params && all_fast; ++i) all_fast = s->pu_ptr_host[i + 1] - s->pu_ptr_host[i] <= 2;
+    for (int gi = 0; gi < 2; ++gi) {
+        const Geom& G = s->geom[gi];
+        for (int v = 0; v < 2; ++v) {
+            Emitter E(d, v == 1, G.te);
+            if (!E.run(why)) { delete s; return nullptr; }
+            std::string src;
+            src += "// generated by libbsvi (specialize.cpp) from a model program: do not edit\n";
+            src += "#define BSVI_SPECIALIZED 1\n";
+            src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
+                       d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
+            src += fmt("#define SPEC_N_POS %u\n", s->n_pos);
+            src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_TE %u\n#define SPEC_DIAG %d\n", d.estimator, G.max_threads, G.te, v);
+            src += fmt("#define SPEC_KEEP_NOISE %u\n", E.keeps_noise() ? d.n_noise : 0u);
+            src += fmt("#define SPEC_FLUSH_OUT_OF_LINE %d\n", s->n_pos > 2 * G.te ? 1 : 0);
+            // (all parameters "fast": the epilogue's generic loop over the LDS working copy is compiled out)
+            src += fmt("#define SPEC_GENERIC_OWNERS %d\n", all_fast ? 0 : 1);
+            src += "#include \"spec_prelude.h\"\n";
+            src += "namespace bsvi {\n";
+            src += "__device__ __forceinline__ void spec_draw(const SpecBody& A, const SpecLane& T, SpecNoise& Z) {\n";
+            src += "    (void)A; (void)T; (void)Z;\n";
+            src += E.draw();
+            src += "}\n";
+            src += "__device__ __forceinline__ void spec_body(const SpecBody& A, SpecLane& T, const SpecNoise& Z, float* TRw, float* WSw) {\n";
+            src += "    (void)Z;\n";
+            if (v == 1) src += "    const float* const noise = A.noise;\n";
+            src += E.declarations();
+            src += E.body();
+            src += "}\n}  // namespace bsvi\n";
+            src += "#include \"spec_main.h\"\n";
+            s->variant[2 * gi + v].src = std::move(src);
+        }
+    }
     return s;
 }
 
@@ -552,19 +684,29 @@ void destroy(Spec* s) {
 }
 
 int upload(Spec* s) {
-    const size_t bytes = 256 + (size_t)s->pu_pos_host.size() * 4 + 256;
+    const size_t n_ptr = s->pu_ptr_host.size(), n_pos = s->pu_pos_host.size();
+    const size_t bytes = 256 + (n_ptr + 2 * n_pos) * 4 + 256;
     hipError_t e = hipMalloc(&s->dev, bytes);
     if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("hipMalloc (specialiser tables): ") + hipGetErrorString(e));
+    std::vector<uint32_t> host(64 + n_ptr + 2 * n_pos, 0u);
+    std::copy(s->pu_ptr_host.begin(), s->pu_ptr_host.end(), host.begin() + 64);
+    std::copy(s->pu_pos_host.begin(), s->pu_pos_host.end(), host.begin() + 64 + n_ptr);
+    std::copy(s->pu_idx_host.begin(), s->pu_idx_host.end(), host.begin() + 64 + n_ptr + n_pos);
     e = hipMemset(s->dev, 0, bytes);
-    if (e == hipSuccess && !s->pu_pos_host.empty())
-        e = hipMemcpy((char*)s->dev + 256, s->pu_pos_host.data(), s->pu_pos_host.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->dev, host.data(), host.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("specialiser tables: ") + hipGetErrorString(e));
     s->tickets = (unsigned int*)s->dev;
-    s->pu_pos = (const uint32_t*)((char*)s->dev + 256);
+    s->pu_ptr = (const uint32_t*)s->dev + 64;
+    s->pu_pos = s->pu_ptr + n_ptr;
+    s->pu_idx = s->pu_pos + n_pos;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        s->n_cus = (uint32_t)cus;
     return BSVI_OK;
 }
 
-const std::string& source(const Spec* s, int variant) { return s->variant[variant ? 1 : 0].src; }
+// variant: 0 training kernel, 1 diagnostic kernel of the one-workgroup geometry; 2, 3 the same of the many-workgroup one
+const std::string& source(const Spec* s, int variant) { return s->variant[variant & 3].src; }
 
 // ---------------------------------------------------------------------------------------------------------------
 //  hiprtc
@@ -636,33 +778,38 @@ static int ensure_compiled(Spec* s, int v) {
 // ---------------------------------------------------------------------------------------------------------------
 //  launch
 // ---------------------------------------------------------------------------------------------------------------
-struct Geo { uint32_t blocks, threads; };
+struct Geo { uint32_t blocks, threads; int geom; };
 static Geo geo(const Spec* s, uint32_t n_local) {
-    const uint32_t waves = (n_local + 63) / 64, max_waves = s->max_threads / 64;
-    if (waves <= max_waves) return Geo{1, waves * 64};
-    // many samples: 256-thread workgroups (one wave per SIMD), every one of them full but the last
-    const uint32_t threads = s->max_threads < 256 ? s->max_threads : 256;
-    return Geo{(n_local + threads - 1) / threads, threads};
+    const uint32_t waves = (n_local + 63) / 64;
+    if (waves <= s->geom[GEOM_ONE].max_threads / 64) return Geo{1, waves * 64, GEOM_ONE};
+    // many samples: 256-thread workgroups (one wave per SIMD), two per CU at most; beyond that every workgroup walks
+    // several chunks of 256 samples
+    const uint32_t threads = s->geom[GEOM_MANY].max_threads;
+    uint32_t blocks = (n_local + threads - 1) / threads;
+    const uint32_t per_cu = s->geom[GEOM_MANY].lds_bytes * 2u <= 160u * 1024u ? 2u : 1u;
+    if (blocks > per_cu * s->n_cus) blocks = per_cu * s->n_cus;
+    return Geo{blocks, threads, GEOM_MANY};
 }
 
 void geometry(const Spec* s, uint32_t n_local, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes) {
     const Geo g = geo(s, n_local);
     if (n_blocks) *n_blocks = g.blocks;
     if (n_threads) *n_threads = g.threads;
-    if (lds_bytes) *lds_bytes = s->lds_bytes;
+    if (lds_bytes) *lds_bytes = s->geom[g.geom].lds_bytes;
 }
 
 size_t workspace_bytes(const Spec* s, uint32_t n_local) {
     const Geo g = geo(s, n_local);
-    return ((size_t)g.blocks * (2 + s->n_ugrad) * 4 + 255) / 256 * 256 + 256;
+    return ((size_t)g.blocks * (2 + s->n_pos) * 4 + 255) / 256 * 256 + 256;
 }
 
 bool applies(const Spec* s, uint32_t n_local, int mode) {
     if (!s || !n_local) return false;
     const char* e = getenv("BSVI_JIT");
     if (e && e[0] == '0') return false;
-    if (s->variant[0].failed || s->variant[1].failed) return false;
-    if (mode == MODE_LOOP && geo(s, n_local).blocks != 1) return false;
+    const Geo g = geo(s, n_local);
+    if (s->variant[2 * g.geom].failed || s->variant[2 * g.geom + 1].failed) return false;
+    if (mode == MODE_LOOP && g.blocks != 1) return false;
     return true;
 }
 
@@ -672,7 +819,8 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     if (!a->obs_dev && s->n_obs) return bsvi_fail(BSVI_ERR_INVALID, "obs_dev is null");
     if (!a->out_dev) return bsvi_fail(BSVI_ERR_INVALID, "out_dev is null");
     if (!a->n_samples_local || !a->n_samples_global) return bsvi_fail(BSVI_ERR_INVALID, "zero samples");
-    const int v = (a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev) ? 1 : 0;
+    const Geo g = geo(s, a->n_samples_local);
+    const int v = 2 * g.geom + ((a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev) ? 1 : 0);
     uint32_t seq;
     {
         std::lock_guard<std::mutex> g(s->mu);
@@ -680,7 +828,6 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
         if (rc) return rc;
         seq = s->launch_seq++;
     }
-    const Geo g = geo(s, a->n_samples_local);
     if (g.blocks > 1 && !L.workspace) return bsvi_fail(BSVI_ERR_INVALID, "workspace_dev is null");
     SpecArgs A;
     memset(&A, 0, sizeof A);
@@ -691,7 +838,7 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     A.out = a->out_dev;
     A.partials = (float*)L.workspace;
     A.ticket = s->tickets + (seq % 64u);     // library-owned, zero between launches
-    A.pu_ptr = p->pu_ptr; A.pu_pos = s->pu_pos; A.pu_idx = p->pu_idx;
+    A.pu_ptr = s->pu_ptr; A.pu_pos = s->pu_pos; A.pu_idx = s->pu_idx;
     A.state = L.state; A.mask = L.mask; A.mask_first = L.mask_first ? L.mask_first : L.mask;
     A.loss_slot = L.loss_slot; A.finite_slot = L.finite_slot;
     A.n_local = a->n_samples_local; A.n_global = a->n_samples_global; A.sample_base = a->sample_base;
