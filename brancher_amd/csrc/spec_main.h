@@ -111,15 +111,14 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
     float* const RED = spec_lds + SPEC_OFF_RED;
     float* const PS = spec_lds + SPEC_OFF_PS;
     uint32_t* const TAB = reinterpret_cast<uint32_t*>(spec_lds + SPEC_OFF_TAB);
-    float* const TR = spec_lds + SPEC_OFF_TR;
-    float* const WSw = WS + wave * SPEC_NUG_PAD;
-    float* const TRw = TR + wave * SPEC_TR_FLOATS;
+    float* const WSw = WS + wave * SPEC_WS_PAD;
 
     SpecLane T;
     T.lane = lane;
     T.n = blockIdx.x * nthreads + tid;
     T.active = false; T.nc = 0; T.nidx = 0;
     T.vz = T.n >> 31;
+    T.tile = wave * SPEC_TR_FLOATS + lane;
     const uint32_t sample_base = SPEC_A->sample_base;
     const uint32_t n_chunks = (SPEC_A->n_local + G * nthreads - 1u) / (G * nthreads);
     const uint32_t mode = SPEC_A->mode;
@@ -249,11 +248,16 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             SPEC_STAMP(1);
             if (chunk == 0) {
                 spec_lds_barrier();                            // the uniform table of this iteration is complete ...
-                for (uint32_t k = lane; k < SPEC_N_POS; k += 64u) WSw[k] = 0.0f;     // ... and the last one's sums are consumed
+#if SPEC_ACCUMULATE_CHUNKS
+                for (uint32_t k = lane; k < SPEC_WS_CELLS; k += 64u) WSw[k] = 0.0f;     // ... and the last one's sums are consumed
+#endif
             }
             SPEC_STAMP(2);
 #if !defined(SPEC_DEBUG_NO_BODY)
-            spec_body(B, T, Z, TRw, WSw);
+            spec_body(B, T, Z, WSw);
+#if SPEC_TILE
+            spec_du_flush(spec_lds + SPEC_OFF_TR + wave * SPEC_TR_FLOATS, WSw, lane);
+#endif
 #endif
             SPEC_STAMP(3);
             const float value = (SPEC_ESTIMATOR == BSVI_EST_BLACKBOX) ? (T.lq * T.f + T.f) : T.f;
@@ -275,11 +279,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             unsigned int* const ticket = SPEC_A->ticket;
             const uint32_t stride = 2u + SPEC_N_POS;
             float* mine = partials + (size_t)blockIdx.x * stride;
-            for (uint32_t k = tid; k < SPEC_N_POS; k += nthreads) {
-                float s = WS[k];
-                for (uint32_t w = 1; w < W; ++w) s += WS[w * SPEC_NUG_PAD + k];
-                mine[2 + k] = s;
-            }
+            for (uint32_t k = tid; k < SPEC_N_POS; k += nthreads) mine[2 + k] = spec_pos_total(WS, k, W);
             if (tid == 0) {
                 float s = 0.0f, c = 0.0f;
                 for (uint32_t w = 0; w < W; ++w) { s += RED[8 + 2 * w]; c += RED[9 + 2 * w]; }
@@ -293,23 +293,26 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             }
             __syncthreads();
             if (RED[2] == 0.0f) return;
-            // slices of rows per column, then the slices in order (G can be thousands of workgroups)
-            const uint32_t slices = (nthreads / stride) ? (nthreads / stride) : 1u;
-            float* const SL = TR;                              // the transpose tiles are free now
-            const uint32_t max_slices = (SPEC_MAX_WAVES * SPEC_TR_FLOATS) / stride;
-            const uint32_t S = slices < max_slices ? slices : max_slices;
-            for (uint32_t i = tid; i < S * stride; i += nthreads) {
-                const uint32_t sl = i / stride, c = i - sl * stride;
+            // column c of the G rows: four interleaved slices per column (G can be hundreds of workgroups), then the slices
+            float* const SL = spec_lds + SPEC_OFF_SCR;
+            for (uint32_t i = tid; i < 4u * stride; i += nthreads) {
+                const uint32_t sl = i & 3u, c = i >> 2;
                 float s = 0.0f;
-                for (uint32_t b = sl; b < G; b += S)
+                for (uint32_t b = sl; b < G; b += 4u)
                     s += __hip_atomic_load(&partials[(size_t)b * stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 SL[i] = s;
             }
             __syncthreads();
             for (uint32_t c = tid; c < stride; c += nthreads) {
-                float s = 0.0f;
-                for (uint32_t sl = 0; sl < S; ++sl) s += SL[sl * stride + c];
-                if (c < 2u) RED[8 + c] = s; else WS[c - 2u] = s;
+                const float s = (SL[4 * c] + SL[4 * c + 1]) + (SL[4 * c + 2] + SL[4 * c + 3]);
+                if (c < 2u) {
+                    RED[8 + c] = s;
+                } else {                                       // the grid total in the first wave's cell of the position
+                    WS[SPEC_WS_CELL(c - 2u)] = s;
+#if !SPEC_TILE
+                    WS[4u * (c - 2u) + 1u] = 0.0f; WS[4u * (c - 2u) + 2u] = 0.0f; WS[4u * (c - 2u) + 3u] = 0.0f;
+#endif
+                }
             }
             if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
@@ -354,15 +357,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             float gsum = 0.0f;
 #pragma unroll
             for (uint32_t e = 0; e < 2u; ++e) {
-                if (e < own.n) {
-                    float s = 0.0f;
-#pragma unroll
-                    for (uint32_t w = 0; w < SPEC_MAX_WAVES; ++w) {
-                        const float x = WS[(w < rows ? w : 0u) * SPEC_NUG_PAD + own.pos[e]];
-                        s += w < rows ? x : 0.0f;
-                    }
-                    gsum += s * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
-                }
+                if (e < own.n) gsum += spec_pos_total(WS, own.pos[e], rows) * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
             }
             const float grad = gsum * scale;
             SPEC_STAMP(8);
@@ -395,9 +390,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             float gsum = 0.0f;
             for (uint32_t j = j0; j < j1; ++j) {
                 const uint32_t pos = TAB[SPEC_TAB_POS + j], k = TAB[SPEC_TAB_IDX + j];
-                float s = WS[pos];
-                for (uint32_t w = 1; w < rows; ++w) s += WS[w * SPEC_NUG_PAD + pos];
-                gsum += s * (__uint_as_float(TAB[4 * k + 3]) * spec_utransform_grad(TAB[4 * k + 1] & 0xFFu, theta));
+                gsum += spec_pos_total(WS, pos, rows) * (__uint_as_float(TAB[4 * k + 3]) * spec_utransform_grad(TAB[4 * k + 1] & 0xFFu, theta));
             }
             const float grad = gsum * scale;
             if (last || !step) out[BSVI_OUT_HEADER + i] = grad;

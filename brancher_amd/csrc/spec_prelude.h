@@ -38,6 +38,7 @@ struct SpecLane {
     uint32_t lane;
     uint32_t off_lo, off_hi; // Philox offset of this iteration
     uint32_t vz;             // always 0, but a per-lane value the compiler cannot prove uniform (SPEC_U)
+    uint32_t tile;           // SPEC_TILE: float offset of this lane's column of the wave's transpose tile
     bool active;
 };
 
@@ -98,43 +99,49 @@ __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane&
 //   U    [SPEC_U_PAD]                   uniform table U, then the observed data
 //   UR   [SPEC_NU_PAD]                  1 / U[k]      } companions of the uniform table: what a Normal node needs
 //   UL   [SPEC_NU_PAD]                  log U[k]      } of a lane-uniform scale
-//   WS   [W][SPEC_NUG_PAD]              per-wave sums of d f / d U, in completion order ("positions")
+//   WS   [W][4 * SPEC_N_POS]            per-wave sums of d f / d U: position p ("completion order") holds the totals
+//                                       of the wave's four 16-lane rows at WS[4p .. 4p+3]
 //   RED  [SPEC_RED_FLOATS]              value / non-finite sums per wave, block totals, flags
 //   PS   [5][SPEC_NP_PAD]               theta and the optimizer state [4][n_params]: the working copy of a launch
 //   TAB                                 uniform entries (4 words each), CSR theta -> positions / uniform indices, masks
 //   OWN  [min(NP, threads)][16]         what the thread that owns a parameter needs per iteration, packed for four
 //                                       ds_read_b128: theta, optimizer state, its (<= 2) uniform entries
-//   TR   [W][SPEC_TE * SPEC_TR_STRIDE]  per-wave transpose tile: the lanes of a wave store their contribution to
-//                                       position p at TR[(p % TE) * 68 + lane]; every TE positions lane j adds up
-//                                       row j with 16 conflict-free ds_read_b128, fixed order — ~2 instructions per
-//                                       entry and lane instead of a 10-instruction DPP reduction per entry
-#ifndef SPEC_TE
-#define SPEC_TE 64
-#endif
-#ifndef SPEC_FLUSH_OUT_OF_LINE
-#define SPEC_FLUSH_OUT_OF_LINE 0
-#endif
+//   SCR                                 scratch of the grid reduction (several workgroups)
+//   TR   [W][64 * 68]                   SPEC_TILE programs (at most 64 positions): per-wave transpose tile, see SPEC_DU
 #ifndef SPEC_GENERIC_OWNERS
 #define SPEC_GENERIC_OWNERS 1
 #endif
-#define SPEC_TR_STRIDE 68      /* 16-byte aligned rows; 16 lanes x 4 consecutive banks tile the 64 banks exactly */
+#ifndef SPEC_ACCUMULATE_CHUNKS
+#define SPEC_ACCUMULATE_CHUNKS 0
+#endif
 #define SPEC_MAX_WAVES (SPEC_MAX_THREADS / 64)
 #define SPEC_U_PAD ((SPEC_N_UNIFORM + SPEC_N_OBS + 3) / 4 * 4)
 #define SPEC_NU_PAD ((SPEC_N_UNIFORM + 3) / 4 * 4)
-#define SPEC_NUG_PAD ((SPEC_N_POS + 3) / 4 * 4 + 4)
+#ifndef SPEC_TILE
+#define SPEC_TILE 0
+#endif
+#if SPEC_TILE
+#define SPEC_WS_PAD ((SPEC_N_POS + 3) / 4 * 4 + 4)
+#define SPEC_TR_STRIDE 68      /* 16-byte aligned rows; 16 lanes x 4 consecutive banks tile the 64 banks exactly */
+#define SPEC_TR_FLOATS (64 * SPEC_TR_STRIDE)
+#else
+#define SPEC_WS_PAD (4 * SPEC_N_POS + 4)
+#define SPEC_TR_FLOATS 0
+#endif
 #define SPEC_RED_FLOATS (2 * SPEC_MAX_WAVES + 8)
 #define SPEC_NP_PAD ((SPEC_N_PARAMS + 3) / 4 * 4 + 4)
 #define SPEC_TAB_WORDS ((4 * SPEC_N_UNIFORM + (2 * SPEC_N_PARAMS + 1) + 2 * SPEC_N_POS + 3) / 4 * 4 + 4)
-#define SPEC_TR_FLOATS (SPEC_TE * SPEC_TR_STRIDE)
+#define SPEC_SCR_FLOATS (4 * (SPEC_N_POS + 2) + 4)
 #define SPEC_OFF_UR SPEC_U_PAD
 #define SPEC_OFF_UL (SPEC_OFF_UR + SPEC_NU_PAD)
 #define SPEC_OFF_WS (SPEC_OFF_UL + SPEC_NU_PAD)
-#define SPEC_OFF_RED (SPEC_OFF_WS + SPEC_MAX_WAVES * SPEC_NUG_PAD)
+#define SPEC_OFF_RED (SPEC_OFF_WS + SPEC_MAX_WAVES * SPEC_WS_PAD)
 #define SPEC_OFF_PS (SPEC_OFF_RED + SPEC_RED_FLOATS)
 #define SPEC_OFF_TAB (SPEC_OFF_PS + 5 * SPEC_NP_PAD)
 #define SPEC_OWN_ROWS (SPEC_N_PARAMS < SPEC_MAX_THREADS ? SPEC_N_PARAMS : SPEC_MAX_THREADS)
 #define SPEC_OFF_OWN (SPEC_OFF_TAB + SPEC_TAB_WORDS)
-#define SPEC_OFF_TR (SPEC_OFF_OWN + 16 * SPEC_OWN_ROWS)
+#define SPEC_OFF_SCR (SPEC_OFF_OWN + 16 * SPEC_OWN_ROWS)
+#define SPEC_OFF_TR (SPEC_OFF_SCR + SPEC_SCR_FLOATS)
 #define SPEC_LDS_FLOATS (SPEC_OFF_TR + SPEC_MAX_WAVES * SPEC_TR_FLOATS)
 __shared__ __attribute__((aligned(16))) float spec_lds[SPEC_LDS_FLOATS];
 
@@ -146,29 +153,74 @@ __shared__ __attribute__((aligned(16))) float spec_lds[SPEC_LDS_FLOATS];
 #define SPEC_UR(k) spec_lds[SPEC_OFF_UR + (k) + T.vz]
 #define SPEC_UL(k) spec_lds[SPEC_OFF_UL + (k) + T.vz]
 
-// contribution of this lane to position `pos` (a literal)
-#define SPEC_DU(pos, val) TRw[((pos) % SPEC_TE) * SPEC_TR_STRIDE + T.lane] = T.active ? (val) : 0.0f
-
 typedef float spec_f4 __attribute__((ext_vector_type(4)));
-// positions [base, base + count) are complete: lane j < count adds the 64 lane contributions of position base + j.
-// Out of line in long programs (several flushes per body): inlined, every flush — 64 registers of reads in flight between
-// two memory-clobbering waits — makes the register allocator spill hundreds of the body's long-lived values (T = 60:
-// 206 spilled registers inlined, none as a call).
-#if SPEC_FLUSH_OUT_OF_LINE
-#define SPEC_FLUSH_FN __device__ __noinline__
-#else
-#define SPEC_FLUSH_FN __device__ __forceinline__
-#endif
-SPEC_FLUSH_FN void spec_du_flush(float* TRw, float* WSw, uint32_t lane, uint32_t base, uint32_t count) {
+
+// Contribution of this lane to position `pos` (a literal).  Two schemes, chosen per program by the generator:
+//
+//  SPEC_TILE (programs with at most 64 positions — BASELINE configs 1 and 2): the lanes of a wave store their
+//  contribution at TR[pos * 68 + lane] of the wave's transpose tile — one instruction — and ONE flush at the end of the
+//  body has lane j add up row j with 16 conflict-free ds_read_b128, in a fixed order.
+//
+//  otherwise: four DPP adds leave every lane with the total of its 16-lane row (quad_perm, quad_perm, row_half_mirror,
+//  row_mirror: a fixed order), and the row's lanes store it — same address, same value — to the row's cell of the
+//  position, WS[4 pos + row].  Five instructions per contribution, but straight-line: with more than 64 positions a
+//  tile needs flushes INSIDE the body, and those — 64 registers of reads between memory fences — cut the body into
+//  regions the register allocator handles badly (2.5 x the registers at T = 60, spilled to scratch).
+//
+// A workgroup that walks several sample chunks (SPEC_ACCUMULATE_CHUNKS) accumulates into the cells instead of storing.
+__device__ __forceinline__ float spec_row_sum(float x) {
+    x += dpp_f<0xB1>(x);
+    x += dpp_f<0x4E>(x);
+    x += dpp_f<0x141>(x);
+    x += dpp_f<0x140>(x);
+    return x;
+}
+#if SPEC_TILE
+#define SPEC_DU(pos, val) spec_lds[SPEC_OFF_TR + T.tile + (pos) * SPEC_TR_STRIDE] = T.active ? (val) : 0.0f
+__device__ __forceinline__ void spec_du_flush(const float* TRw, float* WSw, uint32_t lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's tile stores have landed (LDS is in order)
-    if (lane < count) {
+    if (lane < SPEC_N_POS) {
         const spec_f4* row = reinterpret_cast<const spec_f4*>(TRw + lane * SPEC_TR_STRIDE);
         spec_f4 s = row[0];
 #pragma unroll
         for (uint32_t q = 1; q < 16u; ++q) s += row[q];
-        WSw[base + lane] += (s.x + s.y) + (s.z + s.w);      // (zeroed at the top of the iteration: a wave may run several sample chunks)
+        const float t = (s.x + s.y) + (s.z + s.w);
+#if SPEC_ACCUMULATE_CHUNKS
+        WSw[lane] += t;
+#else
+        WSw[lane] = t;
+#endif
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next tile overwrites the rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next chunk overwrites the rows
+}
+#elif SPEC_ACCUMULATE_CHUNKS
+#define SPEC_DU(pos, val) { float* const c_ = WSw + 4u * (pos) + (T.lane >> 4); *c_ = *c_ + spec_row_sum(T.active ? (val) : 0.0f); }
+#else
+#define SPEC_DU(pos, val) WSw[4u * (pos) + (T.lane >> 4)] = spec_row_sum(T.active ? (val) : 0.0f)
+#endif
+// floats of a wave's sums / cell of position `pos` in them
+#if SPEC_TILE
+#define SPEC_WS_CELLS SPEC_N_POS
+#define SPEC_WS_CELL(pos) (pos)
+#else
+#define SPEC_WS_CELLS (4u * SPEC_N_POS)
+#define SPEC_WS_CELL(pos) (4u * (pos))
+#endif
+// the total of position `pos` over the first `rows` waves' cells, waves in order (literal trip count, clamped addresses:
+// the reads issue back to back)
+__device__ __forceinline__ float spec_pos_total(const float* WS, uint32_t pos, uint32_t rows) {
+    float s = 0.0f;
+#pragma unroll
+    for (uint32_t w = 0; w < SPEC_MAX_WAVES; ++w) {
+#if SPEC_TILE
+        const float t = WS[(w < rows ? w : 0u) * SPEC_WS_PAD + pos];
+#else
+        const spec_f4 q = *reinterpret_cast<const spec_f4*>(WS + (w < rows ? w : 0u) * SPEC_WS_PAD + 4u * pos);
+        const float t = (q.x + q.y) + (q.z + q.w);
+#endif
+        s += w < rows ? t : 0.0f;
+    }
+    return s;
 }
 
 }  // namespace bsvi

@@ -44,9 +44,9 @@ struct Insn { uint32_t w0, dst, a, b, c, s, imm0, imm1; };
 constexpr size_t kMaxVisits = 12000;     // unrolled instruction visits (forward + reverse) a body may have
 constexpr uint32_t kKeepEpsRows = 64;    // up to this many noise rows stay in registers for the reverse sweep
 constexpr uint32_t kRescheduleAboveSlots = 40; // programs with more per-sample slots defer their sinks (register pressure)
-constexpr uint32_t kFenceAboveCode = 160;     // programs longer than this get scheduling fences ...
+constexpr uint32_t kFenceAboveCode = 100;     // programs longer than this get scheduling fences ...
 constexpr uint32_t kFenceEvery = 4;           // ... every this many records
-constexpr uint32_t kAccumulateEntries = 96;   // up to this many gradient-carrying uniform entries accumulate in registers
+constexpr uint32_t kAccumulateEntries = 1u << 30;   // up to this many gradient-carrying uniform entries accumulate in registers
 
 std::string fmt(const char* f, ...) {
     char buf[512];
@@ -67,7 +67,7 @@ std::string flit(uint32_t bits) {       // a float literal that round-trips
 
 class Emitter {
 public:
-    Emitter(const bsvi_program_desc& d, bool diag, uint32_t te) : d_(d), diag_(diag), te_(te) {
+    Emitter(const bsvi_program_desc& d, bool diag) : d_(d), diag_(diag) {
         keep_eps_ = d.n_noise <= kKeepEpsRows;
         // long programs: a gradient contribution leaves through its own position of the transpose tile instead of
         // waiting in an accumulator register for the entry's last contribution
@@ -96,8 +96,6 @@ public:
         // entries nothing contributed to still own a position (their gradient is 0)
         for (uint32_t k = 0; k < d_.n_uniform_grad; ++k)
             if (!du_total_[k]) complete(k, "0.0f");
-        const uint32_t n = (uint32_t)order_.size();
-        if (n % te_) line(fmt("spec_du_flush(TRw, WSw, T.lane, %uu, %uu);", n - n % te_, n % te_));
         return true;
     }
 
@@ -136,7 +134,6 @@ public:
 private:
     const bsvi_program_desc& d_;
     bool diag_;
-    uint32_t te_;
     bool keep_eps_ = true, counting_ = true, direct_du_ = false, reschedule_ = true;
     size_t visits_ = 0;
     std::string body_;
@@ -167,7 +164,6 @@ private:
         const uint32_t pos = (uint32_t)order_.size();
         order_.push_back(k);
         line(fmt("SPEC_DU(%uu, %s);", pos, expr.c_str()));
-        if ((pos + 1) % te_ == 0) line(fmt("spec_du_flush(TRw, WSw, T.lane, %uu, %uu);", pos + 1 - te_, te_));
     }
     // scatter an adjoint: slots accumulate in their register; parameter-sourced uniform entries in theirs, leaving
     // through the transpose tile at their last contribution; constants and observed data take none
@@ -579,7 +575,7 @@ struct Variant {
 //        in the kernel;
 //   MANY larger shards: 256-thread workgroups, sized so that two fit a CU's LDS, each walking several sample chunks.
 enum { GEOM_ONE = 0, GEOM_MANY = 1 };
-struct Geom { uint32_t max_threads = 0, te = 0, lds_bytes = 0; };
+struct Geom { uint32_t max_threads = 0, lds_bytes = 0; };
 
 struct Spec {
     uint32_t n_params = 0, n_uniform = 0, n_ugrad = 0, n_obs = 0, n_noise = 0;
@@ -597,13 +593,15 @@ struct Spec {
     std::mutex mu;
 };
 
-static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs, uint32_t n_pos, uint32_t max_threads, uint32_t te) {
+static bool tiled(uint32_t n_pos) { return n_pos <= 64; }     // SPEC_TILE (spec_prelude.h, SPEC_DU)
+static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs, uint32_t n_pos, uint32_t max_threads) {
     // mirrors the SPEC_OFF_* layout of spec_prelude.h
     const uint32_t W = max_threads / 64;
-    const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4, nug_pad = (n_pos + 3) / 4 * 4 + 4;
+    const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4;
+    const uint32_t ws_pad = tiled(n_pos) ? (n_pos + 3) / 4 * 4 + 4 : 4 * n_pos + 4;
     const uint32_t np_pad = (n_params + 3) / 4 * 4 + 4, tab = (4 * n_uniform + (2 * n_params + 1) + 2 * n_pos + 3) / 4 * 4 + 4;
-    const uint32_t own = 16 * (n_params < max_threads ? n_params : max_threads);
-    return u_pad + 2 * nu_pad + W * nug_pad + (2 * W + 8) + 5 * np_pad + tab + own + W * te * 68;
+    const uint32_t own = 16 * (n_params < max_threads ? n_params : max_threads), scr = 4 * (n_pos + 2) + 4;
+    return u_pad + 2 * nu_pad + W * ws_pad + (2 * W + 8) + 5 * np_pad + tab + own + scr + (tiled(n_pos) ? W * 64 * 68 : 0);
 }
 
 Spec* create(const bsvi_program_desc& d, std::string& why) {
@@ -612,7 +610,7 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     s->n_params = d.n_params; s->n_uniform = d.n_uniform; s->n_ugrad = d.n_uniform_grad; s->n_obs = d.n_obs; s->n_noise = d.n_noise;
     {
         // the positions (and with them the CSR map theta -> positions) do not depend on the geometry
-        Emitter E(d, false, 64);
+        Emitter E(d, false);
         if (!E.run(why)) { delete s; return nullptr; }
         const std::vector<uint32_t>& order = E.order();
         s->n_pos = (uint32_t)order.size();
@@ -628,23 +626,20 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     // launch bounds: a sample keeps its slot values and its noise in registers; 512 threads leave 256 registers per
     // lane, 256 threads the whole 512-entry file (MI355X_MICROARCH.md, register files)
     const uint32_t live = 2 * d.n_slots + (d.n_noise <= kKeepEpsRows ? d.n_noise : 0) + (d.n_uniform_grad <= kAccumulateEntries ? d.n_uniform_grad : 0) + 40;
-    auto fit = [&](uint32_t threads, uint32_t budget_bytes, Geom& g) {
-        for (uint32_t te = 64; te >= 8; te >>= 1) {
-            const uint32_t bytes = lds_floats(d.n_params, d.n_uniform, d.n_obs, s->n_pos, threads, te) * 4u;
-            if (bytes <= budget_bytes) { g.max_threads = threads; g.te = te; g.lds_bytes = bytes; return true; }
-        }
-        return false;
+    auto fit = [&](uint32_t threads, Geom& g) {
+        g.max_threads = threads;
+        g.lds_bytes = lds_floats(d.n_params, d.n_uniform, d.n_obs, s->n_pos, threads) * 4u;
+        return g.lds_bytes <= 160u * 1024u;
     };
-    const uint32_t kLds = 160u * 1024u;
-    bool ok = (live <= 232 && fit(512, kLds, s->geom[GEOM_ONE])) || fit(256, kLds, s->geom[GEOM_ONE]);
-    ok = ok && (fit(256, kLds / 2 - 1024, s->geom[GEOM_MANY]) || fit(256, kLds, s->geom[GEOM_MANY]));
+    bool ok = (live <= 232 && fit(512, s->geom[GEOM_ONE])) || fit(256, s->geom[GEOM_ONE]);
+    ok = ok && fit(256, s->geom[GEOM_MANY]);
     if (!ok) { why = "the program's tables do not fit LDS"; delete s; return nullptr; }
     bool all_fast = d.n_params <= 64;      // every parameter owned by a thread of the smallest workgroup, <= 2 positions
     for (uint32_t i = 0; i < d.n_params && all_fast; ++i) all_fast = s->pu_ptr_host[i + 1] - s->pu_ptr_host[i] <= 2;
     for (int gi = 0; gi < 2; ++gi) {
         const Geom& G = s->geom[gi];
         for (int v = 0; v < 2; ++v) {
-            Emitter E(d, v == 1, G.te);
+            Emitter E(d, v == 1);
             if (!E.run(why)) { delete s; return nullptr; }
             std::string src;
             src += "// generated by libbsvi (specialize.cpp) from a model program: do not edit\n";
@@ -652,9 +647,9 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
             src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
                        d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
             src += fmt("#define SPEC_N_POS %u\n", s->n_pos);
-            src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_TE %u\n#define SPEC_DIAG %d\n", d.estimator, G.max_threads, G.te, v);
+            src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_DIAG %d\n", d.estimator, G.max_threads, v);
+            src += fmt("#define SPEC_ACCUMULATE_CHUNKS %d\n#define SPEC_TILE %d\n", gi == GEOM_MANY ? 1 : 0, tiled(s->n_pos) ? 1 : 0);
             src += fmt("#define SPEC_KEEP_NOISE %u\n", E.keeps_noise() ? d.n_noise : 0u);
-            src += fmt("#define SPEC_FLUSH_OUT_OF_LINE %d\n", s->n_pos > 2 * G.te ? 1 : 0);
             // (all parameters "fast": the epilogue's generic loop over the LDS working copy is compiled out)
             src += fmt("#define SPEC_GENERIC_OWNERS %d\n", all_fast ? 0 : 1);
             src += "#include \"spec_prelude.h\"\n";
@@ -663,7 +658,7 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
             src += "    (void)A; (void)T; (void)Z;\n";
             src += E.draw();
             src += "}\n";
-            src += "__device__ __forceinline__ void spec_body(const SpecBody& A, SpecLane& T, const SpecNoise& Z, float* TRw, float* WSw) {\n";
+            src += "__device__ __forceinline__ void spec_body(const SpecBody& A, SpecLane& T, const SpecNoise& Z, float* WSw) {\n";
             src += "    (void)Z;\n";
             if (v == 1) src += "    const float* const noise = A.noise;\n";
             src += E.declarations();
@@ -786,7 +781,7 @@ static Geo geo(const Spec* s, uint32_t n_local) {
     // several chunks of 256 samples
     const uint32_t threads = s->geom[GEOM_MANY].max_threads;
     uint32_t blocks = (n_local + threads - 1) / threads;
-    const uint32_t per_cu = s->geom[GEOM_MANY].lds_bytes * 2u <= 160u * 1024u ? 2u : 1u;
+    const uint32_t per_cu = s->geom[GEOM_MANY].lds_bytes * 2u <= 160u * 1024u ? 2u : 1u;      // (and 2 x 256 registers per lane)
     if (blocks > per_cu * s->n_cus) blocks = per_cu * s->n_cus;
     return Geo{blocks, threads, GEOM_MANY};
 }
