@@ -378,7 +378,7 @@ class CompiledAmortized:
         theta = np.zeros(p.n_params, dtype=np.float32)
         for par, off, size, _ in p.parameters:
             theta[off:off + size] = par.numpy().reshape(-1)
-        self.params = torch.from_numpy(theta).to(dev)
+        self.params = _engine.broadcast_from_rank0(torch.from_numpy(theta).to(dev))
         self.out = torch.zeros(OUT_HEADER + max(p.n_params, 1), device=dev)
         active, group = p.param_active, p.param_group
         first_group = 0 if np.any(active[group == 0]) else 1
@@ -456,7 +456,7 @@ class CompiledAmortized:
     def _args(self, n_local, n_global, base, noise=None, indices=None, seed=None, offset=0, noise_out=None,
               indices_out=None, fvalue_out=None, logq_out=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        seed = _engine.shared_seed(seed, self.device)
         return AmortArgs(params_dev=ptr(self.params), noise_dev=ptr(noise), indices_dev=ptr(indices), seed=seed,
                          offset=int(offset), n_samples_local=n_local, n_samples_global=n_global, sample_base=base,
                          estimator=1 if self.program.estimator == "blackbox" else 0,
@@ -472,6 +472,8 @@ class CompiledAmortized:
         from brancher_amd import engine
         rank, world = engine.dist_info()
         base, n_local = engine.shard(number_samples, rank, world)
+        if n_local == 0:
+            raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         if offset is None:
             offset = self.iteration
             self.iteration += 1
@@ -552,6 +554,8 @@ class CompiledAmortized:
         cfg = native.make_opt_cfg(optimizer, **opt_params)
         rank, world = engine.dist_info()
         base, n_local = engine.shard(number_samples, rank, world)
+        if n_local == 0:
+            raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         dev, p = self.device, self.program
         K = int(number_iterations)
         loss_curve = torch.zeros(max(K, 1), device=dev)
@@ -575,3 +579,8 @@ class CompiledAmortized:
                 C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         return loss_curve[:K], finite[:K]
+
+
+# every native call of a compiled program runs with its device current (engine._bound_to_device)
+from brancher_amd import engine as _engine  # noqa: E402  (engine imports this module lazily)
+CompiledAmortized = _engine._bound_to_device(CompiledAmortized)

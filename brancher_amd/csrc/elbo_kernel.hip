@@ -1301,16 +1301,34 @@ __global__ void __launch_bounds__(1024) persistent_multi_kernel(const PParams P_
             }
             __syncthreads();                       // every wave's stores are issued and drained (vmcnt(0) + barrier)
             if (threadIdx.x == 0) {
+                // counter[0]: arrivals; counter[1]: abort flag.  The launch is not cooperative: should a workgroup not be
+                // resident (the host checks that there is a CU for each, but other streams / processes can hold CUs), the
+                // others must neither spin forever nor take the process down — the first to give up raises the flag,
+                // everybody leaves the loop, and the rest of the loss curve reads NaN / not finite.
                 uint32_t* counter = P->mw_counter;
                 __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t target = (it + 1u) * n_wg;
                 uint32_t polls = 0;
+                float aborted = 0.0f;
                 while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > (1u << 27)) __builtin_trap();     // a lost workgroup must not hang the device
+                    if (++polls > (1u << 24) || __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        aborted = 1.0f;
+                        break;
+                    }
                 }
+                g_lds[L.red + 3] = aborted;
             }
             __syncthreads();
+            if (g_lds[L.red + 3] != 0.0f) {
+                if (wg == 0)
+                    for (uint32_t j = it + threadIdx.x; j < n_iterations; j += blockDim.x) {
+                        P->loss_curve[j] = __builtin_nanf("");
+                        P->finite_curve[j] = 0.0f;
+                    }
+                return;
+            }
             for (uint32_t k = threadIdx.x; k < n_ug; k += blockDim.x) {
                 float s = 0.0f;
                 for (uint32_t b = 0; b < n_wg; ++b)
@@ -2010,7 +2028,14 @@ static bool multi_persistent_applies(const bsvi_program* p, uint32_t n_local) {
     const char* e = getenv("BSVI_PERSISTENT_MULTI");       // read per call: tests and tools flip it
     if (e && e[0] == '0') return false;
     const uint32_t waves = (n_local + 63) / 64;
-    return waves >= 5 && waves <= kMaxMultiWaves && lds_need(p, 1, SM_LACC, 64, false) <= (size_t)p->max_lds;
+    if (!(waves >= 5 && waves <= kMaxMultiWaves && lds_need(p, 1, SM_LACC, 64, false) <= (size_t)p->max_lds)) return false;
+    // the in-kernel exchange needs every workgroup resident: each takes most of a CU's LDS, so one CU apiece
+    static int n_cus = 0;
+    if (!n_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cus = 64;
+    }
+    return waves * 3u <= (uint32_t)n_cus;        // (up to three program shares per sample wave)
 }
 
 extern "C" int bsvi_persistent_supported(const bsvi_program* p, uint32_t n_local) {

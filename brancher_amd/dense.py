@@ -220,7 +220,7 @@ class CompiledDense:
         theta = np.zeros(p.n_params, dtype=np.float32)
         for par, off, size, _ in p.parameters:
             theta[off:off + size] = par.numpy().reshape(-1)
-        self.params = torch.from_numpy(theta).to(dev)
+        self.params = _engine.broadcast_from_rank0(torch.from_numpy(theta).to(dev))
         self.out = torch.zeros(OUT_HEADER + max(p.n_params, 1), device=dev)
         active = np.ascontiguousarray(p.param_active, dtype=np.uint8)
         group = p.param_group
@@ -269,7 +269,7 @@ class CompiledDense:
     def _args(self, n_local, n_global, base, noise=None, indices=None, seed=None, offset=0, noise_out=None,
               indices_out=None, fvalue_out=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        seed = _engine.shared_seed(seed, self.device)
         return DenseArgs(params_dev=ptr(self.params), noise_dev=ptr(noise), indices_dev=ptr(indices), seed=seed,
                          offset=int(offset), n_samples_local=n_local, n_samples_global=n_global, sample_base=base,
                          out_dev=ptr(self.out), noise_out_dev=ptr(noise_out), indices_out_dev=ptr(indices_out),
@@ -299,6 +299,8 @@ class CompiledDense:
         from brancher_amd import engine
         rank, world = engine.dist_info()
         base, n_local = engine.shard(number_samples, rank, world)
+        if n_local == 0:
+            raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         if offset is None:
             offset = self.iteration
             self.iteration += 1
@@ -337,6 +339,8 @@ class CompiledDense:
         cfg = native.make_opt_cfg(optimizer, **opt_params)
         rank, world = engine.dist_info()
         base, n_local = engine.shard(number_samples, rank, world)
+        if n_local == 0:
+            raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         dev, p = self.device, self.program
         K = int(number_iterations)
         loss_curve = torch.zeros(max(K, 1), device=dev)
@@ -363,3 +367,8 @@ class CompiledDense:
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         return loss_curve[:K], finite[:K]
+
+
+# every native call of a compiled program runs with its device current (engine._bound_to_device)
+from brancher_amd import engine as _engine  # noqa: E402  (engine imports this module lazily)
+CompiledDense = _engine._bound_to_device(CompiledDense)

@@ -91,16 +91,37 @@ def noise_from_named(program, named, n):
 
 
 class FusedLoss:
-    """What ``InferenceMethod.compute_loss`` returns: the loss of one fused ELBO evaluation.
-    The gradients were produced by the same kernel launch, so ``backward()`` has nothing
-    left to do (`brancher/inference.py:96-100`)."""
+    """What ``estimate_log_model_evidence(for_gradient=True)`` / ``InferenceMethod.compute_loss`` return: the value of one
+    fused ELBO evaluation.  The kernel launch that produced the value also produced the gradients (of the LOSS, -ELBO,
+    scaled by 1/N, in the compiled program's output block), so ``backward()`` only records how the value the user holds
+    relates to them: ``grad_scale`` = d(this value) / d(loss).  Negation and multiplication by a number keep the handle —
+    a hand-written loop in the style of `brancher/inference.py:95-108`
+    (``loss = -model.estimate_log_model_evidence(...); loss.backward(); optimizer.update()``) drives the device
+    optimizer with the right sign."""
 
-    def __init__(self, compiled, tensor):
+    def __init__(self, compiled, tensor, grad_scale=1.0):
         self.compiled = compiled
         self.tensor = tensor          # 0-d device tensor
+        self.grad_scale = float(grad_scale)
 
     def backward(self):
+        if self.compiled is not None:
+            self.compiled.pending_grad_scale = self.grad_scale
         return None
+
+    def _scaled(self, c):
+        return FusedLoss(self.compiled, self.tensor * c, self.grad_scale * c)
+
+    def __neg__(self):
+        return self._scaled(-1.0)
+
+    def __mul__(self, c):
+        return self._scaled(float(c))
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, c):
+        return self._scaled(1.0 / float(c))
 
     def detach(self):
         return self.tensor.detach()
@@ -114,10 +135,61 @@ class FusedLoss:
     def cpu(self):
         return self.tensor.cpu()
 
-    def __neg__(self):
-        return -self.tensor
+
+def _bound_to_device(cls):
+    """Every native call of a compiled program runs with the program's device current: the library allocates its tables
+    and launches on the CURRENT HIP device, while buffers and stream belong to `self.device` — `config.set_device('cuda:1')`
+    without a `torch.cuda.set_device(1)` must not split them."""
+    import functools
+
+    def guard(fn):
+        @functools.wraps(fn)
+        def on_device(self, *args, **kwargs):
+            dev = getattr(self, "device", None) or kwargs.get("device") or _device()
+            with torch.cuda.device(dev):
+                return fn(self, *args, **kwargs)
+        return on_device
+
+    for name in ("__init__", "evaluate", "train", "_train_graph", "workspace", "optimizer_step", "decode", "encode", "_apply"):
+        if name in cls.__dict__:
+            setattr(cls, name, guard(cls.__dict__[name]))
+    return cls
 
 
+def broadcast_from_rank0(tensor):
+    """ranks must start from identical parameters (and draw with the same seed): every rank keeps its own copy and only
+    sums are all-reduced, so nothing would ever re-synchronise them"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(tensor, 0)
+    return tensor
+
+
+def shared_seed(seed, device):
+    """the Philox key of a call: the caller's seed, else torch's initial seed — rank 0's on every rank"""
+    value = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFFFFFFFFFF
+    import torch.distributed as dist
+    if seed is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([value], dtype=torch.int64, device=device)
+        dist.broadcast(t, 0)
+        value = int(t.item())
+    return value
+
+
+def optimizer_step(store, cfg, state, mask):
+    """one device optimizer step of the parameters selected by `mask` from the gradients in the store's output block
+    (`bsvi_optimizer_step`): what ``ProbabilisticOptimizer.update()`` runs"""
+    scale = getattr(store, "pending_grad_scale", 1.0)
+    if scale != 1.0:
+        store.out[OUT_HEADER:] *= scale          # the value the user called backward() on was scale * loss
+        store.pending_grad_scale = 1.0
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    with torch.cuda.device(store.device):
+        native.check(store.lib.bsvi_optimizer_step(C.byref(cfg), ptr(store.params), ptr(store.out), ptr(state), ptr(mask),
+                                                   store.n_params, store._stream()))
+
+
+@_bound_to_device
 class CompiledELBO:
     def __init__(self, joint_model, posterior_model, estimator="pathwise", device=None, program=None,
                  bind_parameters=True):
@@ -128,7 +200,7 @@ class CompiledELBO:
         p = self.program
         dev = self.device
         self.n_params = p.n_params
-        self.params = torch.from_numpy(p.initial_params()).to(dev)
+        self.params = broadcast_from_rank0(torch.from_numpy(p.initial_params()).to(dev))
         self.obs = torch.from_numpy(np.ascontiguousarray(p.obs)).to(dev) if p.obs.size else torch.zeros(1, device=dev)
         self.out = torch.zeros(OUT_HEADER + max(p.n_params, 1), device=dev, dtype=torch.float32)
         self.grads_valid = False
@@ -172,7 +244,7 @@ class CompiledELBO:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _seed(self, seed):
-        return int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        return shared_seed(seed, self.device)
 
     def _elbo_args(self, n_local, n_global, base, noise=None, seed=None, offset=0, samples_out=None,
                    noise_out=None, fvalue_out=None):
@@ -310,6 +382,7 @@ class CompiledELBO:
         self.native.ensure_shares(n_local)
         if n_local == 0:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
+        broadcast_from_rank0(self.params)
         dev = self.device
         p = self.program
         K = int(number_iterations)
@@ -421,7 +494,8 @@ def estimate_elbo(joint_model, posterior_model, number_samples, for_gradient=Fal
     compiled = compile_model(joint_model, posterior_model, gradient_estimator)
     res = compiled.evaluate(number_samples)
     if for_gradient:
-        return FusedLoss(compiled, -res["loss"])       # estimate_log_model_evidence returns +ELBO
+        # estimate_log_model_evidence returns +ELBO = -loss; the output block holds d loss / d theta
+        return FusedLoss(compiled, -res["loss"], grad_scale=-1.0)
     return -res["loss"]
 
 
@@ -437,7 +511,10 @@ def _run_sampler(model, posterior_model, number_samples, input_values):
     program = lowering.lower_sampler(model, posterior_model, input_values)
     run = CompiledELBO(model, posterior_model, program=program, bind_parameters=False)
     _sample_tick[0] += 1
-    res = run.evaluate(number_samples, want_samples=True, offset=(1 << 40) + _sample_tick[0])
+    # (sampling programs draw at offsets from 2^62: bits 8..21 of the high word carry the retry index of a rejection
+    #  sampler (philox_raw), so an offset base of 2^40 made attempt 1 of a sampler call reuse the stream of a training
+    #  iteration's attempt 0)
+    res = run.evaluate(number_samples, want_samples=True, offset=(1 << 62) + _sample_tick[0])
     samples = res["samples"]
     out = {}
     for var, slot in program.outputs:

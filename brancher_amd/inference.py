@@ -50,10 +50,32 @@ def perform_inference(joint_model, number_iterations, number_samples=1,
                 optimizers_list.append(prob_opt)
 
     inference_method.check_model_compatibility(joint_model, posterior_model, sampler_model)
-    loss_curve, finite = inference_method.run(joint_model, posterior_model, sampler_model, number_iterations,
-                                              number_samples, optimizer, pretraining_iterations, **opt_params)
-    losses = loss_curve.detach().cpu().numpy()
-    flags = finite.detach().cpu().numpy()
+    if hasattr(inference_method, "run"):
+        # the methods of this module: the whole loop of `inference.py:95-108` runs on the device
+        loss_curve, finite = inference_method.run(joint_model, posterior_model, sampler_model, number_iterations,
+                                                  number_samples, optimizer, pretraining_iterations, **opt_params)
+        losses = loss_curve.detach().cpu().numpy()
+        flags = finite.detach().cpu().numpy()
+    else:
+        # a reference-style InferenceMethod (only compute_loss / correct_gradient, `inference.py:114-126`): the loop
+        # stays here and every step goes through the same device kernels — compute_loss evaluates loss AND gradients in
+        # one launch (engine.FusedLoss), ProbabilisticOptimizer.update() is the device optimizer step
+        losses, flags = [], []
+        for iteration in range(number_iterations):
+            loss = inference_method.compute_loss(joint_model, posterior_model, sampler_model, number_samples)
+            value = float(loss.detach().cpu())
+            flags.append(1.0 if np.isfinite(value) else 0.0)
+            if flags[-1]:
+                for opt in optimizers_list:
+                    opt.zero_grad()
+                loss.backward()
+                if hasattr(inference_method, "correct_gradient"):
+                    inference_method.correct_gradient(joint_model, posterior_model, sampler_model, number_samples)
+                for index, opt in enumerate(optimizers_list):
+                    if index == 0 or iteration > pretraining_iterations:
+                        opt.update()
+            losses.append(value)
+        losses, flags = np.array(losses, dtype=np.float32), np.array(flags)
     for _ in range(int((flags == 0).sum())):
         warnings.warn("Numerical error, skipping sample")
     joint_model.diagnostics.update({"loss curve": np.array(losses)})
@@ -89,11 +111,10 @@ class ReverseKL(InferenceMethod):
         pass
 
     def compute_loss(self, joint_model, posterior_model, sampler_model, number_samples, input_values={}):
-        loss = -joint_model.estimate_log_model_evidence(number_samples=number_samples,
+        return -joint_model.estimate_log_model_evidence(number_samples=number_samples,
                                                         method="ELBO", input_values=input_values,
                                                         for_gradient=True, posterior_model=posterior_model,
                                                         gradient_estimator=self.gradient_estimator)
-        return engine.FusedLoss(None, loss)
 
     def correct_gradient(self, joint_model, posterior_model, sampler_model, number_samples, input_values={}):
         pass

@@ -39,6 +39,7 @@ class ProbabilisticOptimizer:
         self.optimizer_name, self.kwargs = optimizer, dict(kwargs)
         self.link_set = set()
         self.module = EmptyModule()
+        self._device_state = {}     # id(compiled program) -> (optimizer state [4][P], ownership mask [P]) on its device
         models = [model] if isinstance(model, (Variable, ProbabilisticModel)) else list(model)
         for m in models:
             self.add_variable2module(m)
@@ -55,3 +56,37 @@ class ProbabilisticOptimizer:
 
     def parameters(self):
         return self.module.parameters()
+
+    # ---- the reference's step interface (`optimizers.py:69-73`), for hand-written loops in the style of
+    #      `inference.py:95-108`:  loss = method.compute_loss(...); opt.zero_grad(); loss.backward(); opt.update()
+    def zero_grad(self):
+        """nothing to clear: every fused ELBO evaluation overwrites the gradient block of its compiled program"""
+
+    def update(self):
+        """One optimizer step of the parameters this optimizer owns, on the device (`bsvi_optimizer_step`), from the
+        gradients of the most recent ``compute_loss`` / ``estimate_log_model_evidence(for_gradient=True)`` of the
+        compiled program(s) they live in.  Optimizer state (momentum, Adam moments, step counts) is kept per optimizer,
+        as `torch.optim` keeps it per instance."""
+        import numpy as np
+        import torch
+        from brancher_amd import engine
+        if self.optimizer is None:
+            return
+        by_store = {}
+        for par in self.parameters():
+            store = par._store
+            if store is None:
+                raise RuntimeError("parameter {!r} is not part of a compiled model yet: evaluate the loss first".format(par.name))
+            by_store.setdefault(id(store), (store, []))[1].append(par)
+        for store, pars in by_store.values():
+            if not getattr(store, "grads_valid", False):
+                raise RuntimeError("no gradients: call compute_loss(...).backward() before update()")
+            key = id(store)
+            if key not in self._device_state:
+                mask = np.zeros(max(store.n_params, 1), dtype=np.uint8)
+                for par in pars:
+                    mask[par._offset:par._offset + par.size] = 1
+                self._device_state[key] = (torch.zeros(4 * max(store.n_params, 1), device=store.device),
+                                           torch.from_numpy(mask).to(store.device))
+            state, mask = self._device_state[key]
+            engine.optimizer_step(store, self.optimizer, state, mask)

@@ -18,8 +18,7 @@ import numpy as np
 import brancher_amd.distributions as distributions
 import brancher_amd.functions as BF
 import brancher_amd.geometric_ranges as geometric_ranges
-from brancher_amd.variables import var2link, Variable, RootVariable, RandomVariable, PartialLink
-from brancher_amd.utilities import join_sets_list
+from brancher_amd.variables import var2link, Variable, RootVariable, RandomVariable, PartialLink, _Observation
 
 
 class LinkConstructor:
@@ -43,38 +42,44 @@ class LinkConstructor:
         return iter(self.modules)
 
 
+def _leading_dimension(value):
+    """what the range transforms take as `dim`: the leading axis of an array, 1 for a number, [] otherwise"""
+    if isinstance(value, np.ndarray):
+        return value.shape[0]
+    return 1 if isinstance(value, numbers.Number) else []
+
+
 class VariableConstructor(RandomVariable):
-    """`standard_variables.py:32-68`."""
+    """Base of the standard variables (`standard_variables.py:32-68`).  A distribution parameter given as a number or an
+    array becomes a RootVariable named ``<variable>_<parameter>`` holding the UNCONSTRAINED value
+    (``range.inverse_transform``), and the parameter's link is ``range.forward_transform`` of that root — so a learnable
+    scale is optimised on the softplus-inverse scale, a probability on the logit scale (`geometric_ranges.py`).
+    Parameters given as variables or links are used as they are."""
 
     def __init__(self, name, learnable, ranges, is_observed=False, **kwargs):
         self.name = name
-        self._observed = is_observed
-        self._observed_value = None
-        self.construct_deterministic_parents(learnable, ranges, kwargs)
-        self.parents = join_sets_list([var2link(x).vars for x in kwargs.values()
-                                       if isinstance(var2link(x), PartialLink)])
-        self.ancestors = join_sets_list([self.parents] + [parent.ancestors for parent in self.parents])
-        self.link = LinkConstructor(**kwargs)
+        self._observation = _Observation(declared=is_observed)
+        links = {parameter: self._parameter_link(parameter, value, ranges, learnable, is_observed)
+                 for parameter, value in kwargs.items()}
+        self.partial_links = {parameter: var2link(link) for parameter, link in links.items()}
+        self.parents = set()
+        for link in self.partial_links.values():
+            if isinstance(link, PartialLink):
+                self.parents |= link.vars
+        self.ancestors = set(self.parents)
+        for parent in self.parents:
+            self.ancestors |= parent.ancestors
+        self.link = LinkConstructor(**links)
         self.ranges = {}
-        self.dataset = None
-        self.has_random_dataset = False
-        self.has_observed_value = False
         self.is_normalized = True
-        self.partial_links = {k: var2link(link) for k, link in kwargs.items()}
 
-    def construct_deterministic_parents(self, learnable, ranges, kwargs):
-        for parameter_name, value in list(kwargs.items()):
-            if not isinstance(value, (Variable, PartialLink)):
-                if isinstance(value, np.ndarray):
-                    dim = value.shape[0]
-                elif isinstance(value, numbers.Number):
-                    dim = 1
-                else:
-                    dim = []
-                deterministic_parent = RootVariable(ranges[parameter_name].inverse_transform(value, dim),
-                                                    self.name + "_" + parameter_name, learnable,
-                                                    is_observed=self._observed)
-                kwargs.update({parameter_name: ranges[parameter_name].forward_transform(deterministic_parent, dim)})
+    def _parameter_link(self, parameter, value, ranges, learnable, is_observed):
+        if isinstance(value, (Variable, PartialLink)):
+            return value
+        dim = _leading_dimension(value)
+        root = RootVariable(ranges[parameter].inverse_transform(value, dim), "{}_{}".format(self.name, parameter),
+                            learnable, is_observed=is_observed)
+        return ranges[parameter].forward_transform(root, dim)
 
 
 class DeterministicVariable(VariableConstructor):

@@ -1,0 +1,195 @@
+"""The two engines of the scalar path against each other and against the reference fixtures: the program-specialised
+kernels libbsvi generates and compiles with hiprtc (brancher_amd/csrc/specialize.cpp) and the
+interpreter kernels of elbo_kernel.hip (BSVI_JIT=0).  tests/test_gpu_parity.py runs every fixture through the default
+engine (specialised); here the interpreter is forced for the same fixtures, the engines are compared on in-kernel
+(Philox) draws, and the launch geometries / training modes of the specialised kernels are compared with each other.
+Also: hand-written inference loops in the reference's style through the device optimizer."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, golden_cases, rel_err
+from brancher_amd import engine, inference, workloads as W
+from brancher_amd.optimizers import ProbabilisticOptimizer
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+SCALAR = [c for c in golden_cases() if not c.startswith("logreg")]
+
+
+@pytest.fixture
+def interpreter(monkeypatch):
+    monkeypatch.setenv("BSVI_JIT", "0")
+
+
+def grad_check(named, ref, tol):
+    scale = max(np.abs(g).max() for g in ref.values())
+    for name, g_ref in ref.items():
+        assert np.abs(named[name] - g_ref).max() <= tol * scale + 1e-7 * scale, name
+
+
+def test_default_engine_is_the_specialised_kernel():
+    c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+    for mode in (0, 1, 2):
+        info = c.native.engine(300, mode)
+        assert info["engine"] == "specialised" and info["n_blocks"] == 1 and info["n_threads"] == 320
+    many = c.native.engine(262144, 1)
+    assert many["engine"] == "specialised" and many["n_threads"] == 256 and many["n_blocks"] <= 512
+    assert c.native.engine(262144, 2)["engine"] == "interpreter"      # the in-kernel loop is a one-workgroup mode
+
+
+@pytest.mark.parametrize("case", SCALAR)
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_interpreter_matches_reference_golden(case, estimator, interpreter):
+    g = Golden(case)
+    c = engine.compile_model(g.build(), None, estimator)
+    assert c.native.engine(g.N, 0)["engine"] == "interpreter"
+    res = c.evaluate(g.N, noise=g.noise)
+    ref = float(g.data["loss_" + estimator])
+    assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
+    grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL if estimator == "pathwise" else 1e-4)
+
+
+@pytest.mark.parametrize("builder,kwargs,n", [
+    ("build_readme_ar", dict(T=20), 300), ("build_readme_ar", dict(T=20), 5000), ("build_readme_ar", dict(T=60), 700),
+    ("build_readme_ar", dict(T=200), 1024), ("build_beta_binomial", dict(n_obs=30), 4096),
+    ("build_heavy_tails", dict(n_obs=12), 1000), ("build_beta_ar", dict(T=20), 640)])
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_engines_agree_on_philox_draws(builder, kwargs, n, estimator, monkeypatch):
+    """same seed, same offset: both engines draw the same samples (one Philox stream, one set of transforms) and give
+    the same loss and gradients up to summation order"""
+    out = {}
+    for jit in ("1", "0"):
+        monkeypatch.setenv("BSVI_JIT", jit)
+        c = engine.compile_model(getattr(W, builder)(W.native_api(), **kwargs), None, estimator)
+        res = c.evaluate(n, seed=11, offset=5, want_samples=True)
+        out[jit] = (float(res["loss"].item()), res["grads"].cpu().numpy().copy(), res["samples"].cpu().numpy().copy())
+    (la, ga, sa), (lb, gb, sb) = out["1"], out["0"]
+    assert np.abs(sa - sb).max() <= 2e-6 * max(1.0, np.abs(sb).max())
+    assert abs(la - lb) <= 2e-6 * abs(lb)
+    assert np.abs(ga - gb).max() <= (2e-6 if estimator == "pathwise" else 2e-5) * np.abs(gb).max()
+
+
+@pytest.mark.parametrize("optimizer,kw", [("SGD", dict(lr=1e-3)), ("SGD", dict(lr=1e-3, momentum=0.9, nesterov=True)),
+                                          ("Adam", dict(lr=1e-2)), ("Adam", dict(lr=1e-2, amsgrad=True, weight_decay=1e-3))])
+def test_in_kernel_loop_equals_launch_per_iteration(optimizer, kw):
+    """the specialised kernel's training loop (one launch) against its own single-iteration launches (bsvi_svi_step) and
+    the multi-GPU step sequence replayed from HIP graphs: same noise, same optimizer arithmetic"""
+    curves, params = [], []
+    for opts in (dict(), dict(allow_persistent=False), dict(_force_sharded_path=True)):
+        c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+        losses, finite = c.train(40, 300, optimizer, seed=3, **opts, **kw)
+        assert bool(finite.all())
+        curves.append(losses.cpu().numpy())
+        params.append(c.params.cpu().numpy().copy())
+        assert c.last_mode == ("persistent", "stepwise", "graph")[len(curves) - 1]
+    for other in (1, 2):
+        assert rel_err(curves[other], curves[0]) <= 2e-6
+        assert np.abs(params[other] - params[0]).max() <= 2e-5
+
+
+def test_pretraining_iterations_in_the_loop_kernel():
+    """model parameters are stepped only after `pretraining_iterations` (inference.py:102-104): in-kernel loop vs the
+    interpreter's persistent trainer"""
+    def run(jit):
+        os.environ["BSVI_JIT"] = jit
+        try:
+            model = W.build_learnable_model(W.native_api())
+            c = engine.compile_model(model, None, "pathwise")
+            losses, _ = c.train(30, 60, "Adam", seed=5, pretraining_iterations=10, lr=5e-2)
+            return losses.cpu().numpy(), c.params.cpu().numpy().copy()
+        finally:
+            os.environ.pop("BSVI_JIT", None)
+    (la, pa), (lb, pb) = run("1"), run("0")
+    assert rel_err(la, lb) <= 5e-6
+    assert np.abs(pa - pb).max() <= 5e-5 * (1 + np.abs(pb).max())
+
+
+def test_many_workgroup_geometry_sums_like_one_workgroup():
+    """a shard larger than one workgroup: 256-thread workgroups walking sample chunks, rows of sums added by the last one
+    to arrive — against the same samples evaluated as shards that each fit one workgroup (linearity of the sums)"""
+    c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+    n = 256 * 600 + 37                       # more workgroups than the launch has -> several chunks each, ragged tail
+    res = c.evaluate(n, seed=21, offset=2)
+    total = c.out.cpu().numpy().astype(np.float64).copy()
+    again = c.evaluate(n, seed=21, offset=2)
+    assert np.array_equal(c.out.cpu().numpy().astype(np.float64), total)            # bitwise reproducible
+    import ctypes as C
+    from brancher_amd import native
+    acc = np.zeros_like(total)
+    for base in range(0, n, 512):
+        m = min(512, n - base)
+        args = c._elbo_args(m, n, base, None, 21, 2)
+        native.check(c.lib.bsvi_elbo_fwd_bwd(c.native.handle, C.byref(args)))
+        acc += c.out.cpu().numpy().astype(np.float64)
+    scale = float(n)
+    assert abs(acc[0] * -1.0 / scale - total[2]) <= 2e-6 * abs(total[2])
+    assert np.abs(acc[4:] * -1.0 / scale - total[4:]).max() <= 5e-6 * np.abs(total[4:]).max()
+
+
+class _ReferenceStyleKL(inference.InferenceMethod):
+    """an InferenceMethod as a user of the reference would write it (`inference.py:114-151`): compute_loss only"""
+    learnable_model, learnable_sampler, needs_sampler = True, False, False
+
+    def check_model_compatibility(self, joint_model, posterior_model, sampler_model):
+        pass
+
+    def compute_loss(self, joint_model, posterior_model, sampler_model, number_samples, input_values={}):
+        return -joint_model.estimate_log_model_evidence(number_samples=number_samples, method="ELBO", for_gradient=True,
+                                                        posterior_model=posterior_model)
+
+    def correct_gradient(self, joint_model, posterior_model, sampler_model, number_samples, input_values={}):
+        pass
+
+    def post_process(self, joint_model):
+        pass
+
+
+@pytest.mark.parametrize("optimizer,kw", [("SGD", dict(lr=1e-3)), ("Adam", dict(lr=1e-2))])
+def test_reference_style_inference_method_drives_the_device_kernels(optimizer, kw):
+    """perform_inference with a method that only implements compute_loss: the Python loop of inference.py:95-108 over the
+    fused evaluation and ProbabilisticOptimizer.update() — same trajectory as the in-kernel loop on the same draws"""
+    torch.manual_seed(7)
+    a = W.build_readme_ar(W.native_api(), T=20)
+    inference.perform_inference(a, number_iterations=25, number_samples=300, optimizer=optimizer,
+                                inference_method=_ReferenceStyleKL(), **kw)
+    b = W.build_readme_ar(W.native_api(), T=20)
+    inference.perform_inference(b, number_iterations=25, number_samples=300, optimizer=optimizer,
+                                inference_method=inference.ReverseKL(), **kw)
+    la, lb = np.asarray(a.diagnostics["loss curve"]), np.asarray(b.diagnostics["loss curve"])
+    assert la.shape == lb.shape == (25,)
+    assert rel_err(la, lb) <= 5e-6
+    pa = engine.compile_model(a, None, "pathwise").params.cpu().numpy()
+    pb = engine.compile_model(b, None, "pathwise").params.cpu().numpy()
+    assert np.abs(pa - pb).max() <= 2e-5
+
+
+def test_hand_written_loop_with_optimizer_update():
+    """loss = -ELBO; loss.backward(); optimizer.update() — `optimizers.py:69-73`; the ELBO improves"""
+    model = W.build_beta_binomial(W.native_api(), n_obs=30)
+    opt = ProbabilisticOptimizer(model.posterior_model, "Adam", lr=0.05)
+    values = []
+    for _ in range(60):
+        loss = -model.estimate_log_model_evidence(number_samples=512, for_gradient=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.update()
+        values.append(float(loss))
+    assert np.isfinite(values).all()
+    assert np.mean(values[-10:]) < np.mean(values[:10])
+
+
+def test_device_binding_without_set_device():
+    """config.set_device('cuda:1') alone (no torch.cuda.set_device): tables, buffers, stream and launches on cuda:1"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from brancher_amd import config
+    config.set_device("cuda:1")
+    try:
+        c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+        losses, finite = c.train(20, 300, "SGD", seed=1, lr=1e-3)
+        assert losses.device.index == 1 and bool(finite.all())
+    finally:
+        config.set_device("cuda:0")
