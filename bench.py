@@ -308,8 +308,12 @@ def main():
         if spec is not None:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_hbm.sh), committed per round:
             # the timed launch is the larger of the two launches in the summary (the other is the warm-up)
-            traffic = pmc_traffic_bytes("cfg1_spec_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"], column="max_KB") \
-                if args.workload == "cfg1" and not args.samples and args.steps == 20000 and mode == "persistent" else None
+            if args.workload == "cfg1" and not args.samples and args.steps == 20000 and mode == "persistent":
+                traffic = pmc_traffic_bytes("cfg1_spec_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"], column="max_KB")
+            elif args.workload == "cfg1" and not args.samples and mode == "stepwise":
+                traffic = pmc_traffic_bytes("cfg1_spec_stepwise_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"])
+            else:
+                traffic = None
         elif mode == "persistent":
             traffic = None
         else:

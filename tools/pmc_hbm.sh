@@ -1,8 +1,8 @@
 # HBM traffic per dispatch (MI355X_MICROARCH.md "HBM" section: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes,
-# kernel-trace only).  usage: bash tools/pmc_hbm.sh <tag> <bench.py args...>   -> gpurun_out/r1/<tag>_hbm.csv
+# kernel-trace only).  usage: bash tools/pmc_hbm.sh <tag> <bench.py args...>   -> gpurun_out/r2/<tag>_hbm.csv
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r2
 mkdir -p $OUT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_${tag}_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline > /dev/null 2>&1

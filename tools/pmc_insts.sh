@@ -1,6 +1,6 @@
 # instruction mix of one fused ELBO launch (1 wave: number_samples=64), stepwise mode; usage: bash tools/pmc_insts.sh
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r2
 mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d /tmp/pmc_insts -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --mode stepwise --samples 64 --steps 200 --warmup 20 > /dev/null 2>&1
 python3 - <<PY
