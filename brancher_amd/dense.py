@@ -51,8 +51,8 @@ def _is_random(v):
 
 
 def lower_dense(joint, posterior, estimator="pathwise"):
-    if estimator != "pathwise":
-        raise LoweringError("the dense-link path implements the Pathwise estimator only")
+    if estimator not in ("pathwise", "blackbox"):
+        raise LoweringError("the dense-link path implements the Pathwise and BlackBox estimators")
     L = _Lowering(joint, posterior, estimator)
     q_flat = posterior._flatten()
     L.q_by_name = {v.name: v for v in q_flat}
@@ -159,6 +159,7 @@ def lower_dense(joint, posterior, estimator="pathwise"):
 
     uni, n_up = L.uniform_table()
     prog = DenseProgram()
+    prog.estimator = estimator
     L.fill_parameter_tables(prog, uni, n_up)
 
     def base(entry):
@@ -209,7 +210,8 @@ class CompiledDense:
                       q_loc_u=p.q_loc[0], q_scale_u=p.q_scale[0], prior_loc_u=p.prior_loc[0], prior_scale_u=p.prior_scale[0],
                       q_loc_stride=p.q_loc[1], q_scale_stride=p.q_scale[1], prior_loc_stride=p.prior_loc[1],
                       prior_scale_stride=p.prior_scale[1], lik_weight=p.lik_weight, prior_weight=p.prior_weight,
-                      entropy_weight=p.entropy_weight, uniform=ptr(k["uniform"]), consts=ptr(k["consts"]),
+                      entropy_weight=p.entropy_weight, estimator=lowering.EST[getattr(p, "estimator", "pathwise")],
+                      uniform=ptr(k["uniform"]), consts=ptr(k["consts"]),
                       param_uniform_ptr=ptr(k["ptr"]), param_uniform_idx=ptr(k["idx"]), dataset=ptr(k["dataset"]),
                       labels=ptr(k["labels"]))
         handle = C.c_void_p()

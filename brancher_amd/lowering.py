@@ -311,8 +311,16 @@ class _Lowering:
         if var.distribution.kind == D.DIST_LOGNORMAL:          # exp(loc + scale^2 / 2)   (torch log_normal.py:53-54)
             half_var = self.mk("mul", (self.mk("imm", (), 0.5), self.mk("call:square", (params[1],))))
             return self.mk("call:exp", (self.mk("add", (params[0], half_var)),))
-        raise LoweringError("Taylor1 estimator: the analytic mean of %r (%s) is not lowered yet (Normal / LogNormal "
-                            "posteriors)" % (var.name, type(var.distribution).__name__))
+        if var.distribution.kind == D.DIST_LAPLACE:            # loc   (torch laplace.py:51-52)
+            return params[0]
+        if var.distribution.kind == D.DIST_BETA:               # c1 / (c1 + c0)   (torch beta.py:63-64)
+            return self.mk("truediv", (params[0], self.mk("add", (params[0], params[1]))))
+        if var.distribution.kind == D.DIST_BERNOULLI:          # probs = sigmoid(logits)   (torch bernoulli.py:82-83)
+            return self.mk("call:sigmoid", (params[0],))
+        if var.distribution.kind == D.DIST_BINOMIAL:           # total_count * probs   (torch binomial.py:98-99)
+            return self.mk("mul", (params[0], self.mk("call:sigmoid", (params[1],))))
+        raise LoweringError("Taylor1 estimator: %r (%s) has no analytic mean (torch returns NaN for a Cauchy)"
+                            % (var.name, type(var.distribution).__name__))
 
     def p_value(self, var):
         if isinstance(var, RandomVariable) and var.is_observed:
@@ -706,12 +714,19 @@ class _Lowering:
             if self.estimator == "taylor1":
                 # the entropy is evaluated on the means too (`variables.py:851-855` with samples := means): for a
                 # Normal it depends on the scale only, which must therefore not depend on sampled parents
+                # (other distributions: every parameter; discrete ones have no analytic entropy in the reference and
+                #  fall back to -log q at the sampled value, which the means would change)
                 kind = v.distribution.kind
-                ok = (kind == D.DIST_NORMAL and not params[1].has_z) or \
-                     (kind == D.DIST_LOGNORMAL and not params[0].has_z and not params[1].has_z)
+                if kind == D.DIST_NORMAL:
+                    ok = not params[1].has_z
+                elif kind in (D.DIST_LOGNORMAL, D.DIST_LAPLACE, D.DIST_BETA):
+                    ok = not any(p.has_z for p in params)
+                else:
+                    ok = False
                 if not ok:
-                    raise LoweringError("Taylor1 estimator: %r needs a Normal posterior whose scale (LogNormal: loc and "
-                                        "scale) does not depend on other latent variables" % v.name)
+                    raise LoweringError("Taylor1 estimator: the entropy of %r must not depend on other latent variables "
+                                        "(Normal: its scale; LogNormal / Laplace / Beta: every parameter) and be analytic"
+                                        % v.name)
             shape = broadcast_shapes3(*[p.shape for p in params])
             self.slots[v] = SlotInfo(v, self.n_slots, shape, v.distribution.kind)
             self.n_slots += self.slots[v].size

@@ -62,7 +62,7 @@ class DenseDesc(C.Structure):
                 ("prior_scale_u", C.c_uint32), ("q_loc_stride", C.c_uint32), ("q_scale_stride", C.c_uint32),
                 ("prior_loc_stride", C.c_uint32), ("prior_scale_stride", C.c_uint32),
                 ("lik_weight", C.c_float), ("prior_weight", C.c_float), ("entropy_weight", C.c_float),
-                ("reserved", C.c_uint32),
+                ("estimator", C.c_uint32),
                 ("uniform", C.c_void_p), ("consts", C.c_void_p), ("param_uniform_ptr", C.c_void_p),
                 ("param_uniform_idx", C.c_void_p), ("dataset", C.c_void_p), ("labels", C.c_void_p)]
 

@@ -15,7 +15,7 @@ import numpy as np
 def native_api():
     from brancher_amd import standard_variables as sv, variables as v, functions as BF
     return types.SimpleNamespace(
-        NormalVariable=sv.NormalVariable, LogNormalVariable=sv.LogNormalVariable, BetaVariable=sv.BetaVariable,
+        NormalVariable=sv.NormalVariable, LogitNormalVariable=sv.LogitNormalVariable, LogNormalVariable=sv.LogNormalVariable, BetaVariable=sv.BetaVariable,
         BinomialVariable=sv.BinomialVariable, BernulliVariable=sv.BernulliVariable,
         CauchyVariable=sv.CauchyVariable, LaplaceVariable=sv.LaplaceVariable,
         DeterministicVariable=sv.DeterministicVariable, RootVariable=v.RootVariable,
@@ -33,25 +33,28 @@ def ar_data(T, seed=0, b=0.8, driving_noise=1.0, measure_noise=0.3):
     return (x + rng.normal(0., measure_noise, size=T)).astype(np.float32)
 
 
-def build_readme_ar(api, T=20, data=None, driving_noise=1., measure_noise=0.3):
+def build_readme_ar(api, T=20, data=None, driving_noise=1., measure_noise=0.3, logit_normal=False):
     """BASELINE config 1/3: the README state-space AR model (`README.md:25-75`) with the
     logit-Normal coefficient written as a Normal latent + sigmoid, distinct
-    variable names for x and y (the README's duplicate 'x0' is a typo)."""
+    variable names for x and y (the README's duplicate 'x0' is a typo).
+    logit_normal=True writes the coefficient the way the README does — ``b = LogitNormalVariable(0.5, 1., ...)`` and
+    ``b * x[t-1]`` — with this package's LogitNormalVariable (the reference snapshot has none): the same graph."""
     BF = api.BF
     if data is None:
         data = ar_data(T, driving_noise=driving_noise, measure_noise=measure_noise)
     x0 = api.NormalVariable(0., driving_noise, 'x0')
     y0 = api.NormalVariable(x0, measure_noise, 'y0')
-    bl = api.NormalVariable(0.5, 1., 'b_logit')
+    bl = api.LogitNormalVariable(0.5, 1., 'b_logit') if logit_normal else api.NormalVariable(0.5, 1., 'b_logit')
+    coefficient = (lambda v: bl * v) if logit_normal else (lambda v: BF.sigmoid(bl) * v)
     x, y = [x0], [y0]
     for t in range(1, T):
-        x.append(api.NormalVariable(BF.sigmoid(bl) * x[t - 1], driving_noise, "x{}".format(t)))
+        x.append(api.NormalVariable(coefficient(x[t - 1]), driving_noise, "x{}".format(t)))
         y.append(api.NormalVariable(x[t], measure_noise, "y{}".format(t)))
     model = api.ProbabilisticModel(x + y)
     for t, yt in enumerate(y):
         yt.observe(np.array([[float(data[t])]], dtype=np.float32))
 
-    Qb = api.NormalVariable(0.5, 0.5, "b_logit", learnable=True)
+    Qb = (api.LogitNormalVariable if logit_normal else api.NormalVariable)(0.5, 0.5, "b_logit", learnable=True)
     logit_b_post = api.DeterministicVariable(0., 'logit_b_post', learnable=True)
     Qx = [api.NormalVariable(0., 1., 'x0', learnable=True)]
     Qx_mean = [api.DeterministicVariable(0., 'x0_mean', learnable=True)]

@@ -382,7 +382,7 @@ typedef struct bsvi_dense_desc {
     uint32_t q_loc_u, q_scale_u, prior_loc_u, prior_scale_u;
     uint32_t q_loc_stride, q_scale_stride, prior_loc_stride, prior_scale_stride;
     float lik_weight, prior_weight, entropy_weight;
-    uint32_t reserved;
+    uint32_t estimator;                        /* bsvi_estimator: pathwise, or BlackBox (gradient_estimators.py:29-36) */
     const bsvi_uniform_entry* uniform;
     const float* consts;
     const uint32_t* param_uniform_ptr;

@@ -64,7 +64,8 @@ CASES = {
 
 
 # workloads whose posterior is made of Normal variables: the Taylor1 estimator is recorded for them too
-TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_learnable_model", "build_vector_latent")
+TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_learnable_model", "build_vector_latent",
+                    "build_beta_binomial", "build_observed_ar", "build_lognormal_normal")
 
 
 def reference_api():
@@ -180,6 +181,11 @@ def run_case(name, api):
     model = getattr(W, builder)(api, **kwargs)
     model.update_observed_submodel()
     q = model.posterior_model
+    # The reference walks `posterior_model.variables`, a SET of objects hashed by address (variables.py:66,636,894), so
+    # which torch draw goes to which variable changes from run to run.  The fixtures record the noise per variable NAME,
+    # which makes each of them self-consistent either way; walking the variables in name order makes regenerating one
+    # reproducible as well (recorded in meta["posterior_order"]).
+    q._input_variables = sorted(q._input_variables, key=lambda v: v.name)
     roots = named_parameters(model, q)
     out = {}
     for pname, root in roots.items():
@@ -305,7 +311,7 @@ def run_case(name, api):
             out["traj/param_after/" + pname] = root.value.detach().numpy().copy()
 
     meta = dict(case=name, builder=builder, kwargs=kwargs, N=N, seed=seed, trajectory=traj,
-                torch=torch.__version__, numpy=np.__version__,
+                torch=torch.__version__, numpy=np.__version__, posterior_order="sorted by name",
                 reference="LucaAmbrogioni/Brancher @ /root/reference")
     out["meta"] = np.array(json.dumps(meta))
     os.makedirs(OUT, exist_ok=True)

@@ -33,8 +33,6 @@ def is_dense(case):
 @pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
 def test_loss_and_grads_match_reference_golden(case, estimator):
     g = Golden(case)
-    if is_dense(case) and estimator == "blackbox":
-        pytest.skip("the dense-link path implements the Pathwise estimator")
     model, c = compiled_for(g, estimator)
     res = c.evaluate(g.N, noise=g.noise, minibatch=g.minibatch, want_samples=True, want_fvalues=True)
     loss = float(res["loss"].item())
@@ -50,8 +48,20 @@ def test_loss_and_grads_match_reference_golden(case, estimator):
         exact = Oracle(g.build(), dtype=_t.float64).loss_and_grads(g.N, estimator, g.noise, g.minibatch)
         scale = max(np.abs(g.data["lp"]).max(), np.abs(g.data["H"]).max())
         err, err_ref = abs(loss - exact["loss"]), abs(ref - exact["loss"])
-        assert err <= max(4 * err_ref, 1e-6 * scale), (loss, ref, exact["loss"])
-        grad_check(c.named_grads(), {k: v.astype(np.float32) for k, v in exact["grads"].items()}, TOL)
+        # (BlackBox: the value is log q * f + f — a product of the two cancelling sums — so its own magnitude sets the
+        #  rounding: the 1e-5 relative bound of every other workload)
+        assert err <= max(4 * err_ref, 1e-6 * scale, (TOL * abs(exact["loss"]) if estimator == "blackbox" else 0.0)), \
+            (loss, ref, exact["loss"])
+        if estimator == "blackbox":
+            # the score term puts  -(sum_n f_n) / s_r  into every scale gradient: the cancellation error of f (above)
+            # times 1/s.  Same yardstick: as close to the fp64 gradient as the reference's own fp32 gradient is (x4).
+            named, ref_g = c.named_grads(), g.group("grad_blackbox/")
+            gscale = max(np.abs(v).max() for v in exact["grads"].values())
+            for name, g64 in exact["grads"].items():
+                err_g, err_ref_g = np.abs(named[name] - g64).max(), np.abs(ref_g[name] - g64).max()
+                assert err_g <= max(4 * err_ref_g, TOL * gscale), (name, err_g, err_ref_g)
+        else:
+            grad_check(c.named_grads(), {k: v.astype(np.float32) for k, v in exact["grads"].items()}, TOL)
         f64 = exact["f"].reshape(-1)
         assert np.abs(res["f"].cpu().numpy() - f64).max() <= 1e-6 * scale
         return

@@ -193,3 +193,17 @@ def test_device_binding_without_set_device():
         assert losses.device.index == 1 and bool(finite.all())
     finally:
         config.set_device("cuda:0")
+
+
+def test_logit_normal_variable_matches_the_reference_fixture():
+    """README.md:30,56 writes the AR coefficient as ``LogitNormalVariable`` and multiplies with it; this package's
+    LogitNormalVariable (a Normal on the logit scale whose arithmetic goes through sigmoid) gives the model of the
+    reference fixture, which the reference itself can only express as NormalVariable + BF.sigmoid"""
+    g = Golden("readme_ar_T20_N300")
+    model = W.build_readme_ar(W.native_api(), logit_normal=True, **g.meta["kwargs"])
+    for estimator in ("pathwise", "blackbox"):
+        c = engine.compile_model(model, None, estimator)
+        res = c.evaluate(g.N, noise=g.noise)
+        ref = float(g.data["loss_" + estimator])
+        assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
+        grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL if estimator == "pathwise" else 1e-4)

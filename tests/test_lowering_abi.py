@@ -126,3 +126,15 @@ def test_noise_packing_round_trip():
     for name, arr in g.noise.items():
         base, size, _ = prog.noise_rows(name)
         assert np.array_equal(mat[base], arr.reshape(g.N))
+
+
+def test_logit_normal_variable_lowers_to_the_sigmoid_form():
+    """LogitNormalVariable (README.md:30,56; commented out in the reference snapshot) = Normal latent on the logit scale
+    whose use in links is sigmoid(u): the README model written with it lowers to the same program as the explicit form"""
+    from brancher_amd import workloads as W
+    api = W.native_api()
+    a, b = W.build_readme_ar(api, T=6), W.build_readme_ar(api, T=6, logit_normal=True)
+    pa, pb = lowering.lower(a, a.posterior_model, "pathwise"), lowering.lower(b, b.posterior_model, "pathwise")
+    assert np.array_equal(np.asarray(pa.code), np.asarray(pb.code))
+    assert np.array_equal(pa.initial_params(), pb.initial_params())
+    assert [v._type for v in b.flatten() if v.name == "b_logit"] == ["Logit Normal"]
