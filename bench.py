@@ -58,6 +58,8 @@ def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False, column="m
     import csv
     path = os.path.join(PROFILE_DIR, csv_name)
     if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r1", csv_name)      # (the dense / amortised kernels were last profiled in round 1)
+    if not os.path.exists(path):
         return None
     total = 0.0
     hit = False
