@@ -561,15 +561,8 @@ def posterior_sample(model, number_samples, input_values={}):
 
 
 def _frame(sample):
-    import pandas as pd
-    from brancher_amd.variables import RootVariable
-    cols = {}
-    for var, t in sample.items():
-        if isinstance(var, RootVariable):
-            continue
-        a = t.detach().cpu().numpy()
-        cols[var.name] = [float(x) for x in a.reshape(a.shape[0], -1)[:, 0]] if a[0].size == 1 else list(a)
-    return pd.DataFrame(cols)
+    from brancher_amd.pandas_interface import reformat_sample_to_pandas
+    return reformat_sample_to_pandas(sample)
 
 
 def get_sample_frame(model, number_samples, input_values={}):

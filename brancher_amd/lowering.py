@@ -229,6 +229,8 @@ class _Lowering:
     def mk(self, op, args=(), attr=None, shape=None):
         if op in ("root", "z", "obs"):
             key = (op, id(attr))
+        elif op == "elem":
+            key = (op, int(attr)) + tuple(a.key for a in args)
         elif op == "imm":
             key = (op, float(attr))
         elif op == "carr":
@@ -446,7 +448,7 @@ class _Lowering:
 
     # ---------------------------------------------------------------- code generation
     def is_leaf_operand(self, node):
-        return node.op in ("z", "obs", "imm") or self.match_uniform(node) is not None
+        return node.op in ("z", "obs", "imm", "elem") or self.match_uniform(node) is not None
 
     def count_uses(self, roots):
         """per record: every computed (non-leaf, sample-dependent) sub-expression counts once"""
@@ -502,8 +504,10 @@ class _Lowering:
             if n.key in seen:
                 continue
             seen.add(n.key)
-            m = self.match_uniform(n)
-            if m is not None:
+            m = self.match_uniform(n) if n.op != "elem" else None
+            if n.op == "elem":
+                out.append((1, 1, 1))
+            elif m is not None:
                 out.append(tuple(m[0].shape))
             elif n.op in ("z", "obs", "root", "carr") or n.key in self.derived_nodes:
                 out.append(tuple(n.shape))
@@ -542,8 +546,22 @@ class _Lowering:
         hit = self.rec_operands.get(node.key)
         if hit is not None:
             return hit
-        m = self.match_uniform(node)
-        if m is not None:
+        m = self.match_uniform(node) if node.op != "elem" else None
+        if node.op == "elem":
+            # element `attr` (flattened index) of a vector-valued leaf: a fixed operand, no element loop
+            child, j = node.args[0], int(node.attr)
+            mc = self.match_uniform(child)
+            if child.op == "z":
+                res = operand(K_Z, self.slots[child.attr].base + j, 0)
+            elif child.op == "obs":
+                res = operand(K_OBS, self.obs_offset(child.attr) + j, 0)
+            elif mc is not None:
+                leaf, g, a, b = mc
+                is_param, k0 = self.uniform_entries(leaf, g, a, b)
+                res = operand(K_U if is_param else K_UCONST, k0 + j, 0)
+            else:
+                raise LoweringError("an element of a computed vector (%r) is not addressable in the fused kernel" % (child,))
+        elif m is not None:
             leaf, g, a, b = m
             is_param, k0 = self.uniform_entries(leaf, g, a, b)
             off, stride = self.place(leaf.shape)
@@ -658,6 +676,85 @@ class _Lowering:
             out.append(node)
         return out
 
+    # ---------------------------------------------------------------- multivariate normal terms
+    def constant_value(self, e):
+        """numpy value of a link expression made of constants and non-learnable roots only (else None)"""
+        if e.op == "const":
+            return np.asarray(e.attr, dtype=np.float64)
+        if e.op == "var":
+            var = e.attr
+            if isinstance(var, RootVariable) and not var.learnable:
+                return np.asarray(var.value, dtype=np.float64)
+            return None
+        args = [self.constant_value(a) if isinstance(a, sym.Expr) else np.asarray(a, dtype=np.float64) for a in e.args]
+        if any(a is None for a in args):
+            return None
+        if e.op in sym.BINARY_OPS:
+            fn = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "truediv": np.divide, "pow": np.power}[e.op]
+            return fn(args[0], args[1])
+        if e.op == "call" and isinstance(e.attr[0], str):
+            name, kwargs = e.attr
+            if name == "matmul" and len(args) == 2:
+                return np.matmul(args[0], args[1])
+            if name == "transpose":
+                return np.swapaxes(args[0], int(args[1]), int(args[2])) if len(args) == 3 else np.swapaxes(args[0], -2, -1)
+            if name in ("exp", "log", "sqrt", "abs", "sin", "cos", "tanh") and len(args) == 1 and not kwargs:
+                return getattr(np, name)(args[0])
+        return None
+
+    def mvn_terms(self, v):
+        """A MultivariateNormalVariable of the joint model (`standard_variables.py:317-347`, `distributions.py:314-331`)
+        whose covariance is a constant of the model — the prior of a Gaussian process at fixed inputs
+        (`stochastic_processes.py:29-40`, development_playgrounds/GP_playground.py).  With the Cholesky factor L of the
+        covariance,  log N(x | m, L L^T) = sum_i log Normal(u_i | 0, L_ii)  for  u = diag(L) L^-1 (x - m):  D scalar
+        Normal terms whose values are fixed linear combinations of the elements of x - m.  The factorisation is done here,
+        once, in double precision; the kernel sees D Normal records (their reverse mode included).
+        Returns [(term, value IR, [loc IR, scale IR], shape)] like the entries of p_nodes."""
+        links = v.link.expressions()
+        given = [k for k in ("scale_tril", "covariance_matrix", "precision_matrix") if k in links]
+        mat = self.constant_value(links[given[0]].expr)
+        if mat is None:
+            raise LoweringError("the %s of %r depends on learnable or sampled values: only multivariate normals with a "
+                                "constant covariance are lowered" % (given[0], v.name))
+        mat = np.asarray(mat, dtype=np.float64)
+        mat = mat.reshape(mat.shape[-2:])
+        if mat.shape[0] != mat.shape[1]:
+            raise LoweringError("%s of %r is not a square matrix" % (given[0], v.name))
+        if given[0] == "scale_tril":
+            L = np.tril(mat)
+        elif given[0] == "covariance_matrix":
+            L = np.linalg.cholesky(mat)
+        else:
+            L = np.linalg.cholesky(np.linalg.inv(mat))
+        dim = L.shape[0]
+        A = np.diag(np.diag(L)) @ np.linalg.inv(L)
+        value = self.p_value(v)
+        loc = self.from_expr(links["loc"].expr, self.p_value)
+        for what, node in (("value", value), ("loc", loc)):
+            if int(np.prod(node.shape)) not in (1, dim):
+                raise LoweringError("the %s of %r has %d elements, its covariance is %dx%d" % (what, v.name, int(np.prod(node.shape)), dim, dim))
+
+        def element(node, j):
+            if int(np.prod(node.shape)) == 1:
+                return node
+            return self.mk("elem", (node,), j, (1, 1, 1))
+
+        class _Term:                              # what the emission reads of a model variable
+            def __init__(self, var, i):
+                self.is_observed, self.name = var.is_observed, "%s[%d]" % (var.name, i)
+                self.distribution = D.NormalDistribution()
+
+        zero_loc = loc.op == "imm" and loc.attr == 0.0
+        terms = []
+        for i in range(dim):
+            u = None
+            for j in range(i + 1):
+                d = element(value, j) if zero_loc else self.mk("sub", (element(value, j), element(loc, j)))
+                t = self.mk("mul", (self.mk("imm", (), float(A[i, j])), d))
+                u = t if u is None else self.mk("add", (u, t))
+            terms.append((_Term(v, i), u, [self.mk("imm", (), 0.0), self.mk("imm", (), float(L[i, i]))], (1, 1, 1)))
+        return terms
+
     # ---------------------------------------------------------------- driver
     def run(self):
         joint, posterior = self.joint, self.posterior
@@ -736,6 +833,9 @@ class _Lowering:
         p_nodes = []
         for v in p_flat:
             if not isinstance(v, RandomVariable) or getattr(v, "_type", None) == "Deterministic node":
+                continue
+            if v.distribution.kind == D.DIST_MVNORMAL:
+                p_nodes.extend(self.mvn_terms(v))
                 continue
             if v.distribution.kind not in supported:
                 raise LoweringError("distribution of %r is not supported by the fused kernel yet" % v.name)

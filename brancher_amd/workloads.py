@@ -20,7 +20,7 @@ def native_api():
         CauchyVariable=sv.CauchyVariable, LaplaceVariable=sv.LaplaceVariable,
         DeterministicVariable=sv.DeterministicVariable, RootVariable=v.RootVariable,
         CategoricalVariable=sv.CategoricalVariable, EmpiricalVariable=sv.EmpiricalVariable,
-        RandomIndices=sv.RandomIndices,
+        RandomIndices=sv.RandomIndices, MultivariateNormalVariable=sv.MultivariateNormalVariable,
         ProbabilisticModel=v.ProbabilisticModel, BF=BF, name="brancher_amd")
 
 
@@ -217,6 +217,23 @@ def build_dynamic_causal_model(api, steps=30, seed=0):
     Qxi = api.LogNormalVariable(0.1, 0.1, name="xi", learnable=True)
     Qchi = api.LogNormalVariable(0.1, 0.1, name="chi", learnable=True)
     model.set_posterior_model(api.ProbabilisticModel([Qa, Qb, Qc, Qd, Qe, Qxi, Qchi]))
+    return model
+
+
+def build_gp_regression(api, n=8, length_scale=0.6, jitter=1e-3, noise=0.2, seed=0):
+    """Gaussian-process regression at fixed inputs (development_playgrounds/GP_playground.py; `stochastic_processes.py:
+    29-40,83-95`): f ~ MultivariateNormal(0, K) with the squared-exponential covariance of the inputs — a constant of
+    the model —, y ~ Normal(f, noise) observed, mean-field Normal posterior over the function values."""
+    rng = np.random.RandomState(seed)
+    x = np.linspace(-2., 2., n)
+    K = np.exp(-(x[:, None] - x[None, :]) ** 2 / (2 * length_scale ** 2)) + jitter * np.eye(n)
+    f = api.MultivariateNormalVariable(loc=np.zeros((n,)), covariance_matrix=K, name="f")
+    y = api.NormalVariable(f, noise, name="y")
+    model = api.ProbabilisticModel([y])
+    data = np.sin(2 * np.pi * 0.4 * x) + noise * rng.normal(0., 1., (1, n))
+    y.observe(data.astype(np.float32))
+    Qf = api.NormalVariable(loc=np.zeros((n,)), scale=0.8, name="f", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qf]))
     return model
 
 

@@ -32,6 +32,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 CASES = {
     # name: (builder, builder kwargs, N, seed, trajectory spec)
+    "gp_regression_n8_N50": ("build_gp_regression", dict(n=8), 50, 6, dict(iters=5, n=16, optimizer="Adam", lr=2e-2)),
     "readme_ar_T20_N300": ("build_readme_ar", dict(T=20), 300, 0, dict(iters=6, n=64, optimizer="SGD", lr=1e-3)),
     "readme_ar_T5_N7": ("build_readme_ar", dict(T=5), 7, 1, dict(iters=5, n=7, optimizer="Adam", lr=5e-2)),
     "readme_ar_T200_N32": ("build_readme_ar", dict(T=200), 32, 2, None),
@@ -79,7 +80,7 @@ def reference_api():
         CauchyVariable=sv.CauchyVariable, LaplaceVariable=sv.LaplaceVariable,
         DeterministicVariable=sv.DeterministicVariable, RootVariable=v.RootVariable,
         CategoricalVariable=sv.CategoricalVariable, EmpiricalVariable=sv.EmpiricalVariable,
-        RandomIndices=sv.RandomIndices,
+        RandomIndices=sv.RandomIndices, MultivariateNormalVariable=sv.MultivariateNormalVariable,
         ProbabilisticModel=v.ProbabilisticModel, BF=BF, name="reference")
 
 
@@ -138,6 +139,9 @@ def match_noise(q, z, draws):
         if isinstance(dist, (rd.NormalDistribution, rd.LogNormalDistribution, rd.CauchyDistribution,
                              rd.LaplaceDistribution)):
             loc, scale = params["loc"], params["scale"]
+            # (the reference pads parameters with TRAILING singleton axes up to the sample's rank, utilities.py:143-159)
+            loc = loc.reshape(tuple(loc.shape) + (1,) * (sample.dim() - loc.dim()))
+            scale = scale.reshape(tuple(scale.shape) + (1,) * (sample.dim() - scale.dim()))
             kind = {"NormalDistribution": "normal", "LogNormalDistribution": "normal",
                     "CauchyDistribution": "cauchy", "LaplaceDistribution": "uniform"}[type(dist).__name__]
             found = None

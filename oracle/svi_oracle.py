@@ -331,6 +331,19 @@ class Oracle:
             xv = flat.pop("x_data")
             lp = td.categorical.Categorical(**flat).log_prob(xv[:, 0])
             return lp.contiguous().view(n, m)
+        if dist.kind == D.DIST_MVNORMAL:
+            # VectorDistribution preprocessing (distributions.py:257-269): value and the vector parameter `loc` are tiled to
+            # [N*B-flattened rows, D]; the matrix parameter goes to torch as broadcast by the link; log_prob -> [N, B]
+            # (torch multivariate_normal.py: -0.5 * (D log 2pi + |L^-1 (x - loc)|^2) - sum log diag L)
+            both = dict(params)
+            both["x_data"] = x
+            n, m = number_samples_and_datapoints(both)
+            flat = {k: flatten_parent(v, n, m) for k, v in both.items()}
+            for k in ("loc", "x_data"):
+                flat[k] = flat[k].contiguous().view(flat[k].shape[0], int(np.prod(flat[k].shape[1:])))
+            xv = flat.pop("x_data")
+            lp = td.multivariate_normal.MultivariateNormal(**flat).log_prob(xv)
+            return lp.contiguous().view(n, m)
         keys = list(params.keys())
         vals = broadcast_and_squeeze(x, *[params[k] for k in keys])         # distributions.py:201-203
         x = vals[0]

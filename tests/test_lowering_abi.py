@@ -138,3 +138,37 @@ def test_logit_normal_variable_lowers_to_the_sigmoid_form():
     assert np.array_equal(np.asarray(pa.code), np.asarray(pb.code))
     assert np.array_equal(pa.initial_params(), pb.initial_params())
     assert [v._type for v in b.flatten() if v.name == "b_logit"] == ["Logit Normal"]
+
+
+def test_pandas_wire_format_round_trip():
+    """observe(DataFrame) / the frame get_sample returns (`pandas_interface.py:8-58`): one row per datapoint / sample, a
+    column per variable; scalars as floats, vectors as arrays.  A frame of samples observed by a fresh model gives the
+    [datapoints, ...] arrays the lowering stages."""
+    import pandas as pd
+    from brancher_amd import pandas_interface as PI
+    api = W.native_api()
+
+    class V:                                   # stands in for a sampled variable: the unpacking needs a name only
+        def __init__(self, name):
+            self.name = name
+    scalar = np.arange(5, dtype=np.float32).reshape(5, 1, 1, 1)
+    vector = np.arange(15, dtype=np.float32).reshape(5, 1, 3, 1)
+    frame = PI.reformat_sample_to_pandas({V("a"): scalar, V("b"): vector})
+    assert list(frame.columns) == ["a", "b"] and len(frame) == 5
+    assert frame["a"].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+    assert np.array_equal(np.stack(frame["b"].values), vector[:, 0])
+    assert np.array_equal(PI.pandas_frame2value(frame, "b"), vector[:, 0])
+    assert set(PI.pandas_frame2dict(frame)) == {"a", "b"}
+    # observe(DataFrame): rows are datapoints
+    mu = api.NormalVariable(0., 1., "mu")
+    a = api.NormalVariable(mu, 1., "a")
+    model = api.ProbabilisticModel([a])
+    model.observe(frame[["a"]])
+    assert a.is_observed and a._observed_value.shape[:2] == (1, 5)          # [sample axis, datapoints, ...] (utilities.py:226-232)
+    assert np.allclose(a._observed_value.reshape(-1), scalar.reshape(-1))
+    a.unobserve()
+    a.observe(pd.DataFrame({"a": [1.5, 2.5]}))
+    assert a._observed_value.shape[:2] == (1, 2)
+    model.set_posterior_model(api.ProbabilisticModel([api.NormalVariable(0., 1., "mu", learnable=True)]))
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    assert program.obs.size == 2
