@@ -157,6 +157,20 @@ def cpu_baseline(builder, kwargs, n_samples, optimizer, opt_kwargs, dense=False,
                 iters_per_sec=iters / dt, number_samples=n_cpu)
 
 
+def recorded_reference_timings(workload, n_samples, optimizer):
+    """The REAL reference's iteration rate on this workload, recorded once in the build container by
+    oracle/time_reference.py (the reference cannot travel to the GPU box) and reported with the hardware it was taken
+    on: a fixture, not a live measurement -- the live CPU number is the oracle port above."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "reference_cpu_timings.json")
+    if workload != "cfg1" or n_samples != 300 or optimizer != "SGD" or not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    best = max(rec["runs"], key=lambda r: r["iters_per_sec"])
+    return dict(kind="reference", live=False, value=best["iters_per_sec"], unit="it/s", cores=best["threads"],
+                hardware=rec["hardware"], torch=rec["torch"], runs=rec["runs"], sample="%d iterations, %s"
+                % (best["iterations_timed"], rec["workload"]))
+
+
 def self_launch(n_gpus, argv=None, port=None):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a child (one rank per GPU, rendezvous on 127.0.0.1) and pass its output and exit code on."""
@@ -187,6 +201,9 @@ def main():
                     help="untimed iterations of the timed path after the W warm-up steps, to let the clocks ramp (0: off)")
     ap.add_argument("--estimator", default="pathwise", choices=["pathwise", "blackbox", "taylor1"],
                     help="gradient estimator (BASELINE config 5 names both Pathwise and BlackBox)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU): every rank contributes its rank to one all-reduce and rank 0 "
+                         "prints what arrived; exercises the launcher path of --gpus N on a CPU-only box")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -201,6 +218,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        seen = torch.tensor([float(rank), 1.0])
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps(dict(launch_check=True, world=world, rank_sum=seen[0].item(), ranks=seen[1].item(),
+                                  local_rank=local_rank)))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -371,6 +398,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_vae(kwargs, optimizer, opt_kwargs) if amort else \
                 cpu_baseline(builder, kwargs, n_per_gpu, optimizer, opt_kwargs, dense=dense)
+            recorded = recorded_reference_timings(args.workload, n_per_gpu, optimizer)
+            if recorded is not None:
+                line["cpu_baseline"]["reference"] = recorded
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -173,3 +173,24 @@ def test_two_rank_row_shards_of_the_amortised_path():
     scale = max(np.abs(v).max() for v in ref_grads.values())
     for name, gr in ref_grads.items():
         assert np.abs(grads[name].reshape(gr.shape) - gr).max() <= 1e-5 * scale, name
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver may start it): the process becomes the
+    launcher, starts one rank per GPU through torch.distributed.run on 127.0.0.1 and relays their output.  Here the
+    ranks only rendezvous (--launch-check, gloo): the GPU step behind the same entry is covered by the -m gpu suite."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 alone reports
+    assert lines[0]["world"] == 2 and lines[0]["ranks"] == 2.0 and lines[0]["rank_sum"] == 1.0
+    # a mismatch between --gpus and the launcher's world size is refused before anything else happens
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)

@@ -316,6 +316,48 @@ def test_sharded_step_sequence_equals_the_fused_single_gpu_step(optimizer, kw):
 
 
 @pytest.mark.gpu
+def test_dense_path_at_baseline_config4_size():
+    """BASELINE config 4 at FULL size (784 -> 10, dataset 60000, minibatch 512, number_samples 1024), where the oracle
+    would take minutes: the size-independent properties instead -- (1) call-to-call bit equality of the whole output
+    block, (2) the un-normalised sums of two disjoint sample shards (the multi-GPU split, 384 + 640 so that the shards
+    are not tile-symmetric) add up to the sums of the union on the same Philox stream and the same device-drawn
+    minibatch, (3) the minibatch is 512 distinct rows of the 60000, (4) the per-sample values average to the loss."""
+    import ctypes as C
+    from brancher_amd import native
+    api = W.native_api()
+    c = engine.compile_model(W.build_logistic_regression(api, dataset_size=60000, batch_size=512, n_features=784,
+                                                         n_classes=10), None, "pathwise")
+    n = 1024
+    res = c.evaluate(n, seed=21, offset=5, want_indices=True, want_fvalues=True)
+    torch.cuda.synchronize()
+    first = c.out.cpu().numpy().copy()
+    idx = res["indices"].cpu().numpy()
+    assert len(set(idx.tolist())) == 512 and idx.min() >= 0 and idx.max() < 60000
+    loss = float(res["loss"].item())
+    assert np.isfinite(first).all() and float(res["finite"].item()) == 1.0
+    f = res["f"].cpu().numpy().astype(np.float64)
+    assert abs(-f.mean() - loss) <= 2e-6 * abs(loss)
+    for _ in range(2):
+        c.evaluate(n, seed=21, offset=5, want_fvalues=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(c.out.cpu().numpy(), first)
+    # shards: raw sums before the all-reduce / finalize
+    acc = np.zeros_like(first, dtype=np.float64)
+    for base, n_local in ((0, 384), (384, 640)):
+        args = c._args(n_local, n, base, None, None, 21, 5)
+        native.check(c.lib.bsvi_dense_fwd_bwd(c.handle, C.byref(args)))
+        torch.cuda.synchronize()
+        acc += c.out.cpu().numpy().astype(np.float64)
+    args = c._args(n, n, 0, None, None, 21, 5)
+    native.check(c.lib.bsvi_dense_fwd_bwd(c.handle, C.byref(args)))
+    torch.cuda.synchronize()
+    union = c.out.cpu().numpy().astype(np.float64)
+    assert abs(acc[0] - union[0]) <= 2e-6 * abs(union[0])
+    g_scale = np.abs(union[4:]).max()
+    assert np.abs(acc[4:] - union[4:]).max() <= 2e-5 * g_scale
+
+
+@pytest.mark.gpu
 def test_dense_sharded_step_sequence_equals_the_fused_step():
     api = W.native_api()
     kw = dict(dataset_size=256, batch_size=64, n_features=64, n_classes=10, q_scale=0.05)
