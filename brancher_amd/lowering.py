@@ -224,6 +224,7 @@ class _Lowering:
         self.n_derived = 0
         self.temp_base = 0
         self.max_temps = 0
+        self.view_rank, self.view_memo, self.elem_memo, self.view_terms = {}, {}, {}, 0
 
     # ---------------------------------------------------------------- IR construction
     def mk(self, op, args=(), attr=None, shape=None):
@@ -265,16 +266,24 @@ class _Lowering:
             return self.mk("imm", (), float(np.asarray(v).reshape(-1)[0]) if isinstance(v, np.ndarray) else float(v))
         if e.op in sym.BINARY_OPS:
             a, b = self.from_expr(e.args[0], ctx), self.from_expr(e.args[1], ctx)
+            self.check_ranks((a, b), e.op)
             return self.mk(e.op, (a, b))
+        if e.op == "getitem":
+            if isinstance(e.attr, str):
+                raise LoweringError("named outputs (%r) exist for network links only (amortised path)" % (e.attr,))
+            return self.view_index(self.from_expr(e.args[0], ctx), e.attr)
         if e.op == "call":
             fn, kwargs = e.attr
             if not isinstance(fn, str):
                 raise LoweringError("user callables / nn.Modules inside links are not lowered to the fused "
                                     "kernel yet: %r" % (fn,))
+            if fn in ("sum", "transpose") and e.args:
+                return self.view_call(fn, self.from_expr(e.args[0], ctx), list(e.args[1:]), kwargs)
             if kwargs:
                 raise LoweringError("keyword arguments of BF.%s are not supported by the fused kernel" % fn)
             args = [self.from_expr(a, ctx) if isinstance(a, sym.Expr) else self.mk("imm", (), float(a))
                     for a in e.args]
+            self.check_ranks(args, "BF." + fn)
             if fn in UNARY_CALLS and len(args) == 1:
                 return self.mk("call:" + fn, (args[0],))
             if fn in ("delta",) and len(args) == 2:
@@ -283,6 +292,175 @@ class _Lowering:
                 return self.mk({"div": "truediv", "true_divide": "truediv"}.get(fn, fn), tuple(args))
             raise LoweringError("BF.%s is not in the fused kernel's op set" % fn)
         raise LoweringError("link expression node %r is not supported by the fused kernel" % (e.op,))
+
+    # ---------------------------------------------------------------- axis views: sum / transpose / [...]
+    # Inside a link the reference lays a value out [samples x datapoints, d1, d2] (`variables.py:436-449`,
+    # `utilities.py:179-186`) and hands it to torch.sum / torch.transpose (`functions.py:50-62`) or indexes it behind the
+    # first axis (`variables.py:279-289`): axis 1 / 2 of the link tensor are the canonical element axes d1 / d2 here, and
+    # the result is viewed back as [samples, datapoints, ...].  The fused kernel walks an element loop in which every operand
+    # is fixed or contiguous, so these are not instructions: a view node stays symbolic in the IR and is resolved PER OUTPUT
+    # ELEMENT into scalar expressions over single elements of the leaves (`element_of`); a node whose parameters contain
+    # views is emitted as one scalar term per element (`split_elements`).  A reduction over K elements is K-1 adds of the
+    # unrolled element expressions: meant for short vectors (a linear predictor over a handful of weights) — K x E beyond
+    # kMaxViewTerms is refused (the dense path exists for real matrix products).
+    kMaxViewTerms = 4096
+
+    @staticmethod
+    def static_int(x, what):
+        if isinstance(x, sym.Expr):
+            if x.op != "const":
+                raise LoweringError("%s must be a constant" % what)
+            x = x.attr
+        a = np.asarray(x).reshape(-1)
+        if a.size != 1 or float(a[0]) != int(a[0]):
+            raise LoweringError("%s must be an integer constant" % what)
+        return int(a[0])
+
+    def rank_of(self, node):
+        """rank of the link tensor a node stands for: 3 ([rows, d1, d2]) unless an integer index or a sum without
+        keepdim dropped an axis"""
+        return self.view_rank.get(node.key, 3)
+
+    def check_ranks(self, args, what):
+        """torch aligns TRAILING axes: [rows, d] op [rows, d1, d2] would pair the row axis with d1 (the reference then
+        silently mixes Monte-Carlo samples).  Refused instead of reproduced."""
+        ranks = {self.rank_of(a) for a in args if a.op != "imm"}
+        if len(ranks) > 1:
+            raise LoweringError("%s combines link values of different rank (an integer index or a sum without keepdim "
+                                "dropped an axis on one side): torch would broadcast the sample axis against an element "
+                                "axis.  Use keepdim=True / a slice" % what)
+
+    def view_node(self, op, arg, attr, shape, rank):
+        node = self.mk(op, (arg,), attr, shape)
+        if rank != 3:
+            self.view_rank[node.key] = rank
+        return node
+
+    def view_call(self, fn, arg, rest, kwargs):
+        kwargs = dict(kwargs)
+        rank = self.rank_of(arg)
+        B, D1, D2 = arg.shape
+
+        def axis_of(x, what):
+            d = self.static_int(x, what)
+            d = d + rank if d < 0 else d
+            if not 1 <= d < rank:
+                raise LoweringError("%s=%d: axis 0 of a link value is the (sample, datapoint) axis and cannot be reduced or "
+                                    "moved; element axes are 1..%d" % (what, d, rank - 1))
+            return d
+
+        if fn == "sum":
+            dim = kwargs.pop("dim", kwargs.pop("axis", rest[0] if rest else None))
+            keep = kwargs.pop("keepdim", kwargs.pop("keepdims", rest[1] if len(rest) > 1 else False))
+            if dim is None or kwargs:
+                raise LoweringError("BF.sum needs an explicit dim (and only dim / keepdim): a full reduction would sum over "
+                                    "Monte-Carlo samples")
+            d, keep = axis_of(dim, "BF.sum dim"), bool(self.static_int(keep, "BF.sum keepdim"))
+            if d == 1:
+                shape = (B, 1, D2) if keep else (B, D2, 1)
+            else:
+                shape = (B, D1, 1)
+            return self.view_node("vsum", arg, (d, keep), shape, rank if keep else rank - 1)
+        d0 = axis_of(kwargs.pop("dim0", rest[0] if rest else None), "BF.transpose dim0")
+        d1 = axis_of(kwargs.pop("dim1", rest[1] if len(rest) > 1 else None), "BF.transpose dim1")
+        if kwargs:
+            raise LoweringError("BF.transpose takes dim0 and dim1")
+        if d0 == d1:
+            return arg
+        return self.view_node("vperm", arg, None, (B, D2, D1), rank)
+
+    def view_index(self, arg, key):
+        """`x[key]`: key = (whole sample axis, k1[, k2]) with integers (the axis is dropped) or plain slices"""
+        if not isinstance(key, tuple) or not key or key[0] != slice(None, None, None) or len(key) > 3:
+            raise LoweringError("unsupported index %r of a link value" % (key,))
+        rank = self.rank_of(arg)
+        extents = list(arg.shape[1:rank])
+        if len(key) - 1 > len(extents):
+            raise LoweringError("too many indices %r for a link value with %d element axes" % (key[1:], len(extents)))
+        picks = []                                   # per element axis of the argument: ("int", i) | ("range", start, n)
+        for ax, n in enumerate(extents):
+            k = key[1 + ax] if 1 + ax < len(key) else slice(None, None, None)
+            if isinstance(k, slice):
+                if k.step not in (None, 1):
+                    raise LoweringError("strided slices of link values are not lowered")
+                start, stop, _ = k.indices(n)
+                picks.append(("range", start, max(stop - start, 0)))
+            else:
+                i = self.static_int(k, "index")
+                i = i + n if i < 0 else i
+                if not 0 <= i < n:
+                    raise IndexError("index %d is out of bounds for an element axis of extent %d" % (i, n))
+                picks.append(("int", i))
+        kept = [p[2] for p in picks if p[0] == "range"]
+        if any(n == 0 for n in kept):
+            raise LoweringError("empty slice of a link value")
+        shape = (arg.shape[0],) + tuple(kept) + (1,) * (2 - len(kept))
+        return self.view_node("vindex", arg, tuple(picks), shape, 1 + len(kept))
+
+    def has_view(self, node):
+        hit = self.view_memo.get(node.key)
+        if hit is None:
+            hit = node.op in ("vsum", "vperm", "vindex") or any(self.has_view(a) for a in node.args)
+            self.view_memo[node.key] = hit
+        return hit
+
+    def element_of(self, node, idx):
+        """scalar IR for element idx = (b, i, j) of `node` (axes of extent 1 broadcast)"""
+        idx = tuple(0 if node.shape[a] == 1 else idx[a] for a in range(3))
+        key = (node.key, idx)
+        hit = self.elem_memo.get(key)
+        if hit is not None:
+            return hit
+        b, i, j = idx
+        if node.op == "imm" or (node.shape == (1, 1, 1) and not self.has_view(node)):
+            out = node
+        elif node.op in ("z", "obs", "root", "carr") or (not self.has_view(node) and self.match_uniform(node) is not None):
+            out = self.mk("elem", (node,), (b * node.shape[1] + i) * node.shape[2] + j, (1, 1, 1))
+        elif node.op == "vsum":
+            arg, (d, keep) = node.args[0], node.attr
+            if d == 1:
+                terms = [self.element_of(arg, (b, k, j if keep else i)) for k in range(arg.shape[1])]
+            else:
+                terms = [self.element_of(arg, (b, i, k)) for k in range(arg.shape[2])]
+            self.view_terms += len(terms)
+            if self.view_terms > self.kMaxViewTerms:
+                raise LoweringError("BF.sum inside a link is unrolled per element: more than %d terms (use a matmul link, "
+                                    "which runs on the dense path)" % self.kMaxViewTerms)
+            out = terms[0]
+            for t in terms[1:]:
+                out = self.mk("add", (out, t))
+        elif node.op == "vperm":
+            out = self.element_of(node.args[0], (b, j, i))
+        elif node.op == "vindex":
+            src, free = [], [i, j]
+            for p in node.attr:
+                src.append(p[1] if p[0] == "int" else p[1] + free.pop(0))
+            src += [0] * (2 - len(src))
+            out = self.element_of(node.args[0], (b, src[0], src[1]))
+        elif node.op == "elem":
+            out = node
+        else:
+            out = self.mk(node.op, tuple(self.element_of(a, idx) for a in node.args), node.attr)
+        self.elem_memo[key] = out
+        return out
+
+    def split_elements(self, var, value, params, shape):
+        """a model term whose value / parameters contain views -> one scalar term per element (like `mvn_terms`)"""
+        nodes = ([value] if value is not None else []) + list(params)
+        if not any(self.has_view(n) for n in nodes):
+            return None
+
+        class _Element:                            # what the emission reads of a model variable
+            def __init__(self, i):
+                self.is_observed, self.distribution, self.b_axis = var.is_observed, var.distribution, shape[0]
+                self.name = var.name if i is None else "%s[%s]" % (var.name, ",".join(map(str, i)))
+
+        out = []
+        for idx in np.ndindex(*shape):
+            single = shape == (1, 1, 1)
+            out.append((_Element(None if single else idx), None if value is None else self.element_of(value, idx),
+                        [self.element_of(p, idx) for p in params], (1, 1, 1)))
+        return out
 
     # ---------------------------------------------------------------- model contexts
     def q_value(self, var):
@@ -825,6 +1003,11 @@ class _Lowering:
                                         "(Normal: its scale; LogNormal / Laplace / Beta: every parameter) and be analytic"
                                         % v.name)
             shape = broadcast_shapes3(*[p.shape for p in params])
+            if any(self.has_view(p) for p in params):
+                if shape != (1, 1, 1):
+                    raise LoweringError("the parameters of the posterior variable %r use sum / transpose / [...] and are not "
+                                        "one value per sample: only scalar nodes of q take axis views" % v.name)
+                params = [self.element_of(p, (0, 0, 0)) for p in params]
             self.slots[v] = SlotInfo(v, self.n_slots, shape, v.distribution.kind)
             self.n_slots += self.slots[v].size
             q_nodes.append((v, params, shape))
@@ -842,6 +1025,10 @@ class _Lowering:
             value = self.p_value(v)
             params = self.node_params(v, self.p_value)
             shape = broadcast_shapes3(value.shape, *[p.shape for p in params])
+            elements = self.split_elements(v, value, params, shape)
+            if elements is not None:
+                p_nodes.extend(elements)
+                continue
             p_nodes.append((v, value, params, shape))
 
         # -- weights from the [N, B] mean rule
@@ -849,7 +1036,7 @@ class _Lowering:
         for v, params, shape in q_nodes:
             term_b.append(shape[0])
         for v, value, params, shape in p_nodes:
-            term_b.append(1 if v.is_observed else shape[0])
+            term_b.append(1 if v.is_observed else getattr(v, "b_axis", shape[0]))
         bmax = max(term_b) if term_b else 1
         for b in term_b:
             if b not in (1, bmax):
@@ -900,7 +1087,7 @@ class _Lowering:
             self.ensure_derived([value] + params)
             # a model log-prob term has a constant weight and nothing depends on its value: the
             # kernel finishes it (value and adjoints) in the forward sweep
-            w = 1.0 if v.is_observed else weight(shape[0])
+            w = 1.0 if v.is_observed else weight(getattr(v, "b_axis", shape[0]))
             self.for_each_record(shape, [value] + params, True,
                                  lambda: self.emit_node(v.distribution.kind, F_LOGP, params, value=value, w_lp=w))
 

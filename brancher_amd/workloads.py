@@ -271,6 +271,36 @@ def build_vector_latent(api, n_obs=9, dim=4, seed=0):
     return model
 
 
+def build_linear_predictor(api, n_obs=5, dim=4, seed=0):
+    """Axis reductions and static indexing inside links (`functions.py:50-62` wraps torch.sum / torch.transpose;
+    `variables.py:279-289,1037-1053` the `[...]` of variables and links).  Inside a link a value is laid out
+    [samples x datapoints, d1, d2] (`variables.py:436-449`), so ``dim=1`` is the first element axis.  A weight vector w in
+    R^dim, a regression on n_obs feature rows through ``BF.sum(w * features, dim=1, keepdim=True)``, and a second
+    observation built from one element of w (a slice keeps the axis, so the operands of the sum keep one rank) and from a
+    row-vector product after ``BF.transpose``, a third from an integer index."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    features = rng.normal(0., 1., size=(n_obs, dim, 1)).astype(np.float32)
+    targets = rng.normal(0.3, 1.2, size=(n_obs, 1, 1)).astype(np.float32)
+    probe = rng.normal(-0.2, 0.5, size=(3, 1, 1)).astype(np.float32)
+    row = np.linspace(0.5, -1.0, dim).reshape(1, dim).astype(np.float32)
+    w = api.NormalVariable(np.zeros((dim, 1)), np.ones((dim, 1)), "w")
+    b = api.NormalVariable(0., 2., "b")
+    feats = api.DeterministicVariable(features, "features", is_observed=True)     # [datapoints, dim, 1]
+    rowv = api.RootVariable(row, "row")                                            # [1, dim]: a row vector
+    y = api.NormalVariable(BF.sum(w * feats, dim=1, keepdim=True) + b, 0.6, "y")
+    t = api.NormalVariable(w[(slice(2, 3),)] * 2. + BF.sum(BF.transpose(w, 1, 2) * rowv, dim=2, keepdim=True), 0.7, "t")
+    u = api.NormalVariable(w[1], 0.9, "u")              # an integer index drops the axis: [rows, 1]
+    model = api.ProbabilisticModel([y, t, u])
+    y.observe(targets)
+    t.observe(probe)
+    u.observe(probe[:2] + 0.4)
+    Qw = api.NormalVariable(0.1 * np.ones((dim, 1)), 0.8 * np.ones((dim, 1)), "w", learnable=True)
+    Qb = api.NormalVariable(0.2, 1.1, "b", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qw, Qb]))
+    return model
+
+
 def build_learnable_model(api, n_obs=15, seed=0):
     """Learnable parameters in the JOINT model as well as in the posterior (type-II maximum likelihood): the
     likelihood's scale and the prior's location are `learnable=True` roots of p.  `perform_inference` then runs two

@@ -172,3 +172,41 @@ def test_pandas_wire_format_round_trip():
     model.set_posterior_model(api.ProbabilisticModel([api.NormalVariable(0., 1., "mu", learnable=True)]))
     program = lowering.lower(model, model.posterior_model, "pathwise")
     assert program.obs.size == 2
+
+
+def test_axis_views_resolve_to_element_expressions():
+    """BF.sum / BF.transpose / x[...] inside links (`functions.py:50-62`, `variables.py:279-289`): resolved per output
+    element at lowering time — the program holds no new instruction, the y likelihood over 5 datapoints becomes 5 scalar
+    terms whose locations are 4-term sums over single elements of w."""
+    api = W.native_api()
+    model = W.build_linear_predictor(api, n_obs=5, dim=4)
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    s = program.summary()
+    assert s["n_latent"] == 5                                  # w (4 elements) + b
+    # q: w, b; p: y over 5 datapoints, t over 3, u over 2 (one scalar term each), w, b; + one record per shared value
+    assert s["n_records"] == 2 + (5 + 3 + 2) + 2 + s["n_derived"]
+    assert set(lowering.OP) == {"NOP", "NAFF", "NODE", "BIN", "UN", "REC_BEGIN", "REC_END"}
+
+
+def test_axis_views_refuse_what_the_reference_would_mis_broadcast():
+    api = W.native_api()
+    BF = api.BF
+    w = api.NormalVariable(np.zeros((4, 1)), np.ones((4, 1)), "w")
+
+    def lower_with(loc):
+        y = api.NormalVariable(loc, 1., "y")
+        m = api.ProbabilisticModel([y])
+        y.observe(np.zeros((2, 1, 1), dtype=np.float32))
+        m.set_posterior_model(api.ProbabilisticModel([api.NormalVariable(np.zeros((4, 1)), np.ones((4, 1)), "w", learnable=True)]))
+        return lowering.lower(m, m.posterior_model, "pathwise")
+
+    with pytest.raises(lowering.LoweringError, match="different rank"):
+        lower_with(w[(2, 0)] + BF.sum(w, dim=1, keepdim=True))       # [rows] + [rows, 1, 1]
+    with pytest.raises(lowering.LoweringError, match="explicit dim"):
+        lower_with(BF.sum(w))                                          # would sum over Monte-Carlo samples
+    with pytest.raises(lowering.LoweringError, match="axis 0"):
+        lower_with(BF.sum(w, dim=0, keepdim=True))
+    with pytest.raises(IndexError):
+        lower_with(w[7])
+    assert lower_with(BF.sum(BF.transpose(w, 1, 2), dim=2, keepdim=True)).summary()["n_latent"] == 4
+    assert lower_with(w[(slice(1, 3),)][1]).summary()["n_latent"] == 4   # element 2 of w through a slice then an index
