@@ -933,6 +933,52 @@ class _Lowering:
             terms.append((_Term(v, i), u, [self.mk("imm", (), 0.0), self.mk("imm", (), float(L[i, i]))], (1, 1, 1)))
         return terms
 
+    # ---------------------------------------------------------------- categorical likelihood terms
+    def categorical_terms(self, v):
+        """An OBSERVED CategoricalVariable of the joint model whose logits are an ordinary (elementwise) link
+        (`standard_variables.py:280-299`, `distributions.py:275-311`; the dense path serves `logits = matmul(W, x)`).
+        For the label k of a datapoint,  log softmax(l)_k = -log(1 + sum_{c != k} exp(l_c - l_k)) = log sigmoid(-m)  with
+        m = log sum_{c != k} exp(l_c - l_k): the log-probability of the outcome 1 under Bernoulli(logits = -m).  One
+        Bernoulli record per datapoint, its logits a scalar expression over single elements of the class axis
+        (`element_of`); two classes reduce to the Bernoulli likelihood itself.  Labels are data: fixed at lowering time.
+        (A LATENT Categorical cannot be pinned: the reference's own `calculate_log_probability` fails on its one-hot
+        samples under the installed torch.)"""
+        if not (v.is_observed and v.has_observed_value):
+            raise LoweringError("Categorical variable %r: only observed labels are lowered on the scalar path" % v.name)
+        links = v.link.expressions()
+        if "logits" in links:
+            logits = self.from_expr(links["logits"].expr, self.p_value)
+        else:
+            logits = self.mk("call:log", (self.from_expr(links["probs"].expr, self.p_value),))
+        B, C, inner = logits.shape
+        if inner != 1:
+            raise LoweringError("the class axis of %r must be the first element axis ([classes, 1])" % v.name)
+        labels = np.asarray(v._observed_value, dtype=np.float64)
+        labels = labels.reshape(labels.shape[1], -1)[:, 0]                  # [1, datapoints, ...] -> one label per datapoint
+        if np.any(labels != np.round(labels)) or labels.min() < 0 or labels.max() >= C:
+            raise LoweringError("labels of %r must be class indices in [0, %d)" % (v.name, C))
+        if B not in (1, len(labels)):
+            raise LoweringError("%r: %d datapoints of logits against %d labels" % (v.name, B, len(labels)))
+        one = self.mk("imm", (), 1.0)
+
+        class _Label:
+            def __init__(self, i):
+                self.is_observed, self.name, self.distribution = True, "%s[%d]" % (v.name, i), D.BernulliDistribution()
+
+        terms = []
+        for b, k in enumerate(labels.astype(int)):
+            own = self.element_of(logits, (b, int(k), 0))
+            total = None
+            for c in range(C):
+                if c == k:
+                    continue
+                e = self.mk("call:exp", (self.mk("sub", (self.element_of(logits, (b, c, 0)), own)),))
+                total = e if total is None else self.mk("add", (total, e))
+            if total is None:
+                continue                                                     # one class: log-probability 0
+            terms.append((_Label(b), one, [self.mk("call:neg", (self.mk("call:log", (total,)),))], (1, 1, 1)))
+        return terms
+
     # ---------------------------------------------------------------- driver
     def run(self):
         joint, posterior = self.joint, self.posterior
@@ -1019,6 +1065,9 @@ class _Lowering:
                 continue
             if v.distribution.kind == D.DIST_MVNORMAL:
                 p_nodes.extend(self.mvn_terms(v))
+                continue
+            if v.distribution.kind == D.DIST_CATEGORICAL:
+                p_nodes.extend(self.categorical_terms(v))
                 continue
             if v.distribution.kind not in supported:
                 raise LoweringError("distribution of %r is not supported by the fused kernel yet" % v.name)

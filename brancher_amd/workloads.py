@@ -301,6 +301,27 @@ def build_linear_predictor(api, n_obs=5, dim=4, seed=0):
     return model
 
 
+def build_softmax_classifier(api, n_obs=6, n_classes=3, seed=0):
+    """An observed CategoricalVariable whose logits are an elementwise link (no matmul): per-class slopes and offsets
+    (two vector latents) of one scalar regressor, labels observed (`standard_variables.py:280-299`,
+    `distributions.py:275-311`)."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    regressor = rng.normal(0., 1.2, size=(n_obs, 1, 1)).astype(np.float32)
+    labels = rng.randint(0, n_classes, size=(n_obs, 1)).astype(np.float32)
+    x = api.DeterministicVariable(regressor, "regressor", is_observed=True)
+    slope = api.NormalVariable(np.zeros((n_classes, 1)), np.ones((n_classes, 1)), "slope")
+    offset = api.NormalVariable(np.zeros((n_classes, 1)), 2. * np.ones((n_classes, 1)), "offset")
+    k = api.CategoricalVariable(logits=slope * x + BF.tanh(offset), name="k")
+    model = api.ProbabilisticModel([k])
+    k.observe(labels)
+    Qslope = api.NormalVariable(0.1 * np.ones((n_classes, 1)), 0.7 * np.ones((n_classes, 1)), "slope", learnable=True)
+    Qoffset = api.NormalVariable(np.linspace(-0.3, 0.3, n_classes).reshape(n_classes, 1), 0.9 * np.ones((n_classes, 1)),
+                                 "offset", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qslope, Qoffset]))
+    return model
+
+
 def build_learnable_model(api, n_obs=15, seed=0):
     """Learnable parameters in the JOINT model as well as in the posterior (type-II maximum likelihood): the
     likelihood's scale and the prior's location are `learnable=True` roots of p.  `perform_inference` then runs two
