@@ -13,8 +13,11 @@
 //   amort_latent_fwd  eps (Philox or supplied), z, log p(z), H[q], log q per row
 //   gemm<NT>          decoder layers
 //   amort_lik         log p(x | z) per row and dlogits in place (one wave per row)
-//   per layer, last to first:  gemm<TN> dW += dY^T x (K = R split over workgroups, f32 atomics),
-//                              (db += 1^T dY in the same launch),  gemm<NN> dX = (dY W) * act'(x)
+//   per layer, last to first:  gemm<TN> partial dW = dY^T x per slice of K = R (one slice per workgroup, plain stores
+//                              into the workspace; partial db = 1^T dY in the same launch),
+//                              gemm<NN> dX = (dY W) * act'(x)
+//   reduce_partials   ONE launch at the end: every gradient element = the sum of its slices in slice order — the
+//                     gradients (and the loss sums) are bit-reproducible call to call, no float atomics anywhere
 //   layers with a side of width <= 8 (latent heads, first decoder layer) use memory-bound skinny_* kernels instead
 //   amort_latent_bwd  joins decoder dz with prior / entropy / score-function terms, loss sums
 // GEMMs: 128x128x16 workgroup tiles, four waves of 64x64, v_mfma_f32_32x32x2_f32, k-major LDS tiles (row stride 132
@@ -23,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <string>
@@ -39,6 +43,7 @@ using bsvi::u01;
 using bsvi::u32x4;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
@@ -65,7 +70,8 @@ struct GemmArgs {
     int k_chunk;           // TN: rows of K per workgroup (multiple of BK)
     int remap;             // XCD-aware workgroup order
     int tiles;             // TN: output tiles per k split
-    float* bias_grad;      // TN: db[m] += sum_k A[k][m], taken from the A tiles the n = 0 workgroups stream anyway
+    float* bias_grad;      // TN: partial db[split][m] = sum_k A[k][m], taken from the A tiles the n = 0 workgroups stream anyway
+    long part_stride;      // TN: floats between the partial outputs of consecutive k splits (C is the split-0 slice)
 };
 
 __device__ __forceinline__ float act_forward(int act, float v, float post_add) {
@@ -166,13 +172,15 @@ __device__ __forceinline__ void store_mc(float* tile, const Frag<W>& f) {
 #pragma unroll
     for (int i = 0; i < W / 64; ++i) {
         const int k = t / TPR + KR * i;
-        *reinterpret_cast<float4*>(&tile[k * LD + c]) = f.v[i];
+        // (built from the components: copying the float4 object itself through the cast makes the compiler keep the whole
+        //  fragment in scratch memory — a scratch store + load per step in the weight- and input-gradient kernels)
+        *reinterpret_cast<f32x4*>(&tile[k * LD + c]) = f32x4{f.v[i].x, f.v[i].y, f.v[i].z, f.v[i].w};
     }
 }
 
 // TBM x 128 workgroup tile (TBM = 128: waves 2x2 of 64x64; TBM = 64: waves 2x2 of 32x64 — twice the workgroups when
 // the tall operand alone does not fill the chip)
-template <int MODE, int TBM>
+template <int MODE, int TBM, int PF>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
     constexpr int LDA = TBM + 4, LDB = BN + 4, TM = TBM / 64;
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
@@ -182,12 +190,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
     const int n_blocks = gridDim.x;
     int bid = blockIdx.x;
     if (G.remap) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // XCD x gets one contiguous range of tiles
-    int k_begin = 0, k_end = G.K;
+    int k_begin = 0, k_end = G.K, split = 0;
     if (MODE == MODE_TN) {
         // the remapped index runs over (k split, tile) with the tile fastest: an XCD owns whole k splits, so the rows
         // of both operands in a split are fetched into ONE L2 (launch order would spread a split's tiles over all
         // eight and every XCD would pull every row through the fabric)
-        const int split = bid / G.tiles;
+        split = bid / G.tiles;
         bid -= split * G.tiles;
         k_begin = split * G.k_chunk;
         k_end = min(G.K, k_begin + G.k_chunk);
@@ -298,25 +306,28 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
                 fb = load_b(k_begin + step * BK);
             }
         };
-        // ONE register set, two LDS buffers, tiles two steps ahead: tile s+1 is written to LDS right AFTER the barrier
-        // that frees its buffer — a whole step before it is read, so the ds_write -> barrier -> ds_read chain is off the
-        // critical path — and the loads of tile s+2 are re-issued into the same registers at once; they stay in flight
-        // across the step's MFMAs and its barrier (plain global loads survive __syncthreads()).
-        Frag<TBM> fa;
-        Frag<BN> fb;
-        stage(0, fa, fb);
-        if (col_sums) add_cols(fa);
-        store_a(As[0], fa);
-        store_b(Bs[0], fb);
-        if (n_steps > 1) stage(1, fa, fb);
+        // PF register sets, two LDS buffers: tile s+1 is written to LDS right AFTER the barrier that frees its buffer — a
+        // whole step before it is read, so the ds_write -> barrier -> ds_read chain is off the critical path — and the
+        // loads of tile s+1+PF are re-issued into the same registers at once; they stay in flight across PF steps' MFMAs
+        // and barriers (plain global loads survive __syncthreads(); the compiler counts vmcnt so that a store waits for
+        // its own set only).  The loop is unrolled PF times so that the sets are named registers.
+        Frag<TBM> fa[PF];
+        Frag<BN> fb[PF];
+        stage(0, fa[0], fb[0]);
+        if (col_sums) add_cols(fa[0]);
+        store_a(As[0], fa[0]);
+        store_b(Bs[0], fb[0]);
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (1 + p < n_steps) stage(1 + p, fa[p], fb[p]);      // set p holds step 1 + p (+ multiples of PF later)
         __syncthreads();
-        for (int step = 0; step < n_steps; ++step) {
+        auto one_step = [&](int step, Frag<TBM>& ra, Frag<BN>& rb) {
             const int cur = step & 1;
             if (step + 1 < n_steps) {
-                if (col_sums) add_cols(fa);
-                store_a(As[cur ^ 1], fa);
-                store_b(Bs[cur ^ 1], fb);
-                if (step + 2 < n_steps) stage(step + 2, fa, fb);
+                if (col_sums) add_cols(ra);
+                store_a(As[cur ^ 1], ra);
+                store_b(Bs[cur ^ 1], rb);
+                if (step + 1 + PF < n_steps) stage(step + 1 + PF, ra, rb);
             }
             // all operand fragments of a batch first (immediate-offset ds_reads off one base per tile), then the
             // MFMAs back to back: the matrix pipe is not stalled on an LDS round trip every second instruction
@@ -341,6 +352,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
             }
             __syncthreads();
+        };
+        for (int step = 0; step < n_steps; step += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p)
+                if (step + p < n_steps) one_step(step + p, fa[p], fb[p]);   // step s reads set (s mod PF): holds step s + 1
         }
     };
     if (fast) main_loop(std::true_type{}); else main_loop(std::false_type{});
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
             float s = 0.0f;
 #pragma unroll
             for (int q = 0; q < KR; ++q) s += red[q * LDA + threadIdx.x];
-            unsafeAtomicAdd(&G.bias_grad[m0 + threadIdx.x], s);
+            G.bias_grad[(long)split * G.M + m0 + threadIdx.x] = s;     // every (split, m) has exactly one writer
         }
     }
 
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
                     if (G.Y) v *= act_derivative(ACT_OF(G, n), G.Y[(long)m * G.ldy + n], ADD_OF(G, n));
                     *c = G.accumulate ? *c + v : v;
                 } else {
-                    unsafeAtomicAdd(c, v);
+                    c[(long)split * G.part_stride] = v;                    // partial of this k split, summed by reduce_partials
                 }
             }
         }
@@ -403,24 +419,26 @@ __device__ __forceinline__ float skinny_epilogue(const GemmArgs& G, int mode, fl
 
 // K <= 8:  C[r][n] = epilogue(sum_k A[r][k] * B(k, n)),  B(k, n) = B[k * sbk + n * sbn].  One thread per output.
 __global__ __launch_bounds__(256) void skinny_k_kernel(const GemmArgs G, int sbk, int sbn, int mode) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)G.M * G.N) return;
-    const long r = i / G.N;
-    const int n = (int)(i - r * G.N);
-    const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
+    // (32-bit index arithmetic: launch_gemm routes here only when M * N fits; a 64-bit divide costs more than the K <= 8 FMAs)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)G.M * (uint32_t)G.N) return;
+    const uint32_t r = i / (uint32_t)G.N;
+    const int n = (int)(i - r * (uint32_t)G.N);
+    const float* a = G.A + (G.rows ? (long)G.rows[r] : (long)r) * G.lda;
     float acc = 0.0f;
     for (int k = 0; k < G.K; ++k) acc += a[k] * G.B[(long)k * sbk + (long)n * sbn];
-    G.C[r * G.ldc + n] = skinny_epilogue(G, mode, acc, r, n);
+    G.C[(long)r * G.ldc + n] = skinny_epilogue(G, mode, acc, (long)r, n);
 }
 
 // the same for 16-byte-aligned operands and N % 4 == 0: four adjacent outputs per thread, vector loads of B (when it
 // is stored [K][N]), of the bias / of Y / of C, and one 16-byte store
 __global__ __launch_bounds__(256) void skinny_k4_kernel(const GemmArgs G, int sbk, int sbn, int mode) {
-    const int quads = G.N >> 2;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)G.M * quads) return;
-    const long r = i / quads;
-    const int n = (int)(i - r * quads) * 4;
+    const uint32_t quads = (uint32_t)G.N >> 2;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)G.M * quads) return;
+    const uint32_t r32 = i / quads;
+    const int n = (int)(i - r32 * quads) * 4;
+    const long r = (long)r32;
     const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < G.K; ++k) {
@@ -571,19 +589,110 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const GemmArgs G, int na
                     nsum[j] += nv;
                 }
         }
+        float* part = G.C + (long)blockIdx.y * G.part_stride;            // partial of this chunk of rows
 #pragma unroll
         for (int j = 0; j < SKINNY; ++j)
-            if (j < narrow) unsafeAtomicAdd(narrow_is_a ? &G.C[(long)j * G.ldc + w] : &G.C[(long)w * G.ldc + j], acc[j]);
+            if (j < narrow) part[narrow_is_a ? (long)j * G.ldc + w : (long)w * G.ldc + j] = acc[j];
         if (G.bias_grad) {
+            float* bpart = G.bias_grad + (long)blockIdx.y * G.M;
             if (!narrow_is_a) {
-                unsafeAtomicAdd(&G.bias_grad[w], wsum);
+                bpart[w] = wsum;
             } else if (w == 0) {
 #pragma unroll
                 for (int j = 0; j < SKINNY; ++j)
-                    if (j < narrow) unsafeAtomicAdd(&G.bias_grad[j], nsum[j]);
+                    if (j < narrow) bpart[j] = nsum[j];
             }
         }
     }
+}
+
+// ---- fixed-order sums of the partial results ------------------------------------------------------------------------
+// dst(m, n) = [dst(m, n) +] sum_s src[s * stride + m * cols + n], s ascending: the second stage of every reduction over
+// rows (weight / bias gradients: one partial per k split; loss sums: one partial per workgroup of amort_latent_bwd).
+constexpr int kMaxSegments = 40;
+struct Segment {
+    float* dst;
+    const float* src;
+    uint32_t rows, cols, ldd;     // dst is [rows][ldd], the partials are [splits][rows][cols]
+    uint32_t splits;
+    uint32_t first_block;         // of this segment in the launch
+    uint32_t add;                 // keep what dst holds
+    uint32_t vec;                 // 16-byte accesses (set by segment_blocks)
+    uint32_t wide;                // more than 64 slices: a workgroup's four waves share them (set by segment_blocks)
+};
+struct SegmentTable {
+    Segment seg[kMaxSegments];
+    int n;
+};
+
+// eight partials in flight per thread; the association is fixed: slice s goes to accumulator s mod 8, the accumulators
+// are added pairwise at the end
+template <typename V>
+__device__ __forceinline__ V sum_slices(const V* p, size_t stride, uint32_t splits) {
+    V a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = V(0.0f);
+    uint32_t s = 0;
+    for (; s + 8 <= splits; s += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p[(size_t)(s + j) * stride];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (s + j < splits) a[j] += p[(size_t)(s + j) * stride];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+__global__ __launch_bounds__(256) void reduce_partials(const SegmentTable T) {
+    int k = 0;
+    while (k + 1 < T.n && blockIdx.x >= T.seg[k + 1].first_block) ++k;
+    const Segment S = T.seg[k];
+    const uint32_t total = S.rows * S.cols;
+    uint32_t i = (blockIdx.x - S.first_block) * 256u + threadIdx.x;
+    if (S.wide) {
+        // many slices, few outputs (the narrow layers: one slice per 64 rows): 64 outputs per workgroup, its four waves
+        // take the slices w, w + 4, ... and are added in wave order through LDS
+        __shared__ float quarter[4][64];
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        i = (blockIdx.x - S.first_block) * 64u + lane;
+        float v = 0.0f;
+        if (i < total) {
+            const uint32_t mine = (S.splits + 3u - wave) / 4u;                       // slices wave, wave + 4, ...
+            v = sum_slices(S.src + (size_t)wave * total + i, (size_t)4 * total, mine);
+        }
+        quarter[wave][lane] = v;
+        __syncthreads();
+        if (wave == 0 && i < total) {
+            v = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
+            const uint32_t m = i / S.cols, n = i - m * S.cols;
+            float* d = S.dst + (size_t)m * S.ldd + n;
+            *d = S.add ? *d + v : v;
+        }
+        return;
+    }
+    if (S.vec) {                       // four adjacent outputs per thread, 16-byte loads and stores
+        i *= 4u;
+        if (i >= total) return;
+        const f32x4 v = sum_slices(reinterpret_cast<const f32x4*>(S.src + i), total / 4u, S.splits);
+        const uint32_t m = i / S.cols, n = i - m * S.cols;
+        f32x4* d = reinterpret_cast<f32x4*>(S.dst + (size_t)m * S.ldd + n);
+        *d = S.add ? *d + v : v;
+    } else {
+        if (i >= total) return;
+        const float v = sum_slices(S.src + i, (size_t)total, S.splits);
+        const uint32_t m = i / S.cols, n = i - m * S.cols;
+        float* d = S.dst + (size_t)m * S.ldd + n;
+        *d = S.add ? *d + v : v;
+    }
+}
+
+// blocks of reduce_partials a segment needs; decides whether it can use 16-byte accesses
+static uint32_t segment_blocks(Segment& S) {
+    const uint32_t total = S.rows * S.cols;
+    S.wide = S.splits > 64 ? 1u : 0u;
+    if (S.wide) { S.vec = 0; return (total + 63) / 64; }
+    S.vec = (S.cols % 4 == 0 && S.ldd % 4 == 0 && (uintptr_t)S.src % 16 == 0 && (uintptr_t)S.dst % 16 == 0 && total % 4 == 0) ? 1u : 0u;
+    return ((S.vec ? total / 4 : total) + 255) / 256;
 }
 
 // ---- row-wise pieces -------------------------------------------------------------------------------------------
@@ -610,6 +719,7 @@ struct RowParams {
     float* rowlq;            // [R] log q per row
     float* logits; int ld_logits;
     float* out;
+    float* sum_part;         // [workgroups of amort_latent_bwd][2]: partial sums of the estimator value / non-finite count
     float* fvalue_out; float* logq_out;
 };
 
@@ -686,12 +796,24 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
     const float* x = D.dataset + (long)D.idx[r] * D.P;
     float* l = D.logits + (long)r * D.ld_logits;
     float lp = 0.0f;
-    for (int j = lane; j < D.P; j += 64) {
-        const float lj = l[j], xj = x[j];
+    auto element = [&](float lj, float xj) {
+        // e in (0, 1]: log(1 + e) through the hardware log2 is good to ~1e-7 ABSOLUTE, which is what matters in a sum
+        // whose other term is max(l, 0); the reciprocal to 1 ulp
         const float e = __expf(-fabsf(lj));
-        lp += xj * lj - (fmaxf(lj, 0.0f) + log1pf(e));
-        const float sig = lj >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-        l[j] = xj - sig;
+        const float one_e = 1.0f + e, r = __builtin_amdgcn_rcpf(one_e);
+        lp += xj * lj - (fmaxf(lj, 0.0f) + __logf(one_e));
+        const float sig = lj >= 0.0f ? r : e * r;
+        return xj - sig;
+    };
+    if (((D.P | D.ld_logits) & 3) == 0) {          // 16-byte accesses: a wave covers 1 KiB of the row per pass
+        for (int q = lane; q < (D.P >> 2); q += 64) {
+            const float4 lv = *reinterpret_cast<const float4*>(l + 4 * q), xv = *reinterpret_cast<const float4*>(x + 4 * q);
+            float4 o;
+            o.x = element(lv.x, xv.x); o.y = element(lv.y, xv.y); o.z = element(lv.z, xv.z); o.w = element(lv.w, xv.w);
+            *reinterpret_cast<float4*>(l + 4 * q) = o;
+        }
+    } else {
+        for (int j = lane; j < D.P; j += 64) l[j] = element(l[j], x[j]);
     }
     lp = wave_sum64(lp);
     if (lane == 0) D.rowf[r] += lp;
@@ -721,19 +843,21 @@ __global__ __launch_bounds__(256) void amort_latent_bwd(const RowParams D) {
             D.dscale[(long)r * D.ld_scale + d] = gsd * act_derivative(D.act_scale, sd, D.add_scale);
         }
     }
+    // workgroup partial of the two sums (waves in order): reduce_partials adds the workgroups in order
+    __shared__ float red[2][4];
     value = wave_sum64(value);
     bad = wave_sum64(bad);
-    if ((threadIdx.x & 63) == 0) {
-        unsafeAtomicAdd(&D.out[0], value);
-        if (bad != 0.0f) unsafeAtomicAdd(&D.out[1], bad);
-    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = value; red[1][threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        D.sum_part[blockIdx.x * 2 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 // dst[r][c] = src[r][c] for c < n: moves caller-layout rows into / out of the padded value buffers
 __global__ void copy_rows(const float* src, int lds, float* dst, int ldd, long rows, int n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * n) return;
-    const long r = i / n;
+    const long r = rows * n < (1l << 32) ? (long)((uint32_t)i / (uint32_t)n) : i / n;
     const int c = (int)(i - r * n);
     dst[r * ldd + c] = src[r * lds + c];
 }
@@ -889,10 +1013,56 @@ extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
     delete a;
 }
 
+// How a weight-gradient product C[M][N] = A[K][M]^T B[K][N] (K = all rows) is cut along K: every slice writes its own
+// partial [M][N] (and partial column sums of A, [M]) and reduce_partials adds the slices in order.
+struct TnPlan {
+    bool skinny;
+    int tiles, splits, chunk;      // MFMA path: output tiles, grid splits (whole splits per XCD; padding ones exit), rows per split
+    int slices;                    // partials actually written
+};
+static TnPlan tn_plan(int M, int N, int K) {
+    TnPlan p{};
+    if (M <= SKINNY || N <= SKINNY) {
+        p.skinny = true;
+        p.chunk = 64;
+        p.slices = (K + p.chunk - 1) / p.chunk;
+        return p;
+    }
+    // about three workgroups per CU in flight, 64-row output tiles (less padding, half the splits of 128-row tiles);
+    // at most 768 workgroups = three per CU in ONE round (a 769th would make some CU run four)
+    p.tiles = ((M + 63) / 64) * ((N + BN - 1) / BN);
+    int splits = std::max(1, std::min((K + BK - 1) / BK, 768 / std::max(p.tiles, 1)));
+    p.chunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    p.slices = (K + p.chunk - 1) / p.chunk;
+    p.splits = (p.slices + 7) / 8 * 8;
+    return p;
+}
+static size_t align4(size_t n) { return (n + 3) / 4 * 4; }      // partial regions start on 16-byte boundaries
+static size_t tn_partial_floats(int M, int N, int K, bool bias) {
+    const TnPlan p = tn_plan(M, N, K);
+    return align4((size_t)p.slices * M * N) + (bias ? align4((size_t)p.slices * M) : 0);
+}
+
+// floats of the partial sums behind the per-row part of the workspace: one slice set per Linear layer (weights + bias)
+// and the workgroup partials of the loss sums
+static size_t partial_floats(const bsvi_amort* a, size_t R) {
+    size_t n = align4(2 * ((R + 255) / 256));
+    for (const Net* net : {&a->enc, &a->dec})
+        for (const auto& l : net->layers)
+            n += tn_partial_floats((int)l.n_out, (int)l.n_in, (int)R, l.bias_off != 0xFFFFFFFFu);
+    return n + 16;
+}
+
 extern "C" size_t bsvi_amort_workspace_bytes(const bsvi_amort* a, uint32_t n_samples_local) {
     if (!a) return 0;
     const size_t R = (size_t)n_samples_local * a->d.batch_size;
-    return (R * a->floats_per_row + 64) * sizeof(float);
+    return (R * a->floats_per_row + 64 + partial_floats(a, R)) * sizeof(float);
+}
+
+// steps of global loads kept in flight by the MFMA kernels, per operand layout (BSVI_GEMM_PF=<nt><nn><tn>, e.g. 112)
+static int prefetch_depth(int mode) {
+    static const std::string cfg = [] { const char* e = getenv("BSVI_GEMM_PF"); return std::string(e && strlen(e) == 3 ? e : "222"); }();
+    return cfg[mode] == '2' ? 2 : 1;
 }
 
 static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
@@ -904,7 +1074,7 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     if (mode == MODE_TN && (G.M <= SKINNY || G.N <= SKINNY)) {
         const int narrow_is_a = G.M <= G.N ? 1 : 0;
         const int wide = narrow_is_a ? G.N : G.M;
-        const int rows_per_block = 64;
+        const int rows_per_block = tn_plan(G.M, G.N, G.K).chunk;
         dim3 grid((wide + 255) / 256, (G.K + rows_per_block - 1) / rows_per_block);
         hipLaunchKernelGGL(skinny_tn_kernel, grid, dim3(256), 0, stream, G, narrow_is_a, rows_per_block);
         HIP_TRY(hipGetLastError());
@@ -919,7 +1089,7 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
             HIP_TRY(hipGetLastError());
             return BSVI_OK;
         }
-        if (G.K <= SKINNY) {
+        if (G.K <= SKINNY && (uint64_t)G.M * (uint64_t)G.N < (1ull << 32) - 256) {
             auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
             // (B stored [N][K], the forward layout, would need strided scalar loads per output: measured slower)
             const bool vec4 = sbn == 1 && (sbk & 3) == 0 && al16(G.B) && (G.N & 3) == 0 && (G.ldc & 3) == 0 && al16(G.C) &&
@@ -939,19 +1109,15 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     const int tiles_n = (G.N + BN - 1) / BN;
     int tiles = ((G.M + BM - 1) / BM) * tiles_n;
     if (mode == MODE_TN) {
-        // K = all rows: split it so that about three workgroups per CU are in flight.  64-row output tiles: twice the
-        // tiles, so half the splits — every split costs one float atomic per output element — and less padding
-        tiles = ((G.M + 63) / 64) * tiles_n;
-        // at most 768 workgroups = three per CU in ONE round: a 769th would make some CU run four (3.05 per CU on
-        // average is a 4-deep critical path)
-        int splits = std::max(1, std::min((G.K + BK - 1) / BK, 768 / tiles));
-        int chunk = ((G.K + splits - 1) / splits + BK - 1) / BK * BK;
-        splits = ((G.K + chunk - 1) / chunk + 7) / 8 * 8;             // whole splits per XCD; the padding ones exit
-        G.k_chunk = chunk;
+        const TnPlan plan = tn_plan(G.M, G.N, G.K);
+        tiles = plan.tiles;
+        const int splits = plan.splits;
+        G.k_chunk = plan.chunk;
         G.tiles = tiles;
         G.remap = 1;
         dim3 grid(tiles * splits, 1, 1);
-        hipLaunchKernelGGL((gemm_kernel<MODE_TN, 64>), grid, dim3(NTHREADS), 0, stream, G);
+        if (prefetch_depth(mode) == 2) hipLaunchKernelGGL((gemm_kernel<MODE_TN, 64, 2>), grid, dim3(NTHREADS), 0, stream, G);
+        else hipLaunchKernelGGL((gemm_kernel<MODE_TN, 64, 1>), grid, dim3(NTHREADS), 0, stream, G);
     } else {
         // 64-row tiles when 128-row tiles would leave most CUs with one or two workgroups
         static const int half_below = [] { const char* e = getenv("BSVI_GEMM_HALF_BELOW"); return e ? atoi(e) : 1536; }();
@@ -959,12 +1125,17 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
         if (half) tiles = ((G.M + 63) / 64) * tiles_n;
         G.remap = (tiles % 8 == 0) ? 1 : 0;
         dim3 grid(tiles, 1, 1);
+        const bool deep = prefetch_depth(mode) == 2;
         if (mode == MODE_NT) {
-            if (half) hipLaunchKernelGGL((gemm_kernel<MODE_NT, 64>), grid, dim3(NTHREADS), 0, stream, G);
-            else hipLaunchKernelGGL((gemm_kernel<MODE_NT, 128>), grid, dim3(NTHREADS), 0, stream, G);
+            if (half && deep) hipLaunchKernelGGL((gemm_kernel<MODE_NT, 64, 2>), grid, dim3(NTHREADS), 0, stream, G);
+            else if (half) hipLaunchKernelGGL((gemm_kernel<MODE_NT, 64, 1>), grid, dim3(NTHREADS), 0, stream, G);
+            else if (deep) hipLaunchKernelGGL((gemm_kernel<MODE_NT, 128, 2>), grid, dim3(NTHREADS), 0, stream, G);
+            else hipLaunchKernelGGL((gemm_kernel<MODE_NT, 128, 1>), grid, dim3(NTHREADS), 0, stream, G);
         } else {
-            if (half) hipLaunchKernelGGL((gemm_kernel<MODE_NN, 64>), grid, dim3(NTHREADS), 0, stream, G);
-            else hipLaunchKernelGGL((gemm_kernel<MODE_NN, 128>), grid, dim3(NTHREADS), 0, stream, G);
+            if (half && deep) hipLaunchKernelGGL((gemm_kernel<MODE_NN, 64, 2>), grid, dim3(NTHREADS), 0, stream, G);
+            else if (half) hipLaunchKernelGGL((gemm_kernel<MODE_NN, 64, 1>), grid, dim3(NTHREADS), 0, stream, G);
+            else if (deep) hipLaunchKernelGGL((gemm_kernel<MODE_NN, 128, 2>), grid, dim3(NTHREADS), 0, stream, G);
+            else hipLaunchKernelGGL((gemm_kernel<MODE_NN, 128, 1>), grid, dim3(NTHREADS), 0, stream, G);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -982,8 +1153,37 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
     G.act = (int)activation; G.post_add = post_add; G.accumulate = (int)accumulate;
     if (mode == MODE_NT) G.bias = bias_or_y_dev;
     if (mode == MODE_NN) { G.Y = bias_or_y_dev; G.ldy = (int)ldy; }
-    if (mode == MODE_TN) G.bias_grad = const_cast<float*>(bias_or_y_dev);   // [M] accumulator of the column sums of A, or NULL
-    return launch_gemm(mode, G, (hipStream_t)stream);
+    if (mode != MODE_TN) return launch_gemm(mode, G, (hipStream_t)stream);
+    // the product path keeps the partials in its workspace; the hook borrows a buffer for them
+    float* bias_acc = const_cast<float*>(bias_or_y_dev);   // [M] accumulator of the column sums of A, or NULL
+    const TnPlan plan = tn_plan(G.M, G.N, G.K);
+    static float* part = nullptr;          // grow-only, kept for the life of the process (a test / probe hook)
+    static size_t part_floats = 0;
+    const size_t need = tn_partial_floats(G.M, G.N, G.K, bias_acc != nullptr);
+    if (need > part_floats) {
+        (void)hipDeviceSynchronize();
+        if (part) (void)hipFree(part);
+        part = nullptr; part_floats = 0;
+        HIP_TRY(hipMalloc(&part, need * sizeof(float)));
+        part_floats = need;
+    }
+    G.C = part; G.ldc = G.N; G.part_stride = (long)G.M * G.N;
+    G.bias_grad = bias_acc ? part + align4((size_t)plan.slices * G.M * G.N) : nullptr;
+    int rc = launch_gemm(mode, G, (hipStream_t)stream);
+    if (!rc) {
+        SegmentTable T{};
+        T.seg[0] = Segment{c_dev, part, m, n, ldc, (uint32_t)plan.slices, 0u, 1u, 0u, 0u};
+        T.n = 1;
+        uint32_t blocks = segment_blocks(T.seg[0]);
+        if (bias_acc) {
+            T.seg[1] = Segment{bias_acc, G.bias_grad, 1u, m, m, (uint32_t)plan.slices, blocks, 1u, 0u, 0u};
+            T.n = 2;
+            blocks += segment_blocks(T.seg[1]);
+        }
+        hipLaunchKernelGGL(reduce_partials, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T);
+        if (hipGetLastError() != hipSuccess) rc = bsvi_fail(BSVI_ERR_HIP, "reduce_partials launch failed");
+    }
+    return rc;
 }
 
 extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args) {
@@ -1011,6 +1211,18 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     int32_t* idx = (int32_t*)(rowlq + R);
 
     HIP_TRY(hipMemsetAsync(out, 0, (BSVI_OUT_HEADER + (size_t)d.n_params) * sizeof(float), stream));
+
+    // partial sums (second part of the workspace) and the table reduce_partials works through at the end
+    float* part = ws + (R * a->floats_per_row + 64 + 3) / 4 * 4;
+    SegmentTable segments{};
+    uint32_t reduce_blocks = 0;
+    auto add_segment = [&](float* dst, const float* src, uint32_t rows, uint32_t cols, uint32_t splits) -> int {
+        if (segments.n == kMaxSegments) return bsvi_fail(BSVI_ERR_RESOURCE, "too many layers for one reduction launch");
+        Segment& S = segments.seg[segments.n++];
+        S = Segment{dst, src, rows, cols, cols, splits, reduce_blocks, 0u, 0u, 0u};
+        reduce_blocks += segment_blocks(S);
+        return BSVI_OK;
+    };
 
     RowParams D{};
     D.R = (int)R; D.B = B; D.DS = (int)d.dataset_size; D.P = P; D.Dz = Dz;
@@ -1044,6 +1256,9 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.out = out; D.fvalue_out = args->fvalue_out_dev; D.logq_out = args->logq_out_dev;
 
     const dim3 row_grid((unsigned)((R + 255) / 256));
+    D.sum_part = part;
+    part += align4(2 * (size_t)row_grid.x);
+    if (int rc = add_segment(out, D.sum_part, 1, 2, row_grid.x)) return rc;       // out[0] = sum of values, out[1] = non-finite count
     hipLaunchKernelGGL(amort_rows, row_grid, dim3(256), 0, stream, D);
 
     auto forward = [&](const Net& net, bool gather) -> int {
@@ -1079,16 +1294,22 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
             const float* dY = grad(net, l.out_value);
             const int ldy = net.ld[l.out_value];
             const bool from_data = gather && l.in_value == 0;
-            {   // dW[n_out][n_in] += dY^T x
+            {   // dW[n_out][n_in] = dY^T x, db = 1^T dY (same launch): one partial per slice of the rows
                 GemmArgs G{};
                 G.A = dY; G.lda = ldy;
                 G.B = from_data ? a->dataset_dev : val(net, l.in_value);
                 G.ldb = from_data ? P : net.ld[l.in_value];
                 G.rows = from_data ? idx : nullptr;
-                G.C = grads + l.weight_off; G.ldc = (int)l.n_in;
                 G.M = (int)l.n_out; G.N = (int)l.n_in; G.K = (int)R;
-                G.bias_grad = l.bias_off != 0xFFFFFFFFu ? grads + l.bias_off : nullptr;   // db += 1^T dY, same launch
+                const TnPlan plan = tn_plan(G.M, G.N, G.K);
+                const bool has_bias = l.bias_off != 0xFFFFFFFFu;
+                G.C = part; G.ldc = (int)l.n_in; G.part_stride = (long)G.M * G.N;
+                part += align4((size_t)plan.slices * G.M * G.N);
+                G.bias_grad = has_bias ? part : nullptr;
+                if (has_bias) part += align4((size_t)plan.slices * G.M);
                 int rc = launch_gemm(MODE_TN, G, wstream);
+                if (!rc) rc = add_segment(grads + l.weight_off, G.C, l.n_out, l.n_in, (uint32_t)plan.slices);
+                if (!rc && has_bias) rc = add_segment(grads + l.bias_off, G.bias_grad, 1, l.n_out, (uint32_t)plan.slices);
                 if (rc) return rc;
             }
             if (l.in_value != 0 || input_grad) {   // dX = (dY W) * act'(x)
@@ -1129,6 +1350,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         HIP_TRY(hipEventRecord(a->joined, a->side));
         HIP_TRY(hipStreamWaitEvent(stream, a->joined, 0));
     }
+    hipLaunchKernelGGL(reduce_partials, dim3(reduce_blocks), dim3(256), 0, stream, segments);
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }
