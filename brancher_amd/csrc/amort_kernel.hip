@@ -606,6 +606,215 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const GemmArgs G, int na
     }
 }
 
+// ---- the narrow layers, second generation ------------------------------------------------------------------------
+// (the kernels above are the general fallbacks; at the shapes of BASELINE config 5 they ran at 1.2-1.9 TB/s: one wave per
+//  row with a 64-lane butterfly per output, or one dword per thread and step)
+template <int CTRL>
+__device__ __forceinline__ float dpp16(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_total(float v) {      // every lane of a 16-lane DPP row gets the row's sum
+    v += dpp16<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp16<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp16<0x141>(v);    // row_half_mirror
+    v += dpp16<0x140>(v);    // row_mirror
+    return v;
+}
+
+// N <= NP <= 8 row dot products, K % 4 == 0:  C[r][n] = epilogue(sum_k A[r][k] B(k, n)).  Sixteen lanes per row, four rows
+// per wave and pass, two passes in flight: every lane has up to eight independent 16-byte loads outstanding, and the
+// sum over a row's sixteen lanes is four DPP steps per output.  B is staged once per workgroup, transposed and padded to
+// NP outputs with zeros, so that the inner loop has no conditions.
+template <int NP>
+__global__ __launch_bounds__(256) void rowdot_kernel(const GemmArgs G, int sbk, int sbn, int mode, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float bt[];   // [NP][K]
+    const int K = G.K, K4 = K >> 2;
+    for (int i = threadIdx.x; i < NP * K; i += 256) {
+        const int n = i / K, k = i - n * K;
+        bt[i] = n < G.N ? G.B[(long)k * sbk + (long)n * sbn] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, sub = lane >> 4;
+    const long r_begin = (long)blockIdx.x * rows_per_block, r_end = min((long)G.M, r_begin + rows_per_block);
+    constexpr int RP = 2;
+    for (long r0 = r_begin + wave * 4 * RP; r0 < r_end; r0 += 16 * RP) {
+        const float* a[RP];
+        long row[RP];
+        float acc[RP][NP];
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+            row[q] = r0 + 4 * q + sub;
+            const long rr = min(row[q], (long)G.M - 1);                      // rows past the end re-read the last one
+            a[q] = G.A + (G.rows ? (long)G.rows[rr] : rr) * G.lda;
+#pragma unroll
+            for (int n = 0; n < NP; ++n) acc[q][n] = 0.0f;
+        }
+        for (int k4 = l16; k4 < K4; k4 += 64) {                              // four 16-byte loads per row in flight
+            f32x4 av[RP][4];
+#pragma unroll
+            for (int q = 0; q < RP; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = min(k4 + 16 * u, K4 - 1);
+                    av[q][u] = *reinterpret_cast<const f32x4*>(a[q] + 4 * kk);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k4 + 16 * u;
+                if (kk < K4) {
+#pragma unroll
+                    for (int n = 0; n < NP; ++n) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(&bt[n * K + 4 * kk]);
+#pragma unroll
+                        for (int q = 0; q < RP; ++q)
+                            acc[q][n] += (av[q][u].x * bv.x + av[q][u].y * bv.y) + (av[q][u].z * bv.z + av[q][u].w * bv.w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RP; ++q) {
+            float mine = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                const float v = row16_total(acc[q][n]);
+                mine = (l16 == n) ? v : mine;
+            }
+            if (l16 < G.N && row[q] < r_end) G.C[row[q] * G.ldc + l16] = skinny_epilogue(G, mode, mine, row[q], l16);
+        }
+    }
+}
+
+// weight gradient with a narrow side (narrow <= NP <= 8, wide % 4 == 0), one partial per chunk of rows:
+//   out(w, j) = sum_{r in chunk} Wide[r][w] * Narrow[r][j]
+// A thread owns four adjacent w and every RS-th row of the chunk (RS = 256 / (wide / 4) row slots), eight rows in flight;
+// the row slots are added in order through LDS.  Column sums of A ride along (bias gradient).
+template <int NP>
+__global__ __launch_bounds__(256) void outer_kernel(const GemmArgs G, int narrow_is_a, int rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int wide = narrow_is_a ? G.N : G.M, narrow = narrow_is_a ? G.M : G.N;
+    const float* Wd = narrow_is_a ? G.B : G.A;
+    const float* Nr = narrow_is_a ? G.A : G.B;
+    const int ldw = narrow_is_a ? G.ldb : G.lda, ldn = narrow_is_a ? G.lda : G.ldb;
+    const int quads = wide >> 2, q0 = blockIdx.x * 256;
+    const int tpr = min(256, quads - q0), slots = 256 / tpr;                 // threads per row, row slots
+    const int tw = threadIdx.x % tpr, slot = threadIdx.x / tpr;
+    const bool active = slot < slots;
+    const int w = (q0 + tw) * 4;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min((long)G.K, r0 + rows_per_block);
+    f32x4 acc[NP];
+    f32x4 wsum = f32x4(0.0f);
+    float nsum[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { acc[j] = f32x4(0.0f); nsum[j] = 0.0f; }
+    if (active) {
+        constexpr int U = 8;
+        for (long r = r0 + slot; r < r1; r += (long)slots * U) {
+            f32x4 wv[U];
+            float nv[U][NP];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long rr = min(r + (long)u * slots, r1 - 1);            // past the end: re-read, weight 0 below
+                // the gathered operand (data rows) is always B
+                const long rw = (!narrow_is_a || !G.rows) ? rr : (long)G.rows[rr];
+                const long rn = (narrow_is_a || !G.rows) ? rr : (long)G.rows[rr];
+                wv[u] = *reinterpret_cast<const f32x4*>(Wd + rw * ldw + w);
+                // (16-byte loads: columns past `narrow` are the padding of the value buffers — they only reach accumulators
+                //  that are never stored)
+#pragma unroll
+                for (int j4 = 0; j4 < NP; j4 += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Nr + rn * ldn + j4);
+                    nv[u][j4] = v.x;
+                    if (j4 + 1 < NP) nv[u][j4 + 1] = v.y;
+                    if (j4 + 2 < NP) nv[u][j4 + 2] = v.z;
+                    if (j4 + 3 < NP) nv[u][j4 + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + (long)u * slots < r1) {
+                    wsum += wv[u];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) { acc[j] += wv[u] * nv[u][j]; nsum[j] += nv[u][j]; }
+                }
+            }
+        }
+    }
+    // row slots in order: slot 0 adds the others' values as they stand in LDS
+    float* part = G.C + (long)blockIdx.y * G.part_stride;
+    auto fold = [&](f32x4 v) -> f32x4 {
+        __syncthreads();
+        if (active) *reinterpret_cast<f32x4*>(&red[(slot * tpr + tw) * 4]) = v;
+        __syncthreads();
+        f32x4 t = f32x4(0.0f);
+        if (slot == 0)
+            for (int s2 = 0; s2 < slots; ++s2) t += *reinterpret_cast<const f32x4*>(&red[(s2 * tpr + tw) * 4]);
+        return t;
+    };
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (j >= narrow) break;
+        const f32x4 t = fold(acc[j]);
+        if (slot == 0) {
+            if (narrow_is_a) {
+                *reinterpret_cast<f32x4*>(&part[(long)j * G.ldc + w]) = t;
+            } else {
+                part[(long)(w + 0) * G.ldc + j] = t.x; part[(long)(w + 1) * G.ldc + j] = t.y;
+                part[(long)(w + 2) * G.ldc + j] = t.z; part[(long)(w + 3) * G.ldc + j] = t.w;
+            }
+        }
+    }
+    if (G.bias_grad) {
+        float* bpart = G.bias_grad + (long)blockIdx.y * G.M;
+        if (!narrow_is_a) {
+            const f32x4 t = fold(wsum);
+            if (slot == 0) *reinterpret_cast<f32x4*>(&bpart[w]) = t;
+        } else if (blockIdx.x == 0) {
+            f32x4 lo = f32x4(0.0f), hi = f32x4(0.0f);
+            lo.x = nsum[0]; if (NP > 1) lo.y = nsum[1]; if (NP > 2) lo.z = nsum[2]; if (NP > 3) lo.w = nsum[3];
+            if (NP > 4) { hi.x = nsum[4]; hi.y = nsum[5]; hi.z = nsum[6]; hi.w = nsum[7]; }
+            const f32x4 tl = fold(lo), th = NP > 4 ? fold(hi) : f32x4(0.0f);
+            if (threadIdx.x == 0) {
+                const float t[8] = {tl.x, tl.y, tl.z, tl.w, th.x, th.y, th.z, th.w};
+                for (int j = 0; j < narrow; ++j) bpart[j] = t[j];
+            }
+        }
+    }
+}
+
+// K <= 8 (compile time), forward layout (B stored [N][K], N % 4 == 0): four adjacent outputs per thread; their 4 K weights
+// are contiguous.  One thread = 1 + K 16-byte loads, one 16-byte store.
+template <int K>
+__global__ __launch_bounds__(256) void skinny_k4nt_kernel(const GemmArgs G) {
+    const uint32_t quads = (uint32_t)G.N >> 2;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)G.M * quads) return;
+    const uint32_t r32 = i / quads;
+    const int n = (int)(i - r32 * quads) * 4;
+    const long r = (long)r32;
+    const float* a = G.A + (G.rows ? (long)G.rows[r] : r) * G.lda;
+    float av[K], bl[4 * K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) av[k] = a[k];
+    const f32x4* bq = reinterpret_cast<const f32x4*>(G.B + (long)n * K);     // 4 K floats = K 16-byte pieces, aligned
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const f32x4 v = bq[k];
+        bl[4 * k] = v.x; bl[4 * k + 1] = v.y; bl[4 * k + 2] = v.z; bl[4 * k + 3] = v.w;
+    }
+    const f32x4 bias = G.bias ? *reinterpret_cast<const f32x4*>(G.bias + n) : f32x4(0.0f);
+    const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += av[k] * bl[j * K + k];
+        out[j] = act_forward(ACT_OF(G, n + j), acc + bb[j], ADD_OF(G, n + j));
+    }
+    *reinterpret_cast<f32x4*>(G.C + r * G.ldc + n) = f32x4{out[0], out[1], out[2], out[3]};
+}
+
 // ---- fixed-order sums of the partial results ------------------------------------------------------------------------
 // dst(m, n) = [dst(m, n) +] sum_s src[s * stride + m * cols + n], s ascending: the second stage of every reduction over
 // rows (weight / bias gradients: one partial per k split; loss sums: one partial per workgroup of amort_latent_bwd).
@@ -1071,10 +1280,22 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     G.vecA = aligned(G.A, G.lda);
     G.vecB = aligned(G.B, G.ldb);
     // a side of width <= 8: the memory-bound kernels
+    static const bool second_generation = [] { const char* e = getenv("BSVI_NARROW_GEN"); return !(e && e[0] == '1'); }();
     if (mode == MODE_TN && (G.M <= SKINNY || G.N <= SKINNY)) {
         const int narrow_is_a = G.M <= G.N ? 1 : 0;
-        const int wide = narrow_is_a ? G.N : G.M;
+        const int wide = narrow_is_a ? G.N : G.M, narrow = narrow_is_a ? G.M : G.N;
         const int rows_per_block = tn_plan(G.M, G.N, G.K).chunk;
+        const bool wide_vec = narrow_is_a ? G.vecB : G.vecA, narrow_vec = narrow_is_a ? G.vecA : G.vecB;
+        const bool out_vec = !narrow_is_a || (G.ldc % 4 == 0 && (uintptr_t)G.C % 16 == 0 && G.part_stride % 4 == 0);
+        const bool bias_vec = !G.bias_grad || narrow_is_a || (G.M % 4 == 0 && (uintptr_t)G.bias_grad % 16 == 0);
+        if (second_generation && wide % 4 == 0 && wide_vec && narrow_vec && out_vec && bias_vec) {
+            // (the padded leading dimension of the narrow operand covers the 16-byte loads: ld >= 4 ceil(narrow / 4))
+            dim3 grid((wide / 4 + 255) / 256, (G.K + rows_per_block - 1) / rows_per_block);
+            if (narrow <= 4) hipLaunchKernelGGL((outer_kernel<4>), grid, dim3(256), 0, stream, G, narrow_is_a, rows_per_block);
+            else hipLaunchKernelGGL((outer_kernel<8>), grid, dim3(256), 0, stream, G, narrow_is_a, rows_per_block);
+            HIP_TRY(hipGetLastError());
+            return BSVI_OK;
+        }
         dim3 grid((wide + 255) / 256, (G.K + rows_per_block - 1) / rows_per_block);
         hipLaunchKernelGGL(skinny_tn_kernel, grid, dim3(256), 0, stream, G, narrow_is_a, rows_per_block);
         HIP_TRY(hipGetLastError());
@@ -1082,6 +1303,15 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     }
     if (mode != MODE_TN) {
         const int sbk = mode == MODE_NT ? 1 : G.ldb, sbn = mode == MODE_NT ? G.ldb : 1;
+        if (second_generation && G.N <= SKINNY && G.K % 4 == 0 && G.vecA && (size_t)G.K * SKINNY * sizeof(float) <= 64 * 1024) {
+            const int rows_per_block = 32;
+            const dim3 grid((G.M + rows_per_block - 1) / rows_per_block);
+            if (G.N <= 2) hipLaunchKernelGGL((rowdot_kernel<2>), grid, dim3(256), (size_t)2 * G.K * sizeof(float), stream, G, sbk, sbn, mode, rows_per_block);
+            else if (G.N <= 4) hipLaunchKernelGGL((rowdot_kernel<4>), grid, dim3(256), (size_t)4 * G.K * sizeof(float), stream, G, sbk, sbn, mode, rows_per_block);
+            else hipLaunchKernelGGL((rowdot_kernel<8>), grid, dim3(256), (size_t)8 * G.K * sizeof(float), stream, G, sbk, sbn, mode, rows_per_block);
+            HIP_TRY(hipGetLastError());
+            return BSVI_OK;
+        }
         if (G.N <= SKINNY && (size_t)G.N * G.K <= 8192) {
             static const int rows_per_block = [] { const char* e = getenv("BSVI_SKINNY_ROWS"); return e ? atoi(e) : 16; }();
             hipLaunchKernelGGL(skinny_n_kernel, dim3((G.M + rows_per_block - 1) / rows_per_block), dim3(256),
@@ -1091,6 +1321,17 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
         }
         if (G.K <= SKINNY && (uint64_t)G.M * (uint64_t)G.N < (1ull << 32) - 256) {
             auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+            if (second_generation && mode == MODE_NT && G.ldb == G.K && (G.N & 3) == 0 && al16(G.B) && (G.ldc & 3) == 0 && al16(G.C) &&
+                (!G.bias || al16(G.bias))) {
+                const dim3 grid((unsigned)(((long)G.M * (G.N >> 2) + 255) / 256));
+                switch (G.K) {
+#define BSVI_K4NT(KK) case KK: hipLaunchKernelGGL((skinny_k4nt_kernel<KK>), grid, dim3(256), 0, stream, G); break;
+                    BSVI_K4NT(1) BSVI_K4NT(2) BSVI_K4NT(3) BSVI_K4NT(4) BSVI_K4NT(5) BSVI_K4NT(6) BSVI_K4NT(7) BSVI_K4NT(8)
+#undef BSVI_K4NT
+                }
+                HIP_TRY(hipGetLastError());
+                return BSVI_OK;
+            }
             // (B stored [N][K], the forward layout, would need strided scalar loads per output: measured slower)
             const bool vec4 = sbn == 1 && (sbk & 3) == 0 && al16(G.B) && (G.N & 3) == 0 && (G.ldc & 3) == 0 && al16(G.C) &&
                               (!G.bias || al16(G.bias)) && (!G.Y || ((G.ldy & 3) == 0 && al16(G.Y)));
