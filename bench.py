@@ -69,6 +69,19 @@ def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False, column="m
             total += kb * 1024.0 * (2.0 if double_fetch and row["counter"] == "FETCH_SIZE" else 1.0)
             hit = True
     return total if hit else None
+def pmc_dispatches(csv_name, kernel_substring):
+    """number of dispatches of a kernel in a committed PMC summary (None when absent)"""
+    import csv
+    for d in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r1")):
+        path = os.path.join(d, csv_name)
+        if os.path.exists(path):
+            for row in csv.DictReader(open(path)):
+                if kernel_substring in row["kernel"]:
+                    return int(row["dispatches"])
+            return None
+    return None
+
+
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak
 
 
@@ -370,11 +383,12 @@ def main():
             # the whole iteration (~35 launches) is timed; the 20 MFMA GEMMs carry the flops
             flops = amort_flops_per_iteration(program, n_per_gpu)
             tf = flops / (dev_ms * 1e-3 / args.steps) / 1e12
-            # HBM bytes of ALL launches of one iteration (tools/pmc_hbm.sh over 5 iterations of this workload;
+            # HBM bytes of ALL launches of one iteration (tools/pmc_hbm.sh over a short run of this workload;
             # FETCH_SIZE doubled per the guide's gfx950 rule for 16-byte-per-lane reads)
             traffic = pmc_traffic_bytes("cfg5_pmc_hbm_traffic.csv", ["bsvi_amort_impl"], double_fetch=True,
                                         column="total_KB") if args.workload == "cfg5" and not args.samples else None
-            traffic = traffic / 5.0 if traffic else None
+            iterations_profiled = pmc_dispatches("cfg5_pmc_hbm_traffic.csv", "amort_rows")   # one launch per iteration
+            traffic = traffic / iterations_profiled if traffic and iterations_profiled else None
             roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
                             kernel="bsvi_amort_impl::gemm_kernel<0|1|2>",
