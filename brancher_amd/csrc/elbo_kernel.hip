@@ -2130,7 +2130,7 @@ static int train_persistent_impl(const bsvi_program* p, const bsvi_program* cons
     if (!p || !a) return fail(BSVI_ERR_INVALID, "null argument");
     int rc = check_cfg(cfg);
     if (rc) return rc;
-    if (!a->out_dev || !params_dev || !state_dev || !active_mask_dev || !active_mask_first_dev || !loss_curve_dev || !finite_dev)
+    if (!a->out_dev || !params_dev || !active_mask_dev || !active_mask_first_dev || !loss_curve_dev || !finite_dev)
         return fail(BSVI_ERR_INVALID, "null argument");
     if (a->n_samples_local != a->n_samples_global) return fail(BSVI_ERR_INVALID, "persistent trainer is the single-GPU path");
     if (a->offset_dev) return fail(BSVI_ERR_INVALID, "the in-kernel training loop counts its own iterations: offset_dev must be null");
@@ -2139,6 +2139,9 @@ static int train_persistent_impl(const bsvi_program* p, const bsvi_program* cons
                                 pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);
         if (sp) return sp < 0 ? sp : BSVI_OK;
     }
+    // state_dev == NULL (a fresh optimizer whose final state the caller does not want) is served by the program-specialised
+    // kernel only (bsvi_program_engine tells which engine a call would run on)
+    if (!state_dev) return fail(BSVI_ERR_INVALID, "state_dev is null and this call does not run on the specialised kernel");
     const bool multi = multi_persistent_applies(p, a->n_samples_local);
     Geometry g = choose_geometry(p, a->n_samples_local, true);
     if (multi && g.n_blocks != 1) {      // does not fit ONE workgroup, but one wave per workgroup does

@@ -144,7 +144,8 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             PS[i] = params[i];
             if (step) {
 #pragma unroll
-                for (uint32_t s = 0; s < 4u; ++s) PS[(1u + s) * SPEC_NP_PAD + i] = state[(size_t)s * SPEC_N_PARAMS + i];
+                for (uint32_t s = 0; s < 4u; ++s)      // no state buffer: a fresh optimizer (all zeros), nothing written back
+                    PS[(1u + s) * SPEC_NP_PAD + i] = state ? state[(size_t)s * SPEC_N_PARAMS + i] : 0.0f;
                 TAB[SPEC_TAB_MASK + i] = (mask[i] ? 1u : 0u) | (mask_first[i] ? 2u : 0u);
             }
         }
@@ -369,10 +370,12 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
                     float* const params = SPEC_A->params;
                     float* const state = SPEC_A->state;
                     params[tid] = own.theta;
-                    state[tid] = own.s0;
-                    state[(size_t)SPEC_N_PARAMS + tid] = own.s1;
-                    state[2 * (size_t)SPEC_N_PARAMS + tid] = own.s2;
-                    state[3 * (size_t)SPEC_N_PARAMS + tid] = own.st;
+                    if (state) {
+                        state[tid] = own.s0;
+                        state[(size_t)SPEC_N_PARAMS + tid] = own.s1;
+                        state[2 * (size_t)SPEC_N_PARAMS + tid] = own.s2;
+                        state[3 * (size_t)SPEC_N_PARAMS + tid] = own.st;
+                    }
                 } else {
 #pragma unroll
                     for (uint32_t e = 0; e < 2u; ++e)
@@ -401,8 +404,10 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
                 float* const params = SPEC_A->params;
                 float* const state = SPEC_A->state;
                 params[i] = PS[i];
+                if (state) {
 #pragma unroll
-                for (uint32_t s = 0; s < 4u; ++s) state[(size_t)s * SPEC_N_PARAMS + i] = PS[(1u + s) * SPEC_NP_PAD + i];
+                    for (uint32_t s = 0; s < 4u; ++s) state[(size_t)s * SPEC_N_PARAMS + i] = PS[(1u + s) * SPEC_NP_PAD + i];
+                }
             } else {
                 const float theta2 = PS[i];
                 for (uint32_t j = j0; j < j1; ++j) spec_publish_uniform(TAB, TAB[SPEC_TAB_IDX + j], theta2);

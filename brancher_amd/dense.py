@@ -345,9 +345,7 @@ class CompiledDense:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         dev, p = self.device, self.program
         K = int(number_iterations)
-        loss_curve = torch.zeros(max(K, 1), device=dev)
-        finite = torch.ones(max(K, 1), device=dev)
-        state = torch.zeros(4 * max(p.n_params, 1), device=dev)
+        loss_curve, finite, state = engine.training_buffers(K, p.n_params, dev)
         ptr = lambda t: C.c_void_p(t.data_ptr())
         offset0 = self.iteration
         self.iteration += K

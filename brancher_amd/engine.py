@@ -386,10 +386,15 @@ class CompiledELBO:
         dev = self.device
         p = self.program
         K = int(number_iterations)
-        loss_curve = torch.zeros(max(K, 1), device=dev)
-        finite = torch.ones(max(K, 1), device=dev)
-        state = torch.zeros(4 * max(p.n_params, 1), device=dev)
-        ptr = lambda t: C.c_void_p(t.data_ptr())
+        # (_force_sharded_path: run the multi-GPU step sequence on one GPU — tests)
+        persistent = (allow_persistent and world == 1 and not _force_sharded_path
+                      and self.native.persistent_supported(n_local))
+        # the specialised in-kernel loop starts a fresh optimizer itself and nobody reads its final state: no state
+        # buffer, and with it no fill launch in front of the training launch
+        fresh_in_kernel = (persistent and K > 0 and self.native.split_shares(n_local) is None
+                           and self.native.engine(n_local, 2)["engine"] == "specialised")
+        loss_curve, finite, state = training_buffers(K, p.n_params, dev, with_state=not fresh_in_kernel)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         noise_t = None
         if noise_seq is not None:
             # [K][n_noise][n_local] contiguous (the persistent trainer advances by n_noise*n_local per iteration)
@@ -403,9 +408,6 @@ class CompiledELBO:
         if K == 0:
             return loss_curve[:0], finite[:0]
 
-        # (_force_sharded_path: run the multi-GPU step sequence on one GPU — tests)
-        persistent = (allow_persistent and world == 1 and not _force_sharded_path
-                      and self.native.persistent_supported(n_local))
         if persistent:
             args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset0)
             shares = self.native.split_shares(n_local)
@@ -448,6 +450,20 @@ class CompiledELBO:
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         return loss_curve, finite
+
+
+def training_buffers(n_iterations, n_params, device, with_state=True):
+    """loss curve [K], finite flags [K] and optimizer state [4 P] of one `train` call as views of ONE allocation: a single
+    fill launch in front of the training launch instead of three (every kernel path writes the loss and the flag of each
+    iteration it runs, so their initial value is never read; the optimizer state must start at 0).  with_state=False: the
+    kernel keeps the optimizer state to itself — nothing to fill, no launch at all."""
+    K, P = max(int(n_iterations), 1), max(int(n_params), 1)
+    Ka = (K + 3) // 4 * 4                               # views stay 16-byte aligned
+    if not with_state:
+        buf = torch.empty(2 * Ka, device=device)
+        return buf[:K], buf[Ka:Ka + K], None
+    buf = torch.zeros(2 * Ka + 4 * P, device=device)
+    return buf[:K], buf[Ka:Ka + K], buf[2 * Ka:]
 
 
 def _graph_unroll():
