@@ -96,7 +96,9 @@ __device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
     return o;
 }
 
-#ifdef SPEC_NUM_VGPR
+#if defined(SPEC_WAVES_PER_EU)
+#define SPEC_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(SPEC_WAVES_PER_EU, SPEC_WAVES_PER_EU)))
+#elif defined(SPEC_NUM_VGPR)
 #define SPEC_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SPEC_NUM_VGPR)))
 #else
 #define SPEC_VGPR_ATTR
@@ -298,8 +300,20 @@ extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bs
             float* const SL = spec_lds + SPEC_OFF_SCR;
             for (uint32_t i = tid; i < 4u * stride; i += nthreads) {
                 const uint32_t sl = i & 3u, c = i >> 2;
+                // eight loads in flight, added in row order (the same association as one load at a time: with hundreds of
+                // workgroups the one-at-a-time form made this the longest phase of the launch — a serial tail in ONE
+                // workgroup of ~130 dependent L2 round trips while the rest of the chip was idle)
                 float s = 0.0f;
-                for (uint32_t b = sl; b < G; b += 4u)
+                uint32_t b = sl;
+                for (; b + 28u < G; b += 32u) {
+                    float v[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u)
+                        v[u] = __hip_atomic_load(&partials[(size_t)(b + 4u * u) * stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) s += v[u];
+                }
+                for (; b < G; b += 4u)
                     s += __hip_atomic_load(&partials[(size_t)b * stride + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 SL[i] = s;
             }
