@@ -206,7 +206,9 @@ size_t bsvi_workspace_bytes(const bsvi_program* prog, uint32_t n_samples_local);
 
 /* Output block layout (fp32, length 4 + n_params):
  *   out[0] = sum over local samples of the per-sample estimator value (ELBO term, not yet /N)
- *   out[1] = number of non-finite per-sample values seen locally
+ *   out[1] = number of non-finite per-sample values seen locally.  A diagnostic, not a count of samples: when the model's
+ *            log-prob records are split over workgroups (program shares, bsvi_program_set_shares) every share tests its
+ *            own partial value, so one bad sample can be counted once per share (<= n_shares times); out[3] is exact
  *   out[2] = loss = -out[0]/n_samples_global   (filled by bsvi_finalize)
  *   out[3] = finite flag (1 = finite)          (filled by bsvi_finalize)
  *   out[4..] = gradient sums d(sum f)/d theta  (bsvi_finalize scales them to d loss/d theta)
