@@ -103,7 +103,12 @@ __device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
 #else
 #define SPEC_VGPR_ATTR
 #endif
-extern "C" __global__ void __launch_bounds__(SPEC_MAX_THREADS) SPEC_VGPR_ATTR bsvi_spec_kernel(const SpecArgs A_unused) {
+// SPEC_BOUND_THREADS (>= SPEC_MAX_THREADS): the launch bound the register allocator sees.  A bound of 768 / 1024 threads
+// caps a lane at 168 / 128 registers, so that 3 / 4 workgroups of 256 threads share a CU (the throughput regime).
+#ifndef SPEC_BOUND_THREADS
+#define SPEC_BOUND_THREADS SPEC_MAX_THREADS
+#endif
+extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR bsvi_spec_kernel(const SpecArgs A_unused) {
     (void)A_unused;
     const SPEC_CONST_AS char* ka = (const SPEC_CONST_AS char*)__builtin_amdgcn_kernarg_segment_ptr();
 #define SPEC_A ((const SPEC_CONST_AS SpecArgs*)ka)

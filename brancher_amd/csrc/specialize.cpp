@@ -593,15 +593,26 @@ struct Spec {
     std::mutex mu;
 };
 
-static bool tiled(uint32_t n_pos) { return n_pos <= 64; }     // SPEC_TILE (spec_prelude.h, SPEC_DU)
-static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs, uint32_t n_pos, uint32_t max_threads) {
+// throughput regime (many workgroups): workgroups of 256 threads per CU the kernel is compiled for — 2: the whole register
+// file for two waves per SIMD; 3 / 4: the launch bound is raised to 768 / 1024 threads so that a lane gets 168 / 128
+// registers (spilling the rest) and contributions leave through DPP row sums, not the 17 KB-per-wave transpose tile
+static uint32_t many_waves() {
+    static const uint32_t w = [] { const char* e = getenv("BSVI_SPEC_MANY_WAVES"); const int v = e ? atoi(e) : 2; return (uint32_t)(v < 2 ? 2 : v > 4 ? 4 : v); }();
+    return w;
+}
+static bool tiled(uint32_t n_pos, int geom) {     // SPEC_TILE (spec_prelude.h, SPEC_DU)
+    static const bool many_tile = [] { const char* e = getenv("BSVI_SPEC_MANY_TILE"); return !(e && e[0] == '0'); }();
+    if (geom == 1 /* GEOM_MANY */ && (!many_tile || many_waves() > 2)) return false;
+    return n_pos <= 64;
+}
+static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs, uint32_t n_pos, uint32_t max_threads, int geom) {
     // mirrors the SPEC_OFF_* layout of spec_prelude.h
     const uint32_t W = max_threads / 64;
     const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4;
-    const uint32_t ws_pad = tiled(n_pos) ? (n_pos + 3) / 4 * 4 + 4 : 4 * n_pos + 4;
+    const uint32_t ws_pad = tiled(n_pos, geom) ? (n_pos + 3) / 4 * 4 + 4 : 4 * n_pos + 4;
     const uint32_t np_pad = (n_params + 3) / 4 * 4 + 4, tab = (4 * n_uniform + (2 * n_params + 1) + 2 * n_pos + 3) / 4 * 4 + 4;
     const uint32_t own = 16 * (n_params < max_threads ? n_params : max_threads), scr = 4 * (n_pos + 2) + 4;
-    return u_pad + 2 * nu_pad + W * ws_pad + (2 * W + 8) + 5 * np_pad + tab + own + scr + (tiled(n_pos) ? W * 64 * 68 : 0);
+    return u_pad + 2 * nu_pad + W * ws_pad + (2 * W + 8) + 5 * np_pad + tab + own + scr + (tiled(n_pos, geom) ? W * 64 * 68 : 0);
 }
 
 Spec* create(const bsvi_program_desc& d, std::string& why) {
@@ -628,7 +639,7 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     const uint32_t live = 2 * d.n_slots + (d.n_noise <= kKeepEpsRows ? d.n_noise : 0) + (d.n_uniform_grad <= kAccumulateEntries ? d.n_uniform_grad : 0) + 40;
     auto fit = [&](uint32_t threads, Geom& g) {
         g.max_threads = threads;
-        g.lds_bytes = lds_floats(d.n_params, d.n_uniform, d.n_obs, s->n_pos, threads) * 4u;
+        g.lds_bytes = lds_floats(d.n_params, d.n_uniform, d.n_obs, s->n_pos, threads, (int)(&g - s->geom)) * 4u;
         return g.lds_bytes <= 160u * 1024u;
     };
     bool ok = (live <= 232 && fit(512, s->geom[GEOM_ONE])) || fit(256, s->geom[GEOM_ONE]);
@@ -648,7 +659,8 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
                        d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
             src += fmt("#define SPEC_N_POS %u\n", s->n_pos);
             src += fmt("#define SPEC_ESTIMATOR %u\n#define SPEC_MAX_THREADS %u\n#define SPEC_DIAG %d\n", d.estimator, G.max_threads, v);
-            src += fmt("#define SPEC_ACCUMULATE_CHUNKS %d\n#define SPEC_TILE %d\n", gi == GEOM_MANY ? 1 : 0, tiled(s->n_pos) ? 1 : 0);
+            src += fmt("#define SPEC_ACCUMULATE_CHUNKS %d\n#define SPEC_TILE %d\n", gi == GEOM_MANY ? 1 : 0, tiled(s->n_pos, gi) ? 1 : 0);
+            if (gi == GEOM_MANY && many_waves() > 2) src += fmt("#define SPEC_BOUND_THREADS %u\n", 256u * many_waves());
             src += fmt("#define SPEC_KEEP_NOISE %u\n", E.keeps_noise() ? d.n_noise : 0u);
             // (all parameters "fast": the epilogue's generic loop over the LDS working copy is compiled out)
             src += fmt("#define SPEC_GENERIC_OWNERS %d\n", all_fast ? 0 : 1);
@@ -781,7 +793,8 @@ static Geo geo(const Spec* s, uint32_t n_local) {
     // several chunks of 256 samples
     const uint32_t threads = s->geom[GEOM_MANY].max_threads;
     uint32_t blocks = (n_local + threads - 1) / threads;
-    const uint32_t per_cu = s->geom[GEOM_MANY].lds_bytes * 2u <= 160u * 1024u ? 2u : 1u;      // (and 2 x 256 registers per lane)
+    uint32_t per_cu = many_waves();                                                            // (registers: see many_waves)
+    while (per_cu > 1u && s->geom[GEOM_MANY].lds_bytes * per_cu > 160u * 1024u) --per_cu;
     if (blocks > per_cu * s->n_cus) blocks = per_cu * s->n_cus;
     return Geo{blocks, threads, GEOM_MANY};
 }
