@@ -298,7 +298,11 @@ int bsvi_train_persistent(const bsvi_program* prog, const bsvi_elbo_args* args,
 /* Same, with the reference's `pretraining_iterations` rule (inference.py:102-104): parameters
  * selected by active_mask_first_dev are stepped on every iteration, the rest of active_mask_dev
  * only when iteration > pretraining_iterations (the reference's second optimizer, built for the
- * joint model, is skipped on iteration 0 even with the default pretraining_iterations=0). */
+ * joint model, is skipped on iteration 0 even with the default pretraining_iterations=0).
+ * state_dev may be NULL when the call runs on the program-specialised kernel (bsvi_program_engine(prog, n, 2, ...) != 0):
+ * the optimizer then starts from a fresh (all-zero) state kept inside the kernel and its final state is not returned —
+ * what `perform_inference` needs, which builds its optimizers anew on every call (inference.py:77-88) — and the caller
+ * neither allocates nor clears a state buffer.  On the interpreter kernels a NULL state_dev is BSVI_ERR_INVALID. */
 int bsvi_train_persistent2(const bsvi_program* prog, const bsvi_elbo_args* args,
                            const bsvi_opt_cfg* cfg, float* params_dev, float* state_dev,
                            const uint8_t* active_mask_dev, const uint8_t* active_mask_first_dev,
@@ -493,6 +497,9 @@ typedef struct bsvi_amort_args {
 
 int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out);
 void bsvi_amort_destroy(bsvi_amort* a);
+/* Workspace of one bsvi_amort_fwd_bwd call over n_samples_local samples: per-row values and gradients of every layer, and
+ * behind them the per-slice partials of every reduction over rows (weight / bias gradients, loss sums), which one launch at
+ * the end of the call adds in slice order — the output block is bit-reproducible call to call, no float atomics. */
 size_t bsvi_amort_workspace_bytes(const bsvi_amort* a, uint32_t n_samples_local);
 int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args);
 
@@ -505,7 +512,8 @@ int bsvi_amort_apply(const bsvi_amort* a, int network, const float* params_dev, 
 /* Test hook: one launch of the f32 MFMA GEMM behind the amortised path.
  * mode 0: C[M][N] = A[M][K] B[N][K]^T   (+ bias[n], activation)        forward
  * mode 1: C[M][N] = A[M][K] B[K][N]     (* activation'(Y[m][n]))      backward-data
- * mode 2: C[M][N] += A[K][M]^T B[K][N]  (atomic, K split over blocks) backward-weight
+ * mode 2: C[M][N] += A[K][M]^T B[K][N]  (K split over workgroups: per-slice partials in a buffer the hook owns, added
+ *         in slice order by a second launch) backward-weight
  * rows_dev (or NULL) gathers the rows of A (modes 0, 1) / of B (mode 2).
  * bias_or_y_dev: mode 0 bias[N]; mode 1 Y[M][ldy]; mode 2 an [M] accumulator that receives += column sums of A. */
 int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev, float* c_dev, const int32_t* rows_dev,
