@@ -285,6 +285,9 @@ def main():
 
     # ---- timed region: exactly K steps
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import gc
+    gc.collect()
+    gc.disable()                      # (a collection inside a 200 us timed region would be a tenth of it)
     barrier()
     t0 = time.perf_counter()
     ev0.record()
@@ -293,6 +296,7 @@ def main():
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     dev_ms = ev0.elapsed_time(ev1)
     mode = compiled.last_mode
 

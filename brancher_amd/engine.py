@@ -210,6 +210,7 @@ class CompiledELBO:
         self.mask_all = torch.from_numpy(active.copy()).to(dev)
         self.mask_first = torch.from_numpy((active * (group == first_group)).astype(np.uint8)).to(dev)
         self._workspaces = {}
+        self._train_plans = {}
         self._noise_cache = None
         self.iteration = 0          # Philox counter offset: never reuse noise across calls
         if bind_parameters:
@@ -387,13 +388,20 @@ class CompiledELBO:
         p = self.program
         K = int(number_iterations)
         # (_force_sharded_path: run the multi-GPU step sequence on one GPU — tests)
-        persistent = (allow_persistent and world == 1 and not _force_sharded_path
-                      and self.native.persistent_supported(n_local))
-        # the specialised in-kernel loop starts a fresh optimizer itself and nobody reads its final state: no state
-        # buffer, and with it no fill launch in front of the training launch
-        fresh_in_kernel = (persistent and K > 0 and self.native.split_shares(n_local) is None
-                           and self.native.engine(n_local, 2)["engine"] == "specialised")
-        loss_curve, finite, state = training_buffers(K, p.n_params, dev, with_state=not fresh_in_kernel)
+        # which launch path serves this shard: decided once per (shard size, switches) — four library queries that a
+        # short training call (the driver times 20 iterations) would otherwise repeat
+        plan_key = (n_local, bool(allow_persistent), world, bool(_force_sharded_path), os.environ.get("BSVI_JIT"))
+        plan = self._train_plans.get(plan_key)
+        if plan is None:
+            persistent = (allow_persistent and world == 1 and not _force_sharded_path
+                          and self.native.persistent_supported(n_local))
+            shares = self.native.split_shares(n_local) if persistent else None
+            # the specialised in-kernel loop starts a fresh optimizer itself and nobody reads its final state: no state
+            # buffer, and with it no fill launch in front of the training launch
+            fresh = persistent and shares is None and self.native.engine(n_local, 2)["engine"] == "specialised"
+            plan = self._train_plans[plan_key] = (persistent, shares, fresh)
+        persistent, shares, fresh_in_kernel = plan
+        loss_curve, finite, state = training_buffers(K, p.n_params, dev, with_state=not (fresh_in_kernel and K > 0))
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         noise_t = None
         if noise_seq is not None:
@@ -410,7 +418,6 @@ class CompiledELBO:
 
         if persistent:
             args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset0)
-            shares = self.native.split_shares(n_local)
             if shares is not None:
                 # one wave per workgroup AND the model's log-prob records split over workgroups
                 native.check(self.lib.bsvi_train_persistent_split(
