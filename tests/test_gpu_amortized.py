@@ -64,6 +64,38 @@ def test_gemm_matches_torch(mode, shape):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(25600, 256, 784), (25600, 512, 256), (17000, 200, 72)])
+def test_gemm_tall_products_at_config5_rows(mode, shape):
+    """tall products at the row counts of BASELINE config 5 (800 / 1600 / 532 output tiles: several workgroups per CU, edge
+    tiles along M and N): against torch in double precision, and bit-identical call after call."""
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + mode)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    pad = lambda n: (n + 3) // 4 * 4
+    if mode == 0:
+        A, Bm, bias = rnd(M, pad(K)), rnd(N, pad(K)), rnd(N)
+        run = lambda Cm: native.check(lib.bsvi_debug_gemm(0, ptr(A), ptr(Bm), ptr(Cm), None, M, N, K, pad(K), pad(K), N, ptr(bias), 0, 1, 0.0, 0, None))
+        ref = torch.relu(A[:, :K].double() @ Bm[:, :K].double().T + bias.double())
+    else:
+        A, Bm, Y = rnd(M, pad(K)), rnd(K, N), rnd(M, N)
+        run = lambda Cm: native.check(lib.bsvi_debug_gemm(1, ptr(A), ptr(Bm), ptr(Cm), None, M, N, K, pad(K), N, N, ptr(Y), N, 1, 0.0, 0, None))
+        ref = (A[:, :K].double() @ Bm.double()) * (Y > 0).double()
+    outs = []
+    for _ in range(3):
+        Cm = torch.full((M, N), 3.0, device=dev)
+        run(Cm)
+        torch.cuda.synchronize()
+        outs.append(Cm)
+    err = (outs[0].double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+    assert err < 2e-6, err
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_gemm_tall_split_k():
     """backward-weight shape of the workload: K = all rows (tens of thousands), small output"""
     from brancher_amd import native
