@@ -345,6 +345,7 @@ class CompiledDense:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         dev, p = self.device, self.program
         K = int(number_iterations)
+        engine.broadcast_from_rank0(self.params)      # ranks step their own copies: they must start from the same values
         loss_curve, finite, state = engine.training_buffers(K, p.n_params, dev)
         ptr = lambda t: C.c_void_p(t.data_ptr())
         offset0 = self.iteration

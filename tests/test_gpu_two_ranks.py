@@ -1,0 +1,91 @@
+"""The N>1 path on REAL kernels: two processes, one rank each, sharing the one GPU of the test box; collectives over gloo
+(RCCL refuses two ranks on one device — on a multi-GPU node the same code runs with backend "nccl").  Each rank evaluates
+its shard of the Monte-Carlo samples with the HIP kernels, the output blocks are all-reduced, every rank applies the same
+optimizer step: the trajectory must be the single-process one (same Philox streams: a sample's draws depend on its global
+index, not on the rank that evaluates it)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, workload, n_samples, iters, optimizer, opt_kw, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BSVI_GRAPH"] = "0"                # a gloo collective cannot be captured into a HIP graph
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brancher_amd import config, engine, workloads as W
+    config.set_device("cuda:0")
+    torch.manual_seed(1234 + 77 * rank)           # ranks disagree on torch's seed on purpose: rank 0's must win
+    builder, kwargs = workload
+    model = getattr(W, builder)(W.native_api(), **kwargs)
+    c = engine.compile_model(model, None, "pathwise")
+    if rank == 1:                                 # ... and on the initial parameters: broadcast from rank 0 must fix it
+        c.params.add_(0.5)
+    losses, finite = c.train(iters, n_samples, optimizer, seed=11, **opt_kw)
+    res = c.evaluate(n_samples, seed=5, offset=900)
+    torch.cuda.synchronize()
+    out_q.put((rank, losses.cpu().numpy(), c.params.detach().cpu().numpy().copy(), float(res["loss"].item()),
+               c.last_mode, bool(finite.all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single(workload, n_samples, iters, optimizer, opt_kw):
+    sys.path.insert(0, ROOT)
+    from brancher_amd import engine, workloads as W
+    builder, kwargs = workload
+    model = getattr(W, builder)(W.native_api(), **kwargs)
+    c = engine.compile_model(model, None, "pathwise")
+    losses, finite = c.train(iters, n_samples, optimizer, seed=11, allow_persistent=False, **opt_kw)
+    res = c.evaluate(n_samples, seed=5, offset=900)
+    return losses.cpu().numpy(), c.params.detach().cpu().numpy().copy(), float(res["loss"].item())
+
+
+@pytest.mark.parametrize("workload,n_samples,optimizer,opt_kw", [
+    (("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3)),
+    (("build_logistic_regression", dict(dataset_size=256, batch_size=64, n_features=64, n_classes=10, q_scale=0.05)), 96, "Adam", dict(lr=5e-3)),
+    (("build_vae", dict(dataset_size=300, batch_size=20, n_features=40, hidden1=24, hidden2=16, seed=1)), 32, "Adam", dict(lr=1e-3)),
+])
+def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optimizer, opt_kw):
+    import torch.multiprocessing as mp
+    iters = 12
+    ref_losses, ref_params, ref_eval = _single(workload, n_samples, iters, optimizer, opt_kw)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, workload, n_samples, iters, optimizer, opt_kw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        losses, params, ev, mode, finite = got[rank]
+        assert finite and "allreduce" in mode, mode
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(params, ref_params, rtol=2e-5, atol=2e-6)
+        assert abs(ev - ref_eval) <= 2e-5 * abs(ref_eval)
+    # the two ranks hold bit-identical parameters (same sums after the all-reduce, same step)
+    assert np.array_equal(got[0][1], got[1][1])
