@@ -241,13 +241,21 @@ def main():
                                   local_rank=local_rank)))
         dist.destroy_process_group()
         return
-    torch.cuda.set_device(local_rank)
+    # BSVI_BENCH_SHARE_GPU=1 with BSVI_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks
+    # (the ranks share devices, collectives go through the host) — tests/test_gpu_two_ranks.py; never a measurement
+    backend = os.environ.get("BSVI_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if os.environ.get("BSVI_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            os.environ["BSVI_GRAPH"] = "0"          # host-staged collectives cannot be captured into a HIP graph
+            dist.init_process_group(backend)
 
     from brancher_amd import config, engine, workloads as W
-    config.set_device("cuda:%d" % local_rank)
+    config.set_device("cuda:%d" % device_index)
     builder, kwargs, n_per_gpu, optimizer, opt_kwargs, desc = WORKLOADS[args.workload]
     if args.samples:
         n_per_gpu = args.samples

@@ -89,3 +89,23 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
         assert abs(ev - ref_eval) <= 2e-5 * abs(ref_eval)
     # the two ranks hold bit-identical parameters (same sums after the all-reduce, same step)
     assert np.array_equal(got[0][1], got[1][1])
+
+
+def test_bench_with_two_ranks_dry_run():
+    """`python bench.py --gpus 2` end to end — self-launch, rendezvous, sharded steps, barrier + max-over-ranks timing, ONE
+    JSON line from rank 0 — with the two ranks sharing the box's GPU and gloo collectives (a dry run of the flow the driver
+    runs on an 8-GPU node with RCCL; not a measurement)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BSVI_BENCH_BACKEND="gloo", BSVI_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
+                          "--spinup-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 40 and line["scaling"] == "weak" and line["all_finite"]
+    assert line["config"]["number_samples_global"] == 2 * line["config"]["number_samples_per_gpu"] == 600
+    assert "allreduce" in line["config"]["mode"] and line["value"] > 0
+    assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
