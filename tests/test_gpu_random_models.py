@@ -205,3 +205,72 @@ def test_random_vector_model_matches_oracle(seed):
             for name, g in ref["grads"].items():
                 g = np.zeros_like(grads[name]) if g is None else g
                 assert np.abs(grads[name] - np.asarray(g).reshape(grads[name].shape)).max() <= tol * scale, (launch, estimator, name)
+
+
+def build_random_view_model(api, seed):
+    """Axis views inside links (`BF.sum(dim=…)`, `BF.transpose`, `x[…]`, resolved per element at lowering time) and observed
+    Categoricals with elementwise logits: one or two vector latents, a regression on feature rows through a sum over the
+    element axis, optional terms built from single elements / slices / a transposed row product, optionally a softmax
+    classifier over the latent's elements."""
+    rng = np.random.RandomState(9000 + seed)
+    BF = api.BF
+    d = int(rng.choice([2, 3, 5, 8]))
+    n_obs = int(rng.choice([1, 4, 9]))
+    col = lambda a: np.asarray(a, dtype=np.float64).reshape(d, 1)
+    w = api.NormalVariable(col(rng.normal(0., 0.3, d)), col(rng.uniform(0.6, 1.5, d)), "w")
+    b = api.NormalVariable(float(rng.normal(0., 0.5)), 1.5, "b")
+    feats = api.DeterministicVariable(rng.normal(0., 1., size=(n_obs, d, 1)).astype(np.float32), "features", is_observed=True)
+    unary = [lambda v: v, BF.tanh, lambda v: v * v, lambda v: BF.exp(v * 0.2)]
+    f = unary[int(rng.randint(len(unary)))]
+    lin = BF.sum(f(w) * feats, dim=1, keepdim=True) + b
+    observed = []
+    y = api.NormalVariable(lin, float(rng.uniform(0.4, 1.0)), "y")
+    observed.append((y, rng.normal(0.2, 1.0, size=(n_obs, 1, 1)).astype(np.float32)))
+    if rng.rand() < 0.7:
+        i = int(rng.randint(0, d))
+        term = w[(slice(i, i + 1),)] * float(rng.normal(1.0, 0.3))
+        if rng.rand() < 0.6:
+            row = api.RootVariable(rng.normal(0., 0.7, size=(1, d)).astype(np.float32), "row")
+            term = term + BF.sum(BF.transpose(w, 1, 2) * row, dim=2, keepdim=True)
+        t = api.NormalVariable(term, 0.8, "t")
+        observed.append((t, rng.normal(0., 1.0, size=(int(rng.choice([1, 3])), 1, 1)).astype(np.float32)))
+    if rng.rand() < 0.5:
+        j = int(rng.randint(0, d))
+        u = api.NormalVariable(w[j] * float(rng.normal(1.0, 0.2)) + 0.1, 0.9, "u")   # integer index: the axis is dropped (no other latent may join)
+        observed.append((u, rng.normal(0., 1.0, size=(2, 1, 1)).astype(np.float32)))
+    if rng.rand() < 0.6 and d >= 2:
+        n_lab = int(rng.choice([1, 5]))
+        x = api.DeterministicVariable(rng.normal(0., 1., size=(n_lab, 1, 1)).astype(np.float32), "regressor", is_observed=True)
+        k = api.CategoricalVariable(logits=w * x + BF.tanh(w) * 0.5, name="k")
+        observed.append((k, rng.randint(0, d, size=(n_lab, 1)).astype(np.float32)))
+    model = api.ProbabilisticModel([v for v, _ in observed])
+    for v, data in observed:
+        v.observe(data)
+    Qw = api.NormalVariable(col(rng.normal(0., 0.3, d)), col(rng.uniform(0.4, 1.0, d)), "w", learnable=True)
+    Qb = api.NormalVariable(float(rng.normal(0., 0.3)), 0.8, "b", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qw, Qb]))
+    return model
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_view_model_matches_oracle(seed):
+    api = W.native_api()
+    n = int(np.random.RandomState(4000 + seed).choice([2, 64, 130, 600]))
+    for estimator in ("pathwise", "blackbox"):
+        compiled = engine.compile_model(build_random_view_model(api, seed), None, estimator)
+        res = compiled.evaluate(n, seed=seed, offset=2, want_noise=True)
+        noise = res["noise"].cpu().numpy()
+        named = {name: noise[s.base:s.base + s.size].T.reshape((n,) + tuple(s.shape))
+                 for name, s in compiled.program.slot_by_name.items()}
+        ref = Oracle(build_random_view_model(api, seed), dtype=torch.float64).loss_and_grads(n, estimator, named)
+        tol = 2e-5 if estimator == "pathwise" else 3e-4
+        scale = max(1.0, max(np.abs(g).max() for g in ref["grads"].values() if g is not None))
+        for launch in ("diagnostic", "lean"):
+            if launch == "lean":
+                res = compiled.evaluate(n, noise=named)
+            loss = float(res["loss"].item())
+            assert abs(loss - ref["loss"]) <= tol * max(1.0, abs(ref["loss"])), (launch, estimator, loss, ref["loss"])
+            grads = compiled.named_grads()
+            for name, g in ref["grads"].items():
+                g = np.zeros_like(grads[name]) if g is None else g
+                assert np.abs(grads[name] - np.asarray(g).reshape(grads[name].shape)).max() <= tol * scale, (launch, estimator, name)
