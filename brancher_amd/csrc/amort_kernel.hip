@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "bsvi.h"
@@ -1106,6 +1107,7 @@ struct bsvi_amort {
     std::vector<hipEvent_t> ready;
     hipEvent_t joined = nullptr;
     bool overlap = true;
+    bool layers_cover_params = false;   // every parameter is a weight or bias of some layer: reduce_partials writes the whole block
 };
 
 static int pad4(int n) { return (n + 3) / 4 * 4; }
@@ -1202,6 +1204,19 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
             bsvi_amort_destroy(a);
             return bsvi_fail(BSVI_ERR_HIP, "side stream / event creation failed");
         }
+    }
+    {   // do the layers' weights and biases tile [0, n_params) exactly?  Then nothing has to clear the gradient block
+        std::vector<std::pair<size_t, size_t>> spans;
+        for (const Net* net : {&a->enc, &a->dec})
+            for (const auto& l : net->layers) {
+                spans.emplace_back((size_t)l.weight_off, (size_t)l.n_in * l.n_out);
+                if (l.bias_off != 0xFFFFFFFFu) spans.emplace_back((size_t)l.bias_off, (size_t)l.n_out);
+            }
+        std::sort(spans.begin(), spans.end());
+        size_t at = 0;
+        bool exact = true;
+        for (const auto& sp : spans) { exact = exact && sp.first == at; at = sp.first + sp.second; }
+        a->layers_cover_params = exact && at == (size_t)desc->n_params;
     }
     a->d.enc_layers = a->enc.layers.data();
     a->d.dec_layers = a->dec.layers.data();
@@ -1451,7 +1466,8 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     float* rowlq = rowf + R;
     int32_t* idx = (int32_t*)(rowlq + R);
 
-    HIP_TRY(hipMemsetAsync(out, 0, (BSVI_OUT_HEADER + (size_t)d.n_params) * sizeof(float), stream));
+    // (out[0], out[1] and every gradient element are WRITTEN by reduce_partials, out[2], out[3] by the finalize step)
+    if (!a->layers_cover_params) HIP_TRY(hipMemsetAsync(out, 0, (BSVI_OUT_HEADER + (size_t)d.n_params) * sizeof(float), stream));
 
     // partial sums (second part of the workspace) and the table reduce_partials works through at the end
     float* part = ws + (R * a->floats_per_row + 64 + 3) / 4 * 4;
