@@ -281,6 +281,11 @@ def main():
     #      (the driver runs K = 20) is not measured on a GPU whose clocks have not ramped yet
     compiled.train(max(args.warmup, 1), n_global, optimizer, seed=0, allow_persistent=allow_persistent, **opt_kwargs)
     barrier()
+    # no garbage collection from here to the end of the timed region: a collection inside a 200 us region would be a
+    # tenth of it, and a pause between the spin-up and the region would let the clocks drop again
+    import gc
+    gc.collect()
+    gc.disable()
     spun = 0
     if args.spinup_ms > 0:
         chunk = max(args.steps, 200)
@@ -293,9 +298,6 @@ def main():
 
     # ---- timed region: exactly K steps
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    import gc
-    gc.collect()
-    gc.disable()                      # (a collection inside a 200 us timed region would be a tenth of it)
     barrier()
     t0 = time.perf_counter()
     ev0.record()

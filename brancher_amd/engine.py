@@ -211,6 +211,8 @@ class CompiledELBO:
         self.mask_first = torch.from_numpy((active * (group == first_group)).astype(np.uint8)).to(dev)
         self._workspaces = {}
         self._train_plans = {}
+        self._plain_args = {}
+        self._shares_for = None
         self._noise_cache = None
         self.iteration = 0          # Philox counter offset: never reuse noise across calls
         if bind_parameters:
@@ -249,6 +251,16 @@ class CompiledELBO:
 
     def _elbo_args(self, n_local, n_global, base, noise=None, seed=None, offset=0, samples_out=None,
                    noise_out=None, fvalue_out=None):
+        if noise is None and samples_out is None and noise_out is None and fvalue_out is None:
+            # the plain call (Philox noise, no per-sample outputs): one struct per shard, only what changes is set again
+            key = (n_local, n_global, base)
+            args = self._plain_args.get(key)
+            if args is None:
+                args = self._plain_args[key] = self._elbo_args(n_local, n_global, base, None, seed, offset, None, None,
+                                                               torch.empty(0))     # (any non-None output: builds the struct below)
+                args.fvalue_out_dev = None
+            args.seed, args.offset, args.stream = self._seed(seed), int(offset), self._stream()
+            return args
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         return ElboArgs(params_dev=ptr(self.params), obs_dev=ptr(self.obs), noise_dev=ptr(noise),
                         seed=self._seed(seed), offset=int(offset), n_samples_local=n_local,
@@ -277,7 +289,6 @@ class CompiledELBO:
         for_gradient=True + `inference.py:100`).  Returns a dict of device tensors."""
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
-        self.native.ensure_shares(n_local)
         if n_local == 0:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         if offset is None:
@@ -332,6 +343,7 @@ class CompiledELBO:
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
         self.native.ensure_shares(n_local)
+        self._shares_for = n_local
         if self.native.engine(n_local, 2)["engine"] == "specialised":
             return False        # the program-specialised kernel keeps the whole loop in one launch
         return world == 1 and getattr(self.native, "_elbo_shares_set", 0) >= 4 \
@@ -380,7 +392,6 @@ class CompiledELBO:
         cfg = native.make_opt_cfg(optimizer, **opt_params)
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
-        self.native.ensure_shares(n_local)
         if n_local == 0:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         broadcast_from_rank0(self.params)
@@ -392,6 +403,9 @@ class CompiledELBO:
         # short training call (the driver times 20 iterations) would otherwise repeat
         plan_key = (n_local, bool(allow_persistent), world, bool(_force_sharded_path), os.environ.get("BSVI_JIT"))
         plan = self._train_plans.get(plan_key)
+        if plan is None or self._shares_for != n_local:
+            self.native.ensure_shares(n_local)          # (the share set attached to the program follows the last shard size)
+            self._shares_for = n_local
         if plan is None:
             persistent = (allow_persistent and world == 1 and not _force_sharded_path
                           and self.native.persistent_supported(n_local))
