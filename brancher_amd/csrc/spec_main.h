@@ -225,6 +225,18 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #else
 #define SPEC_STAMP(i)
 #endif
+    // One workgroup, noise kept in registers, lean build: the NEXT iteration's standard normals do not depend on anything
+    // this iteration computes, and most waves have idle time right after their body — N = 300 is five waves on four SIMDs,
+    // the hardware favours the older wave of a SIMD, so waves 0-3 wait at the barrier below for wave 4 — so the first wave
+    // of each SIMD draws its next noise THERE.  What is left after the barrier is the owners' epilogue (threads of wave 0)
+    // with only the late waves' draws beside it, instead of the epilogue followed by wave 0's own draw.
+#if SPEC_KEEP_NOISE && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS && !defined(SPEC_DEBUG_NO_DRAW) && !defined(SPEC_NO_EARLY_DRAW)
+#define SPEC_EARLY_DRAW 1
+    SpecNoise Znext;
+    bool noise_ready = false;
+#else
+#define SPEC_EARLY_DRAW 0
+#endif
     for (uint32_t it = 0; it < n_it; ++it) {
         SPEC_STAMP(0);
         // ---- one Monte-Carlo sample per lane and chunk (a workgroup of a large shard walks several chunks of samples, so
@@ -250,6 +262,8 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             SpecNoise Z;
 #if defined(SPEC_DEBUG_NO_DRAW)                                // timing experiment (BSVI_SPEC_DEFINES): what the noise costs
             for (uint32_t r = 0; r < (SPEC_KEEP_NOISE ? SPEC_KEEP_NOISE : 1); ++r) Z.z[r] = 0.25f;
+#elif SPEC_EARLY_DRAW
+            if (noise_ready) Z = Znext; else spec_draw(B, T, Z);
 #else
             spec_draw(B, T, Z);
 #endif
@@ -276,6 +290,17 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         const float bad = wave_sum(lane_bad);
         if (lane == 0) { RED[8 + 2 * wave] = vsum; RED[9 + 2 * wave] = bad; }
         SPEC_STAMP(4);
+#if SPEC_EARLY_DRAW
+        noise_ready = false;
+        if (wave < 4u && n_chunks == 1u && it + 1u < n_it) {     // (a workgroup's first four waves sit on four different SIMDs)
+            const unsigned long long off = off0 + it + 1u;
+            SpecLane Tn = T;
+            Tn.off_lo = (uint32_t)off;
+            Tn.off_hi = (uint32_t)(off >> 32);
+            spec_draw(B0, Tn, Znext);
+            noise_ready = true;
+        }
+#endif
         spec_lds_barrier();                                    // every wave's sums are in WS / RED
         SPEC_STAMP(5);
 
