@@ -167,22 +167,30 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     // the owner rows: built once, read back with four 16-byte LDS loads per iteration (kept in registers across the body
     // they are the first values the allocator spills to scratch: 2.2 us of scratch round trips per iteration)
     spec_f4* const OWN = reinterpret_cast<spec_f4*>(spec_lds + SPEC_OFF_OWN);
+    // The owners are the first threads of wave SPEC_OWNER_WAVE when the workgroup has that wave and every parameter has an
+    // owner (wave 1 by default: with five waves on four SIMDs wave 0 shares its SIMD with the fifth, and the serial epilogue
+    // should not compete with that wave's work), else of wave 0.
+#ifndef SPEC_OWNER_WAVE
+#define SPEC_OWNER_WAVE 1u
+#endif
+    const uint32_t own_base = (!SPEC_GENERIC_OWNERS && SPEC_OWNER_WAVE * 64u + SPEC_N_PARAMS <= nthreads) ? SPEC_OWNER_WAVE * 64u : 0u;
+    const uint32_t oid = tid - own_base;                      // the parameter this thread owns (if < SPEC_N_PARAMS)
     bool own_fast = false;
-    if (tid < SPEC_N_PARAMS) {
-        const uint32_t j0 = TAB[SPEC_TAB_PTR + tid], j1 = TAB[SPEC_TAB_PTR + tid + 1];
+    if (oid < SPEC_N_PARAMS) {
+        const uint32_t j0 = TAB[SPEC_TAB_PTR + oid], j1 = TAB[SPEC_TAB_PTR + oid + 1];
         if (j1 - j0 <= 2u) {
             own_fast = true;
             SpecOwn own;
             own.n = j1 - j0;
             own.mask = 0;
-            own.theta = PS[tid];
+            own.theta = PS[oid];
             own.s0 = own.s1 = own.s2 = own.st = 0.0f;
             own.a[0] = own.a[1] = own.b[0] = own.b[1] = 0.0f;
             own.pos[0] = own.pos[1] = own.k[0] = own.k[1] = own.tr[0] = own.tr[1] = 0;
             if (step) {
-                own.s0 = PS[SPEC_NP_PAD + tid]; own.s1 = PS[2 * SPEC_NP_PAD + tid];
-                own.s2 = PS[3 * SPEC_NP_PAD + tid]; own.st = PS[4 * SPEC_NP_PAD + tid];
-                own.mask = TAB[SPEC_TAB_MASK + tid];
+                own.s0 = PS[SPEC_NP_PAD + oid]; own.s1 = PS[2 * SPEC_NP_PAD + oid];
+                own.s2 = PS[3 * SPEC_NP_PAD + oid]; own.st = PS[4 * SPEC_NP_PAD + oid];
+                own.mask = TAB[SPEC_TAB_MASK + oid];
             }
 #pragma unroll
             for (uint32_t e = 0; e < 2u; ++e) {
@@ -195,7 +203,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                     own.b[e] = __uint_as_float(TAB[4 * k + 3]);
                 }
             }
-            spec_own_store(OWN + 4 * tid, own);
+            spec_own_store(OWN + 4 * oid, own);
         }
     }
 
@@ -292,7 +300,10 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         SPEC_STAMP(4);
 #if SPEC_EARLY_DRAW
         noise_ready = false;
-        if (wave < 4u && n_chunks == 1u && it + 1u < n_it) {     // (a workgroup's first four waves sit on four different SIMDs)
+#ifndef SPEC_EARLY_MASK
+#define SPEC_EARLY_MASK (1u | (1u << SPEC_OWNER_WAVE))          // wave 0 (idle at the barrier) and the owners' wave (busy after it)
+#endif
+        if (((SPEC_EARLY_MASK >> wave) & 1u) && n_chunks == 1u && it + 1u < n_it) {
             const unsigned long long off = off0 + it + 1u;
             SpecLane Tn = T;
             Tn.off_lo = (uint32_t)off;
@@ -386,7 +397,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         const float loss = -vs / (float)n_global;
         const float finite = isfinite(loss) ? 1.0f : 0.0f;
         SPEC_STAMP(7);
-        if (tid == 0) {
+        if (tid == own_base) {
             if (it + 1u == n_it) { out[0] = vs; out[1] = vb; }     // (the output block of the launch's last iteration)
             if (step) {
                 if (it + 1u == n_it) { out[2] = loss; out[3] = finite; }
@@ -398,7 +409,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         const bool last = it + 1u == n_it;
         const uint32_t mask_bit = (mode == SPEC_MODE_LOOP && it <= pretraining) ? 2u : 1u;
         if (own_fast) {
-            SpecOwn own = spec_own_load(OWN + 4 * tid);
+            SpecOwn own = spec_own_load(OWN + 4 * oid);
             float gsum = 0.0f;
 #pragma unroll
             for (uint32_t e = 0; e < 2u; ++e) {
@@ -406,32 +417,32 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             }
             const float grad = gsum * scale;
             SPEC_STAMP(8);
-            if (last || !step) out[BSVI_OUT_HEADER + tid] = grad;
+            if (last || !step) out[BSVI_OUT_HEADER + oid] = grad;
             if (step) {
                 if (finite != 0.0f && (own.mask & mask_bit)) optimizer_apply(cfg, own.theta, own.s0, own.s1, own.s2, own.st, grad);
                 SPEC_STAMP(9);
                 if (last) {
                     float* const params = SPEC_A->params;
                     float* const state = SPEC_A->state;
-                    params[tid] = own.theta;
+                    params[oid] = own.theta;
                     if (state) {
-                        state[tid] = own.s0;
-                        state[(size_t)SPEC_N_PARAMS + tid] = own.s1;
-                        state[2 * (size_t)SPEC_N_PARAMS + tid] = own.s2;
-                        state[3 * (size_t)SPEC_N_PARAMS + tid] = own.st;
+                        state[oid] = own.s0;
+                        state[(size_t)SPEC_N_PARAMS + oid] = own.s1;
+                        state[2 * (size_t)SPEC_N_PARAMS + oid] = own.s2;
+                        state[3 * (size_t)SPEC_N_PARAMS + oid] = own.st;
                     }
                 } else {
 #pragma unroll
                     for (uint32_t e = 0; e < 2u; ++e)
                         if (e < own.n) spec_store_uniform(own.k[e], own.a[e] + own.b[e] * utransform_common(own.tr[e], own.theta));
-                    OWN[4 * tid] = spec_f4{own.theta, own.s0, own.s1, own.s2};
-                    spec_lds[SPEC_OFF_OWN + 16 * tid + 4] = own.st;
+                    OWN[4 * oid] = spec_f4{own.theta, own.s0, own.s1, own.s2};
+                    spec_lds[SPEC_OFF_OWN + 16 * oid + 4] = own.st;
                 }
             }
         }
 #if SPEC_GENERIC_OWNERS      // parameters beyond the workgroup size or with more than two uniform entries: the LDS working copy
         for (uint32_t i = tid; i < SPEC_N_PARAMS; i += nthreads) {
-            if (i == tid && own_fast) continue;
+            if (i == oid && own_fast) continue;
             const float theta = PS[i];
             const uint32_t j0 = TAB[SPEC_TAB_PTR + i], j1 = TAB[SPEC_TAB_PTR + i + 1];
             float gsum = 0.0f;
