@@ -240,7 +240,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     // with only the late waves' draws beside it, instead of the epilogue followed by wave 0's own draw.
 #if SPEC_KEEP_NOISE && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS && !defined(SPEC_DEBUG_NO_DRAW) && !defined(SPEC_NO_EARLY_DRAW)
 #define SPEC_EARLY_DRAW 1
-    SpecNoise Znext;
+    SpecNoise Z;                       // lives across iterations: the early draw overwrites it once the body is done with it
     bool noise_ready = false;
 #else
 #define SPEC_EARLY_DRAW 0
@@ -267,11 +267,13 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             T.lq = 0.0f;
             T.off_lo = (uint32_t)off;
             T.off_hi = (uint32_t)(off >> 32);
+#if !SPEC_EARLY_DRAW
             SpecNoise Z;
+#endif
 #if defined(SPEC_DEBUG_NO_DRAW)                                // timing experiment (BSVI_SPEC_DEFINES): what the noise costs
             for (uint32_t r = 0; r < (SPEC_KEEP_NOISE ? SPEC_KEEP_NOISE : 1); ++r) Z.z[r] = 0.25f;
 #elif SPEC_EARLY_DRAW
-            if (noise_ready) Z = Znext; else spec_draw(B, T, Z);
+            if (!noise_ready) spec_draw(B, T, Z);
 #else
             spec_draw(B, T, Z);
 #endif
@@ -308,7 +310,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             SpecLane Tn = T;
             Tn.off_lo = (uint32_t)off;
             Tn.off_hi = (uint32_t)(off >> 32);
-            spec_draw(B0, Tn, Znext);
+            spec_draw(B0, Tn, Z);
             noise_ready = true;
         }
 #endif
