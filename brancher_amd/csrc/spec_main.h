@@ -273,7 +273,11 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #if defined(SPEC_DEBUG_NO_DRAW)                                // timing experiment (BSVI_SPEC_DEFINES): what the noise costs
             for (uint32_t r = 0; r < (SPEC_KEEP_NOISE ? SPEC_KEEP_NOISE : 1); ++r) Z.z[r] = 0.25f;
 #elif SPEC_EARLY_DRAW
+#if defined(SPEC_DEBUG_LATE_FREE)                              // timing experiment: what the late waves' own draw costs
+            if (!noise_ready && (wave < 4u || it == 0u)) spec_draw(B, T, Z);
+#else
             if (!noise_ready) spec_draw(B, T, Z);
+#endif
 #else
             spec_draw(B, T, Z);
 #endif
