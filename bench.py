@@ -366,6 +366,9 @@ def main():
             # the timed launch is the larger of the two launches in the summary (the other is the warm-up)
             if args.workload == "cfg1" and not args.samples and args.steps == 20000 and mode == "persistent":
                 traffic = pmc_traffic_bytes("cfg1_spec_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"], column="max_KB")
+            elif args.workload == "cfg1" and not args.samples and args.steps == 20 and mode == "persistent":
+                # (the driver's command line: every launch of that profile run is one 20-iteration launch)
+                traffic = pmc_traffic_bytes("cfg1_spec_k20_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"])
             elif args.workload == "cfg1" and not args.samples and mode == "stepwise":
                 traffic = pmc_traffic_bytes("cfg1_spec_stepwise_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"])
             else:
