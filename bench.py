@@ -381,8 +381,11 @@ def main():
         roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
                         iterations_per_launch=units_per_launch, launch_ms=launch_ms,
-                        note="latency-bound workload (SURVEY §8d cfg 1): %.2f us per iteration; the per-iteration "
-                             "floor of a launch-per-step design is ~5-10 us of launch latency"
+                        note="latency / issue-bound workload (SURVEY §8d cfg 1): %.2f us per iteration; HBM is not its "
+                             "roof — the noise is generated in registers, a launch fetches ~25 KB — what bounds it is the "
+                             "serial instruction stream of one wave per sample group (cfg 1: 1 350 VALU instructions per "
+                             "wave and iteration, profiles/r2/pmc_sq_loop.csv) and two workgroup barriers per iteration; "
+                             "a launch-per-step design pays ~5-10 us of launch latency per iteration on top"
                              % (dev_ms * 1e3 / args.steps))
         if dense:
             # the whole iteration (8 launches) is timed; the two MFMA GEMMs are >90 % of it (profiles/)
