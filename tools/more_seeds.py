@@ -5,7 +5,8 @@ import test_gpu_random_models as R
 fails = []
 for name, fn, rng in (("normal", R.test_random_model_matches_oracle, range(24, 160)),
                       ("generic", R.test_random_generic_model_matches_oracle, range(12, 80)),
-                      ("vector", R.test_random_vector_model_matches_oracle, range(16, 100))):
+                      ("vector", R.test_random_vector_model_matches_oracle, range(16, 100)),
+                      ("views", R.test_random_view_model_matches_oracle, range(16, 140))):
     for seed in rng:
         try:
             fn(seed)
