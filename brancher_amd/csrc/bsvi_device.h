@@ -201,6 +201,32 @@ __device__ __forceinline__ void optimizer_apply(const bsvi_opt_cfg& cfg, float& 
         p = p - step_size * (m / denom);
     }
 }
+// The same step for a caller that keeps beta1^st and beta2^st as running double-precision products (p1, p2) next to the
+// state — the in-kernel training loop: one multiply per step instead of a double-precision pow (two of them were a fifth
+// of an iteration of BASELINE config 1 under Adam).  The products differ from pow() by the rounding of at most `st`
+// multiplies (~st * 1e-16 relative): far below the single-precision rounding of the step size they end up in.
+__device__ __forceinline__ void optimizer_apply_running(const bsvi_opt_cfg& cfg, float& p, float& s0, float& s1, float& s2, float& st,
+                                                        float grad, double& p1, double& p2) {
+    if (cfg.kind == BSVI_OPT_SGD) { optimizer_apply(cfg, p, s0, s1, s2, st, grad); return; }
+    if (cfg.maximize) grad = -grad;
+    st = st + 1.0f;
+    p1 *= (double)cfg.beta1;
+    p2 *= (double)cfg.beta2;
+    if (cfg.weight_decay != 0.0f) grad += cfg.weight_decay * p;
+    const float m = s0 + (grad - s0) * (1.0f - cfg.beta1);
+    const float v = cfg.beta2 * s1 + (1.0f - cfg.beta2) * grad * grad;
+    s0 = m;
+    s1 = v;
+    const float step_size = (float)((double)cfg.lr / (1.0 - p1));
+    const float bc2_sqrt = (float)sqrt(1.0 - p2);
+    float vhat = v;
+    if (cfg.amsgrad) {
+        vhat = fmaxf(s2, v);
+        s2 = vhat;
+    }
+    const float denom = sqrtf(vhat) / bc2_sqrt + cfg.eps;
+    p = p - step_size * (m / denom);
+}
 // on memory: state planes `n_params` words apart
 __device__ __forceinline__ void optimizer_update(const bsvi_opt_cfg& cfg, float* params, float* state,
                                                  uint32_t n_params, uint32_t i, float grad) {

@@ -77,16 +77,24 @@ struct SpecOwn {
     float a[2], b[2];                // its uniform entries: U = a + b * g(theta)
     uint32_t pos[2], k[2], tr[2];
     uint32_t n, mask;                // entries (0..2); mask bits (SPEC_TAB_MASK)
+    double p1, p2;                   // Adam: beta1^st, beta2^st as running products (optimizer_apply_running)
 };
+__device__ __forceinline__ void spec_own_store_products(spec_f4* row, const SpecOwn& o) {
+    const unsigned long long a = __double_as_longlong(o.p1), b = __double_as_longlong(o.p2);
+    row[4] = spec_f4{__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b), __uint_as_float((uint32_t)(b >> 32))};
+}
 __device__ __forceinline__ void spec_own_store(spec_f4* row, const SpecOwn& o) {
     row[0] = spec_f4{o.theta, o.s0, o.s1, o.s2};
     row[1] = spec_f4{o.st, o.a[0], o.b[0], o.a[1]};
     row[2] = spec_f4{o.b[1], __uint_as_float(o.pos[0]), __uint_as_float(o.pos[1]), __uint_as_float(o.k[0])};
     row[3] = spec_f4{__uint_as_float(o.k[1]), __uint_as_float(o.tr[0] | (o.tr[1] << 8) | (o.n << 16) | (o.mask << 24)), 0.0f, 0.0f};
+    spec_own_store_products(row, o);
 }
 __device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
-    const spec_f4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+    const spec_f4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4];
     SpecOwn o;
+    o.p1 = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(q4.y) << 32) | __float_as_uint(q4.x)));
+    o.p2 = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(q4.w) << 32) | __float_as_uint(q4.z)));
     o.theta = q0.x; o.s0 = q0.y; o.s1 = q0.z; o.s2 = q0.w;
     o.st = q1.x; o.a[0] = q1.y; o.b[0] = q1.z; o.a[1] = q1.w;
     o.b[1] = q2.x; o.pos[0] = __float_as_uint(q2.y); o.pos[1] = __float_as_uint(q2.z); o.k[0] = __float_as_uint(q2.w);
@@ -185,12 +193,18 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             own.mask = 0;
             own.theta = PS[oid];
             own.s0 = own.s1 = own.s2 = own.st = 0.0f;
+            own.p1 = own.p2 = 1.0;
             own.a[0] = own.a[1] = own.b[0] = own.b[1] = 0.0f;
             own.pos[0] = own.pos[1] = own.k[0] = own.k[1] = own.tr[0] = own.tr[1] = 0;
             if (step) {
                 own.s0 = PS[SPEC_NP_PAD + oid]; own.s1 = PS[2 * SPEC_NP_PAD + oid];
                 own.s2 = PS[3 * SPEC_NP_PAD + oid]; own.st = PS[4 * SPEC_NP_PAD + oid];
                 own.mask = TAB[SPEC_TAB_MASK + oid];
+                const bsvi_opt_cfg cfg0 = SPEC_A->cfg;       // once per launch: the running products start at beta^st
+                if (cfg0.kind != BSVI_OPT_SGD && own.st != 0.0f) {
+                    own.p1 = pow((double)cfg0.beta1, (double)own.st);
+                    own.p2 = pow((double)cfg0.beta2, (double)own.st);
+                }
             }
 #pragma unroll
             for (uint32_t e = 0; e < 2u; ++e) {
@@ -203,7 +217,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                     own.b[e] = __uint_as_float(TAB[4 * k + 3]);
                 }
             }
-            spec_own_store(OWN + 4 * oid, own);
+            spec_own_store(OWN + 5 * oid, own);
         }
     }
 
@@ -415,7 +429,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         const bool last = it + 1u == n_it;
         const uint32_t mask_bit = (mode == SPEC_MODE_LOOP && it <= pretraining) ? 2u : 1u;
         if (own_fast) {
-            SpecOwn own = spec_own_load(OWN + 4 * oid);
+            SpecOwn own = spec_own_load(OWN + 5 * oid);
             float gsum = 0.0f;
 #pragma unroll
             for (uint32_t e = 0; e < 2u; ++e) {
@@ -425,7 +439,8 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             SPEC_STAMP(8);
             if (last || !step) out[BSVI_OUT_HEADER + oid] = grad;
             if (step) {
-                if (finite != 0.0f && (own.mask & mask_bit)) optimizer_apply(cfg, own.theta, own.s0, own.s1, own.s2, own.st, grad);
+                if (finite != 0.0f && (own.mask & mask_bit))
+                    optimizer_apply_running(cfg, own.theta, own.s0, own.s1, own.s2, own.st, grad, own.p1, own.p2);
                 SPEC_STAMP(9);
                 if (last) {
                     float* const params = SPEC_A->params;
@@ -441,8 +456,9 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #pragma unroll
                     for (uint32_t e = 0; e < 2u; ++e)
                         if (e < own.n) spec_store_uniform(own.k[e], own.a[e] + own.b[e] * utransform_common(own.tr[e], own.theta));
-                    OWN[4 * oid] = spec_f4{own.theta, own.s0, own.s1, own.s2};
-                    spec_lds[SPEC_OFF_OWN + 16 * oid + 4] = own.st;
+                    OWN[5 * oid] = spec_f4{own.theta, own.s0, own.s1, own.s2};
+                    spec_lds[SPEC_OFF_OWN + SPEC_OWN_WORDS * oid + 4] = own.st;
+                    if (cfg.kind != BSVI_OPT_SGD) spec_own_store_products(OWN + 5 * oid, own);
                 }
             }
         }

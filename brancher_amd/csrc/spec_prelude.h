@@ -140,7 +140,8 @@ __device__ __forceinline__ PhiloxKey spec_key(const SpecBody& A, const SpecLane&
 #define SPEC_OFF_TAB (SPEC_OFF_PS + 5 * SPEC_NP_PAD)
 #define SPEC_OWN_ROWS (SPEC_N_PARAMS < SPEC_MAX_THREADS ? SPEC_N_PARAMS : SPEC_MAX_THREADS)
 #define SPEC_OFF_OWN (SPEC_OFF_TAB + SPEC_TAB_WORDS)
-#define SPEC_OFF_SCR (SPEC_OFF_OWN + 16 * SPEC_OWN_ROWS)
+#define SPEC_OWN_WORDS 20                  // an owner row: SpecOwn packed (spec_main.h)
+#define SPEC_OFF_SCR (SPEC_OFF_OWN + SPEC_OWN_WORDS * SPEC_OWN_ROWS)
 #define SPEC_OFF_TR (SPEC_OFF_SCR + SPEC_SCR_FLOATS)
 #define SPEC_LDS_FLOATS (SPEC_OFF_TR + SPEC_MAX_WAVES * SPEC_TR_FLOATS)
 __shared__ __attribute__((aligned(16))) float spec_lds[SPEC_LDS_FLOATS];

@@ -611,7 +611,7 @@ static uint32_t lds_floats(uint32_t n_params, uint32_t n_uniform, uint32_t n_obs
     const uint32_t u_pad = (n_uniform + n_obs + 3) / 4 * 4, nu_pad = (n_uniform + 3) / 4 * 4;
     const uint32_t ws_pad = tiled(n_pos, geom) ? (n_pos + 3) / 4 * 4 + 4 : 4 * n_pos + 4;
     const uint32_t np_pad = (n_params + 3) / 4 * 4 + 4, tab = (4 * n_uniform + (2 * n_params + 1) + 2 * n_pos + 3) / 4 * 4 + 4;
-    const uint32_t own = 16 * (n_params < max_threads ? n_params : max_threads), scr = 4 * (n_pos + 2) + 4;
+    const uint32_t own = 20 * (n_params < max_threads ? n_params : max_threads), scr = 4 * (n_pos + 2) + 4;     // SPEC_OWN_WORDS
     return u_pad + 2 * nu_pad + W * ws_pad + (2 * W + 8) + 5 * np_pad + tab + own + scr + (tiled(n_pos, geom) ? W * 64 * 68 : 0);
 }
 
