@@ -274,3 +274,33 @@ def test_random_view_model_matches_oracle(seed):
             for name, g in ref["grads"].items():
                 g = np.zeros_like(grads[name]) if g is None else g
                 assert np.abs(grads[name] - np.asarray(g).reshape(grads[name].shape)).max() <= tol * scale, (launch, estimator, name)
+
+
+@pytest.mark.parametrize("family,seed", [(f, s) for f in ("normal", "generic", "vector", "views") for s in range(6)])
+@pytest.mark.parametrize("optimizer,kw", [("SGD", dict(lr=2e-3)), ("Adam", dict(lr=1e-2))])
+def test_random_model_training_loop_equals_launch_per_iteration(family, seed, optimizer, kw):
+    """The in-kernel training loop (one launch for all iterations: noise of the next iteration drawn early, owners in wave 1,
+    Adam's bias corrections as running products) against one launch per iteration on the same Philox streams: the loss
+    curves and the trained parameters agree to rounding, for sample counts on both sides of a wave and a SIMD boundary."""
+    api = W.native_api()
+    build = {"normal": build_random_model, "generic": build_random_generic_model, "vector": build_random_vector_model,
+             "views": build_random_view_model}[family]
+    n = int(np.random.RandomState(7000 + seed).choice([40, 64, 130, 300, 500]))
+    runs = []
+    for opts in (dict(), dict(allow_persistent=False)):
+        try:
+            c = engine.compile_model(build(api, seed), None, "pathwise")
+        except Exception as exc:
+            from brancher_amd.lowering import LoweringError
+            if isinstance(exc, LoweringError):
+                pytest.skip("not lowered: %s" % exc)
+            raise
+        losses, finite = c.train(15, n, optimizer, seed=100 + seed, **opts, **kw)
+        runs.append((losses.cpu().numpy(), c.params.detach().cpu().numpy().copy(), bool(finite.all()), c.last_mode))
+    (l0, p0, f0, m0), (l1, p1, f1, m1) = runs
+    if not (np.isfinite(l1).all() and f1):
+        pytest.skip("non-finite losses for this draw")
+    assert m1 == "stepwise" and f0
+    scale = max(1.0, np.abs(l1).max())
+    assert np.abs(l0 - l1).max() <= 2e-5 * scale, (m0, l0, l1)
+    assert np.abs(p0 - p1).max() <= 2e-5 * max(1.0, np.abs(p1).max()), m0
