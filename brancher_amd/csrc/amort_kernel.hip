@@ -18,11 +18,13 @@
 //                              gemm<NN> dX = (dY W) * act'(x)
 //   reduce_partials   ONE launch at the end: every gradient element = the sum of its slices in slice order — the
 //                     gradients (and the loss sums) are bit-reproducible call to call, no float atomics anywhere
-//   layers with a side of width <= 8 (latent heads, first decoder layer) use memory-bound skinny_* kernels instead
+//   layers with a side of width <= 8 (latent heads, first decoder layer) use memory-bound kernels instead: rowdot_kernel
+//   (16 lanes per row, DPP row sums), outer_kernel (four-wide outer products, eight rows in flight), skinny_k4[nt]_kernel
+//   (four outputs per thread); the one-output-per-thread skinny_* kernels are the unaligned fallbacks
 //   amort_latent_bwd  joins decoder dz with prior / entropy / score-function terms, loss sums
-// GEMMs: 128x128x16 workgroup tiles, four waves of 64x64, v_mfma_f32_32x32x2_f32, k-major LDS tiles (row stride 132
-// words: transposing stores and MFMA operand reads are both conflict-free), register-staged double-buffered global
-// loads, workgroup order remapped so that the tiles sharing rows of the tall operand sit on one XCD.
+// GEMMs: 128x128x16 or 64x128x16 workgroup tiles, four waves, v_mfma_f32_32x32x2_f32, k-major LDS tiles (row stride 132
+// words: transposing stores and MFMA operand reads are both conflict-free), two register sets of global loads in flight
+// three steps ahead of their use, workgroup order remapped so that the tiles sharing rows of the tall operand sit on one XCD.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
