@@ -892,8 +892,7 @@ class _Lowering:
         given = [k for k in ("scale_tril", "covariance_matrix", "precision_matrix") if k in links]
         mat = self.constant_value(links[given[0]].expr)
         if mat is None:
-            raise LoweringError("the %s of %r depends on learnable or sampled values: only multivariate normals with a "
-                                "constant covariance are lowered" % (given[0], v.name))
+            return self.mvn_terms_symbolic(v, given[0])
         mat = np.asarray(mat, dtype=np.float64)
         mat = mat.reshape(mat.shape[-2:])
         if mat.shape[0] != mat.shape[1]:
@@ -931,6 +930,70 @@ class _Lowering:
                 t = self.mk("mul", (self.mk("imm", (), float(A[i, j])), d))
                 u = t if u is None else self.mk("add", (u, t))
             terms.append((_Term(v, i), u, [self.mk("imm", (), 0.0), self.mk("imm", (), float(L[i, i]))], (1, 1, 1)))
+        return terms
+
+    kMaxSymbolicMvn = 10
+
+    def mvn_terms_symbolic(self, v, given):
+        """The same D Normal terms when the covariance depends on learnable or sampled values (a Gaussian process whose
+        kernel hyper-parameters are inferred: `covariance_matrix = exp(-sqdist / (2 ell^2)) * amp + jitter` with a latent
+        `ell`).  The Cholesky factorisation itself becomes part of the per-sample program, unrolled symbolically over the
+        elements of the covariance link (Cholesky-Banachiewicz, D <= kMaxSymbolicMvn):
+            L_ij = (c_ij - sum_{k<j} L_ik L_jk) / L_jj,   L_ii = sqrt(c_ii - sum_{k<i} L_ik^2),
+        then forward substitution  u_i = d_i - sum_{j<i} L_ij w_j,  w_i = u_i / L_ii  with d = x - m, and
+            log N(x | m, L L^T) = sum_i log Normal(u_i | 0, L_ii).
+        ~D^3 / 3 multiply-adds of ordinary link arithmetic: the reverse mode through the factorisation comes for free, shared
+        entries of L become derived slots (computed once per sample)."""
+        if given == "precision_matrix":
+            raise LoweringError("a precision matrix that depends on learnable or sampled values is not lowered (covariance_matrix "
+                                "and scale_tril are)")
+        links = v.link.expressions()
+        mat = self.from_expr(links[given].expr, self.p_value)
+        B, dim, dim2 = mat.shape
+        if B != 1 or dim != dim2:
+            raise LoweringError("%s of %r must be one square matrix per sample (shape %r)" % (given, v.name, mat.shape))
+        if dim > self.kMaxSymbolicMvn:
+            raise LoweringError("%r: a %dx%d covariance that depends on learnable or sampled values (the factorisation is "
+                                "unrolled per sample; limit %d)" % (v.name, dim, dim, self.kMaxSymbolicMvn))
+        value = self.p_value(v)
+        loc = self.from_expr(links["loc"].expr, self.p_value)
+        for what, node in (("value", value), ("loc", loc)):
+            if int(np.prod(node.shape)) not in (1, dim):
+                raise LoweringError("the %s of %r has %d elements, its covariance is %dx%d" % (what, v.name, int(np.prod(node.shape)), dim, dim))
+        mk = self.mk
+
+        def vec(node, j):                       # element j of a D-vector stored along whichever axis (or a scalar)
+            if int(np.prod(node.shape)) == 1:
+                return self.element_of(node, (0, 0, 0))
+            idx = [0, 0, 0]
+            idx[[a for a in range(3) if node.shape[a] == dim][0]] = j
+            return self.element_of(node, tuple(idx))
+
+        L = [[None] * dim for _ in range(dim)]
+        for i in range(dim):
+            for j in range(i + 1):
+                if given == "scale_tril":
+                    L[i][j] = self.element_of(mat, (0, i, j))
+                    continue
+                acc = self.element_of(mat, (0, i, j))
+                for k in range(j):
+                    acc = mk("sub", (acc, mk("mul", (L[i][k], L[j][k]))))
+                L[i][j] = mk("call:sqrt", (acc,)) if i == j else mk("truediv", (acc, L[j][j]))
+
+        class _Term:
+            def __init__(self, var, i):
+                self.is_observed, self.name = var.is_observed, "%s[%d]" % (var.name, i)
+                self.distribution = D.NormalDistribution()
+                self.b_axis = 1
+
+        zero_loc = loc.op == "imm" and loc.attr == 0.0
+        terms, w = [], []
+        for i in range(dim):
+            u = vec(value, i) if zero_loc else mk("sub", (vec(value, i), vec(loc, i)))
+            for j in range(i):
+                u = mk("sub", (u, mk("mul", (L[i][j], w[j]))))
+            w.append(mk("truediv", (u, L[i][i])))
+            terms.append((_Term(v, i), u, [mk("imm", (), 0.0), L[i][i]], (1, 1, 1)))
         return terms
 
     # ---------------------------------------------------------------- categorical likelihood terms

@@ -237,6 +237,30 @@ def build_gp_regression(api, n=8, length_scale=0.6, jitter=1e-3, noise=0.2, seed
     return model
 
 
+def build_gp_hyperparameters(api, n=5, jitter=1e-2, noise=0.2, seed=0, learnable_amplitude=True):
+    """A Gaussian process whose kernel hyper-parameters are inferred: f ~ MultivariateNormal(0, K(ell, amp)) with the
+    squared-exponential covariance  K = amp * exp(-sqdist / (2 ell^2)) + jitter I  of fixed inputs, a LogNormal latent
+    length-scale `ell` (inferred with a LogNormal posterior) and — type-II maximum likelihood — a learnable amplitude in the
+    joint model; y ~ Normal(f, noise) observed (`distributions.py:314-331`, `standard_variables.py:317-347`; the covariance
+    is an ordinary link expression, `stochastic_processes.py:29-40` builds it the same way from a kernel function)."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    x = np.linspace(-2., 2., n)
+    sqdist = api.RootVariable(((x[:, None] - x[None, :]) ** 2).astype(np.float32), "sqdist")
+    eye = api.RootVariable((jitter * np.eye(n)).astype(np.float32), "jitter")
+    ell = api.LogNormalVariable(-0.5, 0.3, "ell")
+    amp = api.RootVariable(1.3, "amplitude", learnable=True) if learnable_amplitude else 1.3
+    K = BF.exp(sqdist * (-0.5) / (ell * ell)) * amp + eye
+    f = api.MultivariateNormalVariable(loc=np.zeros((n,)), covariance_matrix=K, name="f")
+    y = api.NormalVariable(f, noise, name="y")
+    model = api.ProbabilisticModel([y])
+    y.observe((np.sin(2 * np.pi * 0.3 * x) + noise * rng.normal(0., 1., (1, n))).astype(np.float32))
+    Qell = api.LogNormalVariable(-0.4, 0.2, "ell", learnable=True)
+    Qf = api.NormalVariable(loc=np.zeros((n,)), scale=0.8, name="f", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qell, Qf]))
+    return model
+
+
 def build_map_estimate(api, n_obs=12, seed=0):
     """Point estimates (MAP, `inference.py:251-275`; `examples/MAP_logistic_regression.py:46-56`): the "posterior" is a
     model of learnable RootVariables carrying the latents' names.  No sampling and no entropy: the loss is

@@ -49,6 +49,7 @@ CASES = {
     "vector_latent_d4_N70": ("build_vector_latent", dict(n_obs=9, dim=4), 70, 14, dict(iters=4, n=33, optimizer="SGD", lr=1e-3)),
     "linear_predictor_d4_N40": ("build_linear_predictor", dict(n_obs=5, dim=4), 40, 17, dict(iters=4, n=24, optimizer="Adam", lr=1e-2)),
     "softmax_classifier_C3_N60": ("build_softmax_classifier", dict(n_obs=6, n_classes=3), 60, 19, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
+    "gp_hyperparameters_n5_N80": ("build_gp_hyperparameters", dict(n=5), 80, 23, dict(iters=5, n=32, optimizer="Adam", lr=1e-2)),
     "learnable_model_N60": ("build_learnable_model", dict(n_obs=15), 60, 13, dict(iters=6, n=40, optimizer="Adam", lr=0.02)),
     "discrete_latent_N200": ("build_discrete_latent", dict(n_obs=8), 200, 12, None),
     "heavy_tails_N64": ("build_heavy_tails", dict(n_obs=12), 64, 6, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),

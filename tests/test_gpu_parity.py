@@ -127,6 +127,7 @@ def test_training_trajectory_matches_reference_golden(case, persistent):
     ("build_linear_predictor", dict(n_obs=7, dim=5), 900),       # BF.sum / BF.transpose / x[...] views
     ("build_softmax_classifier", dict(n_obs=9, n_classes=4), 700),   # observed Categorical, elementwise logits
     ("build_gp_regression", dict(n=6), 500),                      # MultivariateNormal prior, constant covariance
+    ("build_gp_hyperparameters", dict(n=6), 400),                 # ... covariance with a latent length-scale: Cholesky in the program
 ])
 @pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
 def test_philox_path_matches_oracle_on_emitted_noise(builder, kwargs, n, estimator):

@@ -210,3 +210,21 @@ def test_axis_views_refuse_what_the_reference_would_mis_broadcast():
         lower_with(w[7])
     assert lower_with(BF.sum(BF.transpose(w, 1, 2), dim=2, keepdim=True)).summary()["n_latent"] == 4
     assert lower_with(w[(slice(1, 3),)][1]).summary()["n_latent"] == 4   # element 2 of w through a slice then an index
+
+
+def test_multivariate_normal_with_a_sampled_covariance_is_unrolled():
+    """`lowering.mvn_terms_symbolic`: a covariance that depends on a latent length-scale -> the Cholesky factorisation becomes
+    link arithmetic of the per-sample program (D Normal terms, entries of L shared as derived slots); limits are refusals"""
+    api = W.native_api()
+    model = W.build_gp_hyperparameters(api, n=5)
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    s = program.summary()
+    assert s["n_latent"] == 6 and s["n_derived"] >= 15            # ell + f[5]; at least the 15 entries of L are shared values
+    names = [p.name for p, _, _, _ in program.parameters]
+    assert "amplitude" in names                                     # the joint model's learnable kernel amplitude gets a gradient
+    with pytest.raises(lowering.LoweringError, match="limit"):
+        big = W.build_gp_hyperparameters(api, n=12)
+        lowering.lower(big, big.posterior_model, "pathwise")
+    # a constant covariance still takes the host-side factorisation (no derived slots for L)
+    const = W.build_gp_regression(api, n=5)
+    assert lowering.lower(const, const.posterior_model, "pathwise").summary()["n_derived"] < 5
