@@ -128,6 +128,8 @@ def test_training_trajectory_matches_reference_golden(case, persistent):
     ("build_softmax_classifier", dict(n_obs=9, n_classes=4), 700),   # observed Categorical, elementwise logits
     ("build_gp_regression", dict(n=6), 500),                      # MultivariateNormal prior, constant covariance
     ("build_gp_hyperparameters", dict(n=6), 400),                 # ... covariance with a latent length-scale: Cholesky in the program
+    ("build_gp_hyperparameters", dict(n=3, learnable_amplitude=False), 130),
+    ("build_gp_hyperparameters", dict(n=9, jitter=3e-2), 70),
 ])
 @pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
 def test_philox_path_matches_oracle_on_emitted_noise(builder, kwargs, n, estimator):
