@@ -288,7 +288,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             for (uint32_t r = 0; r < (SPEC_KEEP_NOISE ? SPEC_KEEP_NOISE : 1); ++r) Z.z[r] = 0.25f;
 #elif SPEC_EARLY_DRAW
 #if defined(SPEC_DEBUG_LATE_FREE)                              // timing experiment: what the late waves' own draw costs
-            if (!noise_ready && (wave < 4u || it == 0u)) spec_draw(B, T, Z);
+            if (!noise_ready && (!((SPEC_DEBUG_LATE_FREE >> wave) & 1u) || it == 0u)) spec_draw(B, T, Z);   // mask of waves whose draws are skipped
 #else
             if (!noise_ready) spec_draw(B, T, Z);
 #endif
@@ -323,7 +323,11 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #ifndef SPEC_EARLY_MASK
 #define SPEC_EARLY_MASK (1u | (1u << SPEC_OWNER_WAVE))          // wave 0 (idle at the barrier) and the owners' wave (busy after it)
 #endif
+#if defined(SPEC_DEBUG_LATE_FREE)
+        if (((SPEC_EARLY_MASK >> wave) & 1u) && !((SPEC_DEBUG_LATE_FREE >> wave) & 1u) && n_chunks == 1u && it + 1u < n_it) {
+#else
         if (((SPEC_EARLY_MASK >> wave) & 1u) && n_chunks == 1u && it + 1u < n_it) {
+#endif
             const unsigned long long off = off0 + it + 1u;
             SpecLane Tn = T;
             Tn.off_lo = (uint32_t)off;
