@@ -228,3 +228,34 @@ def test_multivariate_normal_with_a_sampled_covariance_is_unrolled():
     # a constant covariance still takes the host-side factorisation (no derived slots for L)
     const = W.build_gp_regression(api, n=5)
     assert lowering.lower(const, const.posterior_model, "pathwise").summary()["n_derived"] < 5
+
+
+def test_matrix_kernels_keep_nothing_in_scratch_memory(tmp_path):
+    """The MFMA GEMM kernels of the dense and amortised paths (and the narrow-layer kernels beside them) must not use
+    private (scratch) memory: a staging fragment that the compiler parks there costs a scratch store and load per step —
+    round 1 shipped exactly that in 7 of 11 launches of a config 5 iteration.  Read from the code objects
+    embedded in libbsvi.so (llvm-objdump --offloading, llvm-readelf --notes: `.private_segment_fixed_size` per kernel)."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("no LLVM binary tools in this image")
+    so = os.path.join(os.path.dirname(os.path.abspath(native.__file__)), "libbsvi.so")
+    work = tmp_path / "libbsvi.so"
+    shutil.copy(so, work)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(work)], check=True, capture_output=True, cwd=tmp_path)
+    seen = {}
+    for name in os.listdir(tmp_path):
+        if "gfx950" not in name:
+            continue
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / name)], capture_output=True, text=True).stdout
+        for block in notes.split("- .agpr_count:")[1:]:
+            kernel = re.search(r"\.name:\s+(\S+)", block)
+            scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+            if kernel and scratch:
+                seen[kernel.group(1)] = int(scratch.group(1))
+    watched = [k for k in seen if any(tag in k for tag in ("gemm_kernel", "dense_forwardILi10E", "dense_backward", "rowdot_kernel",
+                                                           "outer_kernel", "skinny_k4", "reduce_partials", "amort_lik"))]
+    assert len(watched) >= 12, sorted(seen)
+    assert {k: seen[k] for k in watched if seen[k] != 0} == {}
