@@ -76,3 +76,26 @@ def test_unrolling_limit_declines():
     # either outcome is legal; when declined the reason is reported
     if src is None:
         assert b"instruction visits" in native.load().bsvi_last_error()
+
+
+def test_config1_kernel_has_no_spills(tmp_path, monkeypatch):
+    """the training-loop kernel of BASELINE config 1: every per-sample value in a register — no scratch memory, no spilled
+    registers (BSVI_JIT_DUMP writes the code object hiprtc produced; llvm-readelf --notes reads its metadata)"""
+    import os
+    import subprocess
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("no llvm-readelf in this image")
+    model = W.build_readme_ar(W.native_api(), T=20)
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    dump = str(tmp_path / "kernel.co")
+    monkeypatch.setenv("BSVI_JIT_DUMP", dump)
+    assert native.jit_compile(native.specialised_source(program, 0) + "\n// (unique: not served from the code cache)\n") > 0
+    notes = subprocess.run([readelf, "--notes", dump], capture_output=True, text=True).stdout
+    meta = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count):\s+(\d+)", notes)}
+    assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0, meta
+    assert meta["vgpr_count"] <= 256                      # up to 8 waves (512 threads) of one workgroup: 256 registers per lane
+    # (scalar registers do spill — ~70 words to vector-register lanes, v_writelane / v_readlane: the 20 round keys of the Philox
+    #  schedule shared by the calls of a draw, the optimizer's constants.  Forcing the keys to be recomputed per call removes a
+    #  third of them but serialises the calls: 190 -> 163 k it/s, DESIGN 4.7)
+    assert meta["sgpr_spill_count"] <= 96, meta
