@@ -30,6 +30,7 @@ def grad_check(named, ref, tol):
         assert np.abs(named[name] - g_ref).max() <= tol * scale + 1e-7 * scale, name
 
 
+@pytest.mark.skipif(os.environ.get("BSVI_JIT") == "0", reason="the suite is being run on the interpreter engine")
 def test_default_engine_is_the_specialised_kernel():
     c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
     for mode in (0, 1, 2):
@@ -90,18 +91,15 @@ def test_in_kernel_loop_equals_launch_per_iteration(optimizer, kw):
         assert np.abs(params[other] - params[0]).max() <= 2e-5
 
 
-def test_pretraining_iterations_in_the_loop_kernel():
+def test_pretraining_iterations_in_the_loop_kernel(monkeypatch):
     """model parameters are stepped only after `pretraining_iterations` (inference.py:102-104): in-kernel loop vs the
     interpreter's persistent trainer"""
     def run(jit):
-        os.environ["BSVI_JIT"] = jit
-        try:
-            model = W.build_learnable_model(W.native_api())
-            c = engine.compile_model(model, None, "pathwise")
-            losses, _ = c.train(30, 60, "Adam", seed=5, pretraining_iterations=10, lr=5e-2)
-            return losses.cpu().numpy(), c.params.cpu().numpy().copy()
-        finally:
-            os.environ.pop("BSVI_JIT", None)
+        monkeypatch.setenv("BSVI_JIT", jit)
+        model = W.build_learnable_model(W.native_api())
+        c = engine.compile_model(model, None, "pathwise")
+        losses, _ = c.train(30, 60, "Adam", seed=5, pretraining_iterations=10, lr=5e-2)
+        return losses.cpu().numpy(), c.params.cpu().numpy().copy()
     (la, pa), (lb, pb) = run("1"), run("0")
     assert rel_err(la, lb) <= 5e-6
     assert np.abs(pa - pb).max() <= 5e-5 * (1 + np.abs(pb).max())
