@@ -49,13 +49,20 @@ __device__ __forceinline__ void spec_lds_barrier() {
 // the rare ones stay out of line behind a real branch.
 __device__ __noinline__ float spec_utransform_rare(uint32_t t, float x) { return utransform((int)t, x); }
 __device__ __noinline__ float spec_utransform_grad_rare(uint32_t t, float x) { return utransform_grad((int)t, x); }
+#ifndef SPEC_RARE_TRANSFORMS
+#define SPEC_RARE_TRANSFORMS 1
+#endif
 __device__ __forceinline__ float utransform_common(uint32_t t, float x) {
+#if SPEC_RARE_TRANSFORMS
     if (t > BSVI_UT_SIGMOID) return spec_utransform_rare(t, x);
+#endif
     const float soft = softplusf_(x), sig = sigmoidf_(x);
     return t == BSVI_UT_IDENTITY ? x : (t == BSVI_UT_SOFTPLUS ? soft : sig);
 }
 __device__ __forceinline__ float spec_utransform_grad(uint32_t t, float x) {
+#if SPEC_RARE_TRANSFORMS
     if (t > BSVI_UT_SIGMOID) return spec_utransform_grad_rare(t, x);
+#endif
     const float s = spec_rcp(1.0f + __expf(-x));               // sigmoid(x) = softplus'(x)
     const float soft = x > 20.0f ? 1.0f : s;
     return t == BSVI_UT_IDENTITY ? 1.0f : (t == BSVI_UT_SOFTPLUS ? soft : s * (1.0f - s));
@@ -409,17 +416,18 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         float* const loss_slot = SPEC_A->loss_slot;
         float* const finite_slot = SPEC_A->finite_slot;
         const bsvi_opt_cfg cfg = SPEC_A->cfg;
-        // (literal trip counts and clamped addresses: the LDS reads issue back to back instead of one round trip per wave)
+        // (literal trip counts and literal addresses — every row of RED exists, the rows of waves this launch does not have are
+        //  read and not selected: the LDS reads are one base register + immediates and issue back to back)
         float vs = 0.0f, vb = 0.0f;
 #pragma unroll
         for (uint32_t w = 0; w < SPEC_MAX_WAVES; ++w) {
-            const uint32_t ww = w < rows ? w : 0u;
-            const float a = RED[8 + 2 * ww], b = RED[9 + 2 * ww];
+            const float a = RED[8 + 2 * w], b = RED[9 + 2 * w];
             vs += w < rows ? a : 0.0f;
             vb += w < rows ? b : 0.0f;
         }
+        // -vs / n is finite exactly when vs is (n >= 1): the optimizer step does not wait for the division
+        const float finite = isfinite(vs) ? 1.0f : 0.0f;
         const float loss = -vs / (float)n_global;
-        const float finite = isfinite(loss) ? 1.0f : 0.0f;
         SPEC_STAMP(7);
         if (tid == own_base) {
             if (it + 1u == n_it) { out[0] = vs; out[1] = vb; }     // (the output block of the launch's last iteration)

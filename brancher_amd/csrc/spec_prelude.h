@@ -207,16 +207,16 @@ __device__ __forceinline__ void spec_du_flush(const float* TRw, float* WSw, uint
 #define SPEC_WS_CELLS (4u * SPEC_N_POS)
 #define SPEC_WS_CELL(pos) (4u * (pos))
 #endif
-// the total of position `pos` over the first `rows` waves' cells, waves in order (literal trip count, clamped addresses:
-// the reads issue back to back)
+// the total of position `pos` over the first `rows` waves' cells, waves in order (literal trip count and row offsets — the
+// rows of all SPEC_MAX_WAVES waves exist, those past `rows` are read and not selected: one address, immediates, back to back)
 __device__ __forceinline__ float spec_pos_total(const float* WS, uint32_t pos, uint32_t rows) {
     float s = 0.0f;
 #pragma unroll
     for (uint32_t w = 0; w < SPEC_MAX_WAVES; ++w) {
 #if SPEC_TILE
-        const float t = WS[(w < rows ? w : 0u) * SPEC_WS_PAD + pos];
+        const float t = WS[w * SPEC_WS_PAD + pos];
 #else
-        const spec_f4 q = *reinterpret_cast<const spec_f4*>(WS + (w < rows ? w : 0u) * SPEC_WS_PAD + 4u * pos);
+        const spec_f4 q = *reinterpret_cast<const spec_f4*>(WS + w * SPEC_WS_PAD + 4u * pos);
         const float t = (q.x + q.y) + (q.z + q.w);
 #endif
         s += w < rows ? t : 0.0f;

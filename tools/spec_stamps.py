@@ -14,10 +14,11 @@ from brancher_amd import engine, workloads as W     # noqa: E402
 api = W.native_api()
 c = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
 n_it = 20000
+n_samples = int(sys.argv[1]) if len(sys.argv) > 1 else 300      # 64: one wave, thread 0 is an owner and waits for nobody
 for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    losses, _ = c.train(n_it, 300, "SGD", lr=1e-3, seed=0)
+    losses, _ = c.train(n_it, n_samples, "SGD", lr=1e-3, seed=0)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     s = losses[:12].cpu().numpy()
