@@ -52,11 +52,16 @@ __device__ __noinline__ float spec_utransform_grad_rare(uint32_t t, float x) { r
 #ifndef SPEC_RARE_TRANSFORMS
 #define SPEC_RARE_TRANSFORMS 1
 #endif
+#ifndef SPEC_UT_MASK
+#define SPEC_UT_MASK 0xFFu
+#endif
 __device__ __forceinline__ float utransform_common(uint32_t t, float x) {
 #if SPEC_RARE_TRANSFORMS
     if (t > BSVI_UT_SIGMOID) return spec_utransform_rare(t, x);
 #endif
-    const float soft = softplusf_(x), sig = sigmoidf_(x);
+    // (both evaluated and selected — unless the program's table has no entry of the kind: SPEC_UT_MASK)
+    const float soft = ((SPEC_UT_MASK >> BSVI_UT_SOFTPLUS) & 1u) ? softplusf_(x) : x;
+    const float sig = ((SPEC_UT_MASK >> BSVI_UT_SIGMOID) & 1u) ? sigmoidf_(x) : x;
     return t == BSVI_UT_IDENTITY ? x : (t == BSVI_UT_SOFTPLUS ? soft : sig);
 }
 __device__ __forceinline__ float spec_utransform_grad(uint32_t t, float x) {
@@ -442,10 +447,15 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         const uint32_t mask_bit = (mode == SPEC_MODE_LOOP && it <= pretraining) ? 2u : 1u;
         if (own_fast) {
             SpecOwn own = spec_own_load(OWN + 5 * oid);
+            // (both positions' rows requested before either sum: an unused entry has position 0, read and not selected)
+            float tot[2];
+#pragma unroll
+            for (uint32_t e = 0; e < 2u; ++e) tot[e] = spec_pos_total(WS, own.pos[e], rows);
             float gsum = 0.0f;
 #pragma unroll
             for (uint32_t e = 0; e < 2u; ++e) {
-                if (e < own.n) gsum += spec_pos_total(WS, own.pos[e], rows) * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
+                const float term = tot[e] * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
+                gsum += e < own.n ? term : 0.0f;
             }
             const float grad = gsum * scale;
             SPEC_STAMP(8);

@@ -647,8 +647,9 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     if (!ok) { why = "the program's tables do not fit LDS"; delete s; return nullptr; }
     bool all_fast = d.n_params <= 64;      // every parameter owned by a thread of the smallest workgroup, <= 2 positions
     for (uint32_t i = 0; i < d.n_params && all_fast; ++i) all_fast = s->pu_ptr_host[i + 1] - s->pu_ptr_host[i] <= 2;
-    bool rare_transforms = false;
-    for (uint32_t k = 0; k < d.n_uniform; ++k) rare_transforms = rare_transforms || d.uniform[k].transform > BSVI_UT_SIGMOID;
+    uint32_t ut_mask = 0;                  // the transforms the program's uniform table uses
+    for (uint32_t k = 0; k < d.n_uniform; ++k) ut_mask |= 1u << (d.uniform[k].transform & 31u);
+    const bool rare_transforms = (ut_mask >> (BSVI_UT_SIGMOID + 1)) != 0;
     for (int gi = 0; gi < 2; ++gi) {
         const Geom& G = s->geom[gi];
         for (int v = 0; v < 2; ++v) {
@@ -667,7 +668,7 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
             // (all parameters "fast": the epilogue's generic loop over the LDS working copy is compiled out)
             src += fmt("#define SPEC_GENERIC_OWNERS %d\n", all_fast ? 0 : 1);
             // (the out-of-line transforms — exp, log, tanh, sqrt, square — are calls: programs without them compile none)
-            src += fmt("#define SPEC_RARE_TRANSFORMS %d\n", rare_transforms ? 1 : 0);
+            src += fmt("#define SPEC_RARE_TRANSFORMS %d\n#define SPEC_UT_MASK 0x%xu\n", rare_transforms ? 1 : 0, ut_mask);
             src += "#include \"spec_prelude.h\"\n";
             src += "namespace bsvi {\n";
             src += "__device__ __forceinline__ void spec_draw(const SpecBody& A, const SpecLane& T, SpecNoise& Z) {\n";
