@@ -383,7 +383,7 @@ def main():
                         iterations_per_launch=units_per_launch, launch_ms=launch_ms,
                         note="latency / issue-bound workload (SURVEY §8d cfg 1): %.2f us per iteration; HBM is not its "
                              "roof — the noise is generated in registers, a launch fetches ~25 KB — what bounds it is the "
-                             "serial instruction stream of one wave per sample group (cfg 1: 1 350 VALU instructions per "
+                             "serial instruction stream of one wave per sample group (cfg 1: 1 335 VALU instructions per "
                              "wave and iteration, profiles/r2/pmc_sq_loop.csv) and two workgroup barriers per iteration; "
                              "a launch-per-step design pays ~5-10 us of launch latency per iteration on top"
                              % (dev_ms * 1e3 / args.steps))
