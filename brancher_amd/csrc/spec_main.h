@@ -161,17 +161,54 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         const float* obs = SPEC_A->obs;
         const float* params = SPEC_A->params;
         const float* state = SPEC_A->state;
-        for (uint32_t i = tid; i < 4u * SPEC_N_UNIFORM; i += nthreads) TAB[i] = uniform[i];
-        for (uint32_t i = tid; i < SPEC_N_PARAMS + 1u; i += nthreads) TAB[SPEC_TAB_PTR + i] = pu_ptr[i];
-        for (uint32_t j = tid; j < SPEC_N_POS; j += nthreads) { TAB[SPEC_TAB_POS + j] = pu_pos[j]; TAB[SPEC_TAB_IDX + j] = pu_idx[j]; }
-        for (uint32_t i = tid; i < SPEC_N_OBS; i += nthreads) spec_lds[SPEC_N_UNIFORM + i] = obs[i];
         const uint8_t* mask = SPEC_A->mask;
         const uint8_t* mask_first = SPEC_A->mask_first;
-        for (uint32_t i = tid; i < SPEC_N_PARAMS; i += nthreads) {
+        // The first trip of every copy loop is REQUESTED before any of them is stored: eight dependent global round trips
+        // (~1 us each, the tables are cold) in a row were most of the launch's prologue — a third of a 20-iteration launch.
+        const bool h_uni = tid < 4u * SPEC_N_UNIFORM, h_ptr = tid < SPEC_N_PARAMS + 1u, h_pos = tid < SPEC_N_POS,
+                   h_obs = tid < SPEC_N_OBS, h_par = tid < SPEC_N_PARAMS;
+        uint32_t r_uni = 0, r_ptr = 0, r_pos = 0, r_idx = 0, r_mask = 0;
+        float r_obs = 0.0f, r_par = 0.0f, r_st[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const bool h_uni2 = tid + nthreads < 4u * SPEC_N_UNIFORM;            // (four words per entry: the table is the long one)
+        uint32_t r_uni2 = 0;
+        if (h_uni) r_uni = uniform[tid];
+        if (h_uni2) r_uni2 = uniform[tid + nthreads];
+        if (h_ptr) r_ptr = pu_ptr[tid];
+        if (h_pos) { r_pos = pu_pos[tid]; r_idx = pu_idx[tid]; }
+        if (h_obs) r_obs = obs[tid];
+        if (h_par) {
+            r_par = params[tid];
+            if (step) {
+                if (state) {
+#pragma unroll
+                    for (uint32_t s = 0; s < 4u; ++s) r_st[s] = state[(size_t)s * SPEC_N_PARAMS + tid];
+                }
+                r_mask = (mask[tid] ? 1u : 0u) | (mask_first[tid] ? 2u : 0u);
+            }
+        }
+        asm volatile("" ::: "memory");        // (the loads stay in front of the stores: the compiler would pair them up again)
+        if (h_uni) TAB[tid] = r_uni;
+        if (h_uni2) TAB[tid + nthreads] = r_uni2;
+        if (h_ptr) TAB[SPEC_TAB_PTR + tid] = r_ptr;
+        if (h_pos) { TAB[SPEC_TAB_POS + tid] = r_pos; TAB[SPEC_TAB_IDX + tid] = r_idx; }
+        if (h_obs) spec_lds[SPEC_N_UNIFORM + tid] = r_obs;
+        if (h_par) {
+            PS[tid] = r_par;
+            if (step) {
+#pragma unroll
+                for (uint32_t s = 0; s < 4u; ++s) PS[(1u + s) * SPEC_NP_PAD + tid] = r_st[s];      // no state buffer: a fresh optimizer (all zeros), nothing written back
+                TAB[SPEC_TAB_MASK + tid] = r_mask;
+            }
+        }
+        for (uint32_t i = tid + 2u * nthreads; i < 4u * SPEC_N_UNIFORM; i += nthreads) TAB[i] = uniform[i];
+        for (uint32_t i = tid + nthreads; i < SPEC_N_PARAMS + 1u; i += nthreads) TAB[SPEC_TAB_PTR + i] = pu_ptr[i];
+        for (uint32_t j = tid + nthreads; j < SPEC_N_POS; j += nthreads) { TAB[SPEC_TAB_POS + j] = pu_pos[j]; TAB[SPEC_TAB_IDX + j] = pu_idx[j]; }
+        for (uint32_t i = tid + nthreads; i < SPEC_N_OBS; i += nthreads) spec_lds[SPEC_N_UNIFORM + i] = obs[i];
+        for (uint32_t i = tid + nthreads; i < SPEC_N_PARAMS; i += nthreads) {
             PS[i] = params[i];
             if (step) {
 #pragma unroll
-                for (uint32_t s = 0; s < 4u; ++s)      // no state buffer: a fresh optimizer (all zeros), nothing written back
+                for (uint32_t s = 0; s < 4u; ++s)
                     PS[(1u + s) * SPEC_NP_PAD + i] = state ? state[(size_t)s * SPEC_N_PARAMS + i] : 0.0f;
                 TAB[SPEC_TAB_MASK + i] = (mask[i] ? 1u : 0u) | (mask_first[i] ? 2u : 0u);
             }
