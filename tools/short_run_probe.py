@@ -16,7 +16,7 @@ t_end = time.perf_counter() + 0.3
 while time.perf_counter() < t_end:
     c.train(200, 300, "SGD", lr=1e-3, seed=0)
     torch.cuda.synchronize()
-for K in (20, 200, 2000):
+for K in (1, 2, 5, 20, 200, 2000):
     rows = []
     for _ in range(30):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
