@@ -65,6 +65,6 @@ struct Launch {
 };
 int launch(Spec* s, const bsvi_program* p, const Launch& L);
 // geometry of that launch (tests / bench)
-void geometry(const Spec* s, uint32_t n_local, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes);
+void geometry(const Spec* s, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes);
 
 }  // namespace bsvi_spec

@@ -2232,7 +2232,7 @@ extern "C" int bsvi_program_engine(const bsvi_program* p, uint32_t n_local, int 
                                    uint32_t* lds_bytes) {
     if (!p) return 0;
     if (!p->spec || !bsvi_spec::applies(p->spec, n_local, mode)) return 0;
-    bsvi_spec::geometry(p->spec, n_local, n_blocks, n_threads, lds_bytes);
+    bsvi_spec::geometry(p->spec, n_local, mode, n_blocks, n_threads, lds_bytes);
     return 1;
 }
 

@@ -230,7 +230,32 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #ifndef SPEC_OWNER_WAVE
 #define SPEC_OWNER_WAVE 1u
 #endif
-    const uint32_t own_base = (!SPEC_GENERIC_OWNERS && SPEC_OWNER_WAVE * 64u + SPEC_N_PARAMS <= nthreads) ? SPEC_OWNER_WAVE * 64u : 0u;
+    // The draw wave.  An iteration takes as long as the chain of the owners' wave: its draw, its body, the sums, the epilogue
+    // (a single wave alone runs at nearly the speed of five, tools/wave_scaling.sh).  The in-kernel loop of a one-workgroup
+    // launch is therefore given one wave more than the samples need (specialize.cpp, geo): it carries no samples and, beside
+    // the epilogue, draws the NEXT iteration's normals of the owners' wave into its own — otherwise unused — transpose tile,
+    // where the owners' wave picks them up behind the next barrier; every other wave draws beside the epilogue too, none
+    // ahead of the barrier.  (Measured, tools/draw_wave_probe.sh: 64 samples 4.68 -> 3.83 us per iteration, 128: 4.79 -> 3.89,
+    // 256: 4.91 -> 4.64; with five and more sample waves two of them share a SIMD and their late draws, not the owners'
+    // chain, set the pace: 300 samples 5.0 -> 5.0.  The roles are a kernel variant of their own, SPEC_WITH_DRAW_WAVE, used
+    // for up to four sample waves: merely compiled in they cost the plain loop 3 %.)  The draws are a function of (seed,
+    // offset, sample index, row) only: who computes them does not change a bit of the result.
+#if SPEC_TILE && SPEC_KEEP_NOISE && SPEC_KEEP_NOISE <= 68 && !SPEC_GENERIC_OWNERS && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS \
+    && !defined(SPEC_DEBUG_NO_DRAW) && !defined(SPEC_NO_EARLY_DRAW) && !defined(SPEC_DEBUG_LATE_FREE) && defined(SPEC_WITH_DRAW_WAVE)
+#define SPEC_DRAW_WAVE 1
+    const bool has_draw_wave = mode == SPEC_MODE_LOOP && G == 1u && W >= 2u && (SPEC_A->n_local + 63u) / 64u < W;
+    const uint32_t fed_index = W == 2u ? 0u : 1u;         // the owners' wave, as without a draw wave (SPEC_OWNER_WAVE)
+    const bool draw_wave = __builtin_amdgcn_readfirstlane((has_draw_wave && wave == W - 1u) ? 1 : 0) != 0;
+    const bool fed_wave = __builtin_amdgcn_readfirstlane((has_draw_wave && wave == fed_index) ? 1 : 0) != 0;
+    float* const NZ = spec_lds + SPEC_OFF_TR + (W - 1u) * SPEC_TR_FLOATS + lane;
+    if (draw_wave) for (uint32_t k = lane; k < SPEC_WS_PAD; k += 64u) WSw[k] = 0.0f;     // its row of sums stays zero
+#else
+#define SPEC_DRAW_WAVE 0
+    const bool has_draw_wave = false, draw_wave = false, fed_wave = false;
+    const uint32_t fed_index = 1u;
+#endif
+    const uint32_t own_base = has_draw_wave ? fed_index * 64u
+                            : (!SPEC_GENERIC_OWNERS && SPEC_OWNER_WAVE * 64u + SPEC_N_PARAMS <= nthreads) ? SPEC_OWNER_WAVE * 64u : 0u;
     const uint32_t oid = tid - own_base;                      // the parameter this thread owns (if < SPEC_N_PARAMS)
     bool own_fast = false;
     if (oid < SPEC_N_PARAMS) {
@@ -339,7 +364,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #if defined(SPEC_DEBUG_LATE_FREE)                              // timing experiment: what the late waves' own draw costs
             if (!noise_ready && (!((SPEC_DEBUG_LATE_FREE >> wave) & 1u) || it == 0u)) spec_draw(B, T, Z);   // mask of waves whose draws are skipped
 #else
-            if (!noise_ready) spec_draw(B, T, Z);
+            if (!noise_ready && !draw_wave && !(fed_wave && it > 0u)) spec_draw(B, T, Z);
 #endif
 #else
             spec_draw(B, T, Z);
@@ -351,12 +376,20 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 for (uint32_t k = lane; k < SPEC_WS_CELLS; k += 64u) WSw[k] = 0.0f;     // ... and the last one's sums are consumed
 #endif
             }
+#if SPEC_DRAW_WAVE
+            if (fed_wave && it > 0u) {                         // drawn by the draw wave beside the last epilogue
+#pragma unroll
+                for (uint32_t r = 0; r < SPEC_KEEP_NOISE; ++r) Z.z[r] = NZ[64u * r];
+            }
+#endif
             SPEC_STAMP(2);
 #if !defined(SPEC_DEBUG_NO_BODY)
-            spec_body(B, T, Z, WSw);
+            if (!draw_wave) {
+                spec_body(B, T, Z, WSw);
 #if SPEC_TILE
-            spec_du_flush(spec_lds + SPEC_OFF_TR + wave * SPEC_TR_FLOATS, WSw, lane);
+                spec_du_flush(spec_lds + SPEC_OFF_TR + wave * SPEC_TR_FLOATS, WSw, lane);
 #endif
+            }
 #endif
             SPEC_STAMP(3);
             const float value = (SPEC_ESTIMATOR == BSVI_EST_BLACKBOX) ? (T.lq * T.f + T.f) : T.f;
@@ -375,7 +408,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #if defined(SPEC_DEBUG_LATE_FREE)
         if (((SPEC_EARLY_MASK >> wave) & 1u) && !((SPEC_DEBUG_LATE_FREE >> wave) & 1u) && n_chunks == 1u && it + 1u < n_it) {
 #else
-        if (((SPEC_EARLY_MASK >> wave) & 1u) && n_chunks == 1u && it + 1u < n_it) {
+        if (((SPEC_EARLY_MASK >> wave) & 1u) && !has_draw_wave && n_chunks == 1u && it + 1u < n_it) {
 #endif
             const unsigned long long off = off0 + it + 1u;
             SpecLane Tn = T;
@@ -387,6 +420,22 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #endif
         spec_lds_barrier();                                    // every wave's sums are in WS / RED
         SPEC_STAMP(5);
+#if SPEC_DRAW_WAVE
+        if (draw_wave && it + 1u < n_it) {                     // (the owners' wave read the last set behind the barrier before the body)
+            const unsigned long long off = off0 + it + 1u;
+            SpecLane Tn = T;
+            Tn.n = fed_index * 64u + lane;
+            Tn.active = Tn.n < B0.n_local;
+            Tn.nc = Tn.active ? Tn.n : (B0.n_local - 1u);
+            Tn.nidx = sample_base + Tn.nc;
+            Tn.off_lo = (uint32_t)off;
+            Tn.off_hi = (uint32_t)(off >> 32);
+            SpecNoise Zf;
+            spec_draw(B0, Tn, Zf);
+#pragma unroll
+            for (uint32_t r = 0; r < SPEC_KEEP_NOISE; ++r) NZ[64u * r] = Zf.z[r];
+        }
+#endif
 
         // ---- several workgroups: every one publishes its row of sums, the last to arrive adds the rows in order
         uint32_t rows = W;                                     // rows of WS / RED that hold sums

@@ -582,13 +582,14 @@ struct Spec {
     uint32_t n_pos = 0;                                   // positions of the transpose tile (>= n_ugrad)
     Geom geom[2];
     std::vector<uint32_t> pu_ptr_host, pu_pos_host, pu_idx_host;   // CSR theta -> (position, uniform entry)
-    Variant variant[4];                                   // [geometry][0 lean, 1 diagnostic]
+    Variant variant[5];                                   // [geometry][0 lean, 1 diagnostic]; 4: lean one-workgroup kernel with the draw wave
     void* dev = nullptr;                                  // [tickets: 256 B][pu_ptr][pu_pos][pu_idx]
     unsigned int* tickets = nullptr;
     const uint32_t* pu_ptr = nullptr;
     const uint32_t* pu_pos = nullptr;
     const uint32_t* pu_idx = nullptr;
     uint32_t n_cus = 256;
+    bool draw_wave_ok = false;                            // the in-kernel loop may be given a wave that draws for the owners' wave
     uint32_t launch_seq = 0;
     std::mutex mu;
 };
@@ -647,6 +648,8 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     if (!ok) { why = "the program's tables do not fit LDS"; delete s; return nullptr; }
     bool all_fast = d.n_params <= 64;      // every parameter owned by a thread of the smallest workgroup, <= 2 positions
     for (uint32_t i = 0; i < d.n_params && all_fast; ++i) all_fast = s->pu_ptr_host[i + 1] - s->pu_ptr_host[i] <= 2;
+    // (spec_main.h, SPEC_DRAW_WAVE: the extra wave hands the normals over through its own, unused, transpose tile)
+    s->draw_wave_ok = all_fast && tiled(s->n_pos, GEOM_ONE) && d.n_noise > 0 && d.n_noise <= kKeepEpsRows;
     uint32_t ut_mask = 0;                  // the transforms the program's uniform table uses
     for (uint32_t k = 0; k < d.n_uniform; ++k) ut_mask |= 1u << (d.uniform[k].transform & 31u);
     const bool rare_transforms = (ut_mask >> (BSVI_UT_SIGMOID + 1)) != 0;
@@ -685,6 +688,8 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
             s->variant[2 * gi + v].src = std::move(src);
         }
     }
+    // (a kernel of its own: the extra roles cost the plain loop 3 % when they are merely compiled in)
+    s->variant[4].src = "#define SPEC_WITH_DRAW_WAVE 1\n" + s->variant[0].src;
     return s;
 }
 
@@ -790,10 +795,21 @@ static int ensure_compiled(Spec* s, int v) {
 // ---------------------------------------------------------------------------------------------------------------
 //  launch
 // ---------------------------------------------------------------------------------------------------------------
-struct Geo { uint32_t blocks, threads; int geom; };
-static Geo geo(const Spec* s, uint32_t n_local) {
+struct Geo { uint32_t blocks, threads; int geom; bool draw_wave = false; };
+// The in-kernel loop is given one wave more than the samples need: it carries no samples and draws the next iteration's
+// normals of the owners' wave, whose chain — draw, body, sums, epilogue — is what an iteration takes (spec_main.h).
+static bool draw_wave() {
+    const char* e = getenv("BSVI_SPEC_DRAW_WAVE");        // (read per call: the tests switch it within a process)
+    return !(e && e[0] == '0');
+}
+static Geo geo(const Spec* s, uint32_t n_local, int mode = MODE_SUMS) {
     const uint32_t waves = (n_local + 63) / 64;
-    if (waves <= s->geom[GEOM_ONE].max_threads / 64) return Geo{1, waves * 64, GEOM_ONE};
+    if (waves <= s->geom[GEOM_ONE].max_threads / 64) {
+        // (up to four sample waves — one per SIMD: beyond that two of them share a SIMD and their draws set the pace, not the owners' chain)
+        const bool extra = mode == MODE_LOOP && s->draw_wave_ok && draw_wave() && waves <= 4 && waves + 1 <= s->geom[GEOM_ONE].max_threads / 64
+                           && !s->variant[4].failed;
+        return Geo{1, (waves + (extra ? 1u : 0u)) * 64, GEOM_ONE, extra};
+    }
     // many samples: 256-thread workgroups (one wave per SIMD), two per CU at most; beyond that every workgroup walks
     // several chunks of 256 samples
     const uint32_t threads = s->geom[GEOM_MANY].max_threads;
@@ -804,8 +820,8 @@ static Geo geo(const Spec* s, uint32_t n_local) {
     return Geo{blocks, threads, GEOM_MANY};
 }
 
-void geometry(const Spec* s, uint32_t n_local, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes) {
-    const Geo g = geo(s, n_local);
+void geometry(const Spec* s, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes) {
+    const Geo g = geo(s, n_local, mode);
     if (n_blocks) *n_blocks = g.blocks;
     if (n_threads) *n_threads = g.threads;
     if (lds_bytes) *lds_bytes = s->geom[g.geom].lds_bytes;
@@ -832,11 +848,13 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     if (!a->obs_dev && s->n_obs) return bsvi_fail(BSVI_ERR_INVALID, "obs_dev is null");
     if (!a->out_dev) return bsvi_fail(BSVI_ERR_INVALID, "out_dev is null");
     if (!a->n_samples_local || !a->n_samples_global) return bsvi_fail(BSVI_ERR_INVALID, "zero samples");
-    const Geo g = geo(s, a->n_samples_local);
-    const int v = 2 * g.geom + ((a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev) ? 1 : 0);
+    Geo g = geo(s, a->n_samples_local, L.mode);
+    int v = 2 * g.geom + ((a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev) ? 1 : 0);
     uint32_t seq;
     {
-        std::lock_guard<std::mutex> g(s->mu);
+        std::lock_guard<std::mutex> lock(s->mu);
+        if (g.draw_wave && v == 0 && ensure_compiled(s, 4) == BSVI_OK) v = 4;
+        else if (g.draw_wave) { g.threads -= 64; g.draw_wave = false; }        // (diagnostic kernel, or the variant did not compile)
         const int rc = ensure_compiled(s, v);
         if (rc) return rc;
         seq = s->launch_seq++;

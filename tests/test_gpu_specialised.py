@@ -36,6 +36,9 @@ def test_default_engine_is_the_specialised_kernel():
     for mode in (0, 1, 2):
         info = c.native.engine(300, mode)
         assert info["engine"] == "specialised" and info["n_blocks"] == 1 and info["n_threads"] == 320
+    # up to four sample waves the in-kernel loop (mode 2) has one wave more than the samples need: it draws for the owners' wave
+    for n, waves in ((50, 1), (128, 2), (256, 4)):
+        assert c.native.engine(n, 1)["n_threads"] == 64 * waves and c.native.engine(n, 2)["n_threads"] == 64 * (waves + 1)
     many = c.native.engine(262144, 1)
     assert many["engine"] == "specialised" and many["n_threads"] == 256 and many["n_blocks"] <= 512
     assert c.native.engine(262144, 2)["engine"] == "interpreter"      # the in-kernel loop is a one-workgroup mode
@@ -89,6 +92,22 @@ def test_in_kernel_loop_equals_launch_per_iteration(optimizer, kw):
     for other in (1, 2):
         assert rel_err(curves[other], curves[0]) <= 2e-6
         assert np.abs(params[other] - params[0]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("n", [50, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("optimizer,kw", [("SGD", dict(lr=1e-3)), ("Adam", dict(lr=1e-2))])
+def test_draw_wave_loop_equals_plain_loop(n, optimizer, kw, monkeypatch):
+    """the loop kernel with the extra wave that draws for the owners' wave (up to four sample waves) against the same loop
+    without it and against launch-per-iteration: the draws depend on (seed, offset, sample, row) only — bit-identical curves"""
+    curves = []
+    for env, opts in (("1", dict()), ("0", dict()), ("1", dict(allow_persistent=False))):
+        monkeypatch.setenv("BSVI_SPEC_DRAW_WAVE", env)
+        c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+        losses, finite = c.train(30, n, optimizer, seed=4, **opts, **kw)
+        assert bool(finite.all())
+        curves.append(losses.cpu().numpy())
+    assert np.array_equal(curves[0], curves[1])
+    assert rel_err(curves[2], curves[0]) <= 2e-6
 
 
 def test_pretraining_iterations_in_the_loop_kernel(monkeypatch):
