@@ -247,7 +247,18 @@ class CompiledELBO:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _seed(self, seed):
+        """the Philox key of a call (rank 0's on every rank): a collective + a host sync when `seed` is None on several
+        ranks, so `evaluate` / `train` resolve it once, up front, and hand the integer down"""
         return shared_seed(seed, self.device)
+
+    def _resolved(self, seed):
+        if seed is None:
+            _, world = dist_info()
+            if world > 1:
+                raise native.NativeError("internal: the seed of a multi-rank call must be resolved before the launch path "
+                                         "(CompiledELBO._seed), never inside it")
+            return shared_seed(None, self.device)
+        return int(seed) & 0x7FFFFFFFFFFFFFFF
 
     def _elbo_args(self, n_local, n_global, base, noise=None, seed=None, offset=0, samples_out=None,
                    noise_out=None, fvalue_out=None):
@@ -259,11 +270,14 @@ class CompiledELBO:
                 args = self._plain_args[key] = self._elbo_args(n_local, n_global, base, None, seed, offset, None, None,
                                                                torch.empty(0))     # (any non-None output: builds the struct below)
                 args.fvalue_out_dev = None
-            args.seed, args.offset, args.stream = self._seed(seed), int(offset), self._stream()
+            # (seed is an integer here: callers resolve `None` ONCE per call, outside any stream capture — resolving it
+            #  is a broadcast + a host sync on several ranks)
+            args.seed, args.offset, args.stream = self._resolved(seed), int(offset), self._stream()
+            args.offset_dev = None
             return args
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         return ElboArgs(params_dev=ptr(self.params), obs_dev=ptr(self.obs), noise_dev=ptr(noise),
-                        seed=self._seed(seed), offset=int(offset), n_samples_local=n_local,
+                        seed=self._resolved(seed), offset=int(offset), n_samples_local=n_local,
                         n_samples_global=n_global, sample_base=base, out_dev=ptr(self.out),
                         samples_out_dev=ptr(samples_out), noise_out_dev=ptr(noise_out),
                         fvalue_out_dev=ptr(fvalue_out), workspace_dev=ptr(self.workspace(n_local)),
@@ -296,6 +310,7 @@ class CompiledELBO:
             self.iteration += 1
         dev = self.device
         p = self.program
+        seed = self._seed(seed)
         noise_t = self._noise_tensor(noise, number_samples, base, n_local)
         samples = torch.empty((p.n_noise, n_local), device=dev) if want_samples else None
         noise_o = torch.empty((p.n_noise, n_local), device=dev) if want_noise else None
@@ -366,7 +381,10 @@ class CompiledELBO:
         def capture(n_steps):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                args = self._elbo_args(n_local, n_global, base, None, seed, 0)        # on the capturing stream
+                # a PRIVATE argument block (the cached one of the plain calls must not keep a pointer to `counters`),
+                # on the capturing stream
+                args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, n_global, base, None, seed, 0))
+                args.stream = self._stream()
                 args.offset_dev = counters.data_ptr()
                 for _ in range(n_steps):
                     native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
@@ -377,12 +395,17 @@ class CompiledELBO:
             return graph
 
         unroll = min(K, _graph_unroll())
+        # the executables, their private pools and the counters they point at stay alive while the replays run
+        keep = [counters]
+        self._graphs = getattr(self, "_graphs", [])[-3:] + [keep]
         main = capture(unroll)
+        keep.append(main)
         for _ in range(K // unroll):
             main.replay()
         if K % unroll:
-            capture(K % unroll).replay()
-        self._graphs = getattr(self, "_graphs", [])[-3:] + [main]      # keep the executables alive while they run
+            tail = capture(K % unroll)
+            keep.append(tail)
+            tail.replay()
 
     def train(self, number_iterations, number_samples, optimizer="Adam", noise_seq=None, seed=None,
               pretraining_iterations=0, allow_persistent=True, minibatch_seq=None, _force_sharded_path=False,
@@ -395,6 +418,7 @@ class CompiledELBO:
         if n_local == 0:
             raise ValueError("number_samples={} is smaller than the number of GPUs {}".format(number_samples, world))
         broadcast_from_rank0(self.params)
+        seed = self._seed(seed)
         dev = self.device
         p = self.program
         K = int(number_iterations)
@@ -438,9 +462,18 @@ class CompiledELBO:
                     self.native.handle, shares, len(shares), C.byref(args), C.byref(cfg), ptr(self.params), ptr(state),
                     ptr(self.mask_all), ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite)))
             else:
-                native.check(self.lib.bsvi_train_persistent2(
-                    self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(self.mask_all),
-                    ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite)))
+                call = lambda st: self.lib.bsvi_train_persistent2(
+                    self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(st), ptr(self.mask_all),
+                    ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite))
+                rc = call(state)
+                if rc != 0 and state is None:
+                    # the plan said "specialised in-kernel loop" before the lazy hiprtc compile; if that compile then
+                    # fails the library leaves the program to the interpreter's trainer, which needs a state buffer:
+                    # forget the plan and run this call (and every later one) with one
+                    self._train_plans[plan_key] = (persistent, shares, False)
+                    loss_curve, finite, state = training_buffers(K, p.n_params, dev, with_state=True)
+                    rc = call(state)
+                native.check(rc)
             self.last_mode = "persistent"
             return loss_curve, finite
 

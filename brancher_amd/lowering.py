@@ -225,6 +225,7 @@ class _Lowering:
         self.temp_base = 0
         self.max_temps = 0
         self.view_rank, self.view_memo, self.elem_memo, self.view_terms = {}, {}, {}, 0
+        self.slot_rank = {}
 
     # ---------------------------------------------------------------- IR construction
     def mk(self, op, args=(), attr=None, shape=None):
@@ -266,8 +267,7 @@ class _Lowering:
             return self.mk("imm", (), float(np.asarray(v).reshape(-1)[0]) if isinstance(v, np.ndarray) else float(v))
         if e.op in sym.BINARY_OPS:
             a, b = self.from_expr(e.args[0], ctx), self.from_expr(e.args[1], ctx)
-            self.check_ranks((a, b), e.op)
-            return self.mk(e.op, (a, b))
+            return self.ranked(self.mk(e.op, (a, b)), self.check_ranks((a, b), e.op))
         if e.op == "getitem":
             if isinstance(e.attr, str):
                 raise LoweringError("named outputs (%r) exist for network links only (amortised path)" % (e.attr,))
@@ -283,13 +283,13 @@ class _Lowering:
                 raise LoweringError("keyword arguments of BF.%s are not supported by the fused kernel" % fn)
             args = [self.from_expr(a, ctx) if isinstance(a, sym.Expr) else self.mk("imm", (), float(a))
                     for a in e.args]
-            self.check_ranks(args, "BF." + fn)
+            rank = self.check_ranks(args, "BF." + fn)
             if fn in UNARY_CALLS and len(args) == 1:
-                return self.mk("call:" + fn, (args[0],))
+                return self.ranked(self.mk("call:" + fn, (args[0],)), rank)
             if fn in ("delta",) and len(args) == 2:
-                return self.mk("delta", tuple(args))
+                return self.ranked(self.mk("delta", tuple(args)), rank)
             if fn in ("add", "sub", "mul", "div", "true_divide", "pow") and len(args) == 2:
-                return self.mk({"div": "truediv", "true_divide": "truediv"}.get(fn, fn), tuple(args))
+                return self.ranked(self.mk({"div": "truediv", "true_divide": "truediv"}.get(fn, fn), tuple(args)), rank)
             raise LoweringError("BF.%s is not in the fused kernel's op set" % fn)
         raise LoweringError("link expression node %r is not supported by the fused kernel" % (e.op,))
 
@@ -318,8 +318,33 @@ class _Lowering:
 
     def rank_of(self, node):
         """rank of the link tensor a node stands for: 3 ([rows, d1, d2]) unless an integer index or a sum without
-        keepdim dropped an axis"""
+        keepdim dropped an axis, or the leaf it derives from has fewer axes: inside a link the reference hands torch the
+        value as [samples x datapoints] + shape[2:] (`variables.py:436-449`, `utilities.py:179-186`), and an unobserved
+        1-D array (d,) is stored [1, 1, d] (`utilities.py:236`) — rank 2, so `dim=-1` / `dim=1` is its d axis and `dim=2`
+        does not exist"""
         return self.view_rank.get(node.key, 3)
+
+    def ranked(self, node, rank):
+        if rank != 3:
+            self.view_rank[node.key] = rank
+        return node
+
+    def root_node(self, var):
+        """a RootVariable leaf; its rank inside links is that of its stored value minus the sample axis"""
+        v = var.value if not var.learnable else var.parameter.numpy()
+        return self.ranked(self.mk("root", (), var, self.root_shape(var)), min(max(np.ndim(v) - 1, 1), 3))
+
+    def z_node(self, var):
+        """a sampled posterior variable; its sample has the rank its parameters broadcast to (`slot_rank`)"""
+        return self.ranked(self.mk("z", (), var, self.slots[var].shape), self.slot_rank.get(var, 3))
+
+    def sample_rank(self, params):
+        """rank (inside links) of a draw from parameters `params`: `broadcast_and_squeeze` (`utilities.py:143-149`) views
+        them [N, B, 1, 1] when every one is a single element per row, else pads the shorter ones with ONE trailing axis
+        (`uniform_shapes`, `utilities.py:274-279`) — the draw has the longest rank"""
+        if all(p.shape[1] * p.shape[2] == 1 for p in params):
+            return 3
+        return max([self.rank_of(p) for p in params if p.op != "imm"] or [3])
 
     def check_ranks(self, args, what):
         """torch aligns TRAILING axes: [rows, d] op [rows, d1, d2] would pair the row axis with d1 (the reference then
@@ -327,8 +352,10 @@ class _Lowering:
         ranks = {self.rank_of(a) for a in args if a.op != "imm"}
         if len(ranks) > 1:
             raise LoweringError("%s combines link values of different rank (an integer index or a sum without keepdim "
-                                "dropped an axis on one side): torch would broadcast the sample axis against an element "
-                                "axis.  Use keepdim=True / a slice" % what)
+                                "dropped an axis on one side, or a 1-D array meets a matrix): torch would broadcast the "
+                                "sample axis against an element axis.  Use keepdim=True / a slice / arrays of equal rank"
+                                % what)
+        return ranks.pop() if ranks else 3
 
     def view_node(self, op, arg, attr, shape, rank):
         node = self.mk(op, (arg,), attr, shape)
@@ -465,13 +492,13 @@ class _Lowering:
     # ---------------------------------------------------------------- model contexts
     def q_value(self, var):
         if isinstance(var, RootVariable):
-            return self.mk("root", (), var, self.root_shape(var))
+            return self.root_node(var)
         if getattr(var, "_type", None) == "Deterministic node":
             return self.from_expr(var.link.expressions()["value"].expr, self.q_value)
         if isinstance(var, RandomVariable):
             if var not in self.slots:
                 raise LoweringError("posterior variable %r is used before it is sampled" % var.name)
-            return self.mk("z", (), var, self.slots[var].shape)
+            return self.z_node(var)
         raise LoweringError("unsupported posterior variable %r" % (var,))
 
     def mean_value(self, var):
@@ -520,7 +547,7 @@ class _Lowering:
                 return self.mean_value(qv)
             return self.q_value(qv)
         if isinstance(var, RootVariable):
-            return self.mk("root", (), var, self.root_shape(var))
+            return self.root_node(var)
         if getattr(var, "_type", None) == "Deterministic node":
             return self.from_expr(var.link.expressions()["value"].expr, self.p_value)
         raise LoweringError("model variable %r is neither observed nor present in the posterior "
@@ -1118,6 +1145,7 @@ class _Lowering:
                                         "one value per sample: only scalar nodes of q take axis views" % v.name)
                 params = [self.element_of(p, (0, 0, 0)) for p in params]
             self.slots[v] = SlotInfo(v, self.n_slots, shape, v.distribution.kind)
+            self.slot_rank[v] = self.sample_rank(params)
             self.n_slots += self.slots[v].size
             q_nodes.append((v, params, shape))
 
@@ -1250,18 +1278,18 @@ class _Lowering:
             if var in given:
                 return const_leaf(var)
             if var in self.slots:
-                return self.mk("z", (), var, self.slots[var].shape)
+                return self.z_node(var)
             return self.q_value(var)
 
         def p_ctx(var):
             if var in given:
                 return const_leaf(var)
             if var in self.slots:
-                return self.mk("z", (), var, self.slots[var].shape)
+                return self.z_node(var)
             if var.name in self.q_by_name:
                 return q_ctx(self.q_by_name[var.name])
             if isinstance(var, RootVariable):
-                return self.mk("root", (), var, self.root_shape(var))
+                return self.root_node(var)
             raise LoweringError("variable %r is used before it is sampled" % var.name)
 
         supported = (D.DIST_NORMAL, D.DIST_LOGNORMAL, D.DIST_CAUCHY, D.DIST_LAPLACE, D.DIST_BETA,
@@ -1281,6 +1309,7 @@ class _Lowering:
             self.n_latent = self.n_slots
             plan_item = (v, params, shape, slot)
             self.slots[v] = slot
+            self.slot_rank[v] = self.sample_rank(params)
             self.outputs.append(plan_item)
         self.temp_base = self.n_slots          # no derived slots in sampling programs
         self.derived_nodes = set()

@@ -252,32 +252,44 @@ class MultivariateNormalVariable(VariableConstructor):
 
 
 class EmpiricalVariable(VariableConstructor):
-    # `standard_variables.py:71-96` — graph construction only (minibatch data path is the
-    # "next" row f-1 of SURVEY §8).
+    """A minibatch of rows of a dataset (`standard_variables.py:71-96`).  Which rows: `indices` (a list, or a
+    `RandomIndices` variable shared with other empirical variables) or, per Monte-Carlo sample, `batch_size` rows drawn
+    without replacement (`distributions.py:436-441`).  On the device the rows are never copied out: the consuming GEMM
+    gathers them from the HBM-resident dataset."""
+
+    _optional = ("batch_size", "indices", "weights")
 
     def __init__(self, dataset, name, learnable=False, is_observed=False, batch_size=None, indices=None,
                  weights=None):
         self._type = "Empirical"
-        input_parameters = {"dataset": dataset, "batch_size": batch_size, "indices": indices, "weights": weights}
-        ranges = {k: geometric_ranges.UnboundedRange() for k, v in input_parameters.items() if v is not None}
-        kwargs = {k: v for k, v in input_parameters.items() if v is not None}
-        super().__init__(name, **kwargs, learnable=learnable, ranges=ranges, is_observed=is_observed)
-        if not batch_size:
-            if indices:
-                batch_size = len(indices)
-            else:
-                raise ValueError("Either the indices or the batch size has to be given as input")
-        self.batch_size = batch_size
-        self.distribution = distributions.EmpiricalDistribution(batch_size=batch_size, is_observed=is_observed)
+        supplied = dict(dataset=dataset)
+        for key, value in zip(self._optional, (batch_size, indices, weights)):
+            if value is not None:
+                supplied[key] = value
+        super().__init__(name, learnable=learnable, is_observed=is_observed,
+                         ranges=dict.fromkeys(supplied, geometric_ranges.UnboundedRange()), **supplied)
+        self.batch_size = self._rows_per_sample(batch_size, indices)
+        self.distribution = distributions.EmpiricalDistribution(batch_size=self.batch_size, is_observed=is_observed)
+
+    @staticmethod
+    def _rows_per_sample(batch_size, indices):
+        """an explicit batch size wins; otherwise a non-empty index collection fixes it (an index *variable* has a
+        `__len__`: `RandomIndices` below)"""
+        if batch_size:
+            return batch_size
+        if indices:
+            return len(indices)
+        raise ValueError("Either the indices or the batch size has to be given as input")
 
 
 class RandomIndices(EmpiricalVariable):
-    # `standard_variables.py:99-112`
+    """`batch_size` distinct positions of `range(dataset_size)` per draw (`standard_variables.py:99-112`): the index
+    variable several `EmpiricalVariable`s of one model share so that features and labels see the same rows."""
 
     def __init__(self, dataset_size, batch_size, name, is_observed=False):
+        positions = list(range(dataset_size))
+        super().__init__(positions, name, is_observed=is_observed, batch_size=batch_size)
         self._type = "Random Index"
-        super().__init__(dataset=list(range(dataset_size)), batch_size=batch_size, is_observed=is_observed,
-                         name=name)
 
     def __len__(self):
         return self.batch_size

@@ -325,6 +325,27 @@ def build_linear_predictor(api, n_obs=5, dim=4, seed=0):
     return model
 
 
+def build_flat_vector_sum(api, n_obs=6, dim=5, seed=0):
+    """A latent written as a FLAT array: ``NormalVariable(np.zeros(dim), np.ones(dim), "w")`` stores its parameters
+    [1, 1, dim] (`utilities.py:236`), so inside links w is [rows, dim] — rank 2 — and ``dim=-1`` / ``dim=1`` both name its
+    dim axis (`functions.py:50-62` hands them to torch.sum as they are).  A weighted sum of w with a flat coefficient
+    array through ``BF.sum(w * coef, dim=-1, keepdim=True)`` and an unweighted one through ``dim=1`` feed two observed
+    Normal variables."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    coef = api.RootVariable(np.linspace(-1., 1.5, dim).astype(np.float32), "coef")          # [1, 1, dim]
+    targets = rng.normal(0.5, 1.0, size=(n_obs,)).astype(np.float32)
+    w = api.NormalVariable(np.zeros(dim), np.ones(dim), "w")
+    y = api.NormalVariable(BF.sum(w * coef, dim=-1, keepdim=True), 0.6, "y")
+    s = api.NormalVariable(BF.sum(w, dim=1, keepdim=True) * 0.5, 0.9, "s")
+    model = api.ProbabilisticModel([y, s])
+    y.observe(targets)
+    s.observe(targets[:3] - 0.2)
+    Qw = api.NormalVariable(0.1 * np.ones(dim), 0.7 * np.ones(dim), "w", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qw]))
+    return model
+
+
 def build_softmax_classifier(api, n_obs=6, n_classes=3, seed=0):
     """An observed CategoricalVariable whose logits are an elementwise link (no matmul): per-class slopes and offsets
     (two vector latents) of one scalar regressor, labels observed (`standard_variables.py:280-299`,

@@ -28,7 +28,7 @@ import numpy as np
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("BSVI_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # (tests regenerate into a temp dir)
 
 CASES = {
     # name: (builder, builder kwargs, N, seed, trajectory spec)
@@ -48,6 +48,7 @@ CASES = {
     "map_estimate_N3": ("build_map_estimate", dict(n_obs=12), 3, 15, dict(iters=6, n=2, optimizer="SGD", lr=0.01)),
     "vector_latent_d4_N70": ("build_vector_latent", dict(n_obs=9, dim=4), 70, 14, dict(iters=4, n=33, optimizer="SGD", lr=1e-3)),
     "linear_predictor_d4_N40": ("build_linear_predictor", dict(n_obs=5, dim=4), 40, 17, dict(iters=4, n=24, optimizer="Adam", lr=1e-2)),
+    "flat_vector_sum_d5_N48": ("build_flat_vector_sum", dict(n_obs=6, dim=5), 48, 29, dict(iters=4, n=24, optimizer="Adam", lr=1e-2)),
     "softmax_classifier_C3_N60": ("build_softmax_classifier", dict(n_obs=6, n_classes=3), 60, 19, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
     "gp_hyperparameters_n5_N80": ("build_gp_hyperparameters", dict(n=5), 80, 23, dict(iters=5, n=32, optimizer="Adam", lr=1e-2)),
     "learnable_model_N60": ("build_learnable_model", dict(n_obs=15), 60, 13, dict(iters=6, n=40, optimizer="Adam", lr=0.02)),

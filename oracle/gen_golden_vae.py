@@ -93,6 +93,7 @@ def run_case(name, api):
     model = W.build_vae(api, **kwargs)
     model.update_observed_submodel()
     q = model.posterior_model
+    q._input_variables = sorted(q._input_variables, key=lambda v: v.name)     # (as in gen_golden.py: a reproducible walk)
     params = module_params(model)
     out = {"param/" + k: p.detach().numpy().copy() for k, p in params.items()}
     dataset = W.vae_data(kwargs["dataset_size"], kwargs["n_features"], kwargs.get("seed", 0))
@@ -156,7 +157,8 @@ def run_case(name, api):
             out["traj/param_after/" + k] = p.detach().numpy().copy()
 
     meta = dict(case=name, builder="build_vae", kwargs=kwargs, N=N, seed=seed, trajectory=traj,
-                torch=torch.__version__, numpy=np.__version__, reference="LucaAmbrogioni/Brancher @ /root/reference")
+                torch=torch.__version__, numpy=np.__version__, posterior_order="sorted by name",
+                reference="LucaAmbrogioni/Brancher @ /root/reference")
     out["meta"] = np.array(json.dumps(meta))
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)

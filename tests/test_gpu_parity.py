@@ -70,8 +70,6 @@ def test_loss_and_grads_match_reference_golden(case, estimator):
     # per-sample terms and the samples themselves
     f_ref = (g.data["lp"] + g.data["H"]).reshape(-1)
     assert rel_err(res["f"].cpu().numpy(), f_ref) <= TOL
-    if is_dense(case):
-        return
     if estimator == "blackbox":
         assert rel_err(res["lq"].cpu().numpy(), g.data["lq"].reshape(-1)) <= TOL
     by_name = c.samples_by_name(res["samples"])
