@@ -2,7 +2,7 @@
 """
 bench.py — ELBO iterations/sec of the fused SVI engine (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3] [--mode auto|persistent|stepwise]
+  python bench.py --gpus N --steps K --warmup W [--workload cfg1|...|cfg5] [--mode auto|persistent|stepwise]
 
 A "step" is one complete SVI iteration of `brancher/inference.py:95-108`: draw number_samples
 reparameterised posterior samples (in-kernel Philox), evaluate log p + entropy over the model
@@ -15,7 +15,10 @@ Monte-Carlo sample axis — every GPU evaluates `number_samples` samples of the 
 iteration and ONE all-reduce (RCCL) of 4+P floats joins them.  `value` is whole-job
 throughput in 300-sample ELBO iterations per second:  (global samples per step / 300) * steps / s.
 
-One JSON line is printed by rank 0.
+One JSON line is printed by rank 0.  On one GPU with the default workload the same line also carries BASELINE
+configs 2-5 (`other_configs`: each timed for 50 iterations in this process after the headline's timed region, with its
+own roofline object), and `roofline.traffic` is measured live (rocprofv3 --pmc passes of this script as child
+processes before the GPU is touched here; see run_traffic_probe).
 """
 import argparse
 import json
@@ -47,39 +50,73 @@ WORKLOADS = {
                  "README AR T=20 at number_samples=262144 (throughput regime of the same kernel)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r2")
+OTHER_CONFIGS = ("cfg2", "cfg3", "cfg4", "cfg5")     # timed after the headline in the same process (N = 1)
+OTHER_STEPS, OTHER_WARMUP, OTHER_SPINUP_MS = 50, 5, 100.0
 
 
-def pmc_traffic_bytes(csv_name, kernel_substrings, double_fetch=False, column="mean_KB_per_dispatch"):
-    """HBM bytes per launch of the named kernel(s) from the committed rocprofv3 PMC summary (FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc passes by tools/pmc_hbm.sh, KB per dispatch).  double_fetch applies
-    the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies the 128-B requests of 16-B-per-lane
-    streaming reads at 64 B).  None when the summary is not there."""
+# ---- HBM traffic, measured live ----------------------------------------------------------------------------------
+# `roofline.traffic` is the HBM bytes the PMC counters saw for the SAME launches this run times: before this process
+# touches the GPU it runs itself twice as a child under `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and
+# WRITE_SIZE in separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes; the child is `--traffic-probe`:
+# the same workloads, the same step counts, no CPU baseline) and reads the per-dispatch counter values back.  No profiler
+# on the box, or a failed pass -> traffic is null and `traffic_note` says why; nothing is looked up in committed files.
+def run_traffic_probe(workloads, steps_of, warmup_of, estimator, mode, samples, timeout_s=420):
     import csv
-    path = os.path.join(PROFILE_DIR, csv_name)
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r1", csv_name)      # (the dense / amortised kernels were last profiled in round 1)
-    if not os.path.exists(path):
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found on this box"
+    rows = []
+    spec = ",".join("%s:%d:%d" % (w, steps_of[w], warmup_of[w]) for w in workloads)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="bsvi_pmc_%s_" % counter, dir="/tmp")
+        cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
+               sys.executable, os.path.abspath(__file__), "--traffic-probe", spec, "--estimator", estimator, "--mode", mode]
+        if samples:
+            cmd += ["--samples", str(samples)]
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                                 stderr=subprocess.STDOUT, timeout=timeout_s, text=True)
+        except Exception as err:      # noqa: BLE001  (timeout, exec failure: the bench goes on without the counters)
+            shutil.rmtree(out_dir, ignore_errors=True)
+            return None, "PMC pass %s did not finish: %s" % (counter, err)
+        files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+        if res.returncode != 0 or not files:
+            shutil.rmtree(out_dir, ignore_errors=True)
+            return None, "PMC pass %s failed (exit %d): %s" % (counter, res.returncode, (res.stdout or "")[-300:])
+        per = {}
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != counter or "bsvi" not in r["Kernel_Name"]:
+                    continue
+                key = (int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]))
+                per[key] = per.get(key, 0.0) + float(r["Counter_Value"])          # (one row per XCD / instance)
+        for (dispatch, kernel, grid), kb in sorted(per.items()):
+            rows.append(dict(counter=counter, dispatch=dispatch, kernel=kernel, grid=grid, bytes=kb * 1024.0))
+        shutil.rmtree(out_dir, ignore_errors=True)
+    return rows, None
+
+
+def traffic_of(rows, kernel_substrings, grid=None, last_only=False, per=1, double_fetch=False):
+    """HBM bytes (FETCH_SIZE + WRITE_SIZE) of the probe's dispatches whose kernel name contains one of the substrings (and
+    whose grid matches): the LAST such dispatch of each counter (`last_only`: the timed launch of an in-kernel loop), else
+    their sum divided by `per` (iterations run by the probe).  double_fetch: the gfx950 rule of MI355X_MICROARCH.md for
+    16-byte-per-lane streaming reads (FETCH_SIZE tallies their 128-B requests at 64 B)."""
+    if not rows:
         return None
-    total = 0.0
-    hit = False
-    for row in csv.DictReader(open(path)):
-        if any(k in row["kernel"] for k in kernel_substrings):
-            kb = float(row[column])
-            total += kb * 1024.0 * (2.0 if double_fetch and row["counter"] == "FETCH_SIZE" else 1.0)
-            hit = True
+    total, hit = 0.0, False
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        sel = [r for r in rows if r["counter"] == counter and any(k in r["kernel"] for k in kernel_substrings)
+               and (grid is None or r["grid"] == grid)]
+        if not sel:
+            continue
+        hit = True
+        scale = 2.0 if (double_fetch and counter == "FETCH_SIZE") else 1.0
+        total += scale * (sel[-1]["bytes"] if last_only else sum(r["bytes"] for r in sel) / max(per, 1))
     return total if hit else None
-def pmc_dispatches(csv_name, kernel_substring):
-    """number of dispatches of a kernel in a committed PMC summary (None when absent)"""
-    import csv
-    for d in (PROFILE_DIR, os.path.join(ROOT, "profiles", "r1")):
-        path = os.path.join(d, csv_name)
-        if os.path.exists(path):
-            for row in csv.DictReader(open(path)):
-                if kernel_substring in row["kernel"]:
-                    return int(row["dispatches"])
-            return None
-    return None
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak
@@ -200,6 +237,191 @@ def self_launch(n_gpus, argv=None, port=None):
     return subprocess.call(cmd, env=env)
 
 
+def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=None, probe_iters=None):
+    """Warm-up, spin-up and the timed region of ONE workload: exactly `steps` SVI iterations between two barriers.
+    Returns (the parts of the JSON line that describe this workload, what the CPU baseline needs)."""
+    import gc
+    import torch
+    import torch.distributed as dist
+    from brancher_amd import engine, workloads as W
+    builder, kwargs, n_per_gpu, optimizer, opt_kwargs, desc = WORKLOADS[workload]
+    if args.samples:
+        n_per_gpu = args.samples
+    if args.dataset_size and "dataset_size" in kwargs:
+        kwargs = dict(kwargs, dataset_size=args.dataset_size)
+    n_global = n_per_gpu * world
+    model = getattr(W, builder)(W.native_api(), **kwargs)
+    compiled = engine.compile_model(model, None, args.estimator)
+    program = compiled.program
+    allow_persistent = args.mode != "stepwise"
+    if args.mode == "auto" and getattr(compiled, "prefers_stepwise", None) and compiled.prefers_stepwise(n_global):
+        allow_persistent = False      # 4+ program shares: launches per iteration beat the persistent trainer (DESIGN 4.4)
+    if args.mode == "persistent" and not (world == 1 and hasattr(compiled, "native") and compiled.native.persistent_supported(n_per_gpu)):
+        raise SystemExit("persistent mode needs one GPU and a sample count that fits one workgroup")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def train(k):
+        return compiled.train(k, n_global, optimizer, seed=0, allow_persistent=allow_persistent, **opt_kwargs)
+
+    # ---- warm-up (untimed): W steps through exactly the path that is timed (this is also where hiprtc compiles the
+    #      program-specialised kernel), then — still untimed — the same path for spinup_ms so that a short timed region
+    #      (the driver runs K = 20) is not measured on a GPU whose clocks have not ramped yet
+    train(max(warmup, 1))
+    barrier()
+    # no garbage collection from here to the end of the timed region: a collection inside a 200 us region would be a
+    # tenth of it, and a pause between the spin-up and the region would let the clocks drop again
+    gc.collect()
+    gc.disable()
+    spun = 0
+    if spinup_ms > 0:
+        chunk = max(steps, 200) if not hasattr(program, "enc_layers") else steps
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < spinup_ms:
+            train(chunk)
+            torch.cuda.synchronize()
+            spun += chunk
+    barrier()
+
+    # ---- timed region: exactly K steps
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    losses, finite = train(steps)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    dev_ms = ev0.elapsed_time(ev1)
+    mode = compiled.last_mode
+
+    t = torch.tensor([dt, dev_ms], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, dev_ms = float(t[0]), float(t[1])
+    ok = bool(torch.isfinite(losses).all()) and bool(finite.all())
+    if rank != 0:
+        return None, None
+
+    iters_per_sec = steps / dt
+    value = iters_per_sec * (n_global / 300.0)
+    dense = hasattr(program, "n_classes")
+    amort = hasattr(program, "enc_layers")
+    geom = dict(kind="dense") if dense else dict(kind="amortized") if amort else compiled.native.geometry(n_per_gpu)
+    spec = None
+    if not dense and not amort:
+        spec = compiled.native.engine(n_per_gpu, 2 if mode == "persistent" else 1 if mode == "stepwise" else 0)
+        spec = spec if spec["engine"] == "specialised" else None
+    # roofline of the dominant kernel (the fused ELBO kernel; in persistent mode one launch covers all K iterations).
+    # Launch duration from HIP events on the launch stream.
+    alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu * (program.batch_size if amort else 1))
+    traffic, traffic_how = None, None
+    iters_probed = (probe_iters or {}).get(workload)
+    if spec is not None:
+        # the program-specialised kernel (DESIGN.md 4.7): ONE launch per bsvi_* call — the whole loop in persistent mode
+        units_per_launch = steps if mode == "persistent" else 1
+        launch_ms = dev_ms / (1 if mode == "persistent" else steps)
+        kernel = "bsvi_spec_kernel (straight-line HIP generated from the model program, hiprtc)"
+        geom = dict(engine="specialised", n_blocks=spec["n_blocks"], n_threads=spec["n_threads"],
+                    lds_bytes=spec["lds_bytes"], storage="registers")
+        if probe_rows:
+            grid = spec["n_blocks"] * spec["n_threads"]
+            if mode == "persistent":
+                traffic = traffic_of(probe_rows, ["bsvi_spec_kernel"], grid=grid, last_only=True)
+                traffic_how = "the timed %d-iteration launch" % steps
+            else:
+                traffic = traffic_of(probe_rows, ["bsvi_spec_kernel"], grid=grid, per=iters_probed or 1)
+                traffic_how = "mean over the probe's %d one-iteration launches" % (iters_probed or 0)
+    elif mode == "persistent":
+        launch_ms, units_per_launch = dev_ms, steps
+        # five or more waves run as one wave per workgroup (persistent_multi_kernel, DESIGN.md 4.4)
+        multi = (n_per_gpu + 63) // 64 >= 5 and os.environ.get("BSVI_PERSISTENT_MULTI", "1") != "0"
+        kernel = "bsvi::persistent_%skernel<%s>" % ("multi_" if multi else "", geom.get("storage", "") or "lds+lane_acc")
+        if multi:
+            shares = int(compiled.lib.bsvi_persistent_split_shares(compiled.native.handle, n_per_gpu))
+            if not getattr(program, "shares", {}).get(shares):
+                shares = 1
+            geom = dict(geom, n_blocks=(n_per_gpu + 63) // 64 * shares, n_waves=1, storage="lds+lane_acc",
+                        program_shares=shares,
+                        note="one wave per workgroup; workgroup w runs share w %% %d of the model's log-prob records "
+                             "on sample wave w / %d; one exchange of partial sums per iteration" % (shares, shares))
+        if probe_rows:
+            traffic = traffic_of(probe_rows, ["persistent_"], last_only=True)
+            traffic_how = "the timed %d-iteration launch" % steps
+    else:
+        launch_ms, units_per_launch = dev_ms / steps, 1
+        kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
+        V = getattr(getattr(compiled, "native", None), "_elbo_shares_set", 0)
+        if not dense and not amort and V >= 2 and os.environ.get("BSVI_ELBO_SHARES", "1") != "0":
+            waves = (n_per_gpu + 63) // 64
+            if geom.get("storage") == "lds+lane_acc" and geom.get("lanes_per_wave") == 64 and waves * V <= 256:
+                geom = dict(geom, n_blocks=waves, n_waves=1)        # one wave per workgroup (share_geometry)
+            geom = dict(geom, n_blocks=geom["n_blocks"] * V, program_shares=V,
+                        note="workgroup b runs share b %% %d of the model's log-prob records on sample group b / %d; "
+                             "reduce_kernel adds the rows of partial sums" % (V, V))
+        if probe_rows and not dense and not amort:
+            traffic = traffic_of(probe_rows, ["elbo_kernel"], per=iters_probed or 1)
+            traffic_how = "elbo_kernel launches of the probe / its %d iterations" % (iters_probed or 0)
+    achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
+    us_iter = dev_ms * 1e3 / steps
+    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                    traffic=traffic, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
+                    iterations_per_launch=units_per_launch, launch_ms=launch_ms,
+                    note="latency / issue-bound workload (SURVEY §8d cfg 1-3): %.2f us per iteration; HBM is not its "
+                         "roof — the noise is generated in registers, a launch fetches the parameters and writes the loss "
+                         "curve — what bounds it is the serial instruction stream of one wave per sample group and the "
+                         "workgroup barriers of an iteration (DESIGN.md 4.7); a launch-per-step design pays ~5-10 us of "
+                         "launch latency per iteration on top" % us_iter)
+    if dense:
+        # the whole iteration (6 launches) is timed; the two MFMA GEMMs are >80 % of it (profiles/)
+        flops = dense_flops_per_iteration(program, n_per_gpu)
+        tf = flops / (dev_ms * 1e-3 / steps) / 1e12
+        if probe_rows:
+            traffic = traffic_of(probe_rows, ["dense_"], per=iters_probed or 1, double_fetch=True)
+            traffic_how = "all dense_* launches of the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
+        roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
+                        kernel="bsvi::dense_forward<10> + bsvi::dense_backward",
+                        algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps,
+                        note="f32-input MFMA; achieved = GEMM flops of one iteration / duration of the whole iteration")
+    if amort:
+        # the whole iteration (~23 launches) is timed; the eleven MFMA GEMMs carry the flops
+        flops = amort_flops_per_iteration(program, n_per_gpu)
+        tf = flops / (dev_ms * 1e-3 / steps) / 1e12
+        if probe_rows:
+            traffic = traffic_of(probe_rows, ["bsvi_amort_impl"], per=iters_probed or 1, double_fetch=True)
+            traffic_how = "all bsvi_amort_impl launches of the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
+        roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
+                        kernel="bsvi_amort_impl::gemm_kernel<0|1|2>",
+                        algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps,
+                        rows_per_iteration=n_per_gpu * program.batch_size,
+                        note="f32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = GEMM flops of one iteration "
+                             "(forward + weight gradient + input gradient of every Linear layer) / duration of "
+                             "the whole iteration")
+    if traffic is not None:
+        roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py before its timed " \
+                                     "regions (child processes, same workloads and step counts): " + traffic_how
+    part = dict(metric="ELBO iters/sec at num_samples=%d per GPU (300-sample-equivalent iterations, whole job)" % n_per_gpu,
+                value=value, unit="it/s", n_gpus=world, steps=steps, warmup=warmup,
+                ms_per_step=dt * 1e3 / steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32", data="synthetic",
+                config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
+                            optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
+                            estimator=args.estimator, mode=mode, parallelism="sample-shard x%d" % world,
+                            grid=geom, untimed_spinup_iterations=spun),
+                iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
+                device_ms_per_step=dev_ms / steps, all_finite=ok,
+                final_loss=float(losses[-1].item()), roofline=roofline)
+    del compiled, model
+    return part, dict(builder=builder, kwargs=kwargs, n=n_per_gpu, optimizer=optimizer, opt_kwargs=opt_kwargs,
+                      dense=dense, amort=amort)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +432,13 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "persistent", "stepwise"])
     ap.add_argument("--samples", type=int, default=0, help="override number_samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
+                    help="after the headline workload, time BASELINE configs 2-5 in the same process and attach them under "
+                         "the `other_configs` key of the same JSON line (auto: when the headline is cfg1 on one GPU)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "on", "off"],
+                    help="measure roofline.traffic live: rocprofv3 --pmc passes of this script as child processes before "
+                         "the timed regions (auto: on one GPU)")
+    ap.add_argument("--traffic-probe", default="", help=argparse.SUPPRESS)       # child mode: "cfg1:K:W,cfg2:K:W,..."
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="untimed iterations of the timed path after the W warm-up steps, to let the clocks ramp (0: off)")
     ap.add_argument("--estimator", default="pathwise", choices=["pathwise", "blackbox", "taylor1"],
@@ -241,6 +470,28 @@ def main():
                                   local_rank=local_rank)))
         dist.destroy_process_group()
         return
+
+    probing = bool(args.traffic_probe)
+    others = [] if probing else list(OTHER_CONFIGS) if (args.other_configs == "on" or (
+        args.other_configs == "auto" and world == 1 and args.workload == "cfg1" and not args.samples)) else []
+    plan = [(args.workload, args.steps, args.warmup, args.spinup_ms)] + \
+           [(w, OTHER_STEPS, OTHER_WARMUP, OTHER_SPINUP_MS) for w in others]
+    if probing:
+        plan = [(w, int(k), int(wu), 0.0) for w, k, wu in (item.split(":") for item in args.traffic_probe.split(","))]
+
+    # ---- live HBM traffic: PMC passes of this same script as children, BEFORE this process initialises the GPU
+    probe_rows, probe_note, probe_iters = None, None, {}
+    if not probing and world == 1 and args.traffic != "off":
+        t_probe = time.perf_counter()
+        steps_of = {w: k for w, k, _, _ in plan}
+        warm_of = {w: max(wu, 1) for w, _, wu, _ in plan}
+        probe_rows, probe_note = run_traffic_probe([w for w, _, _, _ in plan], steps_of, warm_of, args.estimator, args.mode,
+                                                   args.samples)
+        probe_iters = {w: steps_of[w] + warm_of[w] for w in steps_of}
+        probe_seconds = time.perf_counter() - t_probe
+    elif not probing:
+        probe_note = "not measured (%s)" % ("--traffic off" if args.traffic == "off" else "multi-GPU run")
+
     # BSVI_BENCH_SHARE_GPU=1 with BSVI_BENCH_BACKEND=gloo: dry run of the N > 1 flow on a box with fewer GPUs than ranks
     # (the ranks share devices, collectives go through the host) — tests/test_gpu_two_ranks.py; never a measurement
     backend = os.environ.get("BSVI_BENCH_BACKEND", "nccl")
@@ -254,185 +505,38 @@ def main():
             os.environ["BSVI_GRAPH"] = "0"          # host-staged collectives cannot be captured into a HIP graph
             dist.init_process_group(backend)
 
-    from brancher_amd import config, engine, workloads as W
+    from brancher_amd import config
     config.set_device("cuda:%d" % device_index)
-    builder, kwargs, n_per_gpu, optimizer, opt_kwargs, desc = WORKLOADS[args.workload]
-    if args.samples:
-        n_per_gpu = args.samples
-    if args.dataset_size and "dataset_size" in kwargs:
-        kwargs = dict(kwargs, dataset_size=args.dataset_size)
-    n_global = n_per_gpu * world
-    model = getattr(W, builder)(W.native_api(), **kwargs)
-    compiled = engine.compile_model(model, None, args.estimator)
-    program = compiled.program
-    allow_persistent = args.mode != "stepwise"
-    if args.mode == "auto" and getattr(compiled, "prefers_stepwise", None) and compiled.prefers_stepwise(n_global):
-        allow_persistent = False      # 4+ program shares: launches per iteration beat the persistent trainer
-    if args.mode == "persistent" and not (world == 1 and hasattr(compiled, "native") and compiled.native.persistent_supported(n_per_gpu)):
-        raise SystemExit("persistent mode needs one GPU and a sample count that fits one workgroup")
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    line, baseline_of = None, None
+    other_lines = {}
+    for i, (workload, steps, warmup, spinup_ms) in enumerate(plan):
+        if i == 0 or probing:
+            part, info = measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows, probe_iters)
+            if i == 0:
+                line, baseline_of = part, info
+            continue
+        try:        # the other configs never cost the headline its line
+            part, _ = measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows, probe_iters)
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "device_ms_per_step", "iters_per_sec", "samples_per_sec",
+                    "all_finite", "final_loss", "config", "roofline")
+            other_lines[workload] = {k: part[k] for k in keep}
+        except Exception as err:      # noqa: BLE001
+            other_lines[workload] = dict(error="%s: %s" % (type(err).__name__, err))
+        torch.cuda.empty_cache()
 
-    # ---- warm-up (untimed): W steps through exactly the path that is timed (this is also where hiprtc compiles the
-    #      program-specialised kernel), then — still untimed — the same path for --spinup-ms so that a short timed region
-    #      (the driver runs K = 20) is not measured on a GPU whose clocks have not ramped yet
-    compiled.train(max(args.warmup, 1), n_global, optimizer, seed=0, allow_persistent=allow_persistent, **opt_kwargs)
-    barrier()
-    # no garbage collection from here to the end of the timed region: a collection inside a 200 us region would be a
-    # tenth of it, and a pause between the spin-up and the region would let the clocks drop again
-    import gc
-    gc.collect()
-    gc.disable()
-    spun = 0
-    if args.spinup_ms > 0:
-        chunk = max(args.steps, 200)
-        t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-            compiled.train(chunk, n_global, optimizer, seed=0, allow_persistent=allow_persistent, **opt_kwargs)
-            torch.cuda.synchronize()
-            spun += chunk
-    barrier()
-
-    # ---- timed region: exactly K steps
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record()
-    losses, finite = compiled.train(args.steps, n_global, optimizer, seed=0, allow_persistent=allow_persistent,
-                                    **opt_kwargs)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    dev_ms = ev0.elapsed_time(ev1)
-    mode = compiled.last_mode
-
-    t = torch.tensor([dt, dev_ms], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt, dev_ms = float(t[0]), float(t[1])
-    ok = bool(torch.isfinite(losses).all()) and bool(finite.all())
-
-    if rank == 0:
-        iters_per_sec = args.steps / dt
-        value = iters_per_sec * (n_global / 300.0)
-        dense = hasattr(program, "n_classes")
-        amort = hasattr(program, "enc_layers")
-        geom = dict(kind="dense") if dense else dict(kind="amortized") if amort else compiled.native.geometry(n_per_gpu)
-        spec = None
-        if not dense and not amort:
-            spec = compiled.native.engine(n_per_gpu, 2 if mode == "persistent" else 1 if mode == "stepwise" else 0)
-            spec = spec if spec["engine"] == "specialised" else None
-        # roofline of the dominant kernel (the fused ELBO kernel; in persistent mode one launch
-        # covers all K iterations).  Launch duration from HIP events on the launch stream.
-        alg_bytes_iter = algorithmic_bytes_per_iteration(program, n_per_gpu * (program.batch_size if amort else 1))
-        if spec is not None:
-            # the program-specialised kernel: ONE launch per bsvi_* call — the whole loop in persistent mode
-            units_per_launch = args.steps if mode == "persistent" else 1
-            launch_ms = dev_ms / (1 if mode == "persistent" else args.steps)
-            kernel = "bsvi_spec_kernel (straight-line HIP generated from the model program, hiprtc)"
-            geom = dict(engine="specialised", n_blocks=spec["n_blocks"], n_threads=spec["n_threads"],
-                        lds_bytes=spec["lds_bytes"], storage="registers")
-        elif mode == "persistent":
-            launch_ms, launches, units_per_launch = dev_ms, 1, args.steps
-            # five or more waves run as one wave per workgroup (persistent_multi_kernel)
-            multi = (n_per_gpu + 63) // 64 >= 5 and os.environ.get("BSVI_PERSISTENT_MULTI", "1") != "0"
-            kernel = "bsvi::persistent_%skernel<%s>" % ("multi_" if multi else "", geom.get("storage", "") or "lds+lane_acc")
-            if multi:
-                shares = int(compiled.lib.bsvi_persistent_split_shares(compiled.native.handle, n_per_gpu))
-                if not getattr(program, "shares", {}).get(shares):
-                    shares = 1
-                geom = dict(geom, n_blocks=(n_per_gpu + 63) // 64 * shares, n_waves=1, storage="lds+lane_acc",
-                            program_shares=shares,
-                            note="one wave per workgroup; workgroup w runs share w %% %d of the model's log-prob records "
-                                 "on sample wave w / %d; one exchange of partial sums per iteration" % (shares, shares))
-        else:
-            launch_ms, launches, units_per_launch = dev_ms / args.steps, args.steps, 1
-            kernel = "bsvi::elbo_kernel<%s>" % geom.get("storage", "dense")
-            V = getattr(getattr(compiled, "native", None), "_elbo_shares_set", 0)
-            if not dense and not amort and V >= 2 and os.environ.get("BSVI_ELBO_SHARES", "1") != "0":
-                waves = (n_per_gpu + 63) // 64
-                if geom.get("storage") == "lds+lane_acc" and geom.get("lanes_per_wave") == 64 and waves * V <= 256:
-                    geom = dict(geom, n_blocks=waves, n_waves=1)        # one wave per workgroup (share_geometry)
-                geom = dict(geom, n_blocks=geom["n_blocks"] * V, program_shares=V,
-                            note="workgroup b runs share b %% %d of the model's log-prob records on sample group b / %d; "
-                                 "reduce_kernel adds the rows of partial sums" % (V, V))
-        achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
-        if spec is not None:
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (tools/pmc_hbm.sh), committed per round:
-            # the timed launch is the larger of the two launches in the summary (the other is the warm-up)
-            if args.workload == "cfg1" and not args.samples and args.steps == 20000 and mode == "persistent":
-                traffic = pmc_traffic_bytes("cfg1_spec_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"], column="max_KB")
-            elif args.workload == "cfg1" and not args.samples and args.steps == 20 and mode == "persistent":
-                # (the driver's command line: every launch of that profile run is one 20-iteration launch)
-                traffic = pmc_traffic_bytes("cfg1_spec_k20_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"])
-            elif args.workload == "cfg1" and not args.samples and mode == "stepwise":
-                traffic = pmc_traffic_bytes("cfg1_spec_stepwise_pmc_hbm_traffic.csv", ["bsvi_spec_kernel"])
-            else:
-                traffic = None
-        elif mode == "persistent":
-            traffic = None
-        else:
-            traffic = pmc_traffic_bytes("pmc_hbm_traffic.csv", ["elbo_kernel"]) \
-                if args.workload == "cfg1" and not args.samples else None
-        roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=traffic, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
-                        iterations_per_launch=units_per_launch, launch_ms=launch_ms,
-                        note="latency / issue-bound workload (SURVEY §8d cfg 1): %.2f us per iteration; HBM is not its "
-                             "roof — the noise is generated in registers, a launch fetches ~25 KB — what bounds it is the "
-                             "serial instruction stream of one wave per sample group (cfg 1: 1 335 VALU instructions per "
-                             "wave and iteration, profiles/r2/pmc_sq_loop.csv) and two workgroup barriers per iteration; "
-                             "a launch-per-step design pays ~5-10 us of launch latency per iteration on top"
-                             % (dev_ms * 1e3 / args.steps))
-        if dense:
-            # the whole iteration (8 launches) is timed; the two MFMA GEMMs are >90 % of it (profiles/)
-            flops = dense_flops_per_iteration(program, n_per_gpu)
-            tf = flops / (dev_ms * 1e-3 / args.steps) / 1e12
-            traffic = pmc_traffic_bytes("cfg4_pmc_hbm_traffic.csv", ["dense_forward", "dense_backward"],
-                                        double_fetch=True) if args.workload == "cfg4" and not args.samples else None
-            roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
-                            kernel="bsvi::dense_forward<10> + bsvi::dense_backward",
-                            algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / args.steps,
-                            note="f32-input MFMA (v_mfma_f32_16x16x4_f32); achieved = GEMM flops of one iteration / "
-                                 "duration of the whole iteration")
-        if amort:
-            # the whole iteration (~35 launches) is timed; the 20 MFMA GEMMs carry the flops
-            flops = amort_flops_per_iteration(program, n_per_gpu)
-            tf = flops / (dev_ms * 1e-3 / args.steps) / 1e12
-            # HBM bytes of ALL launches of one iteration (tools/pmc_hbm.sh over a short run of this workload;
-            # FETCH_SIZE doubled per the guide's gfx950 rule for 16-byte-per-lane reads)
-            traffic = pmc_traffic_bytes("cfg5_pmc_hbm_traffic.csv", ["bsvi_amort_impl"], double_fetch=True,
-                                        column="total_KB") if args.workload == "cfg5" and not args.samples else None
-            iterations_profiled = pmc_dispatches("cfg5_pmc_hbm_traffic.csv", "amort_rows")   # one launch per iteration
-            traffic = traffic / iterations_profiled if traffic and iterations_profiled else None
-            roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
-                            kernel="bsvi_amort_impl::gemm_kernel<0|1|2>",
-                            algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / args.steps,
-                            rows_per_iteration=n_per_gpu * program.batch_size,
-                            note="f32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = GEMM flops of one iteration "
-                                 "(forward + weight gradient + input gradient of every Linear layer) / duration of "
-                                 "the whole iteration")
-        line = dict(metric="ELBO iters/sec at num_samples=%d per GPU (300-sample-equivalent iterations, whole job)"
-                           % n_per_gpu,
-                    value=value, unit="it/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
-                    dtype="f32", data="synthetic",
-                    config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
-                                optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
-                                estimator=args.estimator, mode=mode, parallelism="sample-shard x%d" % world,
-                                grid=geom, untimed_spinup_iterations=spun),
-                    iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
-                    device_ms_per_step=dev_ms / args.steps, all_finite=ok,
-                    final_loss=float(losses[-1].item()), roofline=roofline)
+    if rank == 0 and not probing:
+        if line["roofline"].get("traffic") is None:
+            line["roofline"]["traffic_note"] = probe_note or "the probe saw no dispatch of this kernel"
+        elif probe_rows is not None:
+            line["roofline"]["traffic_probe_seconds"] = probe_seconds
+        if other_lines:
+            line["other_configs"] = other_lines
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_vae(kwargs, optimizer, opt_kwargs) if amort else \
-                cpu_baseline(builder, kwargs, n_per_gpu, optimizer, opt_kwargs, dense=dense)
-            recorded = recorded_reference_timings(args.workload, n_per_gpu, optimizer)
+            b = baseline_of
+            line["cpu_baseline"] = cpu_baseline_vae(b["kwargs"], b["optimizer"], b["opt_kwargs"]) if b["amort"] else \
+                cpu_baseline(b["builder"], b["kwargs"], b["n"], b["optimizer"], b["opt_kwargs"], dense=b["dense"])
+            recorded = recorded_reference_timings(args.workload, b["n"], b["optimizer"])
             if recorded is not None:
                 line["cpu_baseline"]["reference"] = recorded
         print(json.dumps(line))

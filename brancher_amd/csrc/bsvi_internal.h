@@ -46,6 +46,11 @@ int upload(Spec* s);
 const std::string& source(const Spec* s, int variant);
 // compile a generated translation unit for gfx950 with hiprtc; `code` receives the code object
 int compile(const std::string& src, std::vector<char>& code, std::string& log);
+// the same through the caches (this process's, then the one on disk; a miss compiles and fills both).
+// origin: 1 hiprtc, 2 process cache, 3 disk cache
+int obtain(const std::string& src, std::vector<char>& code, std::string& log, int* origin);
+int last_origin();
+std::string cache_directory();
 // bytes of workspace a launch over n_local samples needs behind the interpreter's region
 size_t workspace_bytes(const Spec* s, uint32_t n_local);
 // true when a launch in `mode` over n_local samples is served by the specialised kernel

@@ -2228,6 +2228,24 @@ extern "C" int bsvi_jit_compile(const char* source, size_t* code_bytes) {
     return BSVI_OK;
 }
 
+extern "C" int bsvi_jit_load(const char* source, size_t* code_bytes, int* origin) {
+    if (!source) return fail(BSVI_ERR_INVALID, "null source");
+    std::vector<char> code;
+    std::string log;
+    const int rc = bsvi_spec::obtain(source, code, log, origin);
+    if (rc) return fail(rc, log);
+    if (code_bytes) *code_bytes = code.size();
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_jit_last_origin(void) { return bsvi_spec::last_origin(); }
+
+extern "C" size_t bsvi_jit_cache_dir(char* buf, size_t capacity) {
+    const std::string dir = bsvi_spec::cache_directory();
+    if (buf && capacity > dir.size()) memcpy(buf, dir.c_str(), dir.size() + 1);
+    return dir.size() + 1;
+}
+
 extern "C" int bsvi_program_engine(const bsvi_program* p, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads,
                                    uint32_t* lds_bytes) {
     if (!p) return 0;

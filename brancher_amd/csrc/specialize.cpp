@@ -17,6 +17,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <errno.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <map>
@@ -759,28 +763,154 @@ int compile(const std::string& src, std::vector<char>& code, std::string& log) {
 static std::mutex g_cache_mu;
 static std::map<std::string, std::vector<char>> g_code_cache;
 
+// ---------------------------------------------------------------------------------------------------------------
+//  code objects on disk: hiprtc costs ~1 s per program (4 s at T = 200) in EVERY process that trains a model; the
+//  generated source is a pure function of the model program, so a second process loads the code object instead.
+//  Key = hash of (generated source, embedded device headers, compile options, target, hiprtc + HIP runtime version);
+//  directory = $BSVI_CACHE_DIR, else $XDG_CACHE_HOME/brancher_amd/jit, else $HOME/.cache/brancher_amd/jit, else
+//  /tmp/brancher_amd-<uid>/jit.  BSVI_JIT_CACHE=0 switches it off.  Files are written to a temporary name and renamed
+//  (atomic on one file system: concurrent ranks compiling the same program race harmlessly); a file carries its own
+//  length and content hash, a truncated or foreign one is ignored and overwritten.
+// ---------------------------------------------------------------------------------------------------------------
+namespace disk_cache {
+
+struct Hash128 { uint64_t a = 0xcbf29ce484222325ull, b = 0x9ae16a3b2f90404full; };
+static void feed(Hash128& h, const void* data, size_t n) {
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; ++i) {
+        h.a = (h.a ^ p[i]) * 0x100000001b3ull;                                   // FNV-1a
+        h.b = (h.b + p[i] + 0x9e3779b97f4a7c15ull) * 0xff51afd7ed558ccdull;      // an independent multiply-xorshift chain
+        h.b ^= h.b >> 29;
+    }
+}
+static void feed(Hash128& h, const std::string& s) { const uint64_t n = s.size(); feed(h, &n, 8); feed(h, s.data(), s.size()); }
+
+static const char* kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+
+static bool enabled() {
+    const char* e = getenv("BSVI_JIT_CACHE");
+    return !(e && e[0] == '0');
+}
+
+static std::string directory() {
+    if (const char* d = getenv("BSVI_CACHE_DIR")) if (d[0]) return d;
+    if (const char* x = getenv("XDG_CACHE_HOME")) if (x[0]) return std::string(x) + "/brancher_amd/jit";
+    if (const char* h = getenv("HOME")) if (h[0]) return std::string(h) + "/.cache/brancher_amd/jit";
+    return fmt("/tmp/brancher_amd-%u/jit", (unsigned)getuid());
+}
+
+static bool make_dirs(const std::string& path) {
+    for (size_t i = 1; i <= path.size(); ++i)
+        if (i == path.size() || path[i] == '/') {
+            const std::string part = path.substr(0, i);
+            if (mkdir(part.c_str(), 0700) != 0 && errno != EEXIST) return false;
+        }
+    return true;
+}
+
+static std::string key_of(const std::string& src) {
+    static const Hash128 base = [] {        // everything but the generated source: the same for every program of a process
+        Hash128 h;
+        for (int i = 0; i < kJitHeaderCount; ++i) { feed(h, std::string(kJitHeaderNames[i])); feed(h, std::string(kJitHeaderTexts[i])); }
+        for (const char* o : kOptions) feed(h, std::string(o));
+        int major = 0, minor = 0, runtime = 0;
+        (void)hiprtcVersion(&major, &minor);
+        (void)hipRuntimeGetVersion(&runtime);
+        feed(h, fmt("hiprtc %d.%d runtime %d abi %d", major, minor, runtime, BSVI_ABI_VERSION));
+        return h;
+    }();
+    Hash128 h = base;
+    feed(h, src);
+    return fmt("%016llx%016llx", (unsigned long long)h.a, (unsigned long long)h.b);
+}
+
+struct Header { char magic[8]; uint64_t size, ha, hb; };
+static const char kMagic[8] = {'B', 'S', 'V', 'I', 'C', 'O', '0', '1'};
+
+static bool load(const std::string& key, std::vector<char>& code) {
+    const std::string path = directory() + "/" + key + ".co";
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    Header H;
+    bool ok = fread(&H, sizeof H, 1, f) == 1 && memcmp(H.magic, kMagic, 8) == 0 && H.size > 0 && H.size < (1ull << 30);
+    if (ok) {
+        code.resize(H.size);
+        ok = fread(code.data(), 1, H.size, f) == H.size && fgetc(f) == EOF;
+    }
+    fclose(f);
+    if (ok) {
+        Hash128 h;
+        feed(h, code.data(), code.size());
+        ok = h.a == H.ha && h.b == H.hb;
+    }
+    if (!ok) code.clear();
+    return ok;
+}
+
+static void store(const std::string& key, const std::vector<char>& code) {
+    const std::string dir = directory();
+    if (!make_dirs(dir)) return;
+    Header H;
+    memcpy(H.magic, kMagic, 8);
+    H.size = code.size();
+    Hash128 h;
+    feed(h, code.data(), code.size());
+    H.ha = h.a; H.hb = h.b;
+    const std::string tmp = dir + "/" + key + fmt(".tmp.%d", (int)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(&H, sizeof H, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), (dir + "/" + key + ".co").c_str()) != 0) (void)remove(tmp.c_str());
+}
+
+}  // namespace disk_cache
+
+// what the last ensure_compiled of this thread did (bsvi_jit_cache_stats): tests and tools read it
+static thread_local int t_last_source = 0;      // 0 none yet, 1 hiprtc, 2 process cache, 3 disk cache
+
+// the code object of a translation unit: this process's cache, the disk cache, or hiprtc (and then both caches)
+int obtain(const std::string& text, std::vector<char>& code, std::string& log, int* origin) {
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        auto it = g_code_cache.find(text);
+        if (it != g_code_cache.end()) code = it->second;
+    }
+    int from = 2;
+    if (code.empty()) {
+        std::string src = text;
+        const bool tuned = getenv("BSVI_SPEC_DEFINES") != nullptr;
+        if (tuned) src = std::string(getenv("BSVI_SPEC_DEFINES")) + "\n" + src;     // tools: timing experiments
+        const bool on_disk = disk_cache::enabled() && !getenv("BSVI_JIT_DUMP");
+        const std::string key = on_disk ? disk_cache::key_of(src) : std::string();
+        if (on_disk && disk_cache::load(key, code)) {
+            from = 3;
+        } else {
+            const int rc = compile(src, code, log);
+            if (rc) return rc;
+            from = 1;
+            if (on_disk) disk_cache::store(key, code);
+        }
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        if (!tuned) g_code_cache[text] = code;
+    }
+    t_last_source = from;
+    if (origin) *origin = from;
+    return BSVI_OK;
+}
+
+int last_origin() { return t_last_source; }
+std::string cache_directory() { return disk_cache::enabled() ? disk_cache::directory() : std::string(); }
+
 static int ensure_compiled(Spec* s, int v) {
     Variant& V = s->variant[v];
     if (V.fn) return BSVI_OK;
     if (V.failed) return BSVI_ERR_UNSUPPORTED;
     std::vector<char> code;
-    {
-        std::lock_guard<std::mutex> g(g_cache_mu);
-        auto it = g_code_cache.find(V.src);
-        if (it != g_code_cache.end()) code = it->second;
-    }
-    if (code.empty()) {
-        std::string log;
-        std::string src = V.src;
-        if (const char* defs = getenv("BSVI_SPEC_DEFINES")) src = std::string(defs) + "\n" + src;     // tools: timing experiments
-        const int rc = compile(src, code, log);
-        if (rc) {
-            V.failed = true;
-            if (getenv("BSVI_DEBUG")) fprintf(stderr, "bsvi: specialised kernel did not compile:\n%s\n", log.c_str());
-            return bsvi_fail(BSVI_ERR_UNSUPPORTED, "specialised kernel did not compile: " + log.substr(0, 400));
-        }
-        std::lock_guard<std::mutex> g(g_cache_mu);
-        if (!getenv("BSVI_SPEC_DEFINES")) g_code_cache[V.src] = code;
+    std::string log;
+    if (obtain(V.src, code, log, nullptr)) {
+        V.failed = true;
+        if (getenv("BSVI_DEBUG")) fprintf(stderr, "bsvi: specialised kernel did not compile:\n%s\n", log.c_str());
+        return bsvi_fail(BSVI_ERR_UNSUPPORTED, "specialised kernel did not compile: " + log.substr(0, 400));
     }
     hipError_t e = hipModuleLoadData(&V.module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&V.fn, V.module, "bsvi_spec_kernel");

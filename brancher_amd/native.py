@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 OUT_HEADER = 4
 
 
@@ -115,6 +115,9 @@ EXPORTS = {
                                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bsvi_program_source": (C.c_size_t, [C.POINTER(ProgramDesc), C.c_int, C.c_char_p, C.c_size_t]),
     "bsvi_jit_compile": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t)]),
+    "bsvi_jit_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "bsvi_jit_last_origin": (C.c_int, []),
+    "bsvi_jit_cache_dir": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "bsvi_program_engine": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]),
     "bsvi_max_lds_bytes": (C.c_int, [C.c_void_p]),
@@ -244,6 +247,24 @@ def jit_compile(source):
     n = C.c_size_t()
     check(load().bsvi_jit_compile(source.encode(), C.byref(n)))
     return n.value
+
+
+JIT_ORIGINS = {0: "none", 1: "hiprtc", 2: "process cache", 3: "disk cache"}
+
+
+def jit_load(source):
+    """the code object of a generated translation unit through the caches (bsvi_jit_load): (bytes, origin name)"""
+    n, origin = C.c_size_t(), C.c_int()
+    check(load().bsvi_jit_load(source.encode(), C.byref(n), C.byref(origin)))
+    return n.value, JIT_ORIGINS[origin.value]
+
+
+def jit_cache_dir():
+    lib = load()
+    need = lib.bsvi_jit_cache_dir(None, 0)
+    buf = C.create_string_buffer(need)
+    lib.bsvi_jit_cache_dir(buf, need)
+    return buf.value.decode()
 
 
 class NativeProgram:

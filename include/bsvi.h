@@ -41,7 +41,7 @@ typedef long long int64_t;
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 5
+#define BSVI_ABI_VERSION 6
 
 typedef enum bsvi_status {
     BSVI_OK = 0,
@@ -348,10 +348,20 @@ int bsvi_svi_step(const bsvi_program* prog, const bsvi_elbo_args* args, const bs
  *   device.  Returns the byte count including the terminator (0: not specialised, see bsvi_last_error) and copies
  *   when `capacity` suffices.
  * bsvi_jit_compile: compile such a translation unit for gfx950 (hiprtc; needs no device).
+ * bsvi_jit_load: the code object of a translation unit the way a program's first launch obtains it — from this
+ *   process's cache, else from the code-object cache on disk (keyed by source, embedded device headers, compile
+ *   options, target and hiprtc / HIP runtime version; $BSVI_CACHE_DIR, else $XDG_CACHE_HOME/brancher_amd/jit, else
+ *   ~/.cache/brancher_amd/jit; BSVI_JIT_CACHE=0 switches the disk cache off), else hiprtc, which then fills both.
+ *   *origin: 1 hiprtc, 2 process cache, 3 disk cache.  Needs no device.
+ * bsvi_jit_last_origin: the same code for the last specialised kernel this thread made ready (0: none yet).
+ * bsvi_jit_cache_dir: the cache directory (byte count including the terminator; 1 = "", the disk cache is off).
  * bsvi_program_engine: 1 when a call in `mode` (0 bsvi_elbo_fwd_bwd, 1 bsvi_svi_step, 2 bsvi_train_persistent*) over
  *   n_local samples is served by the specialised kernel (and its launch geometry), 0 when by the interpreter. */
 size_t bsvi_program_source(const bsvi_program_desc* desc, int variant, char* buf, size_t capacity);
 int bsvi_jit_compile(const char* source, size_t* code_bytes);
+int bsvi_jit_load(const char* source, size_t* code_bytes, int* origin);
+int bsvi_jit_last_origin(void);
+size_t bsvi_jit_cache_dir(char* buf, size_t capacity);
 int bsvi_program_engine(const bsvi_program* prog, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads,
                         uint32_t* lds_bytes);
 

@@ -320,6 +320,32 @@ def test_sharded_step_sequence_equals_the_fused_single_gpu_step(optimizer, kw):
 
 
 @pytest.mark.gpu
+def test_graph_replayed_training_leaves_no_pointer_in_the_cached_argument_block():
+    """The HIP-graph path of the sharded step points `bsvi_elbo_args::offset_dev` at a device counter.  That pointer must
+    live in the capture's private argument block only: a later evaluation, or a persistent training call, on the SAME
+    compiled object has to honour its own (seed, offset) — compared with a fresh program's results."""
+    api = W.native_api()
+    used = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    used.train(40, 300, "SGD", seed=5, lr=1e-3, _force_sharded_path=True)
+    assert used.last_mode == "graph"
+    params = used.params.detach().clone()
+    fresh = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    fresh.params.copy_(params)
+    a, b = used.evaluate(300, seed=11, offset=7), fresh.evaluate(300, seed=11, offset=7)
+    assert float(a["loss"]) == float(b["loss"])
+    assert torch.equal(a["grads"], b["grads"])
+    # the in-kernel loop after the graph path (it rejects a non-null offset_dev), then the graph path again
+    # (the Philox offset of a call continues from the object's iteration counter: align the two objects)
+    used.iteration = fresh.iteration = 500
+    l1, _ = used.train(10, 300, "SGD", seed=3, lr=1e-3)
+    l2, _ = fresh.train(10, 300, "SGD", seed=3, lr=1e-3)
+    assert used.last_mode == "persistent" and torch.equal(l1, l2) and torch.equal(used.params, fresh.params)
+    l1, _ = used.train(33, 300, "Adam", seed=3, lr=1e-3, _force_sharded_path=True)
+    l2, _ = fresh.train(33, 300, "Adam", seed=3, lr=1e-3, _force_sharded_path=True)
+    assert torch.equal(l1, l2) and torch.equal(used.params, fresh.params)
+
+
+@pytest.mark.gpu
 def test_dense_path_at_baseline_config4_size():
     """BASELINE config 4 at FULL size (784 -> 10, dataset 60000, minibatch 512, number_samples 1024), where the oracle
     would take minutes: the size-independent properties instead -- (1) call-to-call bit equality of the whole output

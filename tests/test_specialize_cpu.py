@@ -99,3 +99,48 @@ def test_config1_kernel_has_no_spills(tmp_path, monkeypatch):
     #  schedule shared by the calls of a draw, the optimizer's constants.  Forcing the keys to be recomputed per call removes a
     #  third of them but serialises the calls: 190 -> 163 k it/s)
     assert meta["sgpr_spill_count"] <= 64, meta
+
+
+def test_code_object_cache_on_disk(tmp_path):
+    """A second PROCESS does not pay hiprtc again: the code object of a generated translation unit is stored under the
+    cache directory, keyed by source + embedded headers + options + toolchain version.  Each step below runs in a fresh
+    interpreter (the in-process cache would hide the disk one)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import json, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from brancher_amd import lowering, native, workloads as W\n"
+        "m = W.build_readme_ar(W.native_api(), T=20)\n"
+        "src = native.specialised_source(lowering.lower(m, m.posterior_model, 'pathwise'), 0)\n"
+        "native.load()\n"
+        "t0 = time.perf_counter(); n, origin = native.jit_load(src); t1 = time.perf_counter()\n"
+        "n2, origin2 = native.jit_load(src)\n"
+        "print(json.dumps(dict(n=n, origin=origin, again=origin2, ms=(t1 - t0) * 1e3, dir=native.jit_cache_dir())))\n" % root)
+
+    def run(**env):
+        out = subprocess.run([sys.executable, "-c", script], check=True, capture_output=True, text=True,
+                             env=dict(os.environ, BSVI_CACHE_DIR=str(tmp_path), **env)).stdout
+        return json.loads(out.strip().splitlines()[-1])
+
+    first = run()
+    assert first["origin"] == "hiprtc" and first["again"] == "process cache" and first["dir"] == str(tmp_path)
+    files = [f for f in os.listdir(str(tmp_path)) if f.endswith(".co")]
+    assert len(files) == 1 and not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+    second = run()
+    assert second["origin"] == "disk cache" and second["n"] == first["n"]
+    assert second["ms"] < 50.0, second          # VERDICT r2 item 6: a second process's cold start of cfg 1 under 50 ms
+    # a damaged file is not trusted: it is recompiled and replaced
+    path = os.path.join(str(tmp_path), files[0])
+    blob = bytearray(open(path, "rb").read())
+    blob[len(blob) // 2] ^= 0xFF
+    open(path, "wb").write(bytes(blob))
+    third = run()
+    assert third["origin"] == "hiprtc" and third["n"] == first["n"]
+    assert run()["origin"] == "disk cache"
+    # switched off: no directory, no file read
+    off = run(BSVI_JIT_CACHE="0")
+    assert off["origin"] == "hiprtc" and off["dir"] == ""
