@@ -289,8 +289,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     # ---- timed region: exactly K steps
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    ev0.record()                    # (ahead of the host clock: the events bracket the wall region from outside)
     t0 = time.perf_counter()
-    ev0.record()
     losses, finite = train(steps)
     ev1.record()
     barrier()

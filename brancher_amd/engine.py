@@ -26,6 +26,10 @@ from brancher_amd import native
 from brancher_amd.native import ElboArgs, OUT_HEADER
 
 
+class _Stale(Exception):
+    """a prepared training call no longer matches the object's buffers"""
+
+
 def _device():
     dev = config.get_device()
     if dev.type != "cuda":
@@ -146,6 +150,10 @@ def _bound_to_device(cls):
         @functools.wraps(fn)
         def on_device(self, *args, **kwargs):
             dev = getattr(self, "device", None) or kwargs.get("device") or _device()
+            # (entering torch.cuda.device() costs ~10 us of host time even when nothing changes: a training call of
+            #  20 iterations is ~100 us in all)
+            if dev.index is not None and torch.cuda.current_device() == dev.index:
+                return fn(self, *args, **kwargs)
             with torch.cuda.device(dev):
                 return fn(self, *args, **kwargs)
         return on_device
@@ -211,6 +219,7 @@ class CompiledELBO:
         self.mask_first = torch.from_numpy((active * (group == first_group)).astype(np.uint8)).to(dev)
         self._workspaces = {}
         self._train_plans = {}
+        self._fast_train = {}
         self._plain_args = {}
         self._shares_for = None
         self._noise_cache = None
@@ -407,11 +416,74 @@ class CompiledELBO:
             keep.append(tail)
             tail.replay()
 
+    def _prepare_fast_train(self, n_local, n_global, base, cfg, pretraining):
+        """a repeat of one in-kernel training call (single rank, Philox noise, fresh optimizer inside the kernel) as a
+        closure over pre-built ctypes objects"""
+        args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, n_global, base, None, 0, 0))
+        args.offset_dev = None
+        fn = self.lib.bsvi_train_persistent2
+        handle, p_args, p_cfg = self.native.handle, C.byref(args), C.byref(cfg)
+        params, mask_all, mask_first = (C.c_void_p(t.data_ptr()) for t in (self.params, self.mask_all, self.mask_first))
+        params_ptr = self.params.data_ptr()
+        dev = self.device
+        default_seed = None
+        current_stream = torch.cuda.current_stream
+        empty = torch.empty
+        import torch.distributed as dist
+        is_distributed = dist.is_initialized if dist.is_available() else (lambda: False)
+
+        def run(K, seed):
+            nonlocal default_seed
+            Ka = (K + 3) // 4 * 4
+            # (a sibling estimator re-bound the parameter buffer, or a process group appeared since: the full path decides)
+            if self.params.data_ptr() != params_ptr or is_distributed():
+                self._fast_train.clear()
+                return None
+            if seed is None:
+                if default_seed is None:
+                    default_seed = shared_seed(None, dev)
+                seed = default_seed
+            buf = empty(2 * Ka, device=dev)
+            args.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
+            args.offset = self.iteration
+            args.stream = current_stream(dev).cuda_stream
+            self.iteration += K
+            rc = fn(handle, p_args, p_cfg, params, None, mask_all, mask_first, pretraining, K,
+                    C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * Ka))
+            if rc != 0:                                            # (e.g. the engine was switched by BSVI_JIT since)
+                self.iteration -= K
+                self._fast_train.clear()
+                return None
+            self.grads_valid = True
+            self.last_mode = "persistent"
+            return buf[:K], buf[Ka:Ka + K]
+
+        def call(K, seed):
+            out = run(K, seed)
+            if out is None:                                        # fall back to the full path once; it re-prepares
+                raise _Stale()
+            return out
+        return call
+
     def train(self, number_iterations, number_samples, optimizer="Adam", noise_seq=None, seed=None,
               pretraining_iterations=0, allow_persistent=True, minibatch_seq=None, _force_sharded_path=False,
               **opt_params):
         """`brancher/inference.py:95-108` on the device.  Returns (loss_curve, finite_flags) as
         device tensors of length number_iterations; nothing synchronises with the host."""
+        # The short call (the driver times 20 iterations: ~100 us on the device): everything a repeat of the same call needs
+        # — optimizer block, argument block, ctypes pointers, the launch plan — is kept from the first one, and the call is
+        # a buffer, five stores into the argument block and ONE library call.
+        if noise_seq is None and minibatch_seq is None and not _force_sharded_path and allow_persistent:
+            fast_key = (int(number_samples), optimizer if isinstance(optimizer, str) else None,
+                        int(pretraining_iterations), tuple(sorted(opt_params.items())) if opt_params else ())
+            fast = self._fast_train.get(fast_key)
+            if fast is not None and number_iterations > 0:
+                try:
+                    return fast(int(number_iterations), seed)
+                except _Stale:
+                    pass
+        else:
+            fast_key = None
         cfg = native.make_opt_cfg(optimizer, **opt_params)
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
@@ -466,6 +538,10 @@ class CompiledELBO:
                     self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(st), ptr(self.mask_all),
                     ptr(self.mask_first), int(pretraining_iterations), K, ptr(loss_curve), ptr(finite))
                 rc = call(state)
+                if rc == 0 and state is None and fast_key is not None and fast_key[1] is not None and K > 0 \
+                        and os.environ.get("BSVI_FAST_TRAIN", "1") != "0":
+                    self._fast_train[fast_key] = self._prepare_fast_train(n_local, number_samples, base, cfg,
+                                                                          int(pretraining_iterations))
                 if rc != 0 and state is None:
                     # the plan said "specialised in-kernel loop" before the lazy hiprtc compile; if that compile then
                     # fails the library leaves the program to the interpreter's trainer, which needs a state buffer:
