@@ -343,6 +343,11 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
 class CompiledAmortized:
     """Engine for an amortised model; same surface as engine.CompiledELBO / dense.CompiledDense."""
 
+    def data_path(self):
+        """which matrix-core path serves the layers that read the data rows: "bf16x3" when every dataset value is exactly a
+        bf16 number (three bf16 MFMAs on the exact pieces of the f32 weights), else "f32" (bsvi_amort_exact_data)"""
+        return "bf16x3" if self._exact_data else "f32"
+
     def __init__(self, joint_model, posterior_model, estimator="pathwise", device=None, program=None):
         from brancher_amd import engine
         self.device = device or engine._device()
@@ -373,6 +378,7 @@ class CompiledAmortized:
         handle = C.c_void_p()
         native.check(lib.bsvi_amort_create(C.byref(d), C.byref(handle)))
         self.handle = handle
+        self._exact_data = bool(lib.bsvi_amort_exact_data(handle))
         dev = self.device
         self.n_params = p.n_params
         theta = np.zeros(p.n_params, dtype=np.float32)

@@ -404,6 +404,151 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs G) {
         }
 }
 
+// ---- the layer that reads the DATA rows, on the bf16 matrix cores at f32 accuracy ------------------------------------
+// examples/VAE_playground.py:22-26 binarises its images; pixel counts 0..255 and {0, 1} alike are EXACTLY representable
+// in bf16 (8 significant bits).  With x exact, a product x*w with w split into three bf16 pieces w = hi + mid + lo (8 + 8 +
+// 8 significant bits: the split of an f32 is exact) is the sum of three bf16 products, each exact in the f32 accumulator —
+// so x W^T runs on v_mfma_f32_32x32x16_bf16 (16x the rate of the f32-input MFMA) as THREE MFMAs per tile and k step, with
+// the rounding behaviour of an f32 fma chain (one rounding per accumulation, summation order hi, mid, lo within a k step).
+// bsvi_amort_create checks every dataset value for exactness and keeps a bf16 copy of the dataset, rows padded with zeros
+// to a multiple of 32 columns; xw_split_kernel splits the layer's weights once per iteration (they change every step).
+// A dataset with any inexact value runs on the f32 kernel above.  BSVI_AMORT_XGEMM=0 forces that too.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t xu4 __attribute__((ext_vector_type(4)));   // (ext vectors, not HIP's uint4 struct: copies of that through pointer casts land in scratch)
+constexpr int XBK = 32;                 // k per step: two MFMA k chunks of 16
+constexpr int XLD = 80;                 // LDS row stride in bytes (64 data + 16 pad: 16 consecutive rows hit 16 disjoint bank quads)
+constexpr int XPLANE = 128 * XLD;       // one 128-row operand tile
+
+struct XGemmArgs {
+    const uint16_t* X;      // [DS][Kp] bf16 dataset copy
+    const int32_t* rows;    // gather of the M rows (null: identity)
+    const uint16_t* Wp;     // [3][N][Kp] bf16 pieces of the weights
+    long plane_stride;      // elements between pieces
+    float* C;
+    const float* bias;
+    int M, N, Kp, ldc;
+    int act; float post_add; int split; int act2; float post_add2;
+};
+
+__device__ __forceinline__ uint16_t bf16_bits(float x) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
+__device__ __forceinline__ float bf16_value(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// W [N][K] f32 -> three bf16 pieces [3][N][Kp] (zero beyond K): hi = rne(w), mid = rne(w - hi), lo = rne(w - hi - mid)
+__global__ __launch_bounds__(256) void xw_split_kernel(const float* W, int N, int K, int Kp, uint16_t* Wp) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * Kp) return;
+    const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+    const float w = k < K ? W[(long)n * K + k] : 0.0f;
+    const uint16_t hi = bf16_bits(w);
+    const float r1 = w - bf16_value(hi);
+    const uint16_t mid = bf16_bits(r1);
+    const float r2 = r1 - bf16_value(mid);
+    const long plane = (long)N * Kp;
+    Wp[i] = hi; Wp[plane + i] = mid; Wp[2 * plane + i] = bf16_bits(r2);
+}
+
+// f32 rows -> bf16 rows padded to Kp (tests / the debug hook; the product path converts the dataset once on the host)
+__global__ __launch_bounds__(256) void x_to_bf16_kernel(const float* X, long rows, int K, int Kp, uint16_t* Xb) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Kp) return;
+    const long r = i / Kp;
+    const int k = (int)(i - r * Kp);
+    Xb[i] = k < K ? bf16_bits(X[r * K + k]) : (uint16_t)0;
+}
+
+// C[M][N] = act(X[rows[m]] W^T + bias): 128 x 128 tile, four waves of 64 x 64, single LDS stage with the next step's global
+// loads in flight behind the MFMAs (41 KB of LDS: three workgroups per CU cover each other's barriers)
+__global__ __launch_bounds__(256) void xgemm_nt_kernel(const XGemmArgs G) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * XPLANE];      // A | W hi | W mid | W lo
+    const int tiles_n = (G.N + 127) / 128;
+    int bid = blockIdx.x;
+    const int n_blocks = gridDim.x;
+    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // an XCD takes a contiguous range of tiles
+    const int m0 = (bid / tiles_n) * 128, n0 = (bid % tiles_n) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
+
+    // staging: 16-byte pieces.  A: 512 per step (2 per thread), W: 1536 (6 per thread)
+    const xu4* pa[2];
+    const xu4* pb[6];
+    int sa[2], sb[6];       // LDS byte offsets
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, row = c >> 2, kq = c & 3;
+        const int r = min(m0 + row, G.M - 1);
+        const long phys = G.rows ? (long)G.rows[r] : (long)r;
+        pa[i] = reinterpret_cast<const xu4*>(G.X + phys * G.Kp + kq * 8);
+        sa[i] = row * XLD + kq * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = tid + 256 * i, plane = c >> 9, w = c & 511, col = w >> 2, kq = w & 3;
+        pb[i] = reinterpret_cast<const xu4*>(G.Wp + plane * G.plane_stride + (long)min(n0 + col, G.N - 1) * G.Kp + kq * 8);
+        sb[i] = (1 + plane) * XPLANE + col * XLD + kq * 16;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int n_steps = G.Kp / XBK;
+    xu4 ra[2], rb[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[i] = pa[i][0];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rb[i] = pb[i][0];
+    const unsigned char* at = lds + (wm + lm) * XLD + lk * 16;
+    const unsigned char* bt = lds + XPLANE + (wn + lm) * XLD + lk * 16;
+    for (int step = 0; step < n_steps; ++step) {
+        __syncthreads();                                   // the last step's reads of the stage are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<xu4*>(lds + sa[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<xu4*>(lds + sb[i]) = rb[i];
+        __syncthreads();
+        if (step + 1 < n_steps) {                          // (XBK bf16 = 4 pieces of 16 bytes per row and step)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ra[i] = pa[i][(step + 1) * 4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rb[i] = pb[i][(step + 1) * 4];
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(at + 32 * i * XLD + kc * 32);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bf16x8 b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bt + p * XPLANE + 32 * j * XLD + kc * 32);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: acc[i][j][r] is C[m][n] with m = 32i + 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31)   (as gemm_kernel)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lm;
+            if (n >= G.N) continue;
+            const float bias = G.bias ? G.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * lk + (r & 3);
+                if (m >= G.M) continue;
+                G.C[(long)m * G.ldc + n] = act_forward(ACT_OF(G, n), acc[i][j][r] + bias, ADD_OF(G, n));
+            }
+        }
+}
+
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1100,6 +1245,13 @@ struct bsvi_amort {
     bsvi_amort_desc d;
     Net enc, dec;
     float* dataset_dev = nullptr;
+    // every dataset value is exactly a bf16: the layers that read the data rows run on the bf16 matrix cores at f32
+    // accuracy (xgemm_nt_kernel).  dataset_bf16_dev [DS][data_kp] (rows zero padded to a multiple of 32 columns);
+    // weight_pieces[l]: [3][n_out][data_kp] bf16 pieces of encoder layer l's weights, refreshed every iteration
+    bool data_exact = false;
+    int data_kp = 0;
+    uint16_t* dataset_bf16_dev = nullptr;
+    std::vector<uint16_t*> weight_pieces;
     float* prior_dev = nullptr;    // [2][Dz]
     size_t floats_per_row = 0;     // workspace floats per row (values + gradients + per-row scalars)
     // the weight-gradient GEMM of a layer and its input-gradient GEMM are independent: the former runs on a side
@@ -1193,6 +1345,31 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
         return bsvi_fail(BSVI_ERR_HIP, "hipMalloc of the dataset failed");
     }
     (void)hipMemcpy(a->dataset_dev, desc->dataset, ds_bytes, hipMemcpyHostToDevice);
+    {   // is every value of the dataset exactly a bf16 (binarised images, pixel counts)?  Then keep a bf16 copy for xgemm_nt_kernel
+        const char* xe = getenv("BSVI_AMORT_XGEMM");
+        const size_t n_values = (size_t)desc->dataset_size * desc->n_features;
+        const uint32_t* bits = reinterpret_cast<const uint32_t*>(desc->dataset);
+        bool exact = !(xe && xe[0] == '0') && desc->n_features >= 64;      // (narrow inputs are not GEMM-bound)
+        for (size_t i = 0; exact && i < n_values; ++i) exact = (bits[i] & 0xFFFFu) == 0u;
+        if (exact) {
+            const int Kp = ((int)desc->n_features + XBK - 1) / XBK * XBK;
+            std::vector<uint16_t> host((size_t)desc->dataset_size * Kp, (uint16_t)0);
+            for (size_t r = 0; r < desc->dataset_size; ++r)
+                for (size_t k = 0; k < desc->n_features; ++k) host[r * Kp + k] = (uint16_t)(bits[r * desc->n_features + k] >> 16);
+            bool ok = hipMalloc(&a->dataset_bf16_dev, host.size() * sizeof(uint16_t)) == hipSuccess;
+            if (ok) ok = hipMemcpy(a->dataset_bf16_dev, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice) == hipSuccess;
+            a->weight_pieces.assign(a->enc.layers.size(), nullptr);
+            for (size_t l = 0; ok && l < a->enc.layers.size(); ++l)
+                if (a->enc.layers[l].in_value == 0 && a->enc.layers[l].n_out > SKINNY)
+                    ok = hipMalloc(&a->weight_pieces[l], 3 * (size_t)a->enc.layers[l].n_out * Kp * sizeof(uint16_t)) == hipSuccess;
+            if (!ok) {
+                bsvi_amort_destroy(a);
+                return bsvi_fail(BSVI_ERR_HIP, "hipMalloc of the bf16 dataset copy failed");
+            }
+            a->data_exact = true;
+            a->data_kp = Kp;
+        }
+    }
     (void)hipMemcpy(a->prior_dev, desc->prior_loc, Dz * sizeof(float), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->prior_dev + Dz, desc->prior_scale, Dz * sizeof(float), hipMemcpyHostToDevice);
     const char* ov = getenv("BSVI_AMORT_OVERLAP");
@@ -1228,9 +1405,14 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     return BSVI_OK;
 }
 
+extern "C" int bsvi_amort_exact_data(const bsvi_amort* a) { return (a && a->data_exact) ? 1 : 0; }
+
 extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
     if (!a) return;
     if (a->dataset_dev) (void)hipFree(a->dataset_dev);
+    if (a->dataset_bf16_dev) (void)hipFree(a->dataset_bf16_dev);
+    for (auto p : a->weight_pieces)
+        if (p) (void)hipFree(p);
     if (a->prior_dev) (void)hipFree(a->prior_dev);
     for (auto e : a->ready)
         if (e) (void)hipEventDestroy(e);
@@ -1404,6 +1586,29 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
                                uint32_t m, uint32_t n, uint32_t k, uint32_t lda, uint32_t ldb, uint32_t ldc,
                                const float* bias_or_y_dev, uint32_t ldy, uint32_t activation, float post_add,
                                uint32_t accumulate, void* stream) {
+    if (mode == 3) {
+        // the exact-data forward product C = act(A[rows] B^T + bias) through xgemm_nt_kernel: A (whose values must be exact
+        // in bf16 — not checked here) is converted, B split into its three pieces, in buffers the hook keeps
+        if (!a_dev || !b_dev || !c_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
+        const int Kp = ((int)k + XBK - 1) / XBK * XBK;
+        uint32_t a_rows = m;                       // with a gather the caller passes the number of SOURCE rows in `accumulate`
+        if (rows_dev) a_rows = accumulate;
+        static uint16_t* xb = nullptr; static size_t xb_n = 0;
+        static uint16_t* wp = nullptr; static size_t wp_n = 0;
+        const size_t need_x = (size_t)a_rows * Kp, need_w = 3 * (size_t)n * Kp;
+        if (need_x > xb_n) { (void)hipDeviceSynchronize(); if (xb) (void)hipFree(xb); xb = nullptr; HIP_TRY(hipMalloc(&xb, need_x * 2)); xb_n = need_x; }
+        if (need_w > wp_n) { (void)hipDeviceSynchronize(); if (wp) (void)hipFree(wp); wp = nullptr; HIP_TRY(hipMalloc(&wp, need_w * 2)); wp_n = need_w; }
+        hipStream_t st = (hipStream_t)stream;
+        if (lda != k || ldb != k) return bsvi_fail(BSVI_ERR_INVALID, "mode 3 takes densely stored operands");
+        hipLaunchKernelGGL(x_to_bf16_kernel, dim3((unsigned)((need_x + 255) / 256)), dim3(256), 0, st, a_dev, (long)a_rows, (int)k, Kp, xb);
+        hipLaunchKernelGGL(xw_split_kernel, dim3((unsigned)(((size_t)n * Kp + 255) / 256)), dim3(256), 0, st, b_dev, (int)n, (int)k, Kp, wp);
+        XGemmArgs X{};
+        X.X = xb; X.rows = rows_dev; X.Wp = wp; X.plane_stride = (long)n * Kp; X.C = c_dev; X.ldc = (int)ldc;
+        X.M = (int)m; X.N = (int)n; X.Kp = Kp; X.bias = bias_or_y_dev; X.act = (int)activation; X.post_add = post_add;
+        hipLaunchKernelGGL(xgemm_nt_kernel, dim3((unsigned)(((m + 127) / 128) * ((n + 127) / 128))), dim3(256), 0, st, X);
+        HIP_TRY(hipGetLastError());
+        return BSVI_OK;
+    }
     if (mode < 0 || mode > 2 || !a_dev || !b_dev || !c_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
     GemmArgs G{};
     G.A = a_dev; G.B = b_dev; G.C = c_dev; G.rows = rows_dev;
@@ -1521,9 +1726,29 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     hipLaunchKernelGGL(amort_rows, row_grid, dim3(256), 0, stream, D);
 
     auto forward = [&](const Net& net, bool gather) -> int {
-        for (const auto& l : net.layers) {
+        for (size_t li = 0; li < net.layers.size(); ++li) {
+            const auto& l = net.layers[li];
             GemmArgs G{};
             const bool from_data = gather && l.in_value == 0;
+            if (from_data && a->data_exact && li < a->weight_pieces.size() && a->weight_pieces[li]) {
+                // x W^T with x exact in bf16: three bf16 MFMAs per tile and step on the pieces of W (xgemm_nt_kernel)
+                const int Kp = a->data_kp;
+                uint16_t* pieces = a->weight_pieces[li];
+                const long total = (long)l.n_out * Kp;
+                hipLaunchKernelGGL(xw_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                                   params + l.weight_off, (int)l.n_out, (int)l.n_in, Kp, pieces);
+                XGemmArgs X{};
+                X.X = a->dataset_bf16_dev; X.rows = idx; X.Wp = pieces; X.plane_stride = total;
+                X.C = val(net, l.out_value); X.ldc = net.ld[l.out_value];
+                X.M = (int)R; X.N = (int)l.n_out; X.Kp = Kp;
+                X.bias = l.bias_off != 0xFFFFFFFFu ? params + l.bias_off : nullptr;
+                X.act = (int)l.activation; X.post_add = l.post_add;
+                if (l.split_col > 0 && l.split_col < l.n_out) { X.split = (int)l.split_col; X.act2 = (int)l.activation2; X.post_add2 = l.post_add2; }
+                const unsigned tiles = (unsigned)(((R + 127) / 128) * ((l.n_out + 127) / 128));
+                hipLaunchKernelGGL(xgemm_nt_kernel, dim3(tiles), dim3(256), 0, stream, X);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             G.A = from_data ? a->dataset_dev : val(net, l.in_value);
             G.lda = from_data ? P : net.ld[l.in_value];
             G.rows = from_data ? idx : nullptr;

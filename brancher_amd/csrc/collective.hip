@@ -1,0 +1,252 @@
+// collective.hip — the ONE exchange of the multi-GPU path behind the C ABI (include/bsvi.h).
+//
+// Monte-Carlo samples are sharded over the GPUs of a node; per step every rank holds [4 + P] sums (loss sum, non-finite
+// count, gradient sums) and all ranks need their total.  Two ways to get it, both callable from any host language between
+// bsvi_elbo_fwd_bwd and bsvi_finalize_step:
+//
+//   bsvi_allreduce         RCCL's ncclAllReduce on a communicator the host owns (torch.distributed's, or its own).  The
+//                          library does not link RCCL: the entry point is resolved at the first call from the RCCL
+//                          instance already loaded in the process, so communicator and code come from the same instance.
+//
+//   bsvi_exchange_*        a one-shot direct-write all-reduce for the small messages of this path (188 B at BASELINE
+//                          config 1, 1.6 KB at config 3; RCCL's ring is latency-bound there): every rank owns a region
+//                          of device memory that its peers map through HIP IPC (over xGMI between GPUs); ONE kernel per
+//                          call writes the rank's vector into its slot of every peer's region, publishes a per-call
+//                          sequence number behind a system-scope release, waits for the peers' numbers (bounded: a rank
+//                          that never arrives raises the region's abort word, nothing traps or hangs), and adds the
+//                          slots in rank order — the same association on every rank, so the totals are bit-identical
+//                          everywhere and the replicated optimizer steps stay in lockstep.
+//
+// The reference has no collectives (it is a single-process PyTorch-CPU program); the partitioning is SURVEY §8e.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bsvi.h"
+#include "bsvi_internal.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+//  RCCL through the instance the process already has
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*nccl_error_fn)(int);
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;        // rccl.h: ncclFloat32 = 7, ncclSum = 0
+
+std::mutex g_rccl_mu;
+nccl_allreduce_fn g_allreduce = nullptr;
+nccl_error_fn g_error_string = nullptr;
+std::string g_rccl_origin;
+
+int resolve_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_allreduce) return BSVI_OK;
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    void* lib = nullptr;
+    g_rccl_origin = "global scope";
+    if (!sym) {
+        // loaded, but not in the global scope (a Python extension's dependency): by its soname, without loading a second copy
+        const char* names[] = {getenv("BSVI_RCCL_LIB"), "librccl.so.1", "librccl.so", "libnccl.so.2"};
+        for (const char* name : names) {
+            if (!name || !name[0]) continue;
+            lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (lib) { g_rccl_origin = name; break; }
+        }
+        if (!lib && getenv("BSVI_RCCL_LIB")) {             // the host asked for a specific library: load it
+            lib = dlopen(getenv("BSVI_RCCL_LIB"), RTLD_NOW);
+            if (lib) g_rccl_origin = getenv("BSVI_RCCL_LIB");
+        }
+        if (lib) sym = dlsym(lib, "ncclAllReduce");
+    }
+    if (!sym)
+        return bsvi_fail(BSVI_ERR_UNSUPPORTED, "bsvi_allreduce: no RCCL instance is loaded in this process (create the communicator "
+                                               "first, or name the library in BSVI_RCCL_LIB)");
+    g_allreduce = (nccl_allreduce_fn)sym;
+    void* es = lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+    g_error_string = (nccl_error_fn)es;
+    return BSVI_OK;
+}
+
+}  // namespace
+
+extern "C" int bsvi_allreduce(void* rccl_comm, float* buf_dev, size_t n, void* stream) {
+    if (!rccl_comm || !buf_dev) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_allreduce: null communicator or buffer");
+    if (n == 0) return BSVI_OK;
+    int rc = resolve_rccl();
+    if (rc) return rc;
+    const int res = g_allreduce(buf_dev, buf_dev, n, kNcclFloat32, kNcclSum, rccl_comm, (hipStream_t)stream);
+    if (res != 0)
+        return bsvi_fail(BSVI_ERR_HIP, std::string("ncclAllReduce: ") + (g_error_string ? g_error_string(res) : "error ") + " (" + std::to_string(res) + ")");
+    return BSVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  the one-shot direct-write exchange
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kMaxRanks = 8;           // one node: 8 GPUs, 7 xGMI peers each
+constexpr uint32_t kFlagStride = 16;        // a flag per 64-byte line
+constexpr uint32_t kHeaderWords = 256;      // flags [8 x 16] | abort | timeouts | ... (1 KB)
+
+struct XArgs {
+    unsigned char* peer[kMaxRanks];         // every rank's region as mapped here (peer[rank] = this rank's own)
+    float* buf;
+    uint32_t n, capacity, rank, world, seq;
+    unsigned long long timeout_ticks;       // of the 100 MHz wall clock
+};
+
+__device__ __forceinline__ float* slot_of(unsigned char* region, uint32_t parity, uint32_t r, uint32_t capacity, uint32_t world) {
+    return reinterpret_cast<float*>(region + kHeaderWords * 4) + ((size_t)parity * world + r) * capacity;
+}
+
+// ONE workgroup.  Stores to the peers and the loads of what they wrote are system-scope atomics (relaxed): they bypass this
+// GPU's caches, so a slot written by a peer two calls ago cannot be served stale from L2.
+__global__ __launch_bounds__(256) void exchange_kernel(const XArgs A) {
+    const uint32_t tid = threadIdx.x, parity = A.seq & 1u;
+    __shared__ uint32_t gave_up;
+    if (tid == 0) gave_up = 0;
+    // 1. this rank's vector into its slot of every region (its own included)
+    for (uint32_t i = tid; i < A.n; i += 256) {
+        const float v = A.buf[i];
+        for (uint32_t p = 0; p < A.world; ++p)
+            __hip_atomic_store(slot_of(A.peer[p], parity, A.rank, A.capacity, A.world) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    // 2. publish: "rank's slot of call seq is complete" in every region
+    if (tid < A.world)
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(A.peer[tid]) + A.rank * kFlagStride, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // 3. wait for every rank's number in this rank's region — bounded
+    uint32_t* mine = reinterpret_cast<uint32_t*>(A.peer[A.rank]);
+    if (tid < A.world) {
+        const unsigned long long t0 = wall_clock64();
+        // (sequence numbers only grow; a peer may already be one call ahead)
+        while ((int32_t)(__hip_atomic_load(mine + tid * kFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - A.seq) < 0) {
+            if (wall_clock64() - t0 > A.timeout_ticks) {
+                gave_up = 1;
+                __hip_atomic_store(mine + kMaxRanks * kFlagStride, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // abort word: the call that gave up
+                atomicAdd(mine + kMaxRanks * kFlagStride + 1, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if (gave_up) return;                     // buf keeps this rank's own sums; the host reads bsvi_exchange_status
+    // 4. the total, slots added in rank order
+    unsigned char* region = A.peer[A.rank];
+    for (uint32_t i = tid; i < A.n; i += 256) {
+        float s = 0.0f;
+        for (uint32_t r = 0; r < A.world; ++r)
+            s += __hip_atomic_load(slot_of(region, parity, r, A.capacity, A.world) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        A.buf[i] = s;
+    }
+}
+
+}  // namespace
+
+struct bsvi_exchange {
+    uint32_t rank = 0, world = 1, capacity = 0, seq = 0;
+    size_t bytes = 0;
+    unsigned char* region = nullptr;            // this rank's (device memory)
+    unsigned char* peer[kMaxRanks] = {};
+    bool opened[kMaxRanks] = {};
+    bool connected = false;
+    unsigned long long timeout_ticks = 0;
+};
+
+extern "C" size_t bsvi_exchange_handle_bytes(void) { return sizeof(hipIpcMemHandle_t); }
+
+extern "C" int bsvi_exchange_create(uint32_t rank, uint32_t world, uint32_t capacity_floats, bsvi_exchange** out) {
+    if (!out || world < 1 || world > kMaxRanks || rank >= world || capacity_floats == 0 || capacity_floats > (1u << 14))
+        return bsvi_fail(BSVI_ERR_INVALID, "bsvi_exchange_create: 1..8 ranks and 1..16384 floats (the one-shot form is for small messages; "
+                                           "larger ones belong to bsvi_allreduce)");
+    auto* x = new bsvi_exchange();
+    x->rank = rank; x->world = world; x->capacity = (capacity_floats + 63u) / 64u * 64u;
+    x->bytes = (size_t)kHeaderWords * 4 + 2 * (size_t)world * x->capacity * sizeof(float);
+    // fine-grained (uncached across devices) when the runtime has it; plain device memory serves ranks that share a GPU
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, x->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&p, x->bytes) != hipSuccess) { delete x; return bsvi_fail(BSVI_ERR_HIP, "bsvi_exchange_create: device allocation failed"); }
+    }
+    x->region = (unsigned char*)p;
+    if (hipMemset(x->region, 0, x->bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(x->region);
+        delete x;
+        return bsvi_fail(BSVI_ERR_HIP, "bsvi_exchange_create: clearing the region failed");
+    }
+    x->peer[rank] = x->region;
+    const char* t = getenv("BSVI_EXCHANGE_TIMEOUT_MS");
+    const double ms = t ? atof(t) : 2000.0;
+    x->timeout_ticks = (unsigned long long)((ms > 0 ? ms : 2000.0) * 1e5);      // wall_clock64 ticks at 100 MHz
+    if (world == 1) x->connected = true;
+    *out = x;
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_exchange_export(const bsvi_exchange* x, void* handle_out) {
+    if (!x || !handle_out) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, x->region);
+    if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    memcpy(handle_out, &h, sizeof h);
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_exchange_connect(bsvi_exchange* x, const void* handles) {
+    if (!x || !handles) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    if (x->connected) return BSVI_OK;
+    for (uint32_t r = 0; r < x->world; ++r) {
+        if (r == x->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + (size_t)r * sizeof h, sizeof h);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+        x->peer[r] = (unsigned char*)p;
+        x->opened[r] = true;
+    }
+    x->connected = true;
+    return BSVI_OK;
+}
+
+extern "C" int bsvi_exchange_allreduce(bsvi_exchange* x, float* buf_dev, uint32_t n, void* stream) {
+    if (!x || !buf_dev) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    if (!x->connected) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_exchange_allreduce: the peers' regions are not connected yet");
+    if (n > x->capacity) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_exchange_allreduce: message longer than the exchange's capacity");
+    if (n == 0) return BSVI_OK;
+    XArgs A{};
+    for (uint32_t r = 0; r < x->world; ++r) A.peer[r] = x->peer[r];
+    A.buf = buf_dev; A.n = n; A.capacity = x->capacity; A.rank = x->rank; A.world = x->world;
+    A.seq = ++x->seq;                           // every rank makes the same sequence of calls
+    A.timeout_ticks = x->timeout_ticks;
+    hipLaunchKernelGGL(exchange_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("exchange_kernel launch: ") + hipGetErrorString(e));
+    return BSVI_OK;
+}
+
+// 0: every call so far met its peers; otherwise the sequence number of the last call that gave up waiting (synchronises)
+extern "C" int bsvi_exchange_status(const bsvi_exchange* x) {
+    if (!x) return -1;
+    uint32_t words[2] = {0, 0};
+    if (hipMemcpy(words, x->region + (size_t)kMaxRanks * kFlagStride * 4, sizeof words, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)words[0];
+}
+
+extern "C" void bsvi_exchange_destroy(bsvi_exchange* x) {
+    if (!x) return;
+    for (uint32_t r = 0; r < x->world; ++r)
+        if (x->opened[r] && x->peer[r]) (void)hipIpcCloseMemHandle(x->peer[r]);
+    if (x->region) (void)hipFree(x->region);
+    delete x;
+}

@@ -165,12 +165,24 @@ EXPORTS.update({
     "bsvi_amort_create": (C.c_int, [C.POINTER(AmortDesc), C.POINTER(C.c_void_p)]),
     "bsvi_amort_destroy": (None, [C.c_void_p]),
     "bsvi_amort_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "bsvi_amort_exact_data": (C.c_int, [C.c_void_p]),
     "bsvi_amort_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(AmortArgs)]),
     "bsvi_amort_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "bsvi_debug_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                   C.c_float, C.c_uint32, C.c_void_p]),
+})
+
+EXPORTS.update({
+    "bsvi_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bsvi_exchange_handle_bytes": (C.c_size_t, []),
+    "bsvi_exchange_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "bsvi_exchange_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsvi_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsvi_exchange_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bsvi_exchange_status": (C.c_int, [C.c_void_p]),
+    "bsvi_exchange_destroy": (None, [C.c_void_p]),
 })
 
 _lib = None

@@ -511,6 +511,11 @@ void bsvi_amort_destroy(bsvi_amort* a);
  * behind them the per-slice partials of every reduction over rows (weight / bias gradients, loss sums), which one launch at
  * the end of the call adds in slice order — the output block is bit-reproducible call to call, no float atomics. */
 size_t bsvi_amort_workspace_bytes(const bsvi_amort* a, uint32_t n_samples_local);
+/* 1 when every value of the dataset is exactly a bf16 number (binarised images as in examples/VAE_playground.py:22-26,
+ * pixel counts): the layers that read the data rows then run on the bf16 matrix cores — x W^T as three bf16 MFMAs on the
+ * exact pieces hi + mid + lo of the f32 weights, products exact, f32 accumulation — instead of the f32-input MFMA;
+ * 0: the f32 kernels serve them (also with BSVI_AMORT_XGEMM=0 at create time). */
+int bsvi_amort_exact_data(const bsvi_amort* a);
 int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args);
 
 /* Forward pass of one network (0 = encoder, 1 = decoder) on caller-supplied rows input_dev [n_rows][input width]; the
@@ -541,6 +546,38 @@ int bsvi_debug_math(int fn, int dist, const float* x_dev, const float* p0_dev, c
 /* Diagnostic hook (tools/phase_stamps.py): 10 uint64 = (s_memtime, s_memrealtime) at the phase
  * boundaries prologue / forward / backward / reduction of workgroup 0; NULL switches it off. */
 void bsvi_debug_set_stamps(unsigned long long* stamps_dev);
+
+/* =========================================================================================
+ * The exchange of the multi-GPU path (the reference is single-process and has none).
+ *
+ * Samples are sharded over the GPUs of a node; between bsvi_elbo_fwd_bwd (this rank's sums in out_dev[0 .. 4 + P)) and
+ * bsvi_finalize_step (the replicated optimizer step) every rank needs the TOTAL of the blocks.  The step of a rank is
+ * therefore three C calls on one stream: bsvi_elbo_fwd_bwd, one of the two calls below, bsvi_finalize_step.
+ *
+ * bsvi_allreduce: in-place sum of buf_dev[0 .. n) over the ranks of an RCCL communicator the host owns (`rccl_comm` is an
+ *   ncclComm_t; with PyTorch: ProcessGroupNCCL._comm_ptr()).  The library does not link RCCL: ncclAllReduce is resolved at
+ *   the first call from the RCCL instance already loaded in the process (BSVI_RCCL_LIB names another).  Stream-ordered,
+ *   capturable into a HIP graph like the launches around it.
+ *
+ * bsvi_exchange_*: a one-shot direct-write all-reduce for messages of at most 16384 floats (this path's are 47 to ~400):
+ *   every rank owns a region of device memory; bsvi_exchange_export gives its HIP IPC handle (bsvi_exchange_handle_bytes
+ *   bytes) which the host passes to the other ranks by whatever channel it has; bsvi_exchange_connect takes the handles of
+ *   all ranks ([world][handle bytes], rank order) and maps the peers' regions (over xGMI between GPUs).
+ *   bsvi_exchange_allreduce is ONE one-workgroup kernel: the rank's vector is written into its slot of every region, a
+ *   per-call sequence number is published behind a system-scope release, the kernel waits for the peers' numbers and adds
+ *   the slots in rank order — the same association on every rank, so all ranks hold bit-identical totals.  The wait is
+ *   bounded (BSVI_EXCHANGE_TIMEOUT_MS, default 2000): a rank whose peers never arrive leaves buf_dev unchanged and raises
+ *   the region's abort word — bsvi_exchange_status returns the sequence number of the call that gave up (0: none did).
+ *   Nothing traps or hangs.  Every rank must make the same sequence of bsvi_exchange_allreduce calls. */
+typedef struct bsvi_exchange bsvi_exchange;
+int bsvi_allreduce(void* rccl_comm, float* buf_dev, size_t n, void* stream);
+size_t bsvi_exchange_handle_bytes(void);
+int bsvi_exchange_create(uint32_t rank, uint32_t world, uint32_t capacity_floats, bsvi_exchange** out);
+int bsvi_exchange_export(const bsvi_exchange* x, void* handle_out);
+int bsvi_exchange_connect(bsvi_exchange* x, const void* handles);
+int bsvi_exchange_allreduce(bsvi_exchange* x, float* buf_dev, uint32_t n, void* stream);
+int bsvi_exchange_status(const bsvi_exchange* x);
+void bsvi_exchange_destroy(bsvi_exchange* x);
 
 const char* bsvi_last_error(void);
 int bsvi_abi_version(void);

@@ -111,6 +111,59 @@ def test_gemm_tall_split_k():
     assert ((Cm.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
 
 
+@pytest.mark.parametrize("kind", ["binary", "counts"])
+@pytest.mark.parametrize("shape", [(128, 128, 32), (300, 70, 50), (1000, 136, 784), (25600, 256, 784), (513, 257, 150)])
+def test_exact_data_forward_product_on_the_bf16_matrix_cores(kind, shape):
+    """The layer that reads the data rows when every data value is exactly a bf16 (binarised images, pixel counts 0..255):
+    x W^T as three bf16 MFMAs on the exact pieces of W (xgemm_nt_kernel).  Against torch in double precision at the
+    tolerance of the f32-input kernel, against that kernel itself, and bit-identical call after call."""
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 5 * K)
+    n_src = M // 2 + 7
+    if kind == "binary":
+        src = (torch.rand(n_src, K, generator=g) > 0.5).float().to(dev)
+    else:
+        src = torch.randint(0, 256, (n_src, K), generator=g).float().to(dev)
+    rows = torch.randint(0, n_src, (M,), generator=g).to(torch.int32).to(dev)
+    Bm, bias = (torch.randn(N, K, generator=g) * (1.0 if kind == "binary" else 1.0 / 64)).to(dev), torch.randn(N, generator=g).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    ref = torch.relu(src[rows.long()].double() @ Bm.double().T + bias.double())
+    outs = []
+    for _ in range(2):
+        Cm = torch.full((M, N + 3), 7.0, device=dev)
+        native.check(lib.bsvi_debug_gemm(3, ptr(src), ptr(Bm), ptr(Cm), ptr(rows), M, N, K, K, K, N + 3, ptr(bias), 0, 1, 0.0, n_src, None))
+        torch.cuda.synchronize()
+        assert torch.all(Cm[:, N:] == 7.0)
+        outs.append(Cm[:, :N].clone())
+    scale = ref.abs().max().item() + 1e-12
+    assert (outs[0].double() - ref).abs().max().item() / scale < 2e-6
+    assert torch.equal(outs[0], outs[1])
+    Cf = torch.zeros(M, N, device=dev)
+    native.check(lib.bsvi_debug_gemm(0, ptr(src), ptr(Bm), ptr(Cf), ptr(rows), M, N, K, K, K, N, ptr(bias), 0, 1, 0.0, 0, None))
+    torch.cuda.synchronize()
+    assert (outs[0].double() - Cf.double()).abs().max().item() / scale < 2e-6
+
+
+def test_inexact_data_stays_on_the_f32_kernel():
+    """a dataset with values that are not bf16 numbers must not take the bf16 path: the compiled object says which one it runs"""
+    from brancher_amd import engine, workloads as W
+    import brancher_amd.workloads as Wm
+    api = W.native_api()
+    kw = dict(dataset_size=80, batch_size=10, n_features=96, hidden1=160, hidden2=48, seed=5)
+    exact = engine.compile_model(W.build_vae(api, **kw), None, "pathwise")
+    assert exact.data_path() == "bf16x3"
+    original = Wm.vae_data
+    try:
+        Wm.vae_data = lambda ds, nf, seed=0: original(ds, nf, seed).astype("float32") * 0.3       # 0.3 is not a bf16 number
+        inexact = engine.compile_model(W.build_vae(api, **kw), None, "pathwise")
+    finally:
+        Wm.vae_data = original
+    assert inexact.data_path() == "f32"
+
+
 # ---- the ELBO gradient against the reference's own outputs ------------------------------------------------------
 @pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
 def test_vae_golden_loss_and_grads(vae_golden, estimator):
