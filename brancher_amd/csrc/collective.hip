@@ -94,12 +94,13 @@ namespace {
 
 constexpr uint32_t kMaxRanks = 8;           // one node: 8 GPUs, 7 xGMI peers each
 constexpr uint32_t kFlagStride = 16;        // a flag per 64-byte line
-constexpr uint32_t kHeaderWords = 256;      // flags [8 x 16] | abort | timeouts | ... (1 KB)
+constexpr uint32_t kHeaderWords = 256;      // flags [8 x 16] | abort | timeouts | calls | ... (1 KB)
+constexpr uint32_t kCallsWord = kMaxRanks * kFlagStride + 16;
 
 struct XArgs {
     unsigned char* peer[kMaxRanks];         // every rank's region as mapped here (peer[rank] = this rank's own)
     float* buf;
-    uint32_t n, capacity, rank, world, seq;
+    uint32_t n, capacity, rank, world;
     unsigned long long timeout_ticks;       // of the 100 MHz wall clock
 };
 
@@ -110,9 +111,14 @@ __device__ __forceinline__ float* slot_of(unsigned char* region, uint32_t parity
 // ONE workgroup.  Stores to the peers and the loads of what they wrote are system-scope atomics (relaxed): they bypass this
 // GPU's caches, so a slot written by a peer two calls ago cannot be served stale from L2.
 __global__ __launch_bounds__(256) void exchange_kernel(const XArgs A) {
-    const uint32_t tid = threadIdx.x, parity = A.seq & 1u;
-    __shared__ uint32_t gave_up;
-    if (tid == 0) gave_up = 0;
+    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t gave_up, seq_s;
+    uint32_t* mine = reinterpret_cast<uint32_t*>(A.peer[A.rank]);
+    // the call's sequence number lives in the region (word kCallsWord, touched by this rank's kernels only): the launch is the
+    // same every time, so a HIP graph that captured it replays correctly
+    if (tid == 0) { gave_up = 0; seq_s = mine[kCallsWord] + 1u; }
+    __syncthreads();
+    const uint32_t seq = seq_s, parity = seq & 1u;
     // 1. this rank's vector into its slot of every region (its own included)
     for (uint32_t i = tid; i < A.n; i += 256) {
         const float v = A.buf[i];
@@ -123,16 +129,16 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XArgs A) {
     __syncthreads();
     // 2. publish: "rank's slot of call seq is complete" in every region
     if (tid < A.world)
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(A.peer[tid]) + A.rank * kFlagStride, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(A.peer[tid]) + A.rank * kFlagStride, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) mine[kCallsWord] = seq;
     // 3. wait for every rank's number in this rank's region — bounded
-    uint32_t* mine = reinterpret_cast<uint32_t*>(A.peer[A.rank]);
     if (tid < A.world) {
         const unsigned long long t0 = wall_clock64();
         // (sequence numbers only grow; a peer may already be one call ahead)
-        while ((int32_t)(__hip_atomic_load(mine + tid * kFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - A.seq) < 0) {
+        while ((int32_t)(__hip_atomic_load(mine + tid * kFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
             if (wall_clock64() - t0 > A.timeout_ticks) {
                 gave_up = 1;
-                __hip_atomic_store(mine + kMaxRanks * kFlagStride, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // abort word: the call that gave up
+                __hip_atomic_store(mine + kMaxRanks * kFlagStride, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // abort word: the call that gave up
                 atomicAdd(mine + kMaxRanks * kFlagStride + 1, 1u);
                 break;
             }
@@ -227,7 +233,7 @@ extern "C" int bsvi_exchange_allreduce(bsvi_exchange* x, float* buf_dev, uint32_
     XArgs A{};
     for (uint32_t r = 0; r < x->world; ++r) A.peer[r] = x->peer[r];
     A.buf = buf_dev; A.n = n; A.capacity = x->capacity; A.rank = x->rank; A.world = x->world;
-    A.seq = ++x->seq;                           // every rank makes the same sequence of calls
+    ++x->seq;                                   // (host-side count only: the kernel numbers its calls in the region itself)
     A.timeout_ticks = x->timeout_ticks;
     hipLaunchKernelGGL(exchange_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
     const hipError_t e = hipGetLastError();

@@ -53,14 +53,51 @@ def shard(n_global, rank, world):
     return base, n_local
 
 
+_exchanges = {}          # device index -> collective.Exchange (BSVI_COLLECTIVE=exchange)
+
+
 def allreduce_sums(out):
     """The ONE collective of the multi-GPU path: sum the per-rank output blocks
-    [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.  RCCL over xGMI
-    when `out` is a device tensor (backend "nccl"), gloo in the CPU tests."""
+    [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.  By default torch.distributed's
+    all-reduce (RCCL over xGMI when `out` is a device tensor and the backend is "nccl"; gloo in the CPU tests).
+    BSVI_COLLECTIVE=rccl: the same RCCL call through the C ABI (`bsvi_allreduce` on torch's communicator);
+    BSVI_COLLECTIVE=exchange: the library's one-shot direct-write all-reduce over IPC-mapped peer regions
+    (`bsvi_exchange_*`, messages of up to 16384 floats) — one one-workgroup kernel, no RCCL on the step's path."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return out
+    kind = os.environ.get("BSVI_COLLECTIVE", "torch")
+    if kind == "exchange" and out.is_cuda and out.numel() <= 16384 and out.dtype == torch.float32:
+        from brancher_amd import collective
+        key = out.device.index
+        ex = _exchanges.get(key)
+        if ex is None or ex.capacity < out.numel():
+            # (collective: every rank reaches this with the same message length, outside any stream capture — the graph
+            #  path makes one untimed call of the sequence first)
+            if ex is not None:
+                ex.close()
+            ex = _exchanges[key] = collective.Exchange(max(out.numel(), 1024), device=out.device)
+            ex.capacity = max(out.numel(), 1024)
+        ex.allreduce(out)
+        return out
+    if kind == "rccl" and out.is_cuda and out.dtype == torch.float32:
+        from brancher_amd import collective
+        comm = collective.rccl_comm_ptr()
+        if comm is not None:
+            return collective.rccl_allreduce(out, comm)
+    dist.all_reduce(out, op=dist.ReduceOp.SUM)
     return out
+
+
+def check_exchange(device):
+    """after a training call over the one-shot exchange: did every call meet its peers?  (a rank that gives up keeps its own
+    sums — finite, but no longer the totals — so this must be an error, not a warning)"""
+    ex = _exchanges.get(device.index)
+    if ex is not None:
+        gave_up = ex.status()
+        if gave_up:
+            raise native.NativeError("the one-shot exchange gave up waiting for a peer at its call {} "
+                                     "(BSVI_EXCHANGE_TIMEOUT_MS); the ranks' parameters are no longer in step".format(gave_up))
 
 
 def estimator_name(gradient_estimator):
@@ -560,6 +597,7 @@ class CompiledELBO:
                 self._train_graph(K, n_local, number_samples, base, cfg, state, loss_curve, finite, seed, offset0,
                                   int(pretraining_iterations))
                 self.last_mode = "graph" if world == 1 else "graph+allreduce"
+                check_exchange(dev)
                 return loss_curve, finite
             except (RuntimeError, native.NativeError) as err:      # capture refused: launch by launch below
                 warnings.warn("HIP-graph capture of the sharded step failed ({}); stepping eagerly".format(err))
@@ -579,6 +617,8 @@ class CompiledELBO:
                     C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(mask), p.n_params, number_samples,
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
+        if world > 1:
+            check_exchange(dev)
         return loss_curve, finite
 
 

@@ -23,11 +23,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, workload, n_samples, iters, optimizer, opt_kw, out_q):
+def _worker(rank, world, port, workload, n_samples, iters, optimizer, opt_kw, out_q, collective="torch"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["BSVI_GRAPH"] = "0"                # a gloo collective cannot be captured into a HIP graph
+    os.environ["BSVI_COLLECTIVE"] = collective
+    # a gloo collective cannot be captured into a HIP graph; the library's one-shot exchange is a kernel and can
+    os.environ["BSVI_GRAPH"] = "1" if collective == "exchange" else "0"
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -88,6 +90,34 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
         np.testing.assert_allclose(params, ref_params, rtol=2e-5, atol=2e-6)
         assert abs(ev - ref_eval) <= 2e-5 * abs(ref_eval)
     # the two ranks hold bit-identical parameters (same sums after the all-reduce, same step)
+    assert np.array_equal(got[0][1], got[1][1])
+
+
+def test_two_ranks_over_the_one_shot_exchange_inside_a_hip_graph():
+    """the same trajectory with the library's own exchange (bsvi_exchange_*: the ranks map each other's regions through HIP
+    IPC) in place of the host-staged all-reduce — a kernel, so the step sequence is captured in a HIP graph and replayed
+    with the exchange inside"""
+    import torch.multiprocessing as mp
+    workload, n_samples, optimizer, opt_kw, iters = ("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3), 40
+    ref_losses, ref_params, ref_eval = _single(workload, n_samples, iters, optimizer, opt_kw)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, workload, n_samples, iters, optimizer, opt_kw, q, "exchange")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        losses, params, ev, mode, finite = got[rank]
+        assert finite and mode == "graph+allreduce", mode
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(params, ref_params, rtol=2e-5, atol=2e-6)
     assert np.array_equal(got[0][1], got[1][1])
 
 
