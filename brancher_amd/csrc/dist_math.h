@@ -234,6 +234,8 @@ BSVI_SWITCH_FN float logp_generic(int dist, float x, float p0, float p1) {
         const float norm = p0 * fmaxf(p1, 0.0f) + p0 * log1p_exp_neg_abs_hw(p1) - lfn;
         return x * p1 - lfk - lfnmk - norm;
     }
+    case BSVI_DIST_LINEAR:       // the surrogate of a term computed outside the program (include/bsvi.h)
+        return p0 * x + p1;
     case BSVI_DIST_BERNOULLI: {  // p0 = logits; -binary_cross_entropy_with_logits(l, x)
         return -((1.0f - x) * p0 + (fmaxf(-p0, 0.0f) + log1p_exp_neg_abs_hw(p0)));
     }
@@ -281,6 +283,11 @@ __device__ __forceinline__ void logp_bwd_impl(int dist, float x, float p0, float
     }
     case BSVI_DIST_BINOMIAL:
         g1 += g * (x - p0 * sigmoid_hw(p1));
+        break;
+    case BSVI_DIST_LINEAR:
+        gx += g * p0;
+        g0 += g * x;
+        g1 += g;
         break;
     case BSVI_DIST_BERNOULLI:
         gx += g * p0;

@@ -591,7 +591,7 @@ class CompiledELBO:
             return loss_curve, finite
 
         sharded = world > 1 or _force_sharded_path
-        if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0" and p.n_params <= 1024:
+        if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0":
             # multi-GPU: the step sequence is captured once in a HIP graph and replayed — no Python between the launches
             try:
                 self._train_graph(K, n_local, number_samples, base, cfg, state, loss_curve, finite, seed, offset0,

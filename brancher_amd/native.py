@@ -185,6 +185,60 @@ EXPORTS.update({
     "bsvi_exchange_destroy": (None, [C.c_void_p]),
 })
 
+class MvnInsn(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("flag", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("imm", C.c_float)]
+
+
+class MvnDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("dim", C.c_uint32), ("n_code", C.c_uint32), ("n_mats", C.c_uint32),
+                ("n_slot_inputs", C.c_uint32), ("n_uniform_inputs", C.c_uint32), ("value_is_latent", C.c_uint32),
+                ("reserved", C.c_uint32),
+                ("code", C.POINTER(MvnInsn)), ("mats", C.c_void_p), ("loc", C.c_void_p), ("value", C.c_void_p),
+                ("uniform_inputs", C.c_void_p), ("weight", C.c_float), ("reserved2", C.c_uint32)]
+
+
+class MvnArgs(C.Structure):
+    _fields_ = [("params_dev", C.c_void_p), ("samples_dev", C.c_void_p), ("rows_out_dev", C.c_void_p),
+                ("n_samples_local", C.c_uint32), ("value_row0", C.c_uint32), ("input_rows", C.c_uint32 * 8),
+                ("stream", C.c_void_p)]
+
+
+MVN_KIND = dict(MAT=0, INPUT=1, IMM=2, BIN=3, UN=4)
+EXPORTS.update({
+    "bsvi_mvn_create": (C.c_int, [C.POINTER(MvnDesc), C.POINTER(C.c_void_p)]),
+    "bsvi_mvn_destroy": (None, [C.c_void_p]),
+    "bsvi_mvn_rows_out": (C.c_uint32, [C.POINTER(MvnDesc)]),
+    "bsvi_mvn_eval": (C.c_int, [C.c_void_p, C.POINTER(MvnArgs)]),
+    "bsvi_mvn_source": (C.c_size_t, [C.POINTER(MvnDesc), C.c_char_p, C.c_size_t]),
+})
+
+
+def mvn_desc(node):
+    """lowering.ExternalMvn -> (bsvi_mvn_desc, the arrays it points into)"""
+    code = (MvnInsn * len(node.code))(*[MvnInsn(kind=MVN_KIND[k], flag=f, a=a, b=b, imm=imm) for k, f, a, b, imm in node.code])
+    mats = np.ascontiguousarray(node.mats, dtype=np.float32)
+    loc = np.ascontiguousarray(node.loc, dtype=np.float32)
+    value = np.ascontiguousarray(node.value if node.value is not None else np.zeros(node.dim), dtype=np.float32)
+    uni = np.ascontiguousarray(node.uniform_inputs)
+    keep = dict(code=code, mats=mats, loc=loc, value=value, uni=uni)
+    d = MvnDesc(abi_version=ABI_VERSION, dim=node.dim, n_code=len(node.code), n_mats=mats.shape[0] if mats.size else 0,
+                n_slot_inputs=len(node.slot_inputs), n_uniform_inputs=len(uni), value_is_latent=int(node.value is None),
+                code=code, mats=_ptr(mats), loc=_ptr(loc), value=_ptr(value), uniform_inputs=_ptr(uni) if len(uni) else None,
+                weight=float(node.weight))
+    return d, keep
+
+
+def mvn_source(node):
+    lib = load()
+    d, keep = mvn_desc(node)
+    need = lib.bsvi_mvn_source(C.byref(d), None, 0)
+    if need == 0:
+        raise NativeError("bsvi_mvn_source: " + lib.bsvi_last_error().decode())
+    buf = C.create_string_buffer(need)
+    lib.bsvi_mvn_source(C.byref(d), buf, need)
+    return buf.value.decode()
+
+
 _lib = None
 
 

@@ -64,7 +64,12 @@ typedef enum bsvi_dist {
     BSVI_DIST_BINOMIAL = 6,     /* p0 = total_count, p1 = logits */
     BSVI_DIST_BERNOULLI = 7,    /* p0 = logits                   */
     BSVI_DIST_CATEGORICAL = 8,
-    BSVI_DIST_COUNT = 9
+    /* not a distribution of the reference: the "log-density" p0 * x + p1, linear in its value.  Terms of this kind are how
+     * a quantity computed OUTSIDE the per-sample program enters it with its value and its gradient: the batched
+     * multivariate-normal kernel (bsvi_mvn_*) hands the program log p and d log p / d inputs of a sample as the rows of a
+     * linear surrogate, and the program's reverse sweep carries the coefficients on to the latents and parameters. */
+    BSVI_DIST_LINEAR = 9,
+    BSVI_DIST_COUNT = 10
 } bsvi_dist;
 
 /* ---- the model program: a memory-to-memory instruction set over per-sample slots.
@@ -546,6 +551,61 @@ int bsvi_debug_math(int fn, int dist, const float* x_dev, const float* p0_dev, c
 /* Diagnostic hook (tools/phase_stamps.py): 10 uint64 = (s_memtime, s_memrealtime) at the phase
  * boundaries prologue / forward / backward / reduction of workgroup 0; NULL switches it off. */
 void bsvi_debug_set_stamps(unsigned long long* stamps_dev);
+
+/* =========================================================================================
+ * Batched multivariate-normal nodes (brancher/distributions.py:314-331,
+ * brancher/standard_variables.py:317-347 with `covariance_matrix`).
+ *
+ * log N(x | m, C) and its gradient for a covariance that is an ELEMENTWISE link expression of constant matrices and a
+ * few scalars that differ per Monte-Carlo sample (latent kernel hyper-parameters) or are learnable — the case the
+ * per-sample program cannot hold (D^2 values per sample).  One wave per sample factorises C in LDS (Cholesky,
+ * triangular inverse, C^-1 = L^-T L^-1) and contracts d log p / d C = (alpha alpha^T - C^-1) / 2 with the expression's
+ * derivatives.  The covariance expression arrives as three-address code (temp t = instruction t; the last instruction
+ * is C_ij); the library generates HIP from it and compiles it with hiprtc at the first evaluation (same caches as the
+ * program-specialised ELBO kernels).  dim <= 136 (two matrices in 160 KiB of LDS), at most 8 scalar inputs.
+ *
+ * The node talks to the per-sample program through rows of per-sample values:
+ *   in   samples_dev [rows][n_local]: the slot values of the draw (samples_out of a bsvi_elbo_fwd_bwd call);
+ *        input_rows[k] is the row of scalar input k < n_slot_inputs, value_row0 the first of the dim rows of x when x is
+ *        latent (value_is_latent), params_dev feeds the uniform inputs (a + b * g(params[src]))
+ *   out  rows_out_dev [bsvi_mvn_rows_out][n_local]: g_k = weight * d log p / d input_k for the slot inputs, then for the
+ *        dim elements of a latent x, then for the uniform inputs, then  e = weight * log p - sum_k g_k * input_k.
+ *        e + sum_k g_k * input_k has the value and the gradient of weight * log p at the sample: the program adds it to f
+ *        with BSVI_DIST_LINEAR terms whose coefficients are BSVI_F_GIVEN rows.  A covariance that is not positive
+ *        definite gives NaN rows (the step is then skipped as non-finite, brancher/inference.py:98). */
+typedef enum bsvi_mvn_kind { BSVI_MVN_MAT = 0, BSVI_MVN_INPUT = 1, BSVI_MVN_IMM = 2, BSVI_MVN_BIN = 3, BSVI_MVN_UN = 4 } bsvi_mvn_kind;
+typedef struct bsvi_mvn_insn {
+    uint32_t kind;     /* bsvi_mvn_kind */
+    uint32_t flag;     /* BIN: bsvi_binop, UN: bsvi_unop */
+    uint32_t a, b;     /* MAT: a = matrix index; INPUT: a = input index (slot inputs first, then uniform inputs); BIN / UN: temps */
+    float imm;         /* IMM: the value; UN POWI: the exponent */
+} bsvi_mvn_insn;
+typedef struct bsvi_mvn_desc {
+    uint32_t abi_version, dim, n_code, n_mats;
+    uint32_t n_slot_inputs, n_uniform_inputs, value_is_latent, reserved;
+    const bsvi_mvn_insn* code;                 /* host */
+    const float* mats;                         /* host [n_mats][dim][dim] */
+    const float* loc;                          /* host [dim] */
+    const float* value;                        /* host [dim]: the observed x (value_is_latent == 0) */
+    const bsvi_uniform_entry* uniform_inputs;  /* host [n_uniform_inputs], parameter-sourced */
+    float weight;                              /* of log p in f */
+    uint32_t reserved2;
+} bsvi_mvn_desc;
+typedef struct bsvi_mvn_args {
+    const float* params_dev;
+    const float* samples_dev;
+    float* rows_out_dev;
+    uint32_t n_samples_local, value_row0;
+    uint32_t input_rows[8];
+    void* stream;
+} bsvi_mvn_args;
+typedef struct bsvi_mvn bsvi_mvn;
+int bsvi_mvn_create(const bsvi_mvn_desc* desc, bsvi_mvn** out);
+void bsvi_mvn_destroy(bsvi_mvn* m);
+uint32_t bsvi_mvn_rows_out(const bsvi_mvn_desc* desc);
+int bsvi_mvn_eval(bsvi_mvn* m, const bsvi_mvn_args* args);
+/* the generated translation unit (host only, like bsvi_program_source): byte count including the terminator, 0 on error */
+size_t bsvi_mvn_source(const bsvi_mvn_desc* desc, char* buf, size_t capacity);
 
 /* =========================================================================================
  * The exchange of the multi-GPU path (the reference is single-process and has none).
