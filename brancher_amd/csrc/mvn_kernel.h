@@ -16,6 +16,7 @@
 // Rows are 16-byte aligned with a stride of 4 * odd words: every inner product runs on ds_read_b128 along k, conflict-free
 // across the lanes' rows; both matrices start zeroed so that aligned 4-wide blocks may overrun a triangle's edge.
 //
+// Rows out: coefficients of the slot inputs | of x (when latent) | of the uniform inputs | of m (when learnable) | e.
 // The results leave as the rows of a LINEAR surrogate (lowering.ExternalMvn): g_k = dlogp/d(input k) and
 // e = logp - sum_k g_k input_k, so that  e + sum_k g_k input_k  has the value AND the gradient of log p at this sample —
 // the scalar program adds it to f through BSVI_DIST_LINEAR terms and its reverse sweep carries g_k on.
@@ -29,6 +30,7 @@ struct MvnArgs {
     const float* mats;                    // [MVN_NMATS][D][D]
     const float* vecs;                    // [2][D]: loc, observed value
     const bsvi_uniform_entry* uniform_inputs;
+    const bsvi_uniform_entry* loc_entries;    // [D] when the loc is learnable (MVN_LOC_PARAM), else null
     float* rows_out;                      // the surrogate's rows: [n_rows_out][n_local], row 0 = first input's coefficient
     uint32_t n_local, value_row0;
     uint32_t input_rows[8];
@@ -75,7 +77,12 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
         float v = 0.0f;
         if (i < D) {
             const float x = MVN_VALUE_LATENT ? G.samples[(size_t)(G.value_row0 + i) * G.n_local + n] : G.vecs[D + i];
-            v = x - G.vecs[i];
+            float m = G.vecs[i];
+            if (MVN_LOC_PARAM) {
+                const bsvi_uniform_entry e = G.loc_entries[i];
+                m = e.a + e.b * utransform(e.transform, G.params[e.src]);
+            }
+            v = x - m;
         }
         dvec[i] = v;
         avec[i] = 0.0f;
@@ -238,9 +245,23 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
     if (lane == 0) {
 #pragma unroll
         for (int k = MVN_NSI; k < MVN_NIN; ++k) G.rows_out[(size_t)(row + k - MVN_NSI) * G.n_local + n] = w * gin[k];
-        row += MVN_NIN - MVN_NSI;
-        G.rows_out[(size_t)row * G.n_local + n] = w * logp - lin - linx;
     }
+    row += MVN_NIN - MVN_NSI;
+    float linm = 0.0f;
+    if (MVN_LOC_PARAM) {           // d log p / d m = +alpha
+        for (int t = 0; t < (D + 63) / 64; ++t) {
+            const int i = lane + 64 * t;
+            if (i < D) {
+                const float gm = w * avec[i];
+                G.rows_out[(size_t)(row + i) * G.n_local + n] = gm;
+                const bsvi_uniform_entry e = G.loc_entries[i];
+                linm += gm * (e.a + e.b * utransform(e.transform, G.params[e.src]));
+            }
+        }
+        linm = mvn_wave_sum(linm);
+        row += D;
+    }
+    if (lane == 0) G.rows_out[(size_t)row * G.n_local + n] = w * logp - lin - linx - linm;
 }
 
 }  // namespace bsvi

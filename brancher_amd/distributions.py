@@ -20,8 +20,9 @@ DIST_BETA = 5
 DIST_BINOMIAL = 6
 DIST_BERNOULLI = 7
 DIST_CATEGORICAL = 8
-DIST_EMPIRICAL = 9
-DIST_MVNORMAL = 10
+DIST_LINEAR = 9            # BSVI_DIST_LINEAR: not a distribution — the surrogate of a term computed outside the program
+DIST_EMPIRICAL = 100       # host-side kinds (they never reach an instruction)
+DIST_MVNORMAL = 101
 
 # what the per-latent "noise" input means in given-noise (parity) mode
 NOISE_NONE = 0          # deterministic
@@ -57,6 +58,13 @@ class Distribution:
         """Pick which named link outputs feed kernel operands p0/p1.  Returns a list of
         (name, transform) where transform is None or a string understood by the lowering."""
         return [(name, None) for name in self.kernel_parameters]
+
+
+class LinearSurrogate(Distribution):
+    """"log-density" p0 * x + p1 (include/bsvi.h BSVI_DIST_LINEAR): how the batched multivariate-normal kernel's result
+    enters the per-sample program (lowering.mvn_external).  Never built by a user."""
+    kind = DIST_LINEAR
+    kernel_parameters = ("coefficient", "offset")
 
 
 class DeterministicDistribution(Distribution):

@@ -254,6 +254,19 @@ class CompiledELBO:
         first_group = 0 if np.any(active[group == 0]) else 1
         self.mask_all = torch.from_numpy(active.copy()).to(dev)
         self.mask_first = torch.from_numpy((active * (group == first_group)).astype(np.uint8)).to(dev)
+        # batched multivariate-normal terms (lowering.mvn_external): the BASE program (this one without those terms; it makes
+        # the draw), one bsvi_mvn node per term, and the program's noise tensor whose last rows the nodes fill
+        self._externals = []
+        if getattr(p, "externals", None):
+            self.base_program = lowering.lower(joint_model, posterior_model, estimator, external="omit")
+            if [(q.name, o, n) for q, o, n, _ in self.base_program.parameters] != [(q.name, o, n) for q, o, n, _ in p.parameters]:
+                raise RuntimeError("parameter layouts of the base program and the full program differ")
+            self.base_native = native.NativeProgram(self.base_program)
+            bp = self.base_program
+            self.base_obs = torch.from_numpy(np.ascontiguousarray(bp.obs)).to(dev) if bp.obs.size else torch.zeros(1, device=dev)
+            self.base_out = torch.zeros(OUT_HEADER + max(bp.n_params, 1), device=dev, dtype=torch.float32)
+            self._externals = [native.MvnNode(e) for e in p.externals]
+            self._base_buffers = {}
         self._workspaces = {}
         self._train_plans = {}
         self._fast_train = {}
@@ -329,6 +342,33 @@ class CompiledELBO:
                         fvalue_out_dev=ptr(fvalue_out), workspace_dev=ptr(self.workspace(n_local)),
                         stream=self._stream())
 
+    def _external_rows(self, n_local, n_global, base, noise_t, seed, offset):
+        """Models with batched multivariate-normal terms, per evaluation: (1) the base program draws the posterior's sample
+        (its noise and slot values land in buffers), (2) every bsvi_mvn node reads the draw and writes the rows of its linear
+        surrogate — log p and d log p / d inputs of each sample — behind the real rows of the noise tensor, (3) the caller
+        launches the full program on that tensor.  Returns the tensor [n_noise, n_local]."""
+        p, bp, dev = self.program, self.base_program, self.device
+        bufs = self._base_buffers.get(n_local)
+        if bufs is None:
+            nbytes = self.base_native.workspace_bytes(n_local)
+            if nbytes == 0:
+                raise native.NativeError("the base program does not fit the LDS budget for {} samples".format(n_local))
+            bufs = self._base_buffers[n_local] = dict(ws=torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                                                      samples=torch.empty((bp.n_noise, n_local), device=dev),
+                                                      noise=torch.zeros((p.n_noise, n_local), device=dev))
+        full = noise_t if noise_t is not None else bufs["noise"]
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        args = ElboArgs(params_dev=ptr(self.params), obs_dev=ptr(self.base_obs), noise_dev=ptr(noise_t),
+                        seed=self._resolved(seed), offset=int(offset), n_samples_local=n_local, n_samples_global=n_global,
+                        sample_base=base, out_dev=ptr(self.base_out), samples_out_dev=ptr(bufs["samples"]),
+                        noise_out_dev=None if noise_t is not None else ptr(full), fvalue_out_dev=None,
+                        workspace_dev=ptr(bufs["ws"]), stream=self._stream())
+        native.check(self.lib.bsvi_elbo_fwd_bwd(self.base_native.handle, C.byref(args)))
+        for node in self._externals:
+            node.eval(ptr(self.params), ptr(bufs["samples"]), C.c_void_p(full.data_ptr() + 4 * node.node.row0 * n_local),
+                      n_local, self._stream())
+        return full
+
     def _noise_tensor(self, noise, n_global, base, n_local):
         """named dict / [n_noise, N] array / device tensor -> device [n_noise, n_local] (this rank's columns)"""
         if noise is None:
@@ -361,6 +401,8 @@ class CompiledELBO:
         samples = torch.empty((p.n_noise, n_local), device=dev) if want_samples else None
         noise_o = torch.empty((p.n_noise, n_local), device=dev) if want_noise else None
         fvals = torch.empty((2, n_local), device=dev) if want_fvalues else None
+        if self._externals:
+            noise_t = self._external_rows(n_local, number_samples, base, noise_t, seed, offset)
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
@@ -540,7 +582,7 @@ class CompiledELBO:
             self.native.ensure_shares(n_local)          # (the share set attached to the program follows the last shard size)
             self._shares_for = n_local
         if plan is None:
-            persistent = (allow_persistent and world == 1 and not _force_sharded_path
+            persistent = (allow_persistent and world == 1 and not _force_sharded_path and not self._externals
                           and self.native.persistent_supported(n_local))
             shares = self.native.split_shares(n_local) if persistent else None
             # the specialised in-kernel loop starts a fresh optimizer itself and nobody reads its final state: no state
@@ -591,7 +633,7 @@ class CompiledELBO:
             return loss_curve, finite
 
         sharded = world > 1 or _force_sharded_path
-        if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0":
+        if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0" and not self._externals:
             # multi-GPU: the step sequence is captured once in a HIP graph and replayed — no Python between the launches
             try:
                 self._train_graph(K, n_local, number_samples, base, cfg, state, loss_curve, finite, seed, offset0,
@@ -604,6 +646,8 @@ class CompiledELBO:
                 loss_curve.zero_()
         for it in range(K):
             nz = None if noise_t is None else noise_t[it]
+            if self._externals:
+                nz = self._external_rows(n_local, number_samples, base, nz, seed, offset0 + it)
             args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
             mask = self.mask_all if it > pretraining_iterations else self.mask_first
             if world == 1 and not _force_sharded_path:

@@ -226,6 +226,7 @@ class _Lowering:
         self.max_temps = 0
         self.view_rank, self.view_memo, self.elem_memo, self.view_terms = {}, {}, {}, 0
         self.slot_rank = {}
+        self.externals, self.pseudo_q, self.external_mode = [], [], "inject"
 
     # ---------------------------------------------------------------- IR construction
     def mk(self, op, args=(), attr=None, shape=None):
@@ -980,8 +981,11 @@ class _Lowering:
         if B != 1 or dim != dim2:
             raise LoweringError("%s of %r must be one square matrix per sample (shape %r)" % (given, v.name, mat.shape))
         if dim > self.kMaxSymbolicMvn:
-            raise LoweringError("%r: a %dx%d covariance that depends on learnable or sampled values (the factorisation is "
-                                "unrolled per sample; limit %d)" % (v.name, dim, dim, self.kMaxSymbolicMvn))
+            if given != "covariance_matrix":
+                raise LoweringError("%r: a %dx%d scale_tril that depends on learnable or sampled values (the factorisation is "
+                                    "unrolled per sample up to %d; larger nodes take a covariance_matrix: the batched "
+                                    "kernel)" % (v.name, dim, dim, self.kMaxSymbolicMvn))
+            return self.mvn_external(v, mat)
         value = self.p_value(v)
         loc = self.from_expr(links["loc"].expr, self.p_value)
         for what, node in (("value", value), ("loc", loc)):
@@ -1021,6 +1025,169 @@ class _Lowering:
                 u = mk("sub", (u, mk("mul", (L[i][j], w[j]))))
             w.append(mk("truediv", (u, L[i][i])))
             terms.append((_Term(v, i), u, [mk("imm", (), 0.0), L[i][i]], (1, 1, 1)))
+        return terms
+
+    kMaxExternalMvn = 136
+
+    def mvn_external(self, v, mat):
+        """A MultivariateNormal term too large to unroll (D > kMaxSymbolicMvn) whose covariance is an ELEMENTWISE expression of
+        constant matrices and SCALARS that are sampled or learnable: it leaves the per-sample program for the batched kernel
+        of the library (`bsvi_mvn_*`, csrc/mvn_kernel.h: one wave per sample factorises the covariance in LDS).  Here the
+        covariance link becomes three-address code over (matrix element, scalar input, immediate) leaves, and the term
+        re-enters the program as a LINEAR surrogate  e + sum_k g_k * input_k  (BSVI_DIST_LINEAR records) whose per-sample
+        coefficients are GIVEN rows the kernel fills — value and gradient of log p at the sample, so the program's reverse
+        sweep carries d log p / d inputs on to the posterior's parameters.  (`distributions.py:314-331`,
+        `standard_variables.py:317-347`.)"""
+        if self.estimator in ("taylor1", "importance"):
+            raise LoweringError("%r: the batched multivariate-normal kernel serves the Pathwise and BlackBox estimators (the %s "
+                                "program evaluates the model at values other than the posterior's draws)" % (v.name, self.estimator))
+        links = v.link.expressions()
+        _, dim, _ = mat.shape
+        if dim > self.kMaxExternalMvn:
+            raise LoweringError("%r: a %dx%d covariance (the batched kernel keeps two matrices in LDS: limit %d)"
+                                % (v.name, dim, dim, self.kMaxExternalMvn))
+        host_g = dict(identity=lambda x: x, softplus=lambda x: np.logaddexp(0.0, x), sigmoid=lambda x: 1.0 / (1.0 + np.exp(-x)),
+                      exp=np.exp, log=np.log, tanh=np.tanh, sqrt=np.sqrt, square=np.square)
+        code, mats, memo = [], [], {}
+        slot_inputs, uniform_inputs = [], []          # [(IR node, operand row)], [(IR node, uniform entry tuple)]
+
+        def push(ins):
+            code.append(ins)
+            return len(code) - 1
+
+        def constant(node):
+            """numpy value [dim, dim] of a sample-free, parameter-free node (else None)"""
+            if node.op == "imm":
+                return np.full((dim, dim), float(node.attr))
+            m = self.match_uniform(node)
+            if m is None:
+                return None
+            leaf, g, a, b = m
+            if leaf.op == "root" and leaf.attr.learnable:
+                return None
+            raw = np.asarray(leaf.attr.value if leaf.op == "root" else leaf.attr, dtype=np.float64).reshape(leaf.shape[1:])
+            return np.broadcast_to(a + b * host_g[g](raw), (dim, dim))
+
+        def emit(node):
+            hit = memo.get(node.key)
+            if hit is not None:
+                return hit
+            if any(n not in (1, dim) for n in node.shape[1:]) or node.shape[0] != 1:
+                raise LoweringError("%r: a covariance expression mixes shapes (%r in a %dx%d matrix)" % (v.name, node.shape, dim, dim))
+            arr = constant(node)
+            if arr is not None:
+                if np.all(arr == arr.flat[0]):
+                    t = push(("IMM", 0, 0, 0, float(arr.flat[0])))
+                else:
+                    mats.append(np.ascontiguousarray(arr, dtype=np.float32))
+                    t = push(("MAT", 0, len(mats) - 1, 0, 0.0))
+            elif node.op == "z" or (node.op == "elem" and node.args[0].op == "z"):
+                if node.shape != (1, 1, 1):
+                    raise LoweringError("%r: a sampled VECTOR inside a covariance expression (only scalars per sample are "
+                                        "inputs of the batched kernel)" % v.name)
+                child, j = (node, 0) if node.op == "z" else (node.args[0], int(node.attr))
+                slot_inputs.append((node, self.slots[child.attr].base + j))
+                t = push(("INPUT", 0, ("s", len(slot_inputs) - 1), 0, 0.0))
+            elif not node.has_z and self.match_uniform(node) is not None:
+                leaf, g, a, b = self.match_uniform(node)                     # a learnable scalar behind its range transform
+                if int(np.prod(leaf.shape)) != 1:
+                    raise LoweringError("%r: a learnable ARRAY inside a covariance expression (only scalars are inputs of the "
+                                        "batched kernel)" % v.name)
+                is_param, k0 = self.uniform_entries(leaf, g, a, b)
+                uniform_inputs.append((node, self.uni_param[k0]))
+                t = push(("INPUT", 0, ("u", len(uniform_inputs) - 1), 0, 0.0))
+            elif node.op in BINOP and node.op != "delta":
+                x, y = emit(node.args[0]), emit(node.args[1])
+                t = push(("BIN", BINOP[node.op], x, y, 0.0))
+            elif node.op.startswith("call:") and node.op[5:] in UNOP and node.op[5:] not in ("p2l", "relu", "log1p", "expm1"):
+                t = push(("UN", UNOP[node.op[5:]], emit(node.args[0]), 0, 0.0))
+            else:
+                raise LoweringError("%r: %s inside a covariance expression is not served by the batched kernel" % (v.name, node.op))
+            memo[node.key] = t
+            return t
+
+        emit(mat)
+        if len(slot_inputs) + len(uniform_inputs) > 8:
+            raise LoweringError("%r: more than 8 sampled / learnable scalars in a covariance expression" % v.name)
+        n_s = len(slot_inputs)
+        code = [(k, f, (a[1] if a[0] == "s" else n_s + a[1]) if isinstance(a, tuple) else a, b, imm) for k, f, a, b, imm in code]
+        value = self.p_value(v)
+        loc = self.from_expr(links["loc"].expr, self.p_value)
+        loc_entries, loc_nodes = None, []
+        if loc.op == "imm":
+            loc_vec = np.full(dim, float(loc.attr))
+        else:
+            m = self.match_uniform(loc)
+            if m is None:
+                raise LoweringError("%r: the batched kernel takes a constant or a learnable loc (not one computed from samples)" % v.name)
+            leaf, g, a, b = m
+            size = int(np.prod(leaf.shape))
+            if size not in (1, dim):
+                raise LoweringError("the loc of %r has %d elements, its covariance is %dx%d" % (v.name, size, dim, dim))
+            if leaf.op == "root" and leaf.attr.learnable:
+                # (by the reference's name-collision rule the prior's loc root is often the posterior's learnable mean)
+                is_param, k0 = self.uniform_entries(leaf, g, a, b)
+                loc_entries = np.zeros(dim, dtype=UNIFORM_DTYPE)
+                for i in range(dim):
+                    src, tr, isp, aa, bb = self.uni_param[k0 + (i if size == dim else 0)]
+                    loc_entries[i] = (src, tr, isp, 0, aa, bb)
+                loc_nodes = [self.mk("elem", (loc,), i if size == dim else 0, (1, 1, 1)) for i in range(dim)] if size == dim else [loc] * dim
+                loc_vec = np.zeros(dim)
+            else:
+                raw = np.asarray(leaf.attr.value if leaf.op == "root" else leaf.attr, dtype=np.float64).reshape(-1)
+                loc_vec = np.broadcast_to(a + b * host_g[g](raw), (dim,))
+        node = ExternalMvn()
+        node.name, node.dim, node.code, node.weight = v.name, dim, code, 1.0
+        node.mats = np.stack(mats) if mats else np.zeros((0, dim, dim), np.float32)
+        node.loc = np.ascontiguousarray(loc_vec, dtype=np.float32)
+        node.slot_inputs = [row for _, row in slot_inputs]
+        node.uniform_inputs = np.zeros(len(uniform_inputs), dtype=UNIFORM_DTYPE)
+        for k, (_, (src, tr, is_param, a, b)) in enumerate(uniform_inputs):
+            node.uniform_inputs[k] = (src, tr, is_param, 0, a, b)
+        partners = [n for n, _ in slot_inputs]
+        if value.op == "obs":
+            data = np.asarray(value.attr._observed_value, dtype=np.float32).reshape(-1)
+            if data.size != dim:
+                raise LoweringError("the value of %r has %d elements, its covariance is %dx%d" % (v.name, data.size, dim, dim))
+            node.value, node.value_row0 = data, 0
+        elif value.op == "z" and int(np.prod(value.shape)) == dim:
+            node.value, node.value_row0 = None, self.slots[value.attr].base
+            partners += [self.mk("elem", (value,), j, (1, 1, 1)) for j in range(dim)]
+        else:
+            raise LoweringError("%r: the batched kernel takes an observed value or the draw of ONE posterior variable of %d elements"
+                                % (v.name, dim))
+        partners += [n for n, _ in uniform_inputs]
+        partners += loc_nodes
+        node.loc_entries = loc_entries
+        node.n_rows_out = len(partners) + 1
+        self.externals.append(node)
+        if self.external_mode == "omit":                   # the base program: everything but this term (engine: first launch)
+            return []
+        # the surrogate: one GIVEN row per coefficient (behind the posterior's real rows), one LINEAR record per row
+        node.row0 = self.n_slots
+
+        class _Coefficient:                                # a pseudo posterior variable: its "noise" row holds the coefficient
+            _pseudo, is_observed = True, False
+
+            def __init__(self, name):
+                self.name, self.distribution = name, D.NormalDistribution()
+
+        class _Surrogate:                                  # what the emission reads of a model variable
+            is_observed, b_axis = True, 1
+
+            def __init__(self, name):
+                self.name, self.distribution = name, D.LinearSurrogate()
+
+        terms = []
+        one, zero = self.mk("imm", (), 1.0), self.mk("imm", (), 0.0)
+        for k in range(node.n_rows_out):
+            coeff = _Coefficient("%s/coefficient[%d]" % (v.name, k))
+            self.slots[coeff] = SlotInfo(coeff, self.n_slots, (1, 1, 1), D.DIST_NORMAL)
+            self.n_slots += 1
+            self.pseudo_q.append(coeff)
+            g = self.mk("z", (), coeff, (1, 1, 1))
+            partner = partners[k] if k < len(partners) else one
+            terms.append((_Surrogate("%s/surrogate[%d]" % (v.name, k)), partner, [g, zero], (1, 1, 1)))
         return terms
 
     # ---------------------------------------------------------------- categorical likelihood terms
@@ -1171,6 +1338,11 @@ class _Lowering:
                 continue
             p_nodes.append((v, value, params, shape))
 
+        # -- the coefficient rows of batched multivariate-normal terms: GIVEN pseudo-variables behind the posterior's own rows
+        n_real_q = len(q_nodes)
+        for coeff in self.pseudo_q:
+            q_nodes.append((coeff, [self.mk("imm", (), 0.0), self.mk("imm", (), 1.0)], (1, 1, 1)))
+
         # -- weights from the [N, B] mean rule
         term_b = []
         for v, params, shape in q_nodes:
@@ -1209,6 +1381,11 @@ class _Lowering:
             flags = F_SAMPLE
             w_lp = 0.0
             w_ent = w
+            if getattr(v, "_pseudo", False):
+                # its row of the noise tensor IS its value (a coefficient the batched kernel wrote); no term of its own
+                self.for_each_record(shape, params, False,
+                                     lambda: self.emit_node(dist.kind, F_SAMPLE | F_GIVEN, params, slot=slot, w_lp=0.0, w_ent=0.0))
+                continue
             if self.estimator == "importance":
                 flags |= F_WF | F_GIVEN        # value supplied, log q accumulated, no entropy term
                 w_ent = 0.0
@@ -1443,10 +1620,20 @@ class _Lowering:
         prog.n_slots = self.temp_base + self.max_temps
         self.fill_parameter_tables(prog, uni, n_up)
         prog.slots = dict(self.slots)
-        prog.slot_by_name = {s.name: s for s in self.slots.values()}
+        prog.slot_by_name = {s.name: s for s in self.slots.values() if not getattr(s.var, "_pseudo", False)}
+        # batched multivariate-normal terms (mvn_external): their descriptions, and how many noise rows are the posterior's own
+        prog.externals = list(self.externals)
+        prog.n_real_noise = self.n_latent - len(self.pseudo_q)
         prog.bmax = bmax
         prog.op_count = len(code)
         return prog
+
+
+class ExternalMvn:
+    """A multivariate-normal term evaluated by the batched kernel of the library (lowering.mvn_external): the description
+    `native.mvn_desc` turns into a bsvi_mvn_desc, and where its rows live in the program's noise tensor."""
+    name = dim = code = mats = loc = value = uniform_inputs = slot_inputs = weight = loc_entries = None
+    value_row0 = row0 = n_rows_out = 0
 
 
 def lower_sampler(model, posterior_model=None, input_values=None):
@@ -1454,11 +1641,15 @@ def lower_sampler(model, posterior_model=None, input_values=None):
     return _Lowering(model, posterior_model, "pathwise").run_sampler(input_values)
 
 
-def lower(joint_model, posterior_model=None, estimator="pathwise"):
-    """Compile a (joint, posterior) pair for the fused ELBO kernel."""
+def lower(joint_model, posterior_model=None, estimator="pathwise", external="inject"):
+    """Compile a (joint, posterior) pair for the fused ELBO kernel.  external="omit": the BASE program of a model with
+    batched multivariate-normal terms (`Program.externals`) — the same program without those terms and their surrogate
+    rows, launched first to make the draw the batched kernel reads (same parameter layout, same noise rows)."""
     if posterior_model is None:
         joint_model.check_posterior_model()
         posterior_model = joint_model.posterior_model
     if not isinstance(joint_model, ProbabilisticModel) or not isinstance(posterior_model, ProbabilisticModel):
         raise ValueError("lower() expects probabilistic models")
-    return _Lowering(joint_model, posterior_model, estimator).run()
+    low = _Lowering(joint_model, posterior_model, estimator)
+    low.external_mode = external
+    return low.run()

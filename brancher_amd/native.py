@@ -192,9 +192,9 @@ class MvnInsn(C.Structure):
 class MvnDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("dim", C.c_uint32), ("n_code", C.c_uint32), ("n_mats", C.c_uint32),
                 ("n_slot_inputs", C.c_uint32), ("n_uniform_inputs", C.c_uint32), ("value_is_latent", C.c_uint32),
-                ("reserved", C.c_uint32),
+                ("loc_is_param", C.c_uint32),
                 ("code", C.POINTER(MvnInsn)), ("mats", C.c_void_p), ("loc", C.c_void_p), ("value", C.c_void_p),
-                ("uniform_inputs", C.c_void_p), ("weight", C.c_float), ("reserved2", C.c_uint32)]
+                ("uniform_inputs", C.c_void_p), ("loc_entries", C.c_void_p), ("weight", C.c_float), ("reserved2", C.c_uint32)]
 
 
 class MvnArgs(C.Structure):
@@ -220,12 +220,42 @@ def mvn_desc(node):
     loc = np.ascontiguousarray(node.loc, dtype=np.float32)
     value = np.ascontiguousarray(node.value if node.value is not None else np.zeros(node.dim), dtype=np.float32)
     uni = np.ascontiguousarray(node.uniform_inputs)
-    keep = dict(code=code, mats=mats, loc=loc, value=value, uni=uni)
+    loc_entries = getattr(node, "loc_entries", None)
+    loc_entries = np.ascontiguousarray(loc_entries) if loc_entries is not None else None
+    keep = dict(code=code, mats=mats, loc=loc, value=value, uni=uni, loc_entries=loc_entries)
     d = MvnDesc(abi_version=ABI_VERSION, dim=node.dim, n_code=len(node.code), n_mats=mats.shape[0] if mats.size else 0,
                 n_slot_inputs=len(node.slot_inputs), n_uniform_inputs=len(uni), value_is_latent=int(node.value is None),
+                loc_is_param=int(loc_entries is not None), loc_entries=_ptr(loc_entries) if loc_entries is not None else None,
                 code=code, mats=_ptr(mats), loc=_ptr(loc), value=_ptr(value), uniform_inputs=_ptr(uni) if len(uni) else None,
                 weight=float(node.weight))
     return d, keep
+
+
+class MvnNode:
+    """Owns a ``bsvi_mvn*`` created from a lowering.ExternalMvn (the batched multivariate-normal kernel)."""
+
+    def __init__(self, node):
+        self.lib = load()
+        d, self._keep = mvn_desc(node)
+        handle = C.c_void_p()
+        check(self.lib.bsvi_mvn_create(C.byref(d), C.byref(handle)))
+        self.handle, self.node = handle, node
+        assert int(self.lib.bsvi_mvn_rows_out(C.byref(d))) == node.n_rows_out
+
+    def eval(self, params_ptr, samples_ptr, rows_out_ptr, n_local, stream):
+        args = MvnArgs(params_dev=params_ptr, samples_dev=samples_ptr, rows_out_dev=rows_out_ptr, n_samples_local=n_local,
+                       value_row0=self.node.value_row0, stream=stream)
+        for k, row in enumerate(self.node.slot_inputs):
+            args.input_rows[k] = row
+        check(self.lib.bsvi_mvn_eval(self.handle, C.byref(args)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.bsvi_mvn_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 def mvn_source(node):

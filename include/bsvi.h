@@ -569,7 +569,8 @@ void bsvi_debug_set_stamps(unsigned long long* stamps_dev);
  *        input_rows[k] is the row of scalar input k < n_slot_inputs, value_row0 the first of the dim rows of x when x is
  *        latent (value_is_latent), params_dev feeds the uniform inputs (a + b * g(params[src]))
  *   out  rows_out_dev [bsvi_mvn_rows_out][n_local]: g_k = weight * d log p / d input_k for the slot inputs, then for the
- *        dim elements of a latent x, then for the uniform inputs, then  e = weight * log p - sum_k g_k * input_k.
+ *        dim elements of a latent x, then for the uniform inputs, then for the dim elements of a learnable loc, then
+ *        e = weight * log p - sum_k g_k * input_k.
  *        e + sum_k g_k * input_k has the value and the gradient of weight * log p at the sample: the program adds it to f
  *        with BSVI_DIST_LINEAR terms whose coefficients are BSVI_F_GIVEN rows.  A covariance that is not positive
  *        definite gives NaN rows (the step is then skipped as non-finite, brancher/inference.py:98). */
@@ -582,12 +583,14 @@ typedef struct bsvi_mvn_insn {
 } bsvi_mvn_insn;
 typedef struct bsvi_mvn_desc {
     uint32_t abi_version, dim, n_code, n_mats;
-    uint32_t n_slot_inputs, n_uniform_inputs, value_is_latent, reserved;
+    uint32_t n_slot_inputs, n_uniform_inputs, value_is_latent, loc_is_param;
     const bsvi_mvn_insn* code;                 /* host */
     const float* mats;                         /* host [n_mats][dim][dim] */
     const float* loc;                          /* host [dim] */
     const float* value;                        /* host [dim]: the observed x (value_is_latent == 0) */
     const bsvi_uniform_entry* uniform_inputs;  /* host [n_uniform_inputs], parameter-sourced */
+    const bsvi_uniform_entry* loc_entries;     /* host [dim]: a LEARNABLE loc (loc_is_param; by the reference's name-collision rule
+                                                  the prior's loc root is often the posterior's learnable mean) */
     float weight;                              /* of log p in f */
     uint32_t reserved2;
 } bsvi_mvn_desc;

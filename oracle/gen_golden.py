@@ -51,6 +51,9 @@ CASES = {
     "flat_vector_sum_d5_N48": ("build_flat_vector_sum", dict(n_obs=6, dim=5), 48, 29, dict(iters=4, n=24, optimizer="Adam", lr=1e-2)),
     "softmax_classifier_C3_N60": ("build_softmax_classifier", dict(n_obs=6, n_classes=3), 60, 19, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
     "gp_hyperparameters_n5_N80": ("build_gp_hyperparameters", dict(n=5), 80, 23, dict(iters=5, n=32, optimizer="Adam", lr=1e-2)),
+    # the same model with 32 / 100 inputs: the covariance no longer fits the per-sample program (batched kernel, bsvi_mvn_*)
+    "gp_hyperparameters_n32_N40": ("build_gp_hyperparameters", dict(n=32, jitter=5e-2), 40, 31, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
+    "gp_hyperparameters_n100_N24": ("build_gp_hyperparameters", dict(n=100, jitter=5e-2), 24, 37, dict(iters=3, n=12, optimizer="Adam", lr=1e-2)),
     "learnable_model_N60": ("build_learnable_model", dict(n_obs=15), 60, 13, dict(iters=6, n=40, optimizer="Adam", lr=0.02)),
     "discrete_latent_N200": ("build_discrete_latent", dict(n_obs=8), 200, 12, None),
     "heavy_tails_N64": ("build_heavy_tails", dict(n_obs=12), 64, 6, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
