@@ -186,6 +186,41 @@ def test_philox_path_matches_oracle_on_emitted_noise(builder, kwargs, n, estimat
     assert np.array_equal(first, c.out.cpu().numpy())
 
 
+@pytest.mark.parametrize("n_points,n", [(32, 600), (100, 500), (17, 130)])
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_batched_mvn_philox_path_matches_oracle_on_emitted_noise(n_points, n, estimator):
+    """covariances beyond the per-sample program (bsvi_mvn_*): in-kernel draws at several hundred samples, the oracle on
+    exactly those draws — in double precision as the truth, in single precision (the reference's arithmetic) as yardstick"""
+    import torch as _t
+    from oracle.svi_oracle import Oracle
+    api = W.native_api()
+    kwargs = dict(n=n_points, jitter=5e-2)
+    c = engine.compile_model(W.build_gp_hyperparameters(api, **kwargs), None, estimator)
+    assert len(c.program.externals) == 1 and c.program.externals[0].dim == n_points
+    res = c.evaluate(n, seed=321, offset=3, want_noise=True, want_fvalues=True)
+    assert float(res["finite"].item()) == 1.0
+    noise = res["noise"].cpu().numpy()
+    named = {name: noise[slot.base:slot.base + slot.size].T.reshape((n,) + tuple(slot.shape))
+             for name, slot in c.program.slot_by_name.items()}
+    exact = Oracle(W.build_gp_hyperparameters(api, **kwargs), dtype=_t.float64).loss_and_grads(n, estimator, named)
+    single = Oracle(W.build_gp_hyperparameters(api, **kwargs)).loss_and_grads(n, estimator, named)
+    loss = float(res["loss"].item())
+    assert abs(loss - exact["loss"]) <= max(4 * abs(single["loss"] - exact["loss"]), TOL * abs(exact["loss"])), (loss, exact["loss"])
+    named_g = c.named_grads()
+    gscale = max(np.abs(v).max() for v in exact["grads"].values())
+    for name, g64 in exact["grads"].items():
+        err, yard = np.abs(named_g[name] - g64).max(), np.abs(single["grads"][name] - g64).max()
+        assert err <= max(4 * yard, (2e-5 if estimator == "pathwise" else 2e-4) * gscale), (name, err, yard)
+    # a repeat of the same call is bitwise the same
+    first = c.out.cpu().numpy().copy()
+    c.evaluate(n, seed=321, offset=3)
+    assert np.array_equal(first, c.out.cpu().numpy())
+    # training moves the loss down (three launches per iteration: base program, batched kernel, full program + optimizer)
+    losses, finite = c.train(60, 64, "Adam", lr=2e-2, seed=5)
+    l = losses.cpu().numpy()
+    assert finite.cpu().numpy().all() and c.last_mode == "stepwise" and l[-10:].mean() < l[:10].mean()
+
+
 def test_philox_noise_is_standard_normal_and_shard_invariant():
     api = W.native_api()
     model = W.build_readme_ar(api, T=20)
