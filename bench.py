@@ -37,10 +37,15 @@ WORKLOADS = {
              "beta_binomial.py Beta posterior, 30 observations, number_samples=4096, SGD lr=0.1 (BASELINE config 2)"),
     "cfg3": ("build_readme_ar", dict(T=200), 1024, "SGD", dict(lr=1e-4),
              "README AR state-space T=200, number_samples=8192 sharded as 1024 per GPU (BASELINE config 3)"),
-    "cfg4": ("build_logistic_regression", dict(dataset_size=60000, batch_size=512, n_features=784, n_classes=10),
+    "cfg4": ("build_logistic_regression", dict(dataset_size=60000, batch_size=512, n_features=784, n_classes=10, pixels="uint8",
+                                               q_scale=0.01),
              1024, "Adam", dict(lr=5e-3),
              "Bayesian multinomial logistic regression, dense matmul link 10x784, minibatch 512 of 60000 synthetic "
-             "rows, number_samples=1024, Adam lr=5e-3 (BASELINE config 4)"),
+             "rows of uint8-valued pixels (SURVEY 8d; examples/MNIST_logistic_regression.py feeds raw pixel counts), "
+             "number_samples=1024, Adam lr=5e-3 (BASELINE config 4)"),
+    "cfg4_unit": ("build_logistic_regression", dict(dataset_size=60000, batch_size=512, n_features=784, n_classes=10),
+                  1024, "Adam", dict(lr=5e-3),
+                  "config 4 with features in [0, 1] (not bf16 numbers: the f32-input MFMA kernels serve the products)"),
     "cfg5": ("build_vae", dict(dataset_size=60000, batch_size=100, n_features=784, latent_size=2, hidden1=512, hidden2=256),
              256, "Adam", dict(lr=1e-3),
              "VAE_playground.py MLP VAE 784-256-512-(2,2) / 2-512-256-784, Binomial(1, logits) likelihood, every sample "

@@ -428,6 +428,7 @@ struct XGemmArgs {
     const float* bias;
     int M, N, Kp, ldc;
     int act; float post_add; int split; int act2; float post_add2;
+    int rows_fastest;       // tile order: neighbours share a column tile (the pieces) instead of a row tile (X)
 };
 
 __device__ __forceinline__ uint16_t bf16_bits(float x) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
@@ -456,85 +457,108 @@ __global__ __launch_bounds__(256) void x_to_bf16_kernel(const float* X, long row
     Xb[i] = k < K ? bf16_bits(X[r * K + k]) : (uint16_t)0;
 }
 
-// C[M][N] = act(X[rows[m]] W^T + bias): 128 x 128 tile, four waves of 64 x 64, single LDS stage with the next step's global
-// loads in flight behind the MFMAs (41 KB of LDS: three workgroups per CU cover each other's barriers)
-__global__ __launch_bounds__(256) void xgemm_nt_kernel(const XGemmArgs G) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * XPLANE];      // A | W hi | W mid | W lo
+// C[M][N] = act(X[rows[m]] W^T + bias).  Workgroup tile TBM x 128 (TBM = 256: four waves of 128 x 64; 128: of 64 x 64), single
+// LDS stage with the next step's global loads in flight behind the MFMAs.  The kernel is LDS-bandwidth bound — per k chunk
+// a wave reads FA fragments of X and 3 x 2 of the pieces for 3 x FA x 2 MFMAs — so the exact operand gets the long side of
+// the wave tile: 0.42 fragment reads per MFMA at FA = 4 against 0.67 at FA = 2 (cfg 5's first layer 55 -> see DESIGN 4.6).
+template <int TBM>
+__global__ __launch_bounds__(256, 2) void xgemm_nt_kernel(const XGemmArgs G) {
+    constexpr int FA = TBM / 64, APLANE = TBM * XLD, NA = TBM * 4 / 256;      // X fragments per wave; A stage bytes; A pieces per thread
+    __shared__ __attribute__((aligned(16))) unsigned char lds[APLANE + 3 * XPLANE];      // X | W hi | W mid | W lo
     const int tiles_n = (G.N + 127) / 128;
     int bid = blockIdx.x;
     const int n_blocks = gridDim.x;
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // an XCD takes a contiguous range of tiles
-    const int m0 = (bid / tiles_n) * 128, n0 = (bid % tiles_n) * 128;
+    // ... in which the tiles that share the LARGER operand are neighbours, so that its rows enter one L2 once: with the
+    // pieces of cfg 4's W (49 MB, four row tiles of the minibatch above each column tile) in column-fastest order every XCD
+    // pulled half of them through the fabric — 196 MB per product
+    const int tiles_m = (G.M + TBM - 1) / TBM;
+    int tm, tn;
+    if (G.rows_fastest) { tm = bid % tiles_m; tn = bid / tiles_m; } else { tm = bid / tiles_n; tn = bid % tiles_n; }
+    const int m0 = tm * TBM, n0 = tn * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
+    const int wm = (wave >> 1) * (TBM / 2), wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
 
-    // staging: 16-byte pieces.  A: 512 per step (2 per thread), W: 1536 (6 per thread)
-    const xu4* pa[2];
-    const xu4* pb[6];
-    int sa[2], sb[6];       // LDS byte offsets
+    // staging: 16-byte pieces.  X: TBM * 4 per step (NA per thread), W: 1536 (6 per thread)
+    // (byte offsets from the two base pointers, 32 bits each: the operands are far below 4 GB, and ten 64-bit pointers per
+    //  thread were the difference between one and two waves per SIMD at TBM = 256)
+    const unsigned char* const xbase = reinterpret_cast<const unsigned char*>(G.X);
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(G.Wp);
+    uint32_t pa[NA], pb[6];
+    int sa[NA], sb[6];       // LDS byte offsets
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const int c = tid + 256 * i, row = c >> 2, kq = c & 3;
         const int r = min(m0 + row, G.M - 1);
         const long phys = G.rows ? (long)G.rows[r] : (long)r;
-        pa[i] = reinterpret_cast<const xu4*>(G.X + phys * G.Kp + kq * 8);
+        pa[i] = (uint32_t)((phys * G.Kp + kq * 8) * 2);
         sa[i] = row * XLD + kq * 16;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int c = tid + 256 * i, plane = c >> 9, w = c & 511, col = w >> 2, kq = w & 3;
-        pb[i] = reinterpret_cast<const xu4*>(G.Wp + plane * G.plane_stride + (long)min(n0 + col, G.N - 1) * G.Kp + kq * 8);
-        sb[i] = (1 + plane) * XPLANE + col * XLD + kq * 16;
+        pb[i] = (uint32_t)((plane * G.plane_stride + (long)min(n0 + col, G.N - 1) * G.Kp + kq * 8) * 2);
+        sb[i] = APLANE + plane * XPLANE + col * XLD + kq * 16;
     }
-    f32x16 acc[2][2];
+    auto ldx = [&](uint32_t off, int step) { return *reinterpret_cast<const xu4*>(xbase + off + (size_t)step * (XBK * 2)); };
+    auto ldw = [&](uint32_t off, int step) { return *reinterpret_cast<const xu4*>(wbase + off + (size_t)step * (XBK * 2)); };
+    f32x16 acc[FA][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FA; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // 32-row blocks of this wave that lie inside the matrix (a tile at the bottom edge: the rest is neither read nor multiplied)
+    int live = 0;
+#pragma unroll
+    for (int i = 0; i < FA; ++i) live += (m0 + wm + 32 * i < G.M) ? 1 : 0;
 
     const int n_steps = G.Kp / XBK;
-    xu4 ra[2], rb[6];
+    xu4 ra[NA], rb[6];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i] = pa[i][0];
+    for (int i = 0; i < NA; ++i) ra[i] = ldx(pa[i], 0);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rb[i] = pb[i][0];
+    for (int i = 0; i < 6; ++i) rb[i] = ldw(pb[i], 0);
     const unsigned char* at = lds + (wm + lm) * XLD + lk * 16;
-    const unsigned char* bt = lds + XPLANE + (wn + lm) * XLD + lk * 16;
+    const unsigned char* bt = lds + APLANE + (wn + lm) * XLD + lk * 16;
     for (int step = 0; step < n_steps; ++step) {
         __syncthreads();                                   // the last step's reads of the stage are done
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<xu4*>(lds + sa[i]) = ra[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<xu4*>(lds + sa[i]) = ra[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<xu4*>(lds + sb[i]) = rb[i];
         __syncthreads();
         if (step + 1 < n_steps) {                          // (XBK bf16 = 4 pieces of 16 bytes per row and step)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ra[i] = pa[i][(step + 1) * 4];
+            for (int i = 0; i < NA; ++i) ra[i] = ldx(pa[i], step + 1);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) rb[i] = pb[i][(step + 1) * 4];
+            for (int i = 0; i < 6; ++i) rb[i] = ldw(pb[i], step + 1);
         }
+        if (live == 0) continue;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            bf16x8 a[2];
+            bf16x8 a[FA];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(at + 32 * i * XLD + kc * 32);
+            for (int i = 0; i < FA; ++i) a[i] = *reinterpret_cast<const bf16x8*>(at + 32 * i * XLD + kc * 32);
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 bf16x8 b[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bt + p * XPLANE + 32 * j * XLD + kc * 32);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < FA; ++i) {
+                    if (i < live) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
+                }
             }
         }
     }
     // epilogue: acc[i][j][r] is C[m][n] with m = 32i + 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31)   (as gemm_kernel)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FA; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn + 32 * j + lm;
@@ -547,6 +571,18 @@ __global__ __launch_bounds__(256) void xgemm_nt_kernel(const XGemmArgs G) {
                 G.C[(long)m * G.ldc + n] = act_forward(ACT_OF(G, n), acc[i][j][r] + bias, ADD_OF(G, n));
             }
         }
+}
+
+static void launch_xgemm(XGemmArgs X, hipStream_t stream) {
+    X.rows_fastest = 3L * X.N > (long)X.M ? 1 : 0;      // which operand is the larger one (both have Kp columns)
+    // (measured, cfg 4's two products: 256-row tiles 66 us each at two waves per SIMD — fewer LDS reads per MFMA, but one
+    //  workgroup per CU at these shapes — against 45 us with 128-row tiles at three; BSVI_XGEMM_TALL=1 selects the tall tile)
+    static const bool tall_env = [] { const char* e = getenv("BSVI_XGEMM_TALL"); return e && e[0] == '1'; }();
+    const bool tall = tall_env && X.M >= 256;
+    const int tbm = tall ? 256 : 128;
+    const unsigned tiles = (unsigned)(((X.M + tbm - 1) / tbm) * ((X.N + 127) / 128));
+    if (tall) hipLaunchKernelGGL((xgemm_nt_kernel<256>), dim3(tiles), dim3(256), 0, stream, X);
+    else hipLaunchKernelGGL((xgemm_nt_kernel<128>), dim3(tiles), dim3(256), 0, stream, X);
 }
 
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -1405,6 +1441,18 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     return BSVI_OK;
 }
 
+// C[M][N] = X[rows[m]] W^T through xgemm_nt_kernel for the other kernel families of the library (the dense path's two
+// products, dense_kernel.inc): X exact in bf16 [..][Kp], Wp the three bf16 pieces [3][N][Kp] of the other operand
+int bsvi_xgemm_nt(const uint16_t* X, const int32_t* rows, const uint16_t* Wp, long plane_stride, float* C, int ldc,
+                  int M, int N, int Kp, void* stream) {
+    if (Kp % bsvi_amort_impl::XBK != 0 || M <= 0 || N <= 0) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_xgemm_nt: bad shape");
+    bsvi_amort_impl::XGemmArgs G{};
+    G.X = X; G.rows = rows; G.Wp = Wp; G.plane_stride = plane_stride; G.C = C; G.ldc = ldc; G.M = M; G.N = N; G.Kp = Kp;
+    bsvi_amort_impl::launch_xgemm(G, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, "xgemm_nt_kernel launch failed");
+    return BSVI_OK;
+}
+
 extern "C" int bsvi_amort_exact_data(const bsvi_amort* a) { return (a && a->data_exact) ? 1 : 0; }
 
 extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
@@ -1605,7 +1653,7 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
         XGemmArgs X{};
         X.X = xb; X.rows = rows_dev; X.Wp = wp; X.plane_stride = (long)n * Kp; X.C = c_dev; X.ldc = (int)ldc;
         X.M = (int)m; X.N = (int)n; X.Kp = Kp; X.bias = bias_or_y_dev; X.act = (int)activation; X.post_add = post_add;
-        hipLaunchKernelGGL(xgemm_nt_kernel, dim3((unsigned)(((m + 127) / 128) * ((n + 127) / 128))), dim3(256), 0, st, X);
+        launch_xgemm(X, st);
         HIP_TRY(hipGetLastError());
         return BSVI_OK;
     }
@@ -1744,8 +1792,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 X.bias = l.bias_off != 0xFFFFFFFFu ? params + l.bias_off : nullptr;
                 X.act = (int)l.activation; X.post_add = l.post_add;
                 if (l.split_col > 0 && l.split_col < l.n_out) { X.split = (int)l.split_col; X.act2 = (int)l.activation2; X.post_add2 = l.post_add2; }
-                const unsigned tiles = (unsigned)(((R + 127) / 128) * ((l.n_out + 127) / 128));
-                hipLaunchKernelGGL(xgemm_nt_kernel, dim3(tiles), dim3(256), 0, stream, X);
+                launch_xgemm(X, stream);
                 HIP_TRY(hipGetLastError());
                 continue;
             }

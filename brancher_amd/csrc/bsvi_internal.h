@@ -9,6 +9,10 @@
 
 // records the thread-local message returned by bsvi_last_error() and returns `code`
 int bsvi_fail(int code, const std::string& msg);
+// amort_kernel.hip: C[M][N] = X[rows[m]] W^T on the bf16 matrix cores — X exactly bf16 [..][Kp], Wp the three bf16 pieces
+// [3][N][Kp] (hi, mid, lo) of an f32 operand, Kp a multiple of 32
+int bsvi_xgemm_nt(const uint16_t* X, const int32_t* rows, const uint16_t* Wp, long plane_stride, float* C, int ldc,
+                  int M, int N, int Kp, void* stream);
 
 namespace bsvi_spec { struct Spec; }
 

@@ -188,6 +188,11 @@ def lower_dense(joint, posterior, estimator="pathwise"):
 class CompiledDense:
     """Engine for a dense-link model; same surface as engine.CompiledELBO."""
 
+    def data_path(self):
+        """which matrix-core path serves the two products of an iteration: "bf16x3" when every dataset value is exactly a
+        bf16 number (three bf16 MFMAs on the exact pieces of the f32 operand, bsvi_dense_exact_data), else "f32" """
+        return "bf16x3" if self._exact_data else "f32"
+
     def __init__(self, joint_model, posterior_model, estimator="pathwise", device=None, program=None):
         from brancher_amd import engine
         self.device = device or engine._device()
@@ -217,6 +222,7 @@ class CompiledDense:
         handle = C.c_void_p()
         native.check(lib.bsvi_dense_create(C.byref(d), C.byref(handle)))
         self.handle = handle
+        self._exact_data = bool(lib.bsvi_dense_exact_data(handle))
         dev = self.device
         self.n_params = p.n_params
         theta = np.zeros(p.n_params, dtype=np.float32)

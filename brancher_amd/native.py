@@ -80,6 +80,7 @@ DENSE_EXPORTS = {
     "bsvi_dense_create": (C.c_int, [C.POINTER(DenseDesc), C.POINTER(C.c_void_p)]),
     "bsvi_dense_destroy": (None, [C.c_void_p]),
     "bsvi_dense_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "bsvi_dense_exact_data": (C.c_int, [C.c_void_p]),
     "bsvi_dense_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(DenseArgs)]),
     "bsvi_dense_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bsvi_dense_step": (C.c_int, [C.c_void_p, C.POINTER(DenseArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,

@@ -420,11 +420,15 @@ def build_heavy_tails(api, n_obs=12, seed=1):
     return model
 
 
-def logreg_data(dataset_size, n_features, n_classes, seed=0):
-    """Synthetic stand-in for MNIST (not available offline; SURVEY §8d cfg 4): pixel-like features in
-    [0, 1] and uniformly random labels."""
+def logreg_data(dataset_size, n_features, n_classes, seed=0, pixels="unit"):
+    """Synthetic stand-in for MNIST (not available offline; SURVEY §8d cfg 4) with uniformly random labels.
+    pixels="uint8": pixel counts 0..255 as floats — what `examples/MNIST_logistic_regression.py:15-19` feeds the model
+    (`train.train_data.numpy()`, no normalisation) and what SURVEY §8d prescribes; pixels="unit": features in [0, 1]."""
     rng = np.random.RandomState(seed)
-    X = rng.uniform(0., 1., size=(dataset_size, n_features, 1)).astype(np.float32)
+    if pixels == "uint8":
+        X = rng.randint(0, 256, size=(dataset_size, n_features, 1)).astype(np.float32)
+    else:
+        X = rng.uniform(0., 1., size=(dataset_size, n_features, 1)).astype(np.float32)
     labels = rng.randint(0, n_classes, size=dataset_size)
     return X, labels
 
@@ -470,11 +474,11 @@ def build_map_logistic_regression(api, dataset_size=30, n_features=4, n_classes=
 
 
 def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=784, n_classes=10, seed=0,
-                              prior_scale=10., q_scale=0.1):
+                              prior_scale=10., q_scale=0.1, pixels="unit"):
     """BASELINE config 4: Bayesian multinomial logistic regression with a dense `matmul` link and a
     random minibatch per iteration (`examples/MNIST_logistic_regression.py:15-54`)."""
     BF = api.BF
-    X, labels = logreg_data(dataset_size, n_features, n_classes, seed)
+    X, labels = logreg_data(dataset_size, n_features, n_classes, seed, pixels)
     minibatch_indices = api.RandomIndices(dataset_size=dataset_size, batch_size=batch_size, name="indices",
                                           is_observed=True)
     x = api.EmpiricalVariable(X, indices=minibatch_indices, name="x", is_observed=True)

@@ -431,6 +431,12 @@ typedef struct bsvi_dense_args {
 int bsvi_dense_create(const bsvi_dense_desc* desc, bsvi_dense** out);
 void bsvi_dense_destroy(bsvi_dense* d);
 size_t bsvi_dense_workspace_bytes(const bsvi_dense* d, uint32_t n_samples_local);
+/* 1 when every dataset value is exactly a bf16 number (pixel counts 0..255, binarised images) and the features come in whole
+ * quads: both products of the iteration then have one exact operand — the minibatch — and run on the bf16 matrix cores as
+ * three MFMAs on the exact pieces hi + mid + lo of the other operand (W = mu + s * eps, d f / d logits), products exact,
+ * f32 accumulation; the noise is never stored (both consumers draw it from the same Philox counters).  0: the f32-input MFMA
+ * kernels serve the model (also with BSVI_DENSE_XGEMM=0 at create time). */
+int bsvi_dense_exact_data(const bsvi_dense* d);
 /* ELBO forward+backward of the dense model over this GPU's sample shard; leaves sums in out_dev
  * (then bsvi_finalize / all-reduce / bsvi_optimizer_step as for bsvi_elbo_fwd_bwd). */
 int bsvi_dense_fwd_bwd(const bsvi_dense* d, const bsvi_dense_args* args);

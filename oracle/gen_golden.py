@@ -66,6 +66,13 @@ CASES = {
                                      6, 11, dict(iters=5, n=8, optimizer="Adam", lr=0.05)),
     "logreg_map_C3_P4_DS30_N2": ("build_map_logistic_regression", dict(dataset_size=30, n_features=4, n_classes=3), 2, 17,
                                  dict(iters=5, n=1, optimizer="SGD", lr=0.0025)),
+    # the same with pixel COUNTS 0..255 as the example feeds them (exactly bf16 numbers: the dense path's bf16 matrix-core products)
+    "logreg_pixels_C10_P784_DS24_B16_N4": ("build_logistic_regression",
+                                           dict(dataset_size=24, batch_size=16, n_features=784, n_classes=10, pixels="uint8", q_scale=0.01),
+                                           4, 9, None),
+    "logreg_pixels_C3_P64_DS40_B24_N6": ("build_logistic_regression",
+                                         dict(dataset_size=40, batch_size=24, n_features=64, n_classes=3, pixels="uint8", q_scale=0.02),
+                                         6, 10, dict(iters=4, n=5, optimizer="SGD", lr=1e-7)),     # (SGD: Adam's first steps are the SIGN of gradients that cancel to rounding noise here)
     "logreg_C10_P784_DS24_B16_N4": ("build_logistic_regression",
                                     dict(dataset_size=24, batch_size=16, n_features=784, n_classes=10), 4, 8, None),
 }

@@ -451,6 +451,53 @@ def test_dense_path_at_baseline_config4_size():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_dense_exact_data_path_at_config4_size_equals_the_f32_path(estimator, monkeypatch):
+    """BASELINE config 4 at full size on pixel COUNTS (what the example feeds, exactly bf16 numbers): both products on the
+    bf16 matrix cores — three MFMAs on the exact pieces of W = mu + s * eps and of d f / d logits — against the f32-input
+    MFMA kernels on the same model, seed and offset (same Philox stream, same minibatch): loss, per-sample values and all
+    15 680 gradients; call-to-call bit equality; shard sums add up."""
+    import ctypes as C
+    from brancher_amd import native
+    api = W.native_api()
+    kw = dict(dataset_size=60000, batch_size=512, n_features=784, n_classes=10, pixels="uint8", q_scale=0.01)
+    n = 1024
+    exact = engine.compile_model(W.build_logistic_regression(api, **kw), None, estimator)
+    assert exact.data_path() == "bf16x3"
+    monkeypatch.setenv("BSVI_DENSE_XGEMM", "0")
+    plain = engine.compile_model(W.build_logistic_regression(api, **kw), None, estimator)
+    assert plain.data_path() == "f32"
+    a = exact.evaluate(n, seed=21, offset=5, want_fvalues=True, want_indices=True)
+    b = plain.evaluate(n, seed=21, offset=5, want_fvalues=True, want_indices=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a["indices"], b["indices"])
+    la, lb = float(a["loss"].item()), float(b["loss"].item())
+    fa, fb = a["f"].cpu().numpy().astype(np.float64), b["f"].cpu().numpy().astype(np.float64)
+    assert np.abs(fa - fb).max() <= 2e-5 * np.abs(fb).max(), (np.abs(fa - fb).max(), np.abs(fb).max())
+    assert abs(la - lb) <= (2e-5 if estimator == "pathwise" else 2e-4) * abs(lb), (la, lb)
+    ga, gb = a["grads"].cpu().numpy().astype(np.float64), b["grads"].cpu().numpy().astype(np.float64)
+    assert np.abs(ga - gb).max() <= (5e-5 if estimator == "pathwise" else 5e-4) * np.abs(gb).max(), (np.abs(ga - gb).max(), np.abs(gb).max())
+    first = exact.out.cpu().numpy().copy()
+    for _ in range(2):
+        exact.evaluate(n, seed=21, offset=5, want_fvalues=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(exact.out.cpu().numpy(), first)
+    if estimator == "pathwise":
+        acc = np.zeros_like(first, dtype=np.float64)
+        for base, n_local in ((0, 384), (384, 640)):
+            args = exact._args(n_local, n, base, None, None, 21, 5)
+            native.check(exact.lib.bsvi_dense_fwd_bwd(exact.handle, C.byref(args)))
+            torch.cuda.synchronize()
+            acc += exact.out.cpu().numpy().astype(np.float64)
+        args = exact._args(n, n, 0, None, None, 21, 5)
+        native.check(exact.lib.bsvi_dense_fwd_bwd(exact.handle, C.byref(args)))
+        torch.cuda.synchronize()
+        union = exact.out.cpu().numpy().astype(np.float64)
+        assert abs(acc[0] - union[0]) <= 2e-6 * abs(union[0])
+        assert np.abs(acc[4:] - union[4:]).max() <= 2e-5 * np.abs(union[4:]).max()
+
+
+@pytest.mark.gpu
 def test_dense_sharded_step_sequence_equals_the_fused_step():
     api = W.native_api()
     kw = dict(dataset_size=256, batch_size=64, n_features=64, n_classes=10, q_scale=0.05)

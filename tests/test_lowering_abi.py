@@ -222,9 +222,26 @@ def test_multivariate_normal_with_a_sampled_covariance_is_unrolled():
     assert s["n_latent"] == 6 and s["n_derived"] >= 15            # ell + f[5]; at least the 15 entries of L are shared values
     names = [p.name for p, _, _, _ in program.parameters]
     assert "amplitude" in names                                     # the joint model's learnable kernel amplitude gets a gradient
+    # beyond the unrolling limit the term leaves the program for the batched kernel (bsvi_mvn_*): a description of the
+    # covariance expression, GIVEN coefficient rows behind the posterior's own, LINEAR surrogate records; the BASE program
+    # (external="omit") is the same program without them, with the same parameter layout
+    big = W.build_gp_hyperparameters(api, n=12)
+    full = lowering.lower(big, big.posterior_model, "pathwise")
+    ext = full.externals[0]
+    assert len(full.externals) == 1 and ext.dim == 12 and ext.value is None and ext.loc_entries is not None
+    assert ext.slot_inputs == [0] and len(ext.uniform_inputs) == 1 and ext.mats.shape == (2, 12, 12)
+    assert ext.n_rows_out == 1 + 12 + 1 + 12 + 1 and full.n_noise == full.n_real_noise + ext.n_rows_out and ext.row0 == full.n_real_noise
+    assert all("coefficient" not in name for name in full.slot_by_name)
+    base = lowering.lower(W.build_gp_hyperparameters(api, n=12), None, "pathwise", external="omit")
+    assert base.n_noise == full.n_real_noise and len(base.code) < len(full.code)
+    assert [(q.name, o, n) for q, o, n, _ in base.parameters] == [(q.name, o, n) for q, o, n, _ in full.parameters]
+    source = native.mvn_source(ext)
+    assert "#define MVN_D 12" in source and "mvn_cov" in source and native.jit_compile(source) > 0
     with pytest.raises(lowering.LoweringError, match="limit"):
-        big = W.build_gp_hyperparameters(api, n=12)
-        lowering.lower(big, big.posterior_model, "pathwise")
+        huge = W.build_gp_hyperparameters(api, n=140)
+        lowering.lower(huge, huge.posterior_model, "pathwise")
+    with pytest.raises(lowering.LoweringError, match="Pathwise and BlackBox"):
+        lowering.lower(W.build_gp_hyperparameters(api, n=12), None, "taylor1")
     # a constant covariance still takes the host-side factorisation (no derived slots for L)
     const = W.build_gp_regression(api, n=5)
     assert lowering.lower(const, const.posterior_model, "pathwise").summary()["n_derived"] < 5
