@@ -125,6 +125,9 @@ def traffic_of(rows, kernel_substrings, grid=None, last_only=False, per=1, doubl
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (16x the f32-input rate)
+# a product whose data operand is exactly bf16 runs as THREE bf16 MFMAs on the exact pieces of its f32 operand:
+MFMA_EXACT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0
 
 
 def dense_flops_per_iteration(program, n_local):
@@ -386,13 +389,21 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         flops = dense_flops_per_iteration(program, n_per_gpu)
         tf = flops / (dev_ms * 1e-3 / steps) / 1e12
         if probe_rows:
-            traffic = traffic_of(probe_rows, ["dense_"], per=iters_probed or 1, double_fetch=True)
-            traffic_how = "all dense_* launches of the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
-        roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
-                        kernel="bsvi::dense_forward<10> + bsvi::dense_backward",
-                        algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps,
-                        note="f32-input MFMA; achieved = GEMM flops of one iteration / duration of the whole iteration")
+            traffic = traffic_of(probe_rows, ["dense_", "xgemm_nt"], per=iters_probed or 1, double_fetch=True)
+            traffic_how = "all dense_* and xgemm_nt launches of the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
+        exact = getattr(compiled, "data_path", lambda: "f32")() == "bf16x3"
+        peak = MFMA_EXACT_PEAK_TFLOPS if exact else MFMA_F32_PEAK_TFLOPS
+        roofline = dict(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s",
+                        frac=tf / peak, traffic=traffic,
+                        kernel=("bsvi_amort_impl::xgemm_nt_kernel<128> x2 (logits product, gradient product)" if exact
+                                else "bsvi::dense_forward<10> + bsvi::dense_backward"),
+                        algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps, data_path="bf16x3" if exact else "f32",
+                        frac_of_f32_mfma_peak=tf / MFMA_F32_PEAK_TFLOPS,
+                        note=("the minibatch is exactly bf16 (pixel counts): both products run as three bf16 MFMAs on the exact "
+                              "pieces hi + mid + lo of the f32 operand; peak = dense bf16 MFMA peak / 3; achieved = GEMM flops of "
+                              "one iteration / duration of the whole iteration (9 launches); frac_of_f32_mfma_peak compares with "
+                              "the f32-input MFMA kernels that serve inexact data" if exact else
+                              "f32-input MFMA; achieved = GEMM flops of one iteration / duration of the whole iteration"))
     if amort:
         # the whole iteration (~23 launches) is timed; the eleven MFMA GEMMs carry the flops
         flops = amort_flops_per_iteration(program, n_per_gpu)
@@ -400,14 +411,24 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         if probe_rows:
             traffic = traffic_of(probe_rows, ["bsvi_amort_impl"], per=iters_probed or 1, double_fetch=True)
             traffic_how = "all bsvi_amort_impl launches of the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
-        roofline = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=traffic,
-                        kernel="bsvi_amort_impl::gemm_kernel<0|1|2>",
+        exact = getattr(compiled, "data_path", lambda: "f32")() == "bf16x3"
+        rows = n_per_gpu * program.batch_size
+        # flops of the forward products that read the data rows (bf16 x3 when the data is exactly bf16), the rest on the f32-input MFMA
+        x_flops = sum(2.0 * rows * l.n_in * l.n_out for l in program.enc_layers if l.in_value == 0 and l.n_out > 8) if exact else 0.0
+        roof_s = (flops - x_flops) / (MFMA_F32_PEAK_TFLOPS * 1e12) + x_flops / (MFMA_EXACT_PEAK_TFLOPS * 1e12)
+        peak = flops / roof_s / 1e12
+        roofline = dict(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s",
+                        frac=tf / peak, traffic=traffic,
+                        kernel="bsvi_amort_impl::gemm_kernel<0|1|2>" + (" + xgemm_nt_kernel<128> (first encoder layer)" if exact else ""),
                         algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps,
-                        rows_per_iteration=n_per_gpu * program.batch_size,
-                        note="f32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = GEMM flops of one iteration "
-                             "(forward + weight gradient + input gradient of every Linear layer) / duration of "
-                             "the whole iteration")
+                        rows_per_iteration=rows, data_path="bf16x3" if exact else "f32",
+                        frac_of_f32_mfma_peak=tf / MFMA_F32_PEAK_TFLOPS,
+                        note="f32-input MFMA (v_mfma_f32_32x32x2_f32) for ten of the eleven products" + (
+                             "; the forward product of the layer that reads the (exactly bf16) data rows runs as three bf16 MFMAs on "
+                             "the exact pieces of its weights; peak = flops / (f32-input flops / 157.3 + those flops / (2500 / 3))"
+                             if exact else "") +
+                             "; achieved = GEMM flops of one iteration (forward + weight gradient + input gradient of every Linear "
+                             "layer) / duration of the whole iteration")
     if traffic is not None:
         roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py before its timed " \
                                      "regions (child processes, same workloads and step counts): " + traffic_how
