@@ -573,12 +573,144 @@ __global__ __launch_bounds__(256, 2) void xgemm_nt_kernel(const XGemmArgs G) {
         }
 }
 
+// The same product with LDS-DMA staging (`global_load_lds_dwordx4`: global -> LDS without registers and without the
+// ds_write pass that bounded the kernel above — 13 cycles per ds_write_b128 wave-instruction, ~79 B/clk/CU).  A wave's DMA
+// writes 64 x 16 bytes LINEARLY from a wave-uniform base, so an operand tile is stored as 1 KB chunks of 16 rows x 64 bytes
+// with no padding, and the bank-conflict-free image is made on the SOURCE side: slot (row r, piece sp) of a chunk holds
+// global piece sp ^ ((r >> 2) & 3) of the row; the fragment reads apply the same involution (rows r, r+4, r+8, r+12 of a
+// 16-lane ds_read_b128 group then sit on four different bank quads).  Two LDS stages (64 KB per workgroup, two per CU), ONE
+// barrier per k step: wait for the DMA of step s, barrier, start the DMA of step s+1 into the other stage, multiply.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gmem_ptr_t;
+template <int TBM>
+__global__ __launch_bounds__(256, 2) void xgemm_nt_glds_kernel(const XGemmArgs G) {
+    constexpr int FA = TBM / 64, NXC = TBM / 64;                          // X fragments per wave; X chunks (of 16 rows) per wave
+    constexpr int CHUNK = 1024, APL = 8 * CHUNK, XPL = (TBM / 16) * CHUNK, STAGE = XPL + 3 * APL;      // X (TBM rows) | hi | mid | lo (128 rows each)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    const int tiles_n = (G.N + 127) / 128, tiles_m = (G.M + TBM - 1) / TBM;
+    int bid = blockIdx.x;
+    const int n_blocks = gridDim.x;
+    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);
+    int tm, tn;
+    if (G.rows_fastest) { tm = bid % tiles_m; tn = bid / tiles_m; } else { tm = bid / tiles_n; tn = bid % tiles_n; }
+    const int m0 = tm * TBM, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (TBM / 2), wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
+
+    // DMA sources: wave w fills chunks 2w, 2w+1 of X and chunks 6w .. 6w+5 of the 24 chunks of the pieces.  Lane l of a chunk is
+    // slot (row l >> 2, piece l & 3) and loads global piece (l & 3) ^ ((l >> 4) & 3) of that row.
+    const unsigned char* const xbase = reinterpret_cast<const unsigned char*>(G.X);
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(G.Wp);
+    const int gp = (lane & 3) ^ ((lane >> 4) & 3);
+    uint32_t src[NXC + 6];
+    uint32_t dst[NXC + 6];
+#pragma unroll
+    for (int i = 0; i < NXC; ++i) {
+        const int chunk = NXC * wave + i, row = chunk * 16 + (lane >> 2);
+        const int r = min(m0 + row, G.M - 1);
+        const long phys = G.rows ? (long)G.rows[r] : (long)r;
+        src[i] = (uint32_t)((phys * G.Kp + gp * 8) * 2);
+        dst[i] = chunk * CHUNK;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = 6 * wave + i, plane = c >> 3, chunk = c & 7, col = chunk * 16 + (lane >> 2);
+        src[NXC + i] = (uint32_t)((plane * G.plane_stride + (long)min(n0 + col, G.N - 1) * G.Kp + gp * 8) * 2);
+        dst[NXC + i] = XPL + plane * APL + chunk * CHUNK;
+    }
+    auto issue = [&](int step, int stage) {
+        unsigned char* base = lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NXC; ++i)
+            __builtin_amdgcn_global_load_lds((gmem_ptr_t)(xbase + src[i] + (size_t)step * (XBK * 2)), (lds_ptr_t)(base + dst[i]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((gmem_ptr_t)(wbase + src[NXC + i] + (size_t)step * (XBK * 2)), (lds_ptr_t)(base + dst[NXC + i]), 16, 0, 0);
+    };
+    f32x16 acc[FA][2];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    int live = 0;                          // 32-row blocks of this wave inside the matrix
+#pragma unroll
+    for (int i = 0; i < FA; ++i) live += (m0 + wm + 32 * i < G.M) ? 1 : 0;
+
+    // fragment addresses: row R of a plane, piece q -> (R >> 4) * 1 KB + (R & 15) * 64 + ((q ^ ((R >> 2) & 3)) * 16)
+    int offa[FA][2], offb[2][2];          // [block][k chunk]
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        const int q = 2 * kc + lk;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int ra = wm + 32 * i + lm;
+            offa[i][kc] = (ra >> 4) * CHUNK + (ra & 15) * 64 + ((q ^ ((ra >> 2) & 3)) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rb = wn + 32 * j + lm;
+            offb[j][kc] = XPL + (rb >> 4) * CHUNK + (rb & 15) * 64 + ((q ^ ((rb >> 2) & 3)) * 16);
+        }
+    }
+    const int n_steps = G.Kp / XBK;
+    issue(0, 0);
+    for (int step = 0; step < n_steps; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA of step `step` has landed
+        __syncthreads();                                       // everybody's has; everybody is done with the other stage
+        if (step + 1 < n_steps) issue(step + 1, (step + 1) & 1);
+        const unsigned char* base = lds + (step & 1) * STAGE;
+        if (live == 0) continue;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 a[FA];
+#pragma unroll
+            for (int i = 0; i < FA; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + offa[i][kc]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bf16x8 b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(base + p * APL + offb[j][kc]);
+#pragma unroll
+                for (int i = 0; i < FA; ++i) {
+                    if (i < live) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lm;
+            if (n >= G.N) continue;
+            const float bias = G.bias ? G.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * lk + (r & 3);
+                if (m >= G.M) continue;
+                G.C[(long)m * G.ldc + n] = act_forward(ACT_OF(G, n), acc[i][j][r] + bias, ADD_OF(G, n));
+            }
+        }
+}
+
 static void launch_xgemm(XGemmArgs X, hipStream_t stream) {
     X.rows_fastest = 3L * X.N > (long)X.M ? 1 : 0;      // which operand is the larger one (both have Kp columns)
     // (measured, cfg 4's two products: 256-row tiles 66 us each at two waves per SIMD — fewer LDS reads per MFMA, but one
     //  workgroup per CU at these shapes — against 45 us with 128-row tiles at three; BSVI_XGEMM_TALL=1 selects the tall tile)
     static const bool tall_env = [] { const char* e = getenv("BSVI_XGEMM_TALL"); return e && e[0] == '1'; }();
     const bool tall = tall_env && X.M >= 256;
+    static const bool glds = [] { const char* e = getenv("BSVI_XGEMM_GLDS"); return !(e && e[0] == '0'); }();
+    if (glds) {
+        const unsigned tiles_g = (unsigned)(((X.M + (tall ? 255 : 127)) / (tall ? 256 : 128)) * ((X.N + 127) / 128));
+        if (tall) hipLaunchKernelGGL((xgemm_nt_glds_kernel<256>), dim3(tiles_g), dim3(256), 0, stream, X);
+        else hipLaunchKernelGGL((xgemm_nt_glds_kernel<128>), dim3(tiles_g), dim3(256), 0, stream, X);
+        return;
+    }
     const int tbm = tall ? 256 : 128;
     const unsigned tiles = (unsigned)(((X.M + tbm - 1) / tbm) * ((X.N + 127) / 128));
     if (tall) hipLaunchKernelGGL((xgemm_nt_kernel<256>), dim3(tiles), dim3(256), 0, stream, X);
