@@ -1,0 +1,1 @@
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
