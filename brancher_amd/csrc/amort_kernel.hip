@@ -429,6 +429,10 @@ struct XGemmArgs {
     int M, N, Kp, ldc;
     int act; float post_add; int split; int act2; float post_add2;
     int rows_fastest;       // tile order: neighbours share a column tile (the pieces) instead of a row tile (X)
+    // the split-k form (weight gradient of the data layer): workgroup (tile, split) multiplies k steps
+    // [split * steps_per_split, ...) and writes its partial TRANSPOSED, C + split * part_stride as [N][ldc] with m along a row
+    int steps_per_split;
+    long part_stride;
 };
 
 __device__ __forceinline__ uint16_t bf16_bits(float x) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(uint16_t, b); }
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void xgemm_nt_kernel(const XGemmArgs G) {
 // barrier per k step: wait for the DMA of step s, barrier, start the DMA of step s+1 into the other stage, multiply.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gmem_ptr_t;
-template <int TBM>
+template <int TBM, bool SPLITK>
 __global__ __launch_bounds__(256, 2) void xgemm_nt_glds_kernel(const XGemmArgs G) {
     constexpr int FA = TBM / 64, NXC = TBM / 64;                          // X fragments per wave; X chunks (of 16 rows) per wave
     constexpr int CHUNK = 1024, APL = 8 * CHUNK, XPL = (TBM / 16) * CHUNK, STAGE = XPL + 3 * APL;      // X (TBM rows) | hi | mid | lo (128 rows each)
@@ -591,11 +595,20 @@ __global__ __launch_bounds__(256, 2) void xgemm_nt_glds_kernel(const XGemmArgs G
     int bid = blockIdx.x;
     const int n_blocks = gridDim.x;
     if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);
+    int split = 0;                         // (the tiles of one split are neighbours: they read the same k range of both operands)
+    if constexpr (SPLITK) { const int tiles = tiles_m * tiles_n; split = bid / tiles; bid -= split * tiles; }
     int tm, tn;
     if (G.rows_fastest) { tm = bid % tiles_m; tn = bid / tiles_m; } else { tm = bid / tiles_n; tn = bid % tiles_n; }
     const int m0 = tm * TBM, n0 = tn * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (TBM / 2), wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
+    const int n_steps = G.Kp / XBK;
+    int s_begin = 0, s_end = n_steps;
+    if constexpr (SPLITK) {
+        s_begin = split * G.steps_per_split;
+        s_end = min(n_steps, s_begin + G.steps_per_split);
+        if (s_begin >= s_end) return;      // a padding workgroup of the grid
+    }
 
     // DMA sources: wave w fills chunks 2w, 2w+1 of X and chunks 6w .. 6w+5 of the 24 chunks of the pieces.  Lane l of a chunk is
     // slot (row l >> 2, piece l & 3) and loads global piece (l & 3) ^ ((l >> 4) & 3) of that row.
@@ -654,13 +667,12 @@ __global__ __launch_bounds__(256, 2) void xgemm_nt_glds_kernel(const XGemmArgs G
             offb[j][kc] = XPL + (rb >> 4) * CHUNK + (rb & 15) * 64 + ((q ^ ((rb >> 2) & 3)) * 16);
         }
     }
-    const int n_steps = G.Kp / XBK;
-    issue(0, 0);
-    for (int step = 0; step < n_steps; ++step) {
+    issue(s_begin, 0);
+    for (int step = s_begin; step < s_end; ++step) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA of step `step` has landed
         __syncthreads();                                       // everybody's has; everybody is done with the other stage
-        if (step + 1 < n_steps) issue(step + 1, (step + 1) & 1);
-        const unsigned char* base = lds + (step & 1) * STAGE;
+        if (step + 1 < s_end) issue(step + 1, (step + 1 - s_begin) & 1);
+        const unsigned char* base = lds + ((step - s_begin) & 1) * STAGE;
         if (live == 0) continue;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
@@ -676,11 +688,32 @@ __global__ __launch_bounds__(256, 2) void xgemm_nt_glds_kernel(const XGemmArgs G
                 for (int i = 0; i < FA; ++i) {
                     if (i < live) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) {
+                            // (split-k form, operands exchanged: the accumulator holds the TRANSPOSED tile, a lane's 32 neighbours run along m)
+                            if constexpr (SPLITK) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
+    }
+    if constexpr (SPLITK) {
+        // acc[i][j][r] is C[m][n] with m = 32i + (lane & 31), n = 32j + 8(r>>2) + 4(lane>>5) + (r&3); stored [n][m]
+        float* const Cp = G.C + (long)split * G.part_stride;
+#pragma unroll
+        for (int i = 0; i < FA; ++i) {
+            const int m = m0 + wm + 32 * i + lm;
+            if (m >= G.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn + 32 * j + 8 * (r >> 2) + 4 * lk + (r & 3);
+                    if (n < G.N) Cp[(long)n * G.ldc + m] = acc[i][j][r];
+                }
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < FA; ++i)
@@ -707,14 +740,124 @@ static void launch_xgemm(XGemmArgs X, hipStream_t stream) {
     static const bool glds = [] { const char* e = getenv("BSVI_XGEMM_GLDS"); return !(e && e[0] == '0'); }();
     if (glds) {
         const unsigned tiles_g = (unsigned)(((X.M + (tall ? 255 : 127)) / (tall ? 256 : 128)) * ((X.N + 127) / 128));
-        if (tall) hipLaunchKernelGGL((xgemm_nt_glds_kernel<256>), dim3(tiles_g), dim3(256), 0, stream, X);
-        else hipLaunchKernelGGL((xgemm_nt_glds_kernel<128>), dim3(tiles_g), dim3(256), 0, stream, X);
+        if (tall) hipLaunchKernelGGL((xgemm_nt_glds_kernel<256, false>), dim3(tiles_g), dim3(256), 0, stream, X);
+        else hipLaunchKernelGGL((xgemm_nt_glds_kernel<128, false>), dim3(tiles_g), dim3(256), 0, stream, X);
         return;
     }
     const int tbm = tall ? 256 : 128;
     const unsigned tiles = (unsigned)(((X.M + tbm - 1) / tbm) * ((X.N + 127) / 128));
     if (tall) hipLaunchKernelGGL((xgemm_nt_kernel<256>), dim3(tiles), dim3(256), 0, stream, X);
     else hipLaunchKernelGGL((xgemm_nt_kernel<128>), dim3(tiles), dim3(256), 0, stream, X);
+}
+
+// ---- the weight gradient of the data layer on the same pieces ---------------------------------------------------------
+// dW[n][p] = sum_r dY[r][n] x[idx[r]][p]: the EXACT operand is x again and the f32 operand is dY, so dY is split into
+// three bf16 pieces.  The MFMA wants k (= the row r) contiguous in both operands: dy_split_t_kernel writes the pieces
+// transposed, [3][n_out][Rp], and xt_gather_kernel the gathered data rows transposed, [P][Rp] (it only needs the
+// minibatch indices, so it runs on the side stream beside the forward pass).  xgemm_nt_glds_kernel<128, true> then
+// multiplies slices of the rows (split-k) and writes one partial [n_out][P] per slice for reduce_partials.
+// Rp = R rounded up to 64 (rows beyond R are zero in both operands).
+struct XdwPlan { int Rp, steps, steps_per_split, slices, grid_splits, tiles; };
+static XdwPlan xdw_plan(int P, int n_out, size_t R) {
+    XdwPlan p{};
+    p.Rp = (int)((R + 63) / 64 * 64);
+    p.steps = p.Rp / XBK;
+    p.tiles = ((P + 127) / 128) * ((n_out + 127) / 128);
+    const int want = std::max(1, std::min(p.steps, 512 / std::max(p.tiles, 1)));     // two workgroups per CU, one round
+    p.steps_per_split = (p.steps + want - 1) / want;
+    p.slices = (p.steps + p.steps_per_split - 1) / p.steps_per_split;
+    p.grid_splits = p.slices;
+    while ((p.grid_splits * p.tiles) % 8) ++p.grid_splits;       // whole XCD shares; the padding workgroups exit
+    return p;
+}
+
+// dY [R][ld] f32 -> T [3][N][Rp] bf16 pieces, and the column sums of every 64-row block (the bias gradient's partials)
+__global__ __launch_bounds__(256) void dy_split_t_kernel(const float* dY, int ld, int R, int Rp, int N, uint16_t* T, float* colsum) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, n0 = blockIdx.y * 64, t = threadIdx.x;
+    {
+        const int c = t & 63, n = n0 + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (t >> 6) + 4 * i, r = r0 + row;
+            tile[row][c] = (r < R && n < N) ? dY[(long)r * ld + n] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int c = t >> 2, g = t & 3, n = n0 + c;
+    uint16_t piece[3][16];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float w = tile[16 * g + i][c];
+        s += w;
+        const uint16_t hi = bf16_bits(w);
+        const float r1 = w - bf16_value(hi);
+        const uint16_t mid = bf16_bits(r1);
+        piece[0][i] = hi; piece[1][i] = mid; piece[2][i] = bf16_bits(r1 - bf16_value(mid));
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (n >= N) return;
+    if (colsum && g == 0) colsum[(long)blockIdx.x * N + n] = s;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        xu4 lo, hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            lo[q] = (uint32_t)piece[p][2 * q] | ((uint32_t)piece[p][2 * q + 1] << 16);
+            hi[q] = (uint32_t)piece[p][8 + 2 * q] | ((uint32_t)piece[p][9 + 2 * q] << 16);
+        }
+        xu4* out = reinterpret_cast<xu4*>(T + ((long)p * N + n) * Rp + r0 + 16 * g);
+        out[0] = lo; out[1] = hi;
+    }
+}
+
+// Xb [DS][Kp] bf16, idx [R] -> XT [P][Rp] bf16: XT[p][r] = Xb[idx[r]][p].  A workgroup transposes 64 rows x 128 columns:
+// 16-byte loads along the rows into LDS (row stride 65 words), then a thread takes a PAIR of columns (one word) over eight
+// rows and regroups the halves into the two 16-byte column pieces; the eight threads of a column pair are neighbours,
+// so a column's 64 rows leave as one 128-byte line.
+__global__ __launch_bounds__(256) void xt_gather_kernel(const uint16_t* Xb, const int32_t* idx, int Kp, int P, int R, int Rp, uint16_t* XT) {
+    __shared__ uint32_t tile[64][65];
+    const int r0 = blockIdx.x * 64, p0 = blockIdx.y * 128, t = threadIdx.x;
+    {
+        const int piece = t & 15;              // 16-byte piece of the 256-byte row segment
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (t >> 4) + 16 * i, r = r0 + row;
+            xu4 w = {0u, 0u, 0u, 0u};
+            if (r < R && p0 + 8 * piece < Kp) w = *reinterpret_cast<const xu4*>(Xb + (long)idx[r] * Kp + p0 + 8 * piece);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile[row][4 * piece + q] = w[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = t + 256 * k, g = item & 7, q = item >> 3, p = p0 + 2 * q;
+        if (p >= P) continue;
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = tile[8 * g + i][q];
+        xu4 even, odd;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            even[h] = (w[2 * h] & 0xFFFFu) | (w[2 * h + 1] << 16);
+            odd[h] = (w[2 * h] >> 16) | (w[2 * h + 1] & 0xFFFF0000u);
+        }
+        *reinterpret_cast<xu4*>(XT + (long)p * Rp + r0 + 8 * g) = even;
+        if (p + 1 < P) *reinterpret_cast<xu4*>(XT + (long)(p + 1) * Rp + r0 + 8 * g) = odd;
+    }
+}
+
+// partial[slice][n_out][P] = (dY^T x) over the slice's rows.  XT, T as above.
+static void launch_xdw(const uint16_t* XT, const uint16_t* T, int P, int n_out, const XdwPlan& plan, float* partial, hipStream_t stream) {
+    XGemmArgs X{};
+    X.X = XT; X.rows = nullptr; X.Wp = T; X.plane_stride = (long)n_out * plan.Rp;
+    X.C = partial; X.ldc = P; X.M = P; X.N = n_out; X.Kp = plan.Rp;
+    X.steps_per_split = plan.steps_per_split; X.part_stride = (long)n_out * P;
+    X.rows_fastest = 1;
+    hipLaunchKernelGGL((xgemm_nt_glds_kernel<128, true>), dim3((unsigned)(plan.tiles * plan.grid_splits)), dim3(256), 0, stream, X);
 }
 
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -1233,6 +1376,7 @@ struct RowParams {
     const float* noise_in;
     float* noise_out;
     const float* dataset;    // [DS][P] device
+    const uint16_t* dataset_bf16; int data_kp;     // its exact bf16 copy [DS][data_kp], or null
     const float* loc;  int ld_loc;  int act_loc;  float add_loc;
     const float* scale; int ld_scale; int act_scale; float add_scale;
     float* dloc; float* dscale;
@@ -1330,7 +1474,17 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
         const float sig = lj >= 0.0f ? r : e * r;
         return xj - sig;
     };
-    if (((D.P | D.ld_logits) & 3) == 0) {          // 16-byte accesses: a wave covers 1 KiB of the row per pass
+    if (D.dataset_bf16 && ((D.P | D.ld_logits) & 3) == 0) {      // the exact bf16 copy of the data: half the bytes of the gather
+        const uint16_t* xb = D.dataset_bf16 + (long)D.idx[r] * D.data_kp;
+        for (int q = lane; q < (D.P >> 2); q += 64) {
+            const float4 lv = *reinterpret_cast<const float4*>(l + 4 * q);
+            const uint2 xv = *reinterpret_cast<const uint2*>(xb + 4 * q);
+            float4 o;
+            o.x = element(lv.x, __uint_as_float(xv.x << 16)); o.y = element(lv.y, __uint_as_float(xv.x & 0xFFFF0000u));
+            o.z = element(lv.z, __uint_as_float(xv.y << 16)); o.w = element(lv.w, __uint_as_float(xv.y & 0xFFFF0000u));
+            *reinterpret_cast<float4*>(l + 4 * q) = o;
+        }
+    } else if (((D.P | D.ld_logits) & 3) == 0) {          // 16-byte accesses: a wave covers 1 KiB of the row per pass
         for (int q = lane; q < (D.P >> 2); q += 64) {
             const float4 lv = *reinterpret_cast<const float4*>(l + 4 * q), xv = *reinterpret_cast<const float4*>(x + 4 * q);
             float4 o;
@@ -1420,6 +1574,7 @@ struct bsvi_amort {
     int data_kp = 0;
     uint16_t* dataset_bf16_dev = nullptr;
     std::vector<uint16_t*> weight_pieces;
+    bool xdw = false;              // ... and their weight gradients too (dy_split_t_kernel, xt_gather_kernel, the split-k product)
     float* prior_dev = nullptr;    // [2][Dz]
     size_t floats_per_row = 0;     // workspace floats per row (values + gradients + per-row scalars)
     // the weight-gradient GEMM of a layer and its input-gradient GEMM are independent: the former runs on a side
@@ -1536,6 +1691,8 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
             }
             a->data_exact = true;
             a->data_kp = Kp;
+            const char* xd = getenv("BSVI_AMORT_XDW");
+            a->xdw = !(xd && xd[0] == '0');
         }
     }
     (void)hipMemcpy(a->prior_dev, desc->prior_loc, Dz * sizeof(float), hipMemcpyHostToDevice);
@@ -1545,7 +1702,7 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     if (a->overlap) {
         bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&a->joined, hipEventDisableTiming) == hipSuccess;
-        a->ready.resize(desc->n_enc_layers + desc->n_dec_layers, nullptr);
+        a->ready.resize(desc->n_enc_layers + desc->n_dec_layers + 1, nullptr);      // (the last one: the encoder's forward pass is enqueued)
         for (auto& e : a->ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             bsvi_amort_destroy(a);
@@ -1633,11 +1790,28 @@ static size_t tn_partial_floats(int M, int N, int K, bool bias) {
 
 // floats of the partial sums behind the per-row part of the workspace: one slice set per Linear layer (weights + bias)
 // and the workgroup partials of the loss sums
+// does encoder layer li take its weight gradient through the exact-data product at R rows?
+static bool xdw_layer(const bsvi_amort* a, size_t li, size_t R) {
+    if (!a->xdw || li >= a->weight_pieces.size() || !a->weight_pieces[li]) return false;
+    const size_t Rp = (R + 63) / 64 * 64;
+    const auto& l = a->enc.layers[li];
+    return std::max<size_t>(3 * (size_t)l.n_out, l.n_in) * Rp * 2 < 0xF0000000ull;      // 32-bit byte offsets in the kernel
+}
+static size_t xdw_floats(const bsvi_amort* a, size_t li, size_t R) {      // slice partials, bias partials, the pieces of dY
+    const auto& l = a->enc.layers[li];
+    const XdwPlan p = xdw_plan((int)l.n_in, (int)l.n_out, R);
+    return align4((size_t)p.slices * l.n_out * l.n_in) + align4((size_t)(p.Rp / 64) * l.n_out) + align4(3 * (size_t)l.n_out * p.Rp / 2);
+}
 static size_t partial_floats(const bsvi_amort* a, size_t R) {
     size_t n = align4(2 * ((R + 255) / 256));
+    bool any_xdw = false;
     for (const Net* net : {&a->enc, &a->dec})
-        for (const auto& l : net->layers)
-            n += tn_partial_floats((int)l.n_out, (int)l.n_in, (int)R, l.bias_off != 0xFFFFFFFFu);
+        for (size_t li = 0; li < net->layers.size(); ++li) {
+            const auto& l = net->layers[li];
+            if (net == &a->enc && xdw_layer(a, li, R)) { n += xdw_floats(a, li, R); any_xdw = true; }
+            else n += tn_partial_floats((int)l.n_out, (int)l.n_in, (int)R, l.bias_off != 0xFFFFFFFFu);
+        }
+    if (any_xdw) n += align4((size_t)a->d.n_features * ((R + 63) / 64 * 64) / 2);      // the transposed minibatch rows (bf16)
     return n + 16;
 }
 
@@ -1789,6 +1963,46 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
         HIP_TRY(hipGetLastError());
         return BSVI_OK;
     }
+    if (mode == 4) {
+        // the exact-data weight gradient C[M][N] = A[K][M]^T B[rows[k]][N] (and the column sums of A into bias_or_y_dev):
+        // B (exact in bf16, not checked; `accumulate` source rows, stored densely) is converted, then the product path's
+        // three launches and the reduction over the slices
+        if (!a_dev || !b_dev || !c_dev || !rows_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
+        if (ldb != n) return bsvi_fail(BSVI_ERR_INVALID, "mode 4 takes a densely stored B");
+        const int Kp = ((int)n + XBK - 1) / XBK * XBK;
+        const XdwPlan plan = xdw_plan((int)n, (int)m, k);
+        float* bias_acc = const_cast<float*>(bias_or_y_dev);
+        static uint16_t* xb = nullptr; static size_t xb_n = 0;
+        static float* part = nullptr; static size_t part_n = 0;
+        const size_t need_x = (size_t)accumulate * Kp;
+        const size_t f_slices = align4((size_t)plan.slices * m * n), f_col = align4((size_t)(plan.Rp / 64) * m);
+        const size_t f_t = align4(3 * (size_t)m * plan.Rp / 2), f_xt = align4((size_t)n * plan.Rp / 2);
+        const size_t need_p = f_slices + f_col + f_t + f_xt;
+        if (need_x > xb_n) { (void)hipDeviceSynchronize(); if (xb) (void)hipFree(xb); xb = nullptr; xb_n = 0; HIP_TRY(hipMalloc(&xb, need_x * 2)); xb_n = need_x; }
+        if (need_p > part_n) { (void)hipDeviceSynchronize(); if (part) (void)hipFree(part); part = nullptr; part_n = 0; HIP_TRY(hipMalloc(&part, need_p * 4)); part_n = need_p; }
+        hipStream_t st = (hipStream_t)stream;
+        float* slices = part; float* colsum = part + f_slices;
+        uint16_t* T = reinterpret_cast<uint16_t*>(colsum + f_col);
+        uint16_t* XT = reinterpret_cast<uint16_t*>(colsum + f_col + f_t);
+        hipLaunchKernelGGL(x_to_bf16_kernel, dim3((unsigned)((need_x + 255) / 256)), dim3(256), 0, st, b_dev, (long)accumulate, (int)n, Kp, xb);
+        hipLaunchKernelGGL(xt_gather_kernel, dim3((unsigned)(plan.Rp / 64), (unsigned)((n + 127) / 128)), dim3(256), 0, st,
+                           xb, rows_dev, Kp, (int)n, (int)k, plan.Rp, XT);
+        hipLaunchKernelGGL(dy_split_t_kernel, dim3((unsigned)(plan.Rp / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, st,
+                           a_dev, (int)lda, (int)k, plan.Rp, (int)m, T, bias_acc ? colsum : nullptr);
+        launch_xdw(XT, T, (int)n, (int)m, plan, slices, st);
+        SegmentTable S{};
+        S.seg[0] = Segment{c_dev, slices, m, n, ldc, (uint32_t)plan.slices, 0u, 0u, 0u, 0u};
+        S.n = 1;
+        uint32_t blocks = segment_blocks(S.seg[0]);
+        if (bias_acc) {
+            S.seg[1] = Segment{bias_acc, colsum, 1u, m, m, (uint32_t)(plan.Rp / 64), blocks, 0u, 0u, 0u};
+            S.n = 2;
+            blocks += segment_blocks(S.seg[1]);
+        }
+        hipLaunchKernelGGL(reduce_partials, dim3(blocks), dim3(256), 0, st, S);
+        HIP_TRY(hipGetLastError());
+        return BSVI_OK;
+    }
     if (mode < 0 || mode > 2 || !a_dev || !b_dev || !c_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
     GemmArgs G{};
     G.A = a_dev; G.B = b_dev; G.C = c_dev; G.rows = rows_dev;
@@ -1881,6 +2095,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.indices_in = args->indices_dev; D.idx = idx; D.indices_out = args->indices_out_dev;
     D.noise_in = args->noise_dev; D.noise_out = args->noise_out_dev;
     D.dataset = a->dataset_dev;
+    D.dataset_bf16 = a->data_exact ? a->dataset_bf16_dev : nullptr; D.data_kp = a->data_kp;
     const bsvi_mlp_layer& Lloc = a->enc.layers[a->enc.producer[d.enc_loc_value]];
     const bsvi_mlp_layer& Lscale = a->enc.layers[a->enc.producer[d.enc_scale_value]];
     auto head_act = [](const bsvi_mlp_layer& L, uint32_t col, int& act, float& add) {
@@ -1904,6 +2119,15 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     part += align4(2 * (size_t)row_grid.x);
     if (int rc = add_segment(out, D.sum_part, 1, 2, row_grid.x)) return rc;       // out[0] = sum of values, out[1] = non-finite count
     hipLaunchKernelGGL(amort_rows, row_grid, dim3(256), 0, stream, D);
+
+    // the transposed minibatch rows for the exact-data weight gradients (launched after the encoder's forward pass, below)
+    uint16_t* XT = nullptr;
+    const int Rp = (int)((R + 63) / 64 * 64);
+    for (size_t li = 0; li < a->enc.layers.size() && !XT; ++li)
+        if (a->enc.layers[li].in_value == 0 && xdw_layer(a, li, R)) {
+            XT = reinterpret_cast<uint16_t*>(part);
+            part += align4((size_t)P * Rp / 2);
+        }
 
     auto forward = [&](const Net& net, bool gather) -> int {
         for (size_t li = 0; li < net.layers.size(); ++li) {
@@ -1957,6 +2181,24 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
             const float* dY = grad(net, l.out_value);
             const int ldy = net.ld[l.out_value];
             const bool from_data = gather && l.in_value == 0;
+            if (from_data && XT && xdw_layer(a, (size_t)i, R)) {
+                // dW = dY^T x with x exact in bf16: the pieces of dY, transposed, times the transposed rows (split-k)
+                const XdwPlan plan = xdw_plan((int)l.n_in, (int)l.n_out, R);
+                const bool has_bias = l.bias_off != 0xFFFFFFFFu;
+                float* slices = part;
+                part += align4((size_t)plan.slices * l.n_out * l.n_in);
+                float* colsum = part;
+                part += align4((size_t)(Rp / 64) * l.n_out);
+                uint16_t* T = reinterpret_cast<uint16_t*>(part);
+                part += align4(3 * (size_t)l.n_out * Rp / 2);
+                hipLaunchKernelGGL(dy_split_t_kernel, dim3((unsigned)(Rp / 64), (unsigned)((l.n_out + 63) / 64)), dim3(256), 0, wstream,
+                                   dY, ldy, (int)R, Rp, (int)l.n_out, T, has_bias ? colsum : nullptr);
+                launch_xdw(XT, T, (int)l.n_in, (int)l.n_out, plan, slices, wstream);
+                HIP_TRY(hipGetLastError());
+                int rc = add_segment(grads + l.weight_off, slices, l.n_out, l.n_in, (uint32_t)plan.slices);
+                if (!rc && has_bias) rc = add_segment(grads + l.bias_off, colsum, 1, l.n_out, (uint32_t)(Rp / 64));
+                if (rc) return rc;
+            } else
             {   // dW[n_out][n_in] = dY^T x, db = 1^T dY (same launch): one partial per slice of the rows
                 GemmArgs G{};
                 G.A = dY; G.lda = ldy;
@@ -2000,6 +2242,18 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
 
     int rc = forward(a->enc, true);
     if (rc) return rc;
+    if (XT) {
+        // on the side stream, beside the decoder's f32 products (which leave the memory system idle; beside the encoder's
+        // first product, itself fed from the data rows, it cost that product 12 us)
+        hipStream_t ts = stream;
+        if (a->overlap) {
+            HIP_TRY(hipEventRecord(a->ready.back(), stream));
+            HIP_TRY(hipStreamWaitEvent(a->side, a->ready.back(), 0));
+            ts = a->side;
+        }
+        hipLaunchKernelGGL(xt_gather_kernel, dim3((unsigned)(Rp / 64), (unsigned)((P + 127) / 128)), dim3(256), 0, ts,
+                           a->dataset_bf16_dev, idx, a->data_kp, P, (int)R, Rp, XT);
+    }
     hipLaunchKernelGGL(amort_latent_fwd, row_grid, dim3(256), 0, stream, D);
     rc = forward(a->dec, false);
     if (rc) return rc;

@@ -147,6 +147,47 @@ def test_exact_data_forward_product_on_the_bf16_matrix_cores(kind, shape):
     assert (outs[0].double() - Cf.double()).abs().max().item() / scale < 2e-6
 
 
+@pytest.mark.parametrize("kind", ["binary", "counts"])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (70, 150, 300), (256, 784, 25600), (136, 100, 1000), (257, 96, 4133)])
+def test_exact_data_weight_gradient_on_the_bf16_matrix_cores(kind, shape):
+    """dW = dY^T x[rows] of the layer that reads the data rows, x exact in bf16: the three bf16 pieces of dY, transposed,
+    times the transposed minibatch rows, split over the rows (dy_split_t_kernel, xt_gather_kernel, the split-k form of
+    xgemm_nt_glds_kernel).  Against torch in double precision at the tolerance of the f32-input kernel, against that
+    kernel, the column sums of dY (the bias gradient), and bit-identical call after call."""
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    M, N, K = shape                      # dW is [M = n_out][N = n_in], K rows
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 5 * K)
+    n_src = K // 2 + 7
+    if kind == "binary":
+        src = (torch.rand(n_src, N, generator=g) > 0.5).float().to(dev)
+    else:
+        src = torch.randint(0, 256, (n_src, N), generator=g).float().to(dev)
+    rows = torch.randint(0, n_src, (K,), generator=g).to(torch.int32).to(dev)
+    ld = M + 4
+    dY = torch.randn(K, ld, generator=g).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    ref = dY[:, :M].double().T @ src[rows.long()].double()
+    ref_b = dY[:, :M].double().sum(0)
+    outs = []
+    for _ in range(2):
+        Cm = torch.full((M, N + 4), 7.0, device=dev)
+        colsum = torch.zeros(M, device=dev)
+        native.check(lib.bsvi_debug_gemm(4, ptr(dY), ptr(src), ptr(Cm), ptr(rows), M, N, K, ld, N, N + 4, ptr(colsum), 0, 0, 0.0, n_src, None))
+        torch.cuda.synchronize()
+        assert torch.all(Cm[:, N:] == 7.0)
+        outs.append((Cm[:, :N].clone(), colsum))
+    scale = ref.abs().max().item() + 1e-12
+    assert (outs[0][0].double() - ref).abs().max().item() / scale < 2e-6
+    assert (outs[0][1].double() - ref_b).abs().max().item() / ref_b.abs().max().item() < 2e-6
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    Cf = torch.zeros(M, N, device=dev)
+    native.check(lib.bsvi_debug_gemm(2, ptr(dY), ptr(src), ptr(Cf), ptr(rows), M, N, K, ld, N, N, None, 0, 0, 0.0, 0, None))
+    torch.cuda.synchronize()
+    assert (outs[0][0].double() - Cf.double()).abs().max().item() / scale < 2e-6
+
+
 def test_inexact_data_stays_on_the_f32_kernel():
     """a dataset with values that are not bf16 numbers must not take the bf16 path: the compiled object says which one it runs"""
     from brancher_amd import engine, workloads as W
