@@ -415,18 +415,22 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         rows = n_per_gpu * program.batch_size
         # flops of the forward products that read the data rows (bf16 x3 when the data is exactly bf16), the rest on the f32-input MFMA
         x_flops = sum(2.0 * rows * l.n_in * l.n_out for l in program.enc_layers if l.in_value == 0 and l.n_out > 8) if exact else 0.0
+        xdw = exact and os.environ.get("BSVI_AMORT_XDW", "1") != "0"      # ... and their weight gradients (the data is an operand again)
+        if xdw:
+            x_flops *= 2.0
         roof_s = (flops - x_flops) / (MFMA_F32_PEAK_TFLOPS * 1e12) + x_flops / (MFMA_EXACT_PEAK_TFLOPS * 1e12)
         peak = flops / roof_s / 1e12
         roofline = dict(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s",
                         frac=tf / peak, traffic=traffic,
-                        kernel="bsvi_amort_impl::gemm_kernel<0|1|2>" + (" + xgemm_nt_kernel<128> (first encoder layer)" if exact else ""),
+                        kernel="bsvi_amort_impl::gemm_kernel<0|1|2>" + (" + xgemm_nt_glds_kernel<128> (first encoder layer: forward%s)" % (
+                            " and weight gradient" if xdw else "") if exact else ""),
                         algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps,
                         rows_per_iteration=rows, data_path="bf16x3" if exact else "f32",
                         frac_of_f32_mfma_peak=tf / MFMA_F32_PEAK_TFLOPS,
-                        note="f32-input MFMA (v_mfma_f32_32x32x2_f32) for ten of the eleven products" + (
-                             "; the forward product of the layer that reads the (exactly bf16) data rows runs as three bf16 MFMAs on "
-                             "the exact pieces of its weights; peak = flops / (f32-input flops / 157.3 + those flops / (2500 / 3))"
-                             if exact else "") +
+                        note="f32-input MFMA (v_mfma_f32_32x32x2_f32) for %s of the eleven products" % ("nine" if xdw else "ten" if exact else "all") + (
+                             "; the forward product%s of the layer that reads the (exactly bf16) data rows run%s as three bf16 MFMAs on "
+                             "the exact pieces of the f32 operand; peak = flops / (f32-input flops / 157.3 + those flops / (2500 / 3))"
+                             % ((" and the weight gradient", "") if xdw else ("", "s")) if exact else "") +
                              "; achieved = GEMM flops of one iteration (forward + weight gradient + input gradient of every Linear "
                              "layer) / duration of the whole iteration")
     if traffic is not None:

@@ -532,24 +532,33 @@ def vae_modules(n_features, latent_size, hidden1, hidden2, seed=0):
     return enc, dec
 
 
-def vae_data(dataset_size, n_features, seed=0):
+def vae_data(dataset_size, n_features, seed=0, real=False):
     """synthetic binary images (MNIST is not available offline): rand > 0.5, stored [DS, P, 1] like
-    `VAE_playground.py:24-26`"""
+    `VAE_playground.py:24-26`; `real`: standard-normal rows for the Normal-likelihood variant"""
     rng = np.random.RandomState(seed)
+    if real:
+        return rng.randn(dataset_size, n_features, 1).astype("float32")
     return (rng.rand(dataset_size, n_features, 1) > 0.5).astype("int32")
 
 
-def build_vae(api, dataset_size=64, batch_size=16, n_features=784, latent_size=2, hidden1=512, hidden2=256, seed=0):
+def build_vae(api, dataset_size=64, batch_size=16, n_features=784, latent_size=2, hidden1=512, hidden2=256, seed=0,
+              likelihood="binomial", likelihood_scale=0.5, learnable_prior=False):
     """BASELINE config 5: `examples/VAE_playground.py:64-79` — amortised Normal posterior over a latent code,
-    Binomial(1, logits = decoder(z)) likelihood, every Monte-Carlo sample drawing its own minibatch."""
+    Binomial(1, logits = decoder(z)) likelihood, every Monte-Carlo sample drawing its own minibatch.
+    Variants of the same pattern: `likelihood="normal"` (real-valued rows, Normal(decoder(z), likelihood_scale) — a number
+    or one value per feature), `learnable_prior=True` (the prior's loc and scale are learnable parameters of the joint
+    model, `standard_variables.py:57-68`)."""
     BF = api.BF
-    dataset = vae_data(dataset_size, n_features, seed)
+    dataset = vae_data(dataset_size, n_features, seed, real=(likelihood == "normal"))
     enc, dec = vae_modules(n_features, latent_size, hidden1, hidden2, seed)
     encoder = BF.BrancherFunction(enc)
     decoder = BF.BrancherFunction(dec)
-    z = api.NormalVariable(np.zeros((latent_size,)), np.ones((latent_size,)), name="z")
+    z = api.NormalVariable(np.zeros((latent_size,)), np.ones((latent_size,)), name="z", learnable=learnable_prior)
     decoder_output = api.DeterministicVariable(decoder(z), name="decoder_output")
-    x = api.BinomialVariable(total_count=1, logits=decoder_output["mean"], name="x")
+    if likelihood == "normal":
+        x = api.NormalVariable(decoder_output["mean"], likelihood_scale, name="x")
+    else:
+        x = api.BinomialVariable(total_count=1, logits=decoder_output["mean"], name="x")
     model = api.ProbabilisticModel([x, z])
     Qx = api.EmpiricalVariable(dataset, batch_size=batch_size, name="x", is_observed=True)
     encoder_output = api.DeterministicVariable(encoder(Qx), name="encoder_output")
