@@ -210,20 +210,26 @@ def _network_output(expr, what):
     return e.attr[0], e.args[0].attr, key
 
 
-def _constant_parameter(var, name, positive):
+def _root_parameter(var, name, positive, learnable_ok=False):
+    """(values, Parameter or None) of a distribution argument given as a number / array: the standard constructors store it
+    as a RootVariable behind the range's forward transform (`standard_variables.py:57-68`, `geometric_ranges.py`): root, or
+    0 + softplus(root).  With `learnable=True` on the constructor the root is a parameter; the values are its current ones."""
     link = var.link.expressions()[name]
     e = link.expr
-    # the standard constructors store a constant argument as a RootVariable behind the range's forward transform
-    # (`standard_variables.py:57-68`, `geometric_ranges.py`): root, or 0 + softplus(root)
     roots = [v for v in e.variables() if isinstance(v, RootVariable)]
-    if len(roots) != 1 or len(e.variables()) != 1 or roots[0].learnable:
-        raise LoweringError("amortised path: the prior's %s must be a constant" % name)
+    if len(roots) != 1 or len(e.variables()) != 1 or (roots[0].learnable and not learnable_ok):
+        raise LoweringError("amortised path: %s of %r must be a constant" % (name, var.name))
     raw = np.asarray(roots[0].value, dtype=np.float64).reshape(-1)
+    par = roots[0].parameter if roots[0].learnable else None
     if not positive:
         if e.op != "var":
-            raise LoweringError("amortised path: unexpected transform of the prior's %s" % name)
-        return raw
-    return np.where(raw > 20, raw, np.log1p(np.exp(np.minimum(raw, 20))))
+            raise LoweringError("amortised path: unexpected transform of %s of %r" % (name, var.name))
+        return raw, par
+    return np.where(raw > 20, raw, np.log1p(np.exp(np.minimum(raw, 20)))), par
+
+
+def _constant_parameter(var, name, positive):
+    return _root_parameter(var, name, positive)[0]
 
 
 def lower_amortized(joint, posterior, estimator="pathwise"):
@@ -264,22 +270,33 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     x, z = lik[0], lat[0]
     if z.distribution.kind != D.DIST_NORMAL:
         raise LoweringError("amortised path: the latent prior must be Normal")
-    if x.distribution.kind not in (D.DIST_BINOMIAL, D.DIST_BERNOULLI):
-        raise LoweringError("amortised path: the likelihood must be Binomial(1, logits) / Bernulli(logits)")
+    if x.distribution.kind not in (D.DIST_BINOMIAL, D.DIST_BERNOULLI, D.DIST_NORMAL):
+        raise LoweringError("amortised path: the likelihood must be Binomial(1, logits) / Bernulli(logits) or "
+                            "Normal(decoder output, constant scale)")
     xl = x.link.expressions()
-    if "logits" not in xl:
-        raise LoweringError("amortised path: the likelihood must be parameterised by logits")
-    if x.distribution.kind == D.DIST_BINOMIAL:
-        tc = _constant_parameter(x, "total_count", positive=False)
-        if tc.size != 1 or tc[0] != 1.0:
-            raise LoweringError("amortised path: Binomial likelihood supports total_count = 1 only")
-    dec_link, dec_in, logits_key = _network_output(xl["logits"].expr, "the likelihood's logits")
+    likelihood, lik_scale = "binomial", None
+    if x.distribution.kind == D.DIST_NORMAL:
+        likelihood = "normal"
+        lik_scale = _constant_parameter(x, "scale", positive=True)
+        if lik_scale.size not in (1, P):
+            raise LoweringError("amortised path: the likelihood's scale must be one number or one per feature")
+        lik_scale = np.ascontiguousarray(np.broadcast_to(lik_scale, (P,)), dtype=np.float32)
+        dec_link, dec_in, logits_key = _network_output(xl["loc"].expr, "the likelihood's loc")
+    else:
+        if "logits" not in xl:
+            raise LoweringError("amortised path: the likelihood must be parameterised by logits")
+        if x.distribution.kind == D.DIST_BINOMIAL:
+            tc = _constant_parameter(x, "total_count", positive=False)
+            if tc.size != 1 or tc[0] != 1.0:
+                raise LoweringError("amortised path: Binomial likelihood supports total_count = 1 only")
+        dec_link, dec_in, logits_key = _network_output(xl["logits"].expr, "the likelihood's logits")
     if dec_in is not z:
         raise LoweringError("amortised path: the decoder must be applied to the latent variable")
-    prior_loc = _constant_parameter(z, "loc", positive=False)
-    prior_scale = _constant_parameter(z, "scale", positive=True)
+    # the prior's loc / scale: constants, or (NormalVariable(..., learnable=True)) parameters of the joint model
+    prior_loc, prior_loc_par = _root_parameter(z, "loc", positive=False, learnable_ok=True)
+    prior_scale, prior_scale_par = _root_parameter(z, "scale", positive=True, learnable_ok=True)
     Dz = prior_loc.size
-    if prior_scale.size not in (1, Dz):
+    if prior_scale.size not in (1, Dz) or (prior_scale_par is not None and prior_scale.size != Dz):
         raise LoweringError("amortised path: prior loc / scale shapes differ")
     prior_scale = np.broadcast_to(prior_scale, (Dz,))
 
@@ -311,6 +328,13 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
             offsets[id(par)] = off
             prog.parameters.append((par, off, par.size, group))
             off += par.size
+    # a learnable prior belongs to the joint model's optimizer (inference.py:77-88: ProbabilisticOptimizer(joint_model))
+    prog.prior_loc_off = prog.prior_scale_off = NO_BIAS
+    for par, which in ((prior_loc_par, "prior_loc_off"), (prior_scale_par, "prior_scale_off")):
+        if par is not None:
+            setattr(prog, which, off)
+            prog.parameters.append((par, off, par.size, 1))
+            off += par.size
     prog.n_params = off
     prog.param_active = np.zeros(off, dtype=np.uint8)
     for par, o, size, g in prog.parameters:
@@ -334,6 +358,8 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     prog.prior_loc = np.ascontiguousarray(prior_loc, dtype=np.float32)
     prog.prior_scale = np.ascontiguousarray(prior_scale, dtype=np.float32)
     prog.dataset = Xm
+    prog.likelihood, prog.likelihood_scale = likelihood, lik_scale
+    prog.loc_key, prog.scale_key = loc_key, scale_key
     prog.latent_name, prog.data_name = Qz.name, Qx.name
     prog.links = (enc_link, dec_link)
     prog.n_noise = Dz
@@ -365,16 +391,18 @@ class CompiledAmortized:
             return arr
 
         self._keep = dict(enc=pack(p.enc_layers), dec=pack(p.dec_layers), loc=p.prior_loc, scale=p.prior_scale,
-                          dataset=p.dataset)
+                          dataset=p.dataset, lik_scale=p.likelihood_scale)
         k = self._keep
-        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         d = AmortDesc(abi_version=native.ABI_VERSION, n_params=p.n_params, n_features=p.n_features,
                       latent_dim=p.latent_dim, dataset_size=p.dataset_size, batch_size=p.batch_size,
                       n_enc_layers=len(p.enc_layers), n_dec_layers=len(p.dec_layers),
                       enc_loc_value=p.enc_loc_value, enc_scale_value=p.enc_scale_value,
                       enc_loc_col=p.enc_loc_col, enc_scale_col=p.enc_scale_col,
                       dec_logits_value=p.dec_logits_value, enc_layers=k["enc"], dec_layers=k["dec"],
-                      prior_loc=ptr(k["loc"]), prior_scale=ptr(k["scale"]), dataset=ptr(k["dataset"]))
+                      prior_loc=ptr(k["loc"]), prior_scale=ptr(k["scale"]), dataset=ptr(k["dataset"]),
+                      likelihood=1 if p.likelihood == "normal" else 0, likelihood_scale=ptr(k["lik_scale"]),
+                      prior_loc_off=p.prior_loc_off, prior_scale_off=p.prior_scale_off)
         handle = C.c_void_p()
         native.check(lib.bsvi_amort_create(C.byref(d), C.byref(handle)))
         self.handle = handle

@@ -1384,6 +1384,10 @@ struct RowParams {
     float* z; int ld_z;      // decoder input
     const float* dz;         // decoder-input gradient, [R][ld_z]
     const float* prior_loc; const float* prior_scale;
+    // a learnable prior: raw values in the parameter buffer (loc as stored, scale = softplus(raw)); kNoOffset: the constants above
+    const float* params; uint32_t prior_loc_off, prior_scale_off;
+    float* prior_loc_part; float* prior_scale_part;      // [workgroups of amort_latent_bwd][Dz] partial gradient sums, or null
+    int likelihood; const float* lik_scale;              // BSVI_AMORT_LIK_*; [P] scale of the Normal likelihood
     float* rowf;             // [R] f per row
     float* rowlq;            // [R] log q per row
     float* logits; int ld_logits;
@@ -1423,6 +1427,22 @@ __global__ void amort_rows(const RowParams D) {
     if (D.indices_out) D.indices_out[r] = i;
 }
 
+// p(z)'s parameters for latent dimension d: constants, or the learnable raw values behind the constructor's transforms
+// (loc: identity; scale: 0 + softplus(raw), torch's softplus with threshold 20 — geometric_ranges.py RightHalfLine);
+// dscale = d scale / d raw
+constexpr uint32_t kNoOffset = 0xFFFFFFFFu;
+__device__ __forceinline__ void prior_of(const RowParams& D, int d, float& loc, float& scale, float& dscale) {
+    loc = D.prior_loc_off != kNoOffset ? D.params[D.prior_loc_off + d] : D.prior_loc[d];
+    if (D.prior_scale_off != kNoOffset) {
+        const float raw = D.params[D.prior_scale_off + d];
+        scale = raw > 20.0f ? raw : log1pf(expf(raw));
+        dscale = raw > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-raw));
+    } else {
+        scale = D.prior_scale[d];
+        dscale = 0.0f;
+    }
+}
+
 // z = loc + scale * eps; per row: log p(z), H[q(z|x)], log q(z|x)   (torch normal.py:83-116)
 __global__ void amort_latent_fwd(const RowParams D) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1446,7 +1466,9 @@ __global__ void amort_latent_fwd(const RowParams D) {
             D.eps[(long)r * D.Dz + dd] = e;
             if (D.noise_out) D.noise_out[(long)r * D.Dz + dd] = e;
             D.z[(long)r * D.ld_z + dd] = z;
-            const float pl = D.prior_loc[dd], ps = D.prior_scale[dd], u = (z - pl) / ps;
+            float pl, ps, dps;
+            prior_of(D, dd, pl, ps, dps);
+            const float u = (z - pl) / ps;
             const float lsd = logf(sd);
             lp += -0.5f * u * u - logf(ps) - kHalfLog2Pi;
             H += 0.5f + kHalfLog2Pi + lsd;
@@ -1465,6 +1487,18 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
     const float* x = D.dataset + (long)D.idx[r] * D.P;
     float* l = D.logits + (long)r * D.ld_logits;
     float lp = 0.0f;
+    if (D.likelihood == 1) {
+        // x ~ Normal(mean = decoder value, scale_j): log p = -u^2/2 - log(scale) - log(2 pi)/2, u = (x - mean)/scale;
+        // d log p / d mean = u / scale, written over the means   (torch normal.py:83-90)
+        for (int j = lane; j < D.P; j += 64) {
+            const float sj = D.lik_scale[j], u = (x[j] - l[j]) / sj;
+            lp += -0.5f * u * u - logf(sj) - kHalfLog2Pi;
+            l[j] = u / sj;
+        }
+        lp = wave_sum64(lp);
+        if (lane == 0) D.rowf[r] += lp;
+        return;
+    }
     auto element = [&](float lj, float xj) {
         // e in (0, 1]: log(1 + e) through the hardware log2 is good to ~1e-7 ABSOLUTE, which is what matters in a sum
         // whose other term is max(l, 0); the reciprocal to 1 ulp
@@ -1515,11 +1549,36 @@ __global__ __launch_bounds__(256) void amort_latent_bwd(const RowParams D) {
             const float e = D.eps[(long)r * D.Dz + d];
             const float m = D.loc[(long)r * D.ld_loc + d], sd = D.scale[(long)r * D.ld_scale + d];
             const float z = D.z[(long)r * D.ld_z + d];
-            const float ps = D.prior_scale[d];
-            const float gz = D.dz[(long)r * D.ld_z + d] - (z - D.prior_loc[d]) / (ps * ps);
+            float pl, ps, dps;
+            prior_of(D, d, pl, ps, dps);
+            const float gz = D.dz[(long)r * D.ld_z + d] - (z - pl) / (ps * ps);
             const float gsd = gz * e + (1.0f - score) / sd;
             D.dloc[(long)r * D.ld_loc + d] = gz * act_derivative(D.act_loc, m, D.add_loc);
             D.dscale[(long)r * D.ld_scale + d] = gsd * act_derivative(D.act_scale, sd, D.add_scale);
+        }
+    }
+    if (D.prior_loc_part) {
+        // a learnable prior: d f / d loc = u / scale, d f / d raw scale = (u^2 - 1) / scale * dscale with u = (z - loc) / scale,
+        // summed over the workgroup's rows per latent dimension (f enters both estimators' values with weight one)
+        __shared__ float pr[2][4];
+        for (int d = 0; d < D.Dz; ++d) {
+            float gl = 0.0f, gs = 0.0f;
+            if (r < D.R) {
+                float pl, ps, dps;
+                prior_of(D, d, pl, ps, dps);
+                const float u = (D.z[(long)r * D.ld_z + d] - pl) / ps;
+                gl = u / ps;
+                gs = (u * u - 1.0f) / ps * dps;
+            }
+            gl = wave_sum64(gl);
+            gs = wave_sum64(gs);
+            if ((threadIdx.x & 63) == 0) { pr[0][threadIdx.x >> 6] = gl; pr[1][threadIdx.x >> 6] = gs; }
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                float* dst = threadIdx.x ? D.prior_scale_part : D.prior_loc_part;
+                dst[(long)blockIdx.x * D.Dz + d] = (pr[threadIdx.x][0] + pr[threadIdx.x][1]) + (pr[threadIdx.x][2] + pr[threadIdx.x][3]);
+            }
+            __syncthreads();
         }
     }
     // workgroup partial of the two sums (waves in order): reduce_partials adds the workgroups in order
@@ -1576,6 +1635,7 @@ struct bsvi_amort {
     std::vector<uint16_t*> weight_pieces;
     bool xdw = false;              // ... and their weight gradients too (dy_split_t_kernel, xt_gather_kernel, the split-k product)
     float* prior_dev = nullptr;    // [2][Dz]
+    float* lik_scale_dev = nullptr;   // [P], Normal likelihood
     size_t floats_per_row = 0;     // workspace floats per row (values + gradients + per-row scalars)
     // the weight-gradient GEMM of a layer and its input-gradient GEMM are independent: the former runs on a side
     // stream (fork on an event per layer, one join before the function returns) and fills the CUs the latter's
@@ -1619,6 +1679,15 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
         !desc->prior_loc || !desc->prior_scale || !desc->latent_dim || !desc->batch_size || !desc->n_features)
         return bsvi_fail(BSVI_ERR_INVALID, "incomplete amortised-model description");
     if (desc->batch_size > desc->dataset_size) return bsvi_fail(BSVI_ERR_INVALID, "batch_size exceeds dataset_size");
+    if (desc->likelihood > BSVI_AMORT_LIK_NORMAL) return bsvi_fail(BSVI_ERR_UNSUPPORTED, "unknown likelihood kind");
+    if (desc->likelihood == BSVI_AMORT_LIK_NORMAL) {
+        if (!desc->likelihood_scale) return bsvi_fail(BSVI_ERR_INVALID, "a Normal likelihood needs its scale");
+        for (uint32_t j = 0; j < desc->n_features; ++j)
+            if (!(desc->likelihood_scale[j] > 0.0f)) return bsvi_fail(BSVI_ERR_INVALID, "likelihood scale must be positive");
+    }
+    for (uint32_t off : {desc->prior_loc_off, desc->prior_scale_off})
+        if (off != BSVI_AMORT_CONSTANT && (size_t)off + desc->latent_dim > desc->n_params)
+            return bsvi_fail(BSVI_ERR_INVALID, "learnable prior exceeds the parameter buffer");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return bsvi_fail(BSVI_ERR_NO_DEVICE, "no HIP device");
     auto* a = new bsvi_amort();
@@ -1695,6 +1764,13 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
             a->xdw = !(xd && xd[0] == '0');
         }
     }
+    if (desc->likelihood == BSVI_AMORT_LIK_NORMAL) {
+        if (hipMalloc(&a->lik_scale_dev, desc->n_features * sizeof(float)) != hipSuccess ||
+            hipMemcpy(a->lik_scale_dev, desc->likelihood_scale, desc->n_features * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            bsvi_amort_destroy(a);
+            return bsvi_fail(BSVI_ERR_HIP, "hipMalloc of the likelihood scale failed");
+        }
+    }
     (void)hipMemcpy(a->prior_dev, desc->prior_loc, Dz * sizeof(float), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->prior_dev + Dz, desc->prior_scale, Dz * sizeof(float), hipMemcpyHostToDevice);
     const char* ov = getenv("BSVI_AMORT_OVERLAP");
@@ -1716,6 +1792,8 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
                 spans.emplace_back((size_t)l.weight_off, (size_t)l.n_in * l.n_out);
                 if (l.bias_off != 0xFFFFFFFFu) spans.emplace_back((size_t)l.bias_off, (size_t)l.n_out);
             }
+        for (uint32_t off : {desc->prior_loc_off, desc->prior_scale_off})
+            if (off != BSVI_AMORT_CONSTANT) spans.emplace_back((size_t)off, (size_t)Dz);
         std::sort(spans.begin(), spans.end());
         size_t at = 0;
         bool exact = true;
@@ -1726,6 +1804,7 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     a->d.dec_layers = a->dec.layers.data();
     a->d.dataset = nullptr;
     a->d.prior_loc = a->d.prior_scale = nullptr;
+    a->d.likelihood_scale = nullptr;
     *out = a;
     return BSVI_OK;
 }
@@ -1751,6 +1830,7 @@ extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
     for (auto p : a->weight_pieces)
         if (p) (void)hipFree(p);
     if (a->prior_dev) (void)hipFree(a->prior_dev);
+    if (a->lik_scale_dev) (void)hipFree(a->lik_scale_dev);
     for (auto e : a->ready)
         if (e) (void)hipEventDestroy(e);
     if (a->joined) (void)hipEventDestroy(a->joined);
@@ -1812,6 +1892,8 @@ static size_t partial_floats(const bsvi_amort* a, size_t R) {
             else n += tn_partial_floats((int)l.n_out, (int)l.n_in, (int)R, l.bias_off != 0xFFFFFFFFu);
         }
     if (any_xdw) n += align4((size_t)a->d.n_features * ((R + 63) / 64 * 64) / 2);      // the transposed minibatch rows (bf16)
+    if (a->d.prior_loc_off != BSVI_AMORT_CONSTANT || a->d.prior_scale_off != BSVI_AMORT_CONSTANT)
+        n += 2 * align4(((R + 255) / 256) * (size_t)a->d.latent_dim);                  // a learnable prior's gradient partials
     return n + 16;
 }
 
@@ -2110,6 +2192,8 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.dloc = grad(a->enc, d.enc_loc_value) + d.enc_loc_col; D.dscale = grad(a->enc, d.enc_scale_value) + d.enc_scale_col;
     D.eps = eps; D.z = val(a->dec, 0); D.ld_z = a->dec.ld[0]; D.dz = grad(a->dec, 0);
     D.prior_loc = a->prior_dev; D.prior_scale = a->prior_dev + Dz;
+    D.params = params; D.prior_loc_off = d.prior_loc_off; D.prior_scale_off = d.prior_scale_off;
+    D.likelihood = (int)d.likelihood; D.lik_scale = a->lik_scale_dev;
     D.rowf = rowf; D.rowlq = rowlq;
     D.logits = val(a->dec, d.dec_logits_value); D.ld_logits = a->dec.ld[d.dec_logits_value];
     D.out = out; D.fvalue_out = args->fvalue_out_dev; D.logq_out = args->logq_out_dev;
@@ -2118,6 +2202,16 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.sum_part = part;
     part += align4(2 * (size_t)row_grid.x);
     if (int rc = add_segment(out, D.sum_part, 1, 2, row_grid.x)) return rc;       // out[0] = sum of values, out[1] = non-finite count
+    if (d.prior_loc_off != BSVI_AMORT_CONSTANT || d.prior_scale_off != BSVI_AMORT_CONSTANT) {
+        D.prior_loc_part = part;
+        part += align4((size_t)row_grid.x * Dz);
+        D.prior_scale_part = part;
+        part += align4((size_t)row_grid.x * Dz);
+        int rc = BSVI_OK;
+        if (d.prior_loc_off != BSVI_AMORT_CONSTANT) rc = add_segment(grads + d.prior_loc_off, D.prior_loc_part, 1, (uint32_t)Dz, row_grid.x);
+        if (!rc && d.prior_scale_off != BSVI_AMORT_CONSTANT) rc = add_segment(grads + d.prior_scale_off, D.prior_scale_part, 1, (uint32_t)Dz, row_grid.x);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(amort_rows, row_grid, dim3(256), 0, stream, D);
 
     // the transposed minibatch rows for the exact-data weight gradients (launched after the encoder's forward pass, below)

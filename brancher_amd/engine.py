@@ -764,13 +764,105 @@ def _run_sampler(model, posterior_model, number_samples, input_values):
     return out
 
 
+def _amortized_engine(model):
+    """the amortised engine of a joint model whose links are encoder / decoder networks (amortized.py), or None"""
+    posterior = getattr(model, "posterior_model", None)
+    if not posterior:
+        return None
+    compiled = compile_model(model, posterior, None)
+    return compiled if type(compiled).__name__ == "CompiledAmortized" else None
+
+
+def _given(input_values, var):
+    """the caller's value for `var`: keyed by the variable or by its name"""
+    for key, value in (input_values or {}).items():
+        if key is var or key == var.name or getattr(key, "name", None) == var.name:
+            return value.detach().cpu().numpy() if torch.is_tensor(value) else np.asarray(value, dtype=np.float32)
+    return None
+
+
+def _amortized_sample(model, compiled, number_samples, input_values):
+    """`ProbabilisticModel._get_sample` of an amortised model (variables.py:732-742; the posterior-predictive step of
+    examples/VAE_playground.py:90-103): z from its prior or from the caller, the decoder's outputs through
+    bsvi_amort_apply, x from its likelihood.  Device tensors in the reference's layout: z [N, 1, Dz],
+    decoder_output {key: [N, 1, P]}, x [N, 1, P, 1]."""
+    from brancher_amd.variables import RootVariable
+    p, dev, N = compiled.program, compiled.device, int(number_samples)
+    by_name = {v.name: v for v in model.flatten()}
+    z_var, x_var = by_name[p.latent_name], by_name[p.data_name]
+    _sample_tick[0] += 1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed((1 << 40) + _sample_tick[0])
+    named = compiled.named_params()
+    given_z = _given(input_values, z_var)
+    if given_z is not None:
+        rows = given_z.reshape(-1, p.latent_dim)[:N] if given_z.size >= N * p.latent_dim else given_z.reshape(1, p.latent_dim)
+        z = torch.from_numpy(np.array(np.broadcast_to(rows, (N, p.latent_dim)), dtype=np.float32)).to(dev)
+    else:
+        loc, scale = p.prior_loc, p.prior_scale
+        for par, off, size, _ in p.parameters:               # a learnable prior: the current values
+            if off == p.prior_loc_off:
+                loc = named[par.name].reshape(-1)
+            if off == p.prior_scale_off:
+                raw = named[par.name].reshape(-1).astype(np.float64)
+                scale = np.where(raw > 20, raw, np.log1p(np.exp(np.minimum(raw, 20)))).astype(np.float32)
+        z = torch.from_numpy(np.asarray(loc, dtype=np.float32)).to(dev) + \
+            torch.from_numpy(np.asarray(scale, dtype=np.float32)).to(dev) * torch.randn((N, p.latent_dim), device=dev, generator=gen)
+    out = {z_var: z.reshape(N, 1, p.latent_dim)}
+    decoded = {key: compiled.decode(z, key) for key in p.dec_outputs}
+    for var in model.flatten():
+        if getattr(var, "_type", None) == "Deterministic node" and var.name not in (p.latent_name, p.data_name):
+            out[var] = {key: value.reshape(N, 1, -1) for key, value in decoded.items()}
+    given_x = _given(input_values, x_var)
+    if given_x is not None:
+        x = torch.from_numpy(np.array(np.broadcast_to(given_x.reshape(-1, p.n_features)[:N], (N, p.n_features)),
+                                      dtype=np.float32)).to(dev)
+    elif p.likelihood == "normal":
+        x = decoded[p.logits_key] + torch.from_numpy(p.likelihood_scale).to(dev) * \
+            torch.randn((N, p.n_features), device=dev, generator=gen)
+    else:
+        x = torch.bernoulli(torch.sigmoid(decoded[p.logits_key]), generator=gen)
+    out[x_var] = x.reshape(N, 1, p.n_features, 1)
+    for var in model.flatten():                                # tiled roots (`RootVariable._get_sample`, variables.py:367-375)
+        if isinstance(var, RootVariable) and var not in out and isinstance(var.value, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(var.value, dtype=np.float32)).to(dev)
+            out[var] = t.expand((N,) + tuple(t.shape[1:])).contiguous() if t.shape[0] == 1 else t
+    return out
+
+
+def _amortized_posterior_sample(model, compiled, number_samples):
+    """`ProbabilisticModel._get_posterior_sample` of an amortised model (variables.py:796-805, 903-907): one minibatch per
+    sample and z = loc(x) + scale(x) eps from the encoder, keyed by the JOINT model's variables of the same names; the
+    joint model then has nothing left to sample (both of its random variables are given) — x [N, B, P, 1], z [N, B, Dz]."""
+    p, N = compiled.program, int(number_samples)
+    by_name = {v.name: v for v in model.flatten()}
+    keep = compiled.out.clone()                       # (the draw runs through bsvi_amort_fwd_bwd: leave the caller's gradients alone)
+    _sample_tick[0] += 1
+    res = compiled.evaluate(N, seed=None, offset=(1 << 62) + _sample_tick[0], want_noise=True, want_indices=True)
+    idx, eps = res["indices"].long().reshape(-1), res["noise"]
+    compiled.out.copy_(keep)
+    rows = torch.from_numpy(p.dataset).to(compiled.device)[idx]
+    z = compiled.encode(rows, p.loc_key) + compiled.encode(rows, p.scale_key) * eps
+    return {by_name[p.data_name]: rows.reshape(N, p.batch_size, p.n_features, 1),
+            by_name[p.latent_name]: z.reshape(N, p.batch_size, p.latent_dim)}
+
+
 def sample_model(model, number_samples, observed=False, input_values={}):
     """`ProbabilisticModel._get_sample` (variables.py:732-742)."""
     if observed:
         from brancher_amd.variables import RandomVariable
         return {v: torch.from_numpy(v._observed_value) for v in model._flatten()
                 if isinstance(v, RandomVariable) and v.is_observed and v.has_observed_value}
-    return _run_sampler(model, None, number_samples, input_values)
+    try:
+        return _run_sampler(model, None, number_samples, input_values)
+    except lowering.LoweringError as scalar_error:
+        try:
+            compiled = _amortized_engine(model)
+        except lowering.LoweringError:
+            compiled = None
+        if compiled is None:
+            raise scalar_error
+        return _amortized_sample(model, compiled, number_samples, input_values)
 
 
 def sample_variables(variables, number_samples, observed=False, input_values={}):
@@ -782,7 +874,19 @@ def sample_variables(variables, number_samples, observed=False, input_values={})
 def posterior_sample(model, number_samples, input_values={}):
     """`ProbabilisticModel._get_posterior_sample` (variables.py:796-805): posterior draws re-keyed to the
     joint model's variables by name, then the remaining variables of the joint model (posterior predictive)."""
-    raw = _run_sampler(model, model.posterior_model, number_samples, input_values)
+    try:
+        raw = _run_sampler(model, model.posterior_model, number_samples, input_values)
+    except lowering.LoweringError as scalar_error:
+        try:
+            compiled = _amortized_engine(model)
+        except lowering.LoweringError:
+            compiled = None
+        if compiled is None:
+            raise scalar_error
+        out = _amortized_posterior_sample(model, compiled, number_samples)
+        for var, value in (input_values or {}).items():
+            out[var] = value if torch.is_tensor(value) else torch.as_tensor(np.asarray(value, dtype=np.float32))
+        return out
     mapping = lowering.get_model_mapping(model.posterior_model, model)
     out = {}
     for var, value in raw.items():

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 OUT_HEADER = 4
 
 
@@ -147,9 +147,10 @@ class AmortDesc(C.Structure):
                 ("batch_size", C.c_uint32), ("n_enc_layers", C.c_uint32), ("n_dec_layers", C.c_uint32),
                 ("enc_loc_value", C.c_uint32), ("enc_scale_value", C.c_uint32),
                 ("enc_loc_col", C.c_uint32), ("enc_scale_col", C.c_uint32),
-                ("dec_logits_value", C.c_uint32), ("reserved", C.c_uint32),
+                ("dec_logits_value", C.c_uint32), ("likelihood", C.c_uint32),
                 ("enc_layers", C.POINTER(MlpLayer)), ("dec_layers", C.POINTER(MlpLayer)),
-                ("prior_loc", C.c_void_p), ("prior_scale", C.c_void_p), ("dataset", C.c_void_p)]
+                ("prior_loc", C.c_void_p), ("prior_scale", C.c_void_p), ("dataset", C.c_void_p),
+                ("likelihood_scale", C.c_void_p), ("prior_loc_off", C.c_uint32), ("prior_scale_off", C.c_uint32)]
 
 
 class AmortArgs(C.Structure):

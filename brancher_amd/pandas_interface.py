@@ -12,6 +12,8 @@ import pandas as pd
 def _cell(sample_value):
     """what one sample of one variable looks like in a frame: a float for a scalar, the vector for a single datapoint
     with several components, otherwise the array with its datapoint axis first (`pandas_interface.py:33-43`)"""
+    if isinstance(sample_value, dict):               # a deterministic node that holds a network's dict of outputs
+        return {key: _cell(value) for key, value in sample_value.items()}
     a = np.asarray(sample_value)
     if a.size == 1:
         return float(a.reshape(-1)[0])
@@ -25,6 +27,11 @@ def reformat_sample_to_pandas(sample):
     columns = {}
     for var, value in sample.items():
         if type(var).__name__ == "RootVariable":
+            continue
+        if isinstance(value, dict):
+            parts = {key: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for key, v in value.items()}
+            n_rows = next(iter(parts.values())).shape[0]
+            columns[var.name] = [_cell({key: a[n] for key, a in parts.items()}) for n in range(n_rows)]
             continue
         arr = value.detach().cpu().numpy() if hasattr(value, "detach") else np.asarray(value)
         columns[var.name] = [_cell(arr[n]) for n in range(arr.shape[0])]

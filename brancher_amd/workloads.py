@@ -556,6 +556,8 @@ def build_vae(api, dataset_size=64, batch_size=16, n_features=784, latent_size=2
     z = api.NormalVariable(np.zeros((latent_size,)), np.ones((latent_size,)), name="z", learnable=learnable_prior)
     decoder_output = api.DeterministicVariable(decoder(z), name="decoder_output")
     if likelihood == "normal":
+        if not np.isscalar(likelihood_scale):
+            likelihood_scale = np.asarray(likelihood_scale, dtype=np.float64)
         x = api.NormalVariable(decoder_output["mean"], likelihood_scale, name="x")
     else:
         x = api.BinomialVariable(total_count=1, logits=decoder_output["mean"], name="x")

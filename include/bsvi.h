@@ -41,7 +41,7 @@ typedef long long int64_t;
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 6
+#define BSVI_ABI_VERSION 7
 
 typedef enum bsvi_status {
     BSVI_OK = 0,
@@ -489,13 +489,22 @@ typedef struct bsvi_amort_desc {
     uint32_t n_enc_layers, n_dec_layers;          /* topologically ordered */
     uint32_t enc_loc_value, enc_scale_value;      /* encoder values feeding q(z | x) = Normal(loc, scale)  */
     uint32_t enc_loc_col, enc_scale_col;          /* first column of loc / scale inside those values (merged heads) */
-    uint32_t dec_logits_value, reserved;          /* decoder value feeding Binomial(1, logits)             */
+    uint32_t dec_logits_value, likelihood;        /* decoder value feeding the likelihood; BSVI_AMORT_LIK_*  */
     const bsvi_mlp_layer* enc_layers;
     const bsvi_mlp_layer* dec_layers;
     const float* prior_loc;                       /* [latent_dim] host: p(z) = Normal(prior_loc, prior_scale) */
     const float* prior_scale;
     const float* dataset;                         /* [dataset_size][n_features] host copy */
+    /* ABI 7 */
+    const float* likelihood_scale;                /* [n_features] host, BSVI_AMORT_LIK_NORMAL: x ~ Normal(decoder value, scale) */
+    /* a learnable prior (`NormalVariable(..., learnable=True)`, standard_variables.py:57-68): offsets of its raw values in
+     * the parameter buffer — loc as stored, scale = softplus(raw) (geometric_ranges.py RightHalfLine) — or
+     * BSVI_AMORT_CONSTANT: the constants above */
+    uint32_t prior_loc_off, prior_scale_off;
 } bsvi_amort_desc;
+#define BSVI_AMORT_LIK_BINOMIAL1 0u               /* Binomial(1, logits = decoder value)  (examples/VAE_playground.py:71) */
+#define BSVI_AMORT_LIK_NORMAL 1u
+#define BSVI_AMORT_CONSTANT 0xFFFFFFFFu
 
 typedef struct bsvi_amort bsvi_amort;
 

@@ -34,6 +34,18 @@ CASES = {
     # full 784-256-512-(2,2) / 2-512-256-784 architecture is covered by the oracle-vs-HIP tests
     "vae_P784_H72_H40_DS24_B8_N2": (dict(dataset_size=24, batch_size=8, n_features=784, hidden1=72, hidden2=40),
                                     2, 23, None),
+    # the pattern one notch wider: real-valued rows under a Normal likelihood with a constant scale (one number / one per
+    # feature), and a prior whose loc and scale are learnable parameters of the joint model
+    "vae_normal_P20_H12_H8_DS30_B6_N4": (dict(dataset_size=30, batch_size=6, n_features=20, hidden1=12, hidden2=8,
+                                              likelihood="normal", likelihood_scale=0.7), 4, 24,
+                                         dict(iters=5, n=4, optimizer="Adam", lr=1e-2)),
+    "vae_learnable_prior_P16_H10_H8_DS24_B5_N5": (dict(dataset_size=24, batch_size=5, n_features=16, hidden1=10, hidden2=8,
+                                                       latent_size=3, learnable_prior=True), 5, 25,
+                                                  dict(iters=5, n=5, optimizer="Adam", lr=1e-2)),
+    "vae_normal_learnable_prior_P140_H72_H40_DS40_B12_N6": (
+        dict(dataset_size=40, batch_size=12, n_features=140, hidden1=72, hidden2=40, latent_size=4, likelihood="normal",
+             likelihood_scale=[0.4 + 0.01 * j for j in range(140)], learnable_prior=True), 6, 26,
+        dict(iters=4, n=6, optimizer="SGD", lr=1e-3)),
 }
 
 
@@ -60,6 +72,11 @@ def module_params(model):
     for tag, m in (("enc", enc), ("dec", dec)):
         for k, p in m.named_parameters():
             out["%s/%s" % (tag, k)] = p
+    # learnable roots of the joint model (a learnable prior): the tensor behind the RootVariable's ParameterModule
+    for v in sorted(model.flatten(), key=lambda v: v.name):
+        if type(v).__name__ == "RootVariable" and getattr(v, "learnable", False):
+            (p,) = list(v.link.parameters())
+            out["prior/" + v.name] = p
     return out
 
 
@@ -96,7 +113,8 @@ def run_case(name, api):
     q._input_variables = sorted(q._input_variables, key=lambda v: v.name)     # (as in gen_golden.py: a reproducible walk)
     params = module_params(model)
     out = {"param/" + k: p.detach().numpy().copy() for k, p in params.items()}
-    dataset = W.vae_data(kwargs["dataset_size"], kwargs["n_features"], kwargs.get("seed", 0))
+    dataset = W.vae_data(kwargs["dataset_size"], kwargs["n_features"], kwargs.get("seed", 0),
+                         real=kwargs.get("likelihood") == "normal")
 
     capture = {}
     orig = q._get_sample

@@ -13,6 +13,7 @@ checks the torch.fx lowering of brancher_amd/amortized.py independently:
   z         = loc + sd * eps                           Normal rsample                      distributions.py:111-124
   logits    = decoder(z)
   lp        = sum_j Binomial(1, logits).log_prob(x) + sum_d Normal(prior).log_prob(z)      variables.py:486-520
+              (variants: sum_j Normal(decoder(z), constant scale).log_prob(x); a learnable prior Normal(loc, softplus(raw)))
   H         = sum_d Normal(loc, sd).entropy() + log(N)   (entropy of the minibatch variable, distributions.py:464-473:
               Categorical(ones(dataset.shape[0])) where the dataset has been tiled to N samples)   variables.py:156-162
   lq        = sum_d Normal(loc, sd).log_prob(z)
@@ -42,13 +43,35 @@ class VaeOracle:
         self.prior_loc = torch.from_numpy(prog.prior_loc).to(dtype)
         self.prior_scale = torch.from_numpy(prog.prior_scale).to(dtype)
         self.B, self.Dz = prog.batch_size, prog.latent_dim
+        # the widened pattern: Normal likelihood with a constant scale; a learnable prior (raw values: loc as stored, scale
+        # behind softplus — standard_variables.py:57-68, geometric_ranges.py RightHalfLine)
+        self.likelihood = prog.likelihood
+        self.lik_scale = None if prog.likelihood_scale is None else torch.from_numpy(prog.likelihood_scale).to(dtype)
+        self.prior_raw = {}
+        for par, off, size, group in prog.parameters:
+            if off in (prog.prior_loc_off, prog.prior_scale_off):
+                self.prior_raw[par.name] = torch.nn.Parameter(torch.from_numpy(np.asarray(par.numpy(), dtype=np.float64)).to(dtype))
+                if off == prog.prior_loc_off:
+                    self._loc_name = par.name
+                else:
+                    self._scale_name = par.name
+        self.prior_loc_learnable = prog.prior_loc_off != 0xFFFFFFFF
+        self.prior_scale_learnable = prog.prior_scale_off != 0xFFFFFFFF
 
     def named_parameters(self):
         out = {}
         for tag, m in (("enc", self.enc), ("dec", self.dec)):
             for k, p in m.named_parameters():
                 out["%s/%s" % (tag, k)] = p
+        for k, p in self.prior_raw.items():
+            out["prior/" + k] = p
         return out
+
+    def prior(self):
+        loc = self.prior_raw[self._loc_name].reshape(-1) if self.prior_loc_learnable else self.prior_loc
+        scale = torch.nn.functional.softplus(self.prior_raw[self._scale_name].reshape(-1)) if self.prior_scale_learnable \
+            else self.prior_scale
+        return loc, scale
 
     def terms(self, rows, eps):
         rows = torch.as_tensor(np.asarray(rows, dtype=np.int64))
@@ -58,8 +81,12 @@ class VaeOracle:
         loc, sd = out["mean"], out["sd"]
         z = loc + sd * eps
         logits = self.dec(z)["mean"]
-        lp = td.Binomial(total_count=1, logits=logits).log_prob(x).sum(-1) \
-            + td.Normal(self.prior_loc, self.prior_scale).log_prob(z).sum(-1)
+        ploc, pscale = self.prior()
+        if self.likelihood == "normal":
+            lik = td.Normal(logits, self.lik_scale).log_prob(x).sum(-1)
+        else:
+            lik = td.Binomial(total_count=1, logits=logits).log_prob(x).sum(-1)
+        lp = lik + td.Normal(ploc, pscale).log_prob(z).sum(-1)
         q = td.Normal(loc, sd)
         # the minibatch variable is part of the posterior and has an "analytic entropy": Categorical(ones(n)).entropy()
         # with n = dataset.shape[0], which for the sample-tiled dataset is the NUMBER OF SAMPLES, not the dataset
@@ -84,7 +111,8 @@ class VaeOracle:
 
     def train(self, iters, rows_seq, eps_seq, optimizer="Adam", **opt_kwargs):
         cls = getattr(torch.optim, optimizer)
-        opts = [cls(self.enc.parameters(), **opt_kwargs), cls(self.dec.parameters(), **opt_kwargs)]
+        opts = [cls(self.enc.parameters(), **opt_kwargs),
+                cls(list(self.dec.parameters()) + list(self.prior_raw.values()), **opt_kwargs)]
         losses = []
         for it in range(iters):
             loss, _ = self.loss(rows_seq[it], eps_seq[it], "pathwise")

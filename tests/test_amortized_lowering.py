@@ -122,7 +122,7 @@ def test_graphs_outside_the_pattern_are_rejected():
     data = W.vae_data(20, 12)
     z = api.NormalVariable(np.zeros((2,)), np.ones((2,)), name="z")
     out = api.DeterministicVariable(BF.BrancherFunction(dec)(z), name="decoder_output")
-    x = api.NormalVariable(out["mean"], 1.0, name="x")                 # a Normal likelihood through the decoder
+    x = api.NormalVariable(out["mean"], 1.0, name="x", learnable=True)       # a Normal likelihood with a LEARNABLE scale
     model = api.ProbabilisticModel([x, z])
     Qx = api.EmpiricalVariable(data, batch_size=5, name="x", is_observed=True)
     eo = api.DeterministicVariable(BF.BrancherFunction(enc)(Qx), name="encoder_output")
@@ -134,6 +134,30 @@ def test_graphs_outside_the_pattern_are_rejected():
         amortized.lower_amortized(W.build_vae(api, dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6),
                                   None if False else W.build_vae(api, dataset_size=20, batch_size=5, n_features=12,
                                                                   hidden1=8, hidden2=6).posterior_model, "taylor1")
+
+
+def test_widened_pattern_normal_likelihood_and_learnable_prior():
+    """Normal(decoder(z), constant scale) likelihood; NormalVariable(..., learnable=True) prior: its two roots join the
+    decoder's optimizer group behind the networks' tensors (inference.py:77-88)"""
+    api = W.native_api()
+    kw = dict(dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6)
+    p = amortized.lower_amortized(*(lambda m: (m, m.posterior_model))(W.build_vae(api, likelihood="normal", likelihood_scale=0.7, **kw)))
+    assert p.likelihood == "normal" and p.likelihood_scale.shape == (12,) and np.allclose(p.likelihood_scale, 0.7, rtol=1e-6)
+    assert p.prior_loc_off == p.prior_scale_off == amortized.NO_BIAS
+    assert p.dataset.dtype == np.float32 and len(np.unique(p.dataset)) > 2
+    per_feature = [0.4 + 0.01 * j for j in range(12)]
+    m = W.build_vae(api, likelihood="normal", likelihood_scale=per_feature, learnable_prior=True, latent_size=3, **kw)
+    p = amortized.lower_amortized(m, m.posterior_model, "blackbox")
+    assert np.allclose(p.likelihood_scale, per_feature, rtol=1e-6)
+    names = {par.name: (off, size, group) for par, off, size, group in p.parameters}
+    assert names["z_loc"] == (p.prior_loc_off, 3, 1) and names["z_scale"] == (p.prior_scale_off, 3, 1)
+    assert p.prior_scale_off == p.prior_loc_off + 3 and p.n_params == p.prior_scale_off + 3
+    assert np.all(p.param_active[p.prior_loc_off:] == 1) and np.all(p.param_group[p.prior_loc_off:] == 1)
+    raw = [par for par, *_ in p.parameters if par.name == "z_scale"][0].numpy().reshape(-1)
+    assert np.allclose(np.log1p(np.exp(raw)), 1.0, atol=1e-6)             # stored behind the softplus of its range
+    with pytest.raises(LoweringError):                                    # a scale that is neither one number nor one per feature
+        bad = W.build_vae(api, likelihood="normal", likelihood_scale=[0.5, 0.6, 0.7], **kw)
+        amortized.lower_amortized(bad, bad.posterior_model)
 
 
 def test_c_abi_structs_match_the_header():

@@ -16,9 +16,14 @@ def _module_view(compiled, named):
     """{"enc/l1.weight": array} from the engine's flat buffers"""
     enc_link, dec_link = compiled.program.links
     out = {}
+    seen = set()
     for tag, link in (("enc", enc_link), ("dec", dec_link)):
         for pname, par in link.named.items():
             out["%s/%s" % (tag, pname)] = named[par.name]
+            seen.add(par.name)
+    for par, off, size, group in compiled.program.parameters:      # a learnable prior's roots
+        if par.name not in seen:
+            out["prior/" + par.name] = named[par.name]
     return out
 
 
@@ -198,7 +203,7 @@ def test_inexact_data_stays_on_the_f32_kernel():
     assert exact.data_path() == "bf16x3"
     original = Wm.vae_data
     try:
-        Wm.vae_data = lambda ds, nf, seed=0: original(ds, nf, seed).astype("float32") * 0.3       # 0.3 is not a bf16 number
+        Wm.vae_data = lambda ds, nf, seed=0, real=False: original(ds, nf, seed).astype("float32") * 0.3       # 0.3 is not a bf16 number
         inexact = engine.compile_model(W.build_vae(api, **kw), None, "pathwise")
     finally:
         Wm.vae_data = original
@@ -293,6 +298,57 @@ def test_vae_device_rng_properties():
     assert not np.array_equal(r3["indices"].cpu().numpy(), idx)
     ref = VaeOracle(model, dtype=torch.float64).loss_and_grads(idx, eps.reshape(N, B, 2), "pathwise")
     assert abs(loss1 - ref["loss"]) <= TOL * abs(ref["loss"])
+
+
+def test_vae_frame_level_samplers_match_the_reference_structure():
+    """`model.get_sample` (the posterior-predictive step of examples/VAE_playground.py:90-103) and
+    `model.get_posterior_sample` (variables.py:796-812) of an amortised model, against what the real reference returns
+    (tests/golden/frames/vae_frames.npz, oracle/gen_golden_vae_frames.py): columns, cell shapes, and for a given latent
+    value the decoder output itself."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from brancher_amd import workloads as W
+    fx = np.load(os.path.join(GOLDEN, "frames", "vae_frames.npz"))
+    meta = json.loads(str(fx["meta"]))
+    model = W.build_vae(W.native_api(), **meta["kwargs"])
+    roots = {"x_total_count", "z_scale", "z_loc"}                 # (frames here carry no root columns)
+    # ancestral sample of the joint model
+    frame = model.get_sample(2)
+    assert set(frame.columns) == set(meta["get_sample_columns"]) - roots and len(frame) == 2
+    raw = meta["get_sample_raw"]
+    assert frame["z"].values[0].shape == tuple(raw["z"][2:])
+    assert frame["x"].values[1].shape == tuple(raw["x"][2:]) and set(np.unique(frame["x"].values[1])) <= {0.0, 1.0}
+    assert frame["decoder_output"].values[0]["mean"].shape == tuple(raw["decoder_output"]["mean"][2:])
+    # a given latent value: the decoder output is the reference's
+    z = model.get_variable("z")
+    given = model.get_sample(1, input_values={z: fx["z_value"]})
+    assert set(given.columns) == set(meta["get_sample_given_columns"]) - roots
+    assert np.array_equal(np.asarray(given["z"].values[0], dtype=np.float32), fx["z_given_cell"])
+    got = np.asarray(given["decoder_output"].values[0]["mean"])
+    assert np.abs(got - fx["decoder_mean_given_z"]).max() <= 1e-5 * (1 + np.abs(fx["decoder_mean_given_z"]).max())
+    assert np.asarray(given["x"].values[0]).shape == fx["x_given_cell"].shape
+    # posterior sample: a minibatch per sample and z from the encoder, keyed like the joint model's variables
+    N = 200
+    post = model._get_posterior_sample(N)
+    by_name = {v.name: t for v, t in post.items()}
+    assert set(by_name) == set(meta["get_posterior_sample_raw"])
+    B, P, Dz = meta["kwargs"]["batch_size"], meta["kwargs"]["n_features"], 2
+    x, zs = by_name["x"].cpu().numpy(), by_name["z"].cpu().numpy()
+    assert x.shape == (N, B, P, 1) and zs.shape == (N, B, Dz)
+    assert all(v.name in ("x", "z") and v in model.flatten() for v in post)
+    data = W.vae_data(meta["kwargs"]["dataset_size"], P)[..., 0].astype(np.float32)
+    for n in range(0, N, 37):
+        which = [int(np.flatnonzero((data == x[n, b, :, 0]).all(1))[0]) for b in range(B)]
+        assert len(set(which)) == B                                # distinct rows, like np.random.choice(replace=False)
+    enc = model.vae_modules[0]
+    with torch.no_grad():
+        out = enc(torch.from_numpy(x.reshape(N * B, P, 1)))
+    resid = (zs.reshape(N * B, Dz) - out["mean"].numpy()) / out["sd"].numpy()
+    assert abs(resid.mean()) < 0.1 and 0.9 < resid.std() < 1.1
+    pframe = model.get_posterior_sample(3)
+    assert list(pframe.columns) == meta["get_posterior_sample_columns"] and len(pframe) == 3
+    assert pframe["x"].values[0].shape == (B, P, 1) and pframe["z"].values[2].shape == (B, Dz)
 
 
 def test_vae_perform_inference_api():
