@@ -931,14 +931,75 @@ def importance_log_weights(joint_model, posterior_model, q_samples):
     return res["f"], res["lq"]
 
 
-def log_probability(variables, values, include_parents=True, model=None):
+def _variable_log_probability(variables, values, include_parents, reevaluate=True):
+    """`Variable.calculate_log_probability(values, reevaluate=…, include_parents=…)` (variables.py:486-520): the variable's own
+    log-probability at the caller's values plus that of its ancestors.  Served by the evaluation program of
+    `importance_log_weights` on the variable's own graph: the model is ProbabilisticModel([var]) (the variable and its
+    ancestors), its "posterior" the unobserved random variables among them, which take the caller's values
+    (BSVI_F_GIVEN); observed variables use their data.  An own term is the difference between a graph with and without
+    its variable.  As in the reference, with `reevaluate=True` (the default of the variable-level call) the recursion over
+    `parents` does NOT stop at a visited node: an ancestor reached along k paths is counted k times; `reevaluate=False`
+    counts every ancestor once (what the model-level call does).  Device tensor [N, 1]."""
+    from brancher_amd.variables import ProbabilisticModel, RandomVariable
+
+    def is_random(v):
+        return isinstance(v, RandomVariable) and getattr(v, "_type", None) != "Deterministic node"
+
+    def graph_log_p(members):
+        graph = ProbabilisticModel(list(members))
+        latents = [v for v in graph.flatten() if is_random(v) and not v.is_observed]
+        given = {}
+        for v in latents:
+            value = _given(values, v)
+            if value is None:
+                raise ValueError("calculate_log_probability needs a value for {!r}".format(v.name))
+            given[v] = value
+        log_p, _ = importance_log_weights(graph, ProbabilisticModel(latents), given)
+        return log_p.reshape(-1, 1)
+
+    def random_parents(v):          # the random variables directly above v (looking through deterministic nodes and roots)
+        found, stack = [], list(v.parents)
+        while stack:
+            p = stack.pop()
+            if is_random(p):
+                if p not in found:
+                    found.append(p)
+            else:
+                stack.extend(p.parents)
+        return found
+
+    def own(v):
+        above = random_parents(v)
+        return graph_log_p([v]) - graph_log_p(above) if above else graph_log_p([v])
+
+    (var,) = variables
+    if not include_parents:
+        return own(var)
+    total = graph_log_p([var])
+    if not reevaluate:
+        return total
+    paths = {}                      # ancestor -> number of paths from var (the reference's recursion visits it that often)
+
+    def walk(v, weight):
+        for p in v.parents:
+            if is_random(p):
+                paths[p] = paths.get(p, 0) + weight
+            walk(p, weight)
+
+    walk(var, 1)
+    for ancestor, count in sorted(paths.items(), key=lambda kv: kv[0].name):
+        if count > 1:
+            total = total + (count - 1) * own(ancestor)
+    return total
+
+
+def log_probability(variables, values, include_parents=True, model=None, reevaluate=True):
     """`ProbabilisticModel.calculate_log_probability(rv_values)` (variables.py:718-727): the sum of the node
     log-probabilities of a model at caller-supplied values of its latent variables (observed variables use their
     observed values), one number per sample — a device tensor [N, 1].  Served by the evaluation program of
     `importance_log_weights`: for a joint model it is the `log p` output, for its posterior model the `log q` output."""
     if model is None:
-        raise NotImplementedError("calculate_log_probability of a single variable is not served by the fused kernel; "
-                                  "call it on the ProbabilisticModel")
+        return _variable_log_probability(list(variables), values, include_parents, reevaluate)
     joint = getattr(model, "joint_model", None)
     if joint is not None:                                   # a PosteriorModel: log q(values)
         _, log_q = importance_log_weights(joint, model, values)

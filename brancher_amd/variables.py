@@ -268,7 +268,7 @@ class RandomVariable(Variable):
     def calculate_log_probability(self, input_values, reevaluate=True, for_gradient=False,
                                   include_parents=True, normalized=True):
         from brancher_amd import engine
-        return engine.log_probability([self], input_values, include_parents=include_parents)
+        return engine.log_probability([self], input_values, include_parents=include_parents, reevaluate=reevaluate)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

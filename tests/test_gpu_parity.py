@@ -536,6 +536,29 @@ def test_importance_weights_match_reference_log_densities(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lognormal_normal", "vector_latent"])
+def test_single_variable_log_probability_matches_the_reference(case):
+    """`Variable.calculate_log_probability(values, include_parents=…)` (variables.py:486-520) against the reference's own
+    numbers (tests/golden/frames/variable_log_probability.npz, oracle/gen_golden_logprob.py): an observed variable, latents
+    with and without random parents, vector-valued nodes; the own term and the visit-once sum over the ancestors."""
+    import json
+    import os
+    from conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "frames", "variable_log_probability.npz"))
+    meta = json.loads(str(fx["meta"]))["cases"][case]
+    model = getattr(W, meta["builder"])(W.native_api(), **meta["kwargs"])
+    prefix = case + "/value/"
+    values = {model.get_variable(k[len(prefix):]): fx[k] for k in fx.files if k.startswith(prefix)}
+    for name in meta["variables"]:
+        var = model.get_variable(name)
+        for flag, tag in ((True, "with_parents"), (False, "own")):
+            ref = fx["%s/logp/%s/%s" % (case, name, tag)]
+            got = var.calculate_log_probability(values, include_parents=flag).cpu().numpy()
+            assert got.shape == ref.shape, (name, tag)
+            assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (name, tag)
+
+
+@pytest.mark.gpu
 def test_map_inference_through_the_public_api_matches_the_reference_trajectory():
     """`perform_inference(..., inference_method=MAP())` (inference.py:251-275): no sampling, so the loss curve and the
     parameters after 6 SGD steps are deterministic — compared with the reference's own run."""
