@@ -82,7 +82,36 @@ __device__ __noinline__ double digamma_d(double x) {
     }
     return result + log(x) - 0.5 / x - y + add;
 }
-BSVI_DEV float digammaf_(float x) { return (float)digamma_d((double)x); }
+// torch.digamma on a float tensor runs calc_digamma(float) — float arithmetic throughout (ATen/native/Math.h, the overload
+// below the double one; only the reflection term for negative arguments goes through double).  This is what the
+// reference's Beta / Gamma entropies and log-prob gradients see, and it costs a fifth of the double path on the GPU
+// (the loop of reciprocals and the logarithm); `digamma_d` stays for dirichlet_grad_one, whose CPU instantiation
+// accumulates in double.
+__device__ __noinline__ float digammaf_(float x) {
+    if (x == 0.0f) return copysignf(INFINITY, -x);
+    float add = 0.0f;
+    if (x < 0.0f) {
+        if (x == truncf(x)) return NAN;
+        float q;
+        const float r = modff(x, &q);
+        add = -(float)(M_PI / tan(M_PI * (double)r));
+        x = 1.0f - x;
+    }
+    float result = 0.0f;
+    while (x < 10.0f) { result -= 1.0f / x; x += 1.0f; }
+    if (x == 10.0f) return result + 2.25175258906672110764f + add;
+    const float A[7] = {8.33333333333333333333E-2f, -2.10927960927960927961E-2f, 7.57575757575757575758E-3f,
+                        -4.16666666666666666667E-3f, 3.96825396825396825397E-3f, -8.33333333333333333333E-3f,
+                        8.33333333333333333333E-2f};
+    float y = 0.0f;
+    if (x < 1.0e17f) {
+        const float z = 1.0f / (x * x);
+        float p = A[0];
+        for (int i = 1; i < 7; ++i) p = p * z + A[i];
+        y = z * p;
+    }
+    return result + logf(x) - 0.5f / x - y + add;
+}
 
 __device__ __noinline__ float trigammaf_(float xf) {
     double x = xf, sign = 1.0, result = 0.0;
