@@ -226,6 +226,7 @@ class _Lowering:
         self.max_temps = 0
         self.view_rank, self.view_memo, self.elem_memo, self.view_terms = {}, {}, {}, 0
         self.slot_rank = {}
+        self.mean_entropy = {}      # Taylor1: q variable -> its parameters rebuilt on the parents' means (entropy-only record)
         self.externals, self.pseudo_q, self.external_mode = [], [], "inject"
 
     # ---------------------------------------------------------------- IR construction
@@ -1300,11 +1301,13 @@ class _Lowering:
                 elif kind in (D.DIST_LOGNORMAL, D.DIST_LAPLACE, D.DIST_BETA):
                     ok = not any(p.has_z for p in params)
                 else:
-                    ok = False
+                    raise LoweringError("Taylor1 estimator: %r has no analytic entropy (the reference falls back to -log q "
+                                        "at the mean, which torch rejects for discrete values)" % v.name)
                 if not ok:
-                    raise LoweringError("Taylor1 estimator: the entropy of %r must not depend on other latent variables "
-                                        "(Normal: its scale; LogNormal / Laplace / Beta: every parameter) and be analytic"
-                                        % v.name)
+                    # the entropy of this node depends on other latents: its term is evaluated on THEIR means
+                    # (`variables.py:851-855` with samples := means, `gradient_estimators.py:47-56`) — an entropy-only
+                    # record behind the sampling record, with the node's parameters rebuilt on mean_value
+                    self.mean_entropy[v] = self.node_params(v, self.mean_value)
             shape = broadcast_shapes3(*[p.shape for p in params])
             if any(self.has_view(p) for p in params):
                 if shape != (1, 1, 1):
@@ -1363,6 +1366,8 @@ class _Lowering:
         # -- shared sample-dependent sub-expressions become derived slots (computed once per sample)
         for v, params, shape in q_nodes:
             self.count_uses(params)
+            if v in self.mean_entropy:
+                self.count_uses(self.mean_entropy[v])
         for v, value, params, shape in p_nodes:
             self.count_uses([value] + params)
         self.derived_nodes = {k for k, c in self.use_count.items() if c >= 2}
@@ -1389,6 +1394,16 @@ class _Lowering:
             if self.estimator == "importance":
                 flags |= F_WF | F_GIVEN        # value supplied, log q accumulated, no entropy term
                 w_ent = 0.0
+            elif v in self.mean_entropy:
+                # Taylor1, entropy on the parents' means: the sampling record carries no term, the record behind it
+                # reads the same distribution's parameters evaluated on the means and adds w * H
+                mean_params = self.mean_entropy[v]
+                self.ensure_derived(mean_params)
+                self.for_each_record(shape, params, False,
+                                     lambda: self.emit_node(dist.kind, F_SAMPLE, params, slot=slot, w_lp=0.0, w_ent=0.0))
+                self.for_each_record(shape, mean_params, False,
+                                     lambda: self.emit_node(dist.kind, F_ENT, mean_params, value=self.z_node(v), w_lp=0.0, w_ent=w))
+                continue
             elif dist.has_analytic_entropy:
                 flags |= F_ENT
             else:

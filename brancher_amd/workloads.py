@@ -295,6 +295,28 @@ def build_vector_latent(api, n_obs=9, dim=4, seed=0):
     return model
 
 
+def build_scale_from_latent(api, n_obs=6, seed=0):
+    """A posterior whose SCALES are sampled: u ~ Normal(0.3 z, 0.7 s) and w ~ LogNormal(0.2 u, 0.4 s) with s a LogNormal
+    latent of q.  Under the Taylor1 estimator (`gradient_estimators.py:47-56`) the entropies of u and w are evaluated on
+    the MEANS of s and u, not on their draws."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    data = rng.normal(0.5, 1.0, size=(n_obs, 1)).astype(np.float32)
+    s = api.LogNormalVariable(0., 0.3, "s")
+    z = api.NormalVariable(0., 1.5, "z")
+    u = api.NormalVariable(BF.tanh(z) * 0.5, s, "u")
+    w = api.LogNormalVariable(0.1 * u, 0.5, "w")
+    x = api.NormalVariable(z * 2. + u, 0.8 * w, "x")
+    model = api.ProbabilisticModel([x])
+    x.observe(data)
+    Qs = api.LogNormalVariable(0.1, 0.2, "s", learnable=True)
+    Qz = api.NormalVariable(0., 1., "z", learnable=True)
+    Qu = api.NormalVariable(Qz * 0.3, Qs * 0.7, "u")
+    Qw = api.LogNormalVariable(Qu * 0.2, Qs * 0.4, "w")
+    model.set_posterior_model(api.ProbabilisticModel([Qs, Qz, Qu, Qw]))
+    return model
+
+
 def build_linear_predictor(api, n_obs=5, dim=4, seed=0):
     """Axis reductions and static indexing inside links (`functions.py:50-62` wraps torch.sum / torch.transpose;
     `variables.py:279-289,1037-1053` the `[...]` of variables and links).  Inside a link a value is laid out

@@ -36,6 +36,8 @@ CASES = {
     "readme_ar_T20_N300": ("build_readme_ar", dict(T=20), 300, 0, dict(iters=6, n=64, optimizer="SGD", lr=1e-3)),
     "readme_ar_T5_N7": ("build_readme_ar", dict(T=5), 7, 1, dict(iters=5, n=7, optimizer="Adam", lr=5e-2)),
     "readme_ar_T200_N32": ("build_readme_ar", dict(T=200), 32, 2, None),
+    # scales of q that are sampled latents: Taylor1 evaluates those entropies on the parents' means
+    "scale_from_latent_N60": ("build_scale_from_latent", dict(n_obs=6), 60, 31, dict(iters=4, n=30, optimizer="Adam", lr=1e-2)),
     "beta_ar_T20_N100": ("build_beta_ar", dict(T=20), 100, 3, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
     "beta_binomial_N512": ("build_beta_binomial", dict(n_obs=30), 512, 4, dict(iters=6, n=128, optimizer="SGD", lr=0.1)),
     "lognormal_normal_N100": ("build_lognormal_normal", dict(n_obs=20), 100, 5,
@@ -79,7 +81,7 @@ CASES = {
 
 
 # workloads whose posterior is made of Normal variables: the Taylor1 estimator is recorded for them too
-TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_learnable_model", "build_vector_latent",
+TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_learnable_model", "build_vector_latent", "build_scale_from_latent",
                     "build_beta_binomial", "build_observed_ar", "build_lognormal_normal")
 
 

@@ -276,3 +276,20 @@ def test_matrix_kernels_keep_nothing_in_scratch_memory(tmp_path):
                                                            "outer_kernel", "skinny_k4", "reduce_partials", "amort_lik"))]
     assert len(watched) >= 12, sorted(seen)
     assert {k: seen[k] for k in watched if seen[k] != 0} == {}
+
+
+def test_taylor1_entropy_on_the_means_of_sampled_parents():
+    """a posterior scale that is itself a sampled latent: under Taylor1 (gradient_estimators.py:47-56) the entropy of the
+    node is evaluated on the parents' MEANS — the sampling record carries no entropy term and an entropy-only record with
+    the parameters rebuilt on the means follows it; the Pathwise program of the same model keeps one record per node"""
+    api = W.native_api()
+    F_SAMPLE, F_ENT = lowering.F_SAMPLE, lowering.F_ENT
+    counts = {}
+    for est in ("pathwise", "taylor1"):
+        p = lowering.lower(W.build_scale_from_latent(api), None, est)
+        flags = [(int(w[0]) >> 8) & 0xFF for w in p.code if (int(w[0]) & 0xFF) in (lowering.OP["NAFF"], lowering.OP["NODE"])]
+        counts[est] = (sum(1 for f in flags if f & F_SAMPLE), sum(1 for f in flags if f == F_ENT),
+                       sum(1 for f in flags if (f & F_SAMPLE) and (f & F_ENT)))
+    assert counts["pathwise"] == (4, 0, 4)          # s, z, u, w: sample + entropy in one record
+    assert counts["taylor1"] == (4, 2, 2)           # u and w: entropy-only records on the means of s (and u)
+
