@@ -51,6 +51,10 @@ struct KParams {
     float* samples_out;
     float* noise_out;
     float* fvalue_out;
+    // caller-supplied per-sample weights of the gradient (bsvi_elbo_args::f_weight_dev / q_weight_dev): sum_n a_n grad f_n +
+    // b_n grad log q_n instead of the estimator's own a_n = 1, b_n = stopgrad(f_n); NULL otherwise
+    const float* f_weight;
+    const float* q_weight;
     float* partials;   // [grid][2 + n_uniform_grad]
     float* zglobal;    // ZG variant: [2 * n_slots][n_pad]
     unsigned long long* stamps;   // diagnostic build only: phase time stamps of block 0 (or NULL)
@@ -106,7 +110,7 @@ struct Lay {   // wave-uniform layout
 
 // per-lane state — lives in registers: never take its address across a call
 struct Lane {
-    float f, lq, fweight, mask;
+    float f, lq, fweight, mask;      // fweight: the score term's weight of a log q adjoint ALREADY times the lane's mask
     uint32_t n, nc, tid, wave, lane;
     uint32_t zrow;              // byte address of this sample's slot row in LDS
     uint32_t nidx;              // global sample index (Philox counter)
@@ -409,7 +413,7 @@ __device__ __forceinline__ void fast_backward(const KParams& K, Lane& T, const A
     const float rS = __builtin_amdgcn_rcpf(S);
     float gloc = 0.0f, gS = 0.0f, gv = 0.0f;
     if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
-        const float gw = (w_lp + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
+        const float gw = w_lp * T.mask + ((flags & BSVI_F_WF) ? T.fweight : 0.0f);
         const float d = v - loc, t = d * (rS * rS);
         gv = -gw * t;
         gloc = gw * t;
@@ -528,7 +532,7 @@ __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, La
         const float rS = __builtin_amdgcn_rcpf(S);
         float gloc = 0.0f, gS = 0.0f, gv = 0.0f;
         if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
-            const float gw = (__uint_as_float(I.imm0) + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
+            const float gw = __uint_as_float(I.imm0) * T.mask + ((flags & BSVI_F_WF) ? T.fweight : 0.0f);
             const float d = v - loc, t = d * (rS * rS);
             gv = -gw * t;
             gloc = gw * t;
@@ -600,7 +604,7 @@ __device__ __forceinline__ void exec_backward(const KParams& K, const Lay& L, La
         const float v = ld_opnd<SM>(K, T, I.dst, e);
         float gv = 0.0f, g0 = 0.0f, g1 = 0.0f;
         if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
-            const float gw = (__uint_as_float(I.imm0) + ((flags & BSVI_F_WF) ? T.fweight : 0.0f)) * T.mask;
+            const float gw = __uint_as_float(I.imm0) * T.mask + ((flags & BSVI_F_WF) ? T.fweight : 0.0f);
             const float4 r = logp_bwd_generic(dist, v, p0, p1, gw);
             gv += r.x; g0 += r.y; g1 += r.z;
         }
@@ -689,7 +693,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     T.n = block_first_sample + T.wave * L.lpw + T.lane;
     const bool active = T.lane < L.lpw && T.n < K.n_local;
     T.nc = active ? T.n : (K.n_local - 1);
-    T.mask = active ? 1.0f : 0.0f;
+    T.mask = active ? (K.f_weight ? K.f_weight[T.nc] : 1.0f) : 0.0f;
     T.f = 0.0f;
     T.lq = 0.0f;
     T.fweight = 0.0f;
@@ -809,7 +813,7 @@ __device__ __forceinline__ void elbo_block(const KParams& K, const Lay& L, uint3
     }
     BSVI_STAMP(2)
     const float value = (K.estimator == BSVI_EST_BLACKBOX) ? (T.lq * T.f + T.f) : T.f;
-    T.fweight = T.f;
+    T.fweight = K.q_weight ? (active ? K.q_weight[T.nc] : 0.0f) : T.f * T.mask;
     if (OUT && K.fvalue_out && active) {
         K.fvalue_out[T.n] = T.f;
         K.fvalue_out[(size_t)K.n_local + T.n] = T.lq;
@@ -1787,6 +1791,7 @@ static int try_spec(const bsvi_program* p, const bsvi_elbo_args* a, int mode, co
                     float* state, const uint8_t* mask, const uint8_t* mask_first, uint32_t pretraining, uint32_t n_iterations,
                     float* loss_slot, float* finite_slot) {
     if (!p->spec || g_debug_stamps || !bsvi_spec::applies(p->spec, a->n_samples_local, mode)) return 0;
+    if (a->f_weight_dev || a->q_weight_dev) return 0;       // caller-weighted gradients: the interpreter kernels
     bsvi_spec::Launch L;
     L.a = a; L.mode = mode; L.cfg = cfg; L.params = params; L.state = state; L.mask = mask; L.mask_first = mask_first;
     L.pretraining_iterations = pretraining; L.n_iterations = n_iterations; L.loss_slot = loss_slot; L.finite_slot = finite_slot;
@@ -1809,6 +1814,7 @@ static int fill_kparams(const bsvi_program* p, const bsvi_elbo_args* a, const Ge
     K.code = p->code; K.aux = p->aux; K.uniform = p->uniform; K.consts = p->consts;
     K.params = a->params_dev; K.obs = a->obs_dev; K.noise = a->noise_dev;
     K.samples_out = a->samples_out_dev; K.noise_out = a->noise_out_dev; K.fvalue_out = a->fvalue_out_dev;
+    K.f_weight = a->f_weight_dev; K.q_weight = a->q_weight_dev;
     K.partials = (float*)a->workspace_dev;
     K.zglobal = (float*)((char*)a->workspace_dev + partial_bytes(p, g));
     K.stamps = g_debug_stamps;
@@ -1904,6 +1910,8 @@ static Geometry share_geometry(const bsvi_program* p, Geometry g, uint32_t n_loc
 extern "C" int bsvi_elbo_fwd_bwd(const bsvi_program* p, const bsvi_elbo_args* a) {
     if (!p || !a) return fail(BSVI_ERR_INVALID, "null argument");
     if (!a->out_dev) return fail(BSVI_ERR_INVALID, "out_dev is null");
+    if (a->q_weight_dev && p->d.estimator != BSVI_EST_BLACKBOX)
+        return fail(BSVI_ERR_INVALID, "q_weight_dev needs a program lowered for the BlackBox estimator (its records accumulate log q)");
     {
         const int sp = try_spec(p, a, bsvi_spec::MODE_SUMS, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr);
         if (sp) return sp < 0 ? sp : BSVI_OK;

@@ -419,6 +419,27 @@ class CompiledELBO:
             res["f"], res["lq"] = fvals[0], fvals[1]
         return res
 
+    def evaluate_weighted(self, number_samples, f_weight, q_weight, seed, offset, noise=None):
+        """The second pass of a user-defined gradient estimator (`custom_estimator_loss`): with the draw of (seed, offset)
+        again, leave  -(sum_n a_n grad f_n + b_n grad log q_n)  in the output block — the gradient of loss = -g(f, log q) for
+        a_n = dg/df_n, b_n = dg/dlog q_n (bsvi_elbo_args::f_weight_dev / q_weight_dev; the program must be a BlackBox one)."""
+        rank, world = dist_info()
+        base, n_local = shard(number_samples, rank, world)
+        if self._externals:
+            raise NotImplementedError("user-defined gradient estimators on models with batched multivariate-normal terms")
+        a = f_weight.reshape(-1)[base:base + n_local].contiguous().float()
+        b = q_weight.reshape(-1)[base:base + n_local].contiguous().float()
+        noise_t = self._noise_tensor(noise, number_samples, base, n_local)
+        args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, number_samples, base, None, self._seed(seed), int(offset)))
+        args.stream = self._stream()
+        args.noise_dev = noise_t.data_ptr() if noise_t is not None else None
+        args.f_weight_dev, args.q_weight_dev = a.data_ptr(), b.data_ptr()
+        native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
+        allreduce_sums(self.out)
+        native.check(self.lib.bsvi_finalize(self.native.handle, C.c_void_p(self.out.data_ptr()), 1, self._stream()))
+        self.grads_valid = True
+        return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
+
     def named_grads(self):
         g = self.out[OUT_HEADER:].detach().cpu().numpy()
         out = {}
@@ -720,7 +741,88 @@ def compile_model(joint_model, posterior_model=None, gradient_estimator=None):
     return compiled
 
 
+def is_custom_estimator(gradient_estimator):
+    """a user-defined `GradientEstimator` subclass (seam B2, `gradient_estimators.py:17-26`): a class (or instance) with its
+    own `__call__` and no kernel of its own"""
+    from brancher_amd import gradient_estimators as ge
+    cls = gradient_estimator if isinstance(gradient_estimator, type) else type(gradient_estimator)
+    return gradient_estimator is not None and not isinstance(gradient_estimator, str) \
+        and isinstance(cls, type) and issubclass(cls, ge.GradientEstimator) and getattr(cls, "kernel_name", None) is None
+
+
+class _OpaqueSamples(dict):
+    """what `sampler._get_sample` hands a user-defined estimator: the draw itself stays on the device inside the kernel;
+    the estimator passes it on to `function` / `calculate_log_probability` unchanged (`samples.update(empirical)` is fine)"""
+
+
+def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_samples, noise=None):
+    """A user-defined gradient estimator (`gradient_estimators.py:17-26`, instantiated at `variables.py:856-857`): a torch
+    scalar g built from `self.function(samples)` — f_n = log p + entropy per sample — and
+    `self.sampler.calculate_log_probability(samples)` — log q_n — of ONE draw `self.sampler._get_sample(n)`.
+    Two passes of the fused kernel around the user's torch code: (1) f and log q per sample (`fvalue_out_dev`); the
+    estimator runs on two leaf tensors holding them, and autograd on those N-vectors gives a_n = dg/df_n, b_n = dg/dlog q_n;
+    (2) the same draw again with the weights: the output block receives d(-g)/d theta = -(sum_n a_n grad f_n + b_n grad log q_n),
+    reparameterisation path included (the reference drops `differentiable=False`, `variables.py:567`).  Returns +g as a
+    FusedLoss.  The estimator must hand the sample object on untouched — a Taylor1-style substitution of values is a
+    different program (and built in)."""
+    if isinstance(estimator_cls, type):
+        make = estimator_cls
+    else:
+        make = type(estimator_cls)
+    compiled = compile_model(joint_model, posterior_model, "blackbox")
+    if type(compiled).__name__ != "CompiledELBO":
+        raise NotImplementedError("user-defined gradient estimators are served on the scalar path")
+    N = int(number_samples)
+    seed = compiled._seed(None)
+    offset = compiled.iteration
+    compiled.iteration += 1
+    first = compiled.evaluate(N, seed=seed, offset=offset, want_fvalues=True, noise=noise)     # (noise: parity tests)
+    rank, world = dist_info()
+    if world > 1:
+        raise NotImplementedError("user-defined gradient estimators on several ranks")
+    F = first["f"].detach().clone().reshape(-1, 1).requires_grad_(True)
+    LQ = first["lq"].detach().clone().reshape(-1, 1).requires_grad_(True)
+    token = _OpaqueSamples()
+    drawn = []
+
+    def check(samples):
+        if samples is not token:
+            raise NotImplementedError("a user-defined gradient estimator must pass the samples of sampler._get_sample on "
+                                      "unchanged (the draw lives in the kernel)")
+
+    class Sampler:
+        variables = getattr(posterior_model, "variables", [])
+
+        def _get_sample(self, n_samples, differentiable=True, **_):
+            if int(n_samples) != N or drawn:
+                raise NotImplementedError("a user-defined gradient estimator draws ONE sample set of number_samples")
+            drawn.append(True)
+            return token
+
+        def calculate_log_probability(self, samples, **_):
+            check(samples)
+            return LQ
+
+    def function(samples):
+        check(samples)
+        return F
+
+    value = make(function, Sampler(), {})(N)
+    if not torch.is_tensor(value) or value.numel() != 1:
+        raise ValueError("a gradient estimator returns a scalar tensor")
+    if value.requires_grad:
+        value.backward()
+    a = F.grad if F.grad is not None else torch.zeros_like(F)
+    b = LQ.grad if LQ.grad is not None else torch.zeros_like(LQ)
+    compiled.evaluate_weighted(N, a, b, seed, offset, noise=noise)
+    return FusedLoss(compiled, value.detach().reshape(()), grad_scale=-1.0)
+
+
 def estimate_elbo(joint_model, posterior_model, number_samples, for_gradient=False, gradient_estimator=None):
+    if for_gradient and is_custom_estimator(gradient_estimator):
+        return custom_estimator_loss(joint_model, posterior_model, gradient_estimator, number_samples)
+    if is_custom_estimator(gradient_estimator):
+        gradient_estimator = None           # (the value alone: mean of log p + entropy, `variables.py:858-866`)
     compiled = compile_model(joint_model, posterior_model, gradient_estimator)
     res = compiled.evaluate(number_samples)
     if for_gradient:

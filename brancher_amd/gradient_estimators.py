@@ -12,6 +12,18 @@ same fused kernel (include/bsvi.h `bsvi_estimator`), which evaluates
 BlackBox reproduces the reference exactly, including that its value is not the ELBO and that
 reparameterisable nodes still carry the pathwise term (the ``differentiable=False`` flag is
 dropped at `variables.py:567`).
+
+A USER-DEFINED subclass (the reference's seam: ctor ``(function, sampler, empirical_samples)``, ``__call__(n_samples)``
+returning a scalar) runs as written: ``self.sampler._get_sample(n)`` hands out the draw as an opaque object,
+``self.function(samples)`` and ``self.sampler.calculate_log_probability(samples)`` return the per-sample f and log q
+as torch tensors [N, 1] on the device, and whatever scalar the estimator forms from them is differentiated through two
+passes of the fused kernel (`engine.custom_estimator_loss`): e.g. a score-function estimator with a baseline,
+
+    class Baseline(GradientEstimator):
+        def __call__(self, n):
+            s = self.sampler._get_sample(n, differentiable=False); s.update(self.empirical_samples)
+            f = self.function(s)
+            return (self.sampler.calculate_log_probability(s) * (f - f.mean()).detach() + f).mean()
 """
 from abc import ABC, abstractmethod
 

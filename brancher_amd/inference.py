@@ -50,7 +50,7 @@ def perform_inference(joint_model, number_iterations, number_samples=1,
                 optimizers_list.append(prob_opt)
 
     inference_method.check_model_compatibility(joint_model, posterior_model, sampler_model)
-    if hasattr(inference_method, "run"):
+    if hasattr(inference_method, "run") and not engine.is_custom_estimator(getattr(inference_method, "gradient_estimator", None)):
         # the methods of this module: the whole loop of `inference.py:95-108` runs on the device
         loss_curve, finite = inference_method.run(joint_model, posterior_model, sampler_model, number_iterations,
                                                   number_samples, optimizer, pretraining_iterations, **opt_params)

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 OUT_HEADER = 4
 
 
@@ -44,7 +44,7 @@ class ElboArgs(C.Structure):
                 ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
                 ("out_dev", C.c_void_p), ("samples_out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p),
                 ("fvalue_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p),
-                ("offset_dev", C.c_void_p)]
+                ("offset_dev", C.c_void_p), ("f_weight_dev", C.c_void_p), ("q_weight_dev", C.c_void_p)]
 
 
 class OptCfg(C.Structure):

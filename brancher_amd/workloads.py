@@ -24,6 +24,36 @@ def native_api():
         ProbabilisticModel=v.ProbabilisticModel, BF=BF, name="brancher_amd")
 
 
+def custom_estimators(ge):
+    """User-defined gradient estimators written against the reference's seam (`gradient_estimators.py:17-26`: ctor
+    `(function, sampler, empirical_samples)`, `__call__(n_samples)` -> scalar).  `ge` is the gradient_estimators module of
+    either library: the SAME class bodies run on the reference (PyTorch-CPU autograd) and here (two passes of the fused
+    kernel, engine.custom_estimator_loss)."""
+    import torch
+
+    class BaselineEstimator(ge.GradientEstimator):
+        """score-function estimator with the batch mean of f as a baseline (a control variate), plus the pathwise term"""
+
+        def __call__(self, n_samples):
+            samples = self.sampler._get_sample(n_samples, differentiable=False)
+            samples.update(self.empirical_samples)
+            f = self.function(samples)
+            log_q = self.sampler.calculate_log_probability(samples)
+            return (log_q * (f - f.mean()).detach() + f).mean()
+
+    class SoftmaxWeightedEstimator(ge.GradientEstimator):
+        """pathwise gradients weighted by a softmax of the (detached) values: favours the better samples"""
+
+        def __call__(self, n_samples):
+            samples = self.sampler._get_sample(n_samples, differentiable=True)
+            samples.update(self.empirical_samples)
+            f = self.function(samples)
+            w = torch.softmax(0.1 * f.detach().reshape(-1), dim=0).reshape(f.shape)
+            return (w * f).sum()
+
+    return dict(baseline=BaselineEstimator, softmax=SoftmaxWeightedEstimator)
+
+
 def ar_data(T, seed=0, b=0.8, driving_noise=1.0, measure_noise=0.3):
     rng = np.random.RandomState(seed)
     x = np.zeros(T)

@@ -41,7 +41,7 @@ typedef long long int64_t;
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 7
+#define BSVI_ABI_VERSION 8
 
 typedef enum bsvi_status {
     BSVI_OK = 0,
@@ -239,6 +239,13 @@ typedef struct bsvi_elbo_args {
     const uint64_t* offset_dev;   /* NULL, or a device word added to `offset` when the launch executes: a step
                                      sequence captured in a HIP graph advances it on the device
                                      (bsvi_finalize_step_counted) and is replayed unchanged            */
+    /* ABI 8 — caller-weighted gradients, the second pass of a user-defined GradientEstimator
+     * (gradient_estimators.py:17-26: any scalar g(f, log q) of the per-sample values): with a_n = dg/df_n and
+     * b_n = dg/dlog q_n the call leaves sum_n a_n grad f_n + b_n grad log q_n in out_dev[4..] (bsvi_elbo_fwd_bwd only;
+     * the first pass reads f and log q through fvalue_out_dev, same seed and offset).  NULL: the estimator's own
+     * weights (a_n = 1; BlackBox: b_n = f_n).  q_weight_dev needs a BlackBox program. */
+    const float* f_weight_dev;    /* [n_samples_local] or NULL */
+    const float* q_weight_dev;    /* [n_samples_local] or NULL */
 } bsvi_elbo_args;
 
 /* One ELBO forward+backward over this GPU's sample shard: q-sampling, p log-prob, q entropy

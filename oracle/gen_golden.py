@@ -85,6 +85,10 @@ TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_l
                     "build_beta_binomial", "build_observed_ar", "build_lognormal_normal")
 
 
+# ... and two user-defined estimators (workloads.custom_estimators) for these
+CUSTOM_ESTIMATOR_BUILDERS = ("build_readme_ar", "build_vector_latent", "build_heavy_tails")
+
+
 def reference_api():
     sys.path.insert(0, REF)
     sys.path.insert(0, ROOT)
@@ -290,6 +294,26 @@ def run_case(name, api):
         for pname, root in roots.items():
             g = root.link.parameter.grad
             out["grad_taylor1/" + pname] = np.zeros_like(out["param/" + pname]) if g is None else g.detach().numpy().copy()
+
+    if CASES[name][0] in CUSTOM_ESTIMATOR_BUILDERS:
+        # user-defined estimators (the GradientEstimator seam, gradient_estimators.py:17-26) on the same draws
+        import brancher_amd.workloads as Wm
+        for est_name, est in sorted(Wm.custom_estimators(ge).items()):
+            for root in roots.values():
+                root.link.parameter.grad = None
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            with DrawRecorder() as rec:
+                loss = inference.ReverseKL(gradient_estimator=est).compute_loss(model, q, None, N)
+            loss.backward()
+            noise = match_noise(q, captured["z"], rec.draws)
+            for k, v in noise.items():
+                assert np.array_equal(out["noise/" + k], v), "estimators drew different noise"
+            out["loss_custom_" + est_name] = np.float32(loss.detach().numpy())
+            for pname, root in roots.items():
+                g = root.link.parameter.grad
+                out["grad_custom_%s/%s" % (est_name, pname)] = (np.zeros_like(out["param/" + pname]) if g is None
+                                                                else g.detach().numpy().copy())
 
     if all(type(v).__name__ == "RootVariable" for v in q.flatten()):
         # point estimates: the reference's MAP inference method on the same model (inference.py:251-275)

@@ -465,6 +465,12 @@ class Oracle:
             f = self.function(means, empirical)
             value = f.mean()
             lq = None
+        elif callable(estimator):
+            # a user-defined GradientEstimator (gradient_estimators.py:17-26): any scalar of the per-sample f and log q of
+            # one draw, differentiated by autograd — `estimator(f, log_q)` restates its __call__ on the two tensors
+            lq = self.model_log_prob(self.q, samples)
+            f = self.function(samples, empirical)
+            value = estimator(f, lq)
         else:
             raise ValueError(estimator)
         if return_parts:
