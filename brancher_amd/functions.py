@@ -74,7 +74,29 @@ class BrancherFunction(object):
             return l.string if isinstance(l, PartialLink) else str(a)
         return self.name + "(" + ", ".join([s(a) for a in list(args) + list(kwargs.values())]) + ")"
 
+    def _traced(self, args, kwargs):
+        """A plain Python callable (`BrancherFunction(lambda a, b: torch.exp(a) * 0.5 + torch.tanh(b))`,
+        `functions.py:28-41`): called ONCE with the symbolic arguments — arithmetic on links builds links, torch functions
+        dispatch through ``BrancherClass.__torch_function__`` — so that the closure becomes an ordinary link expression
+        the lowering can compile.  None when the callable does something that cannot be traced (it then stays an
+        opaque node and the lowering names it)."""
+        if isinstance(self.fn, str) or self.links or not callable(self.fn):
+            return None
+        try:
+            out = self.fn(*[var2link(a) if isinstance(a, (Variable, PartialLink)) else a for a in args],
+                          **{k: var2link(v) if isinstance(v, (Variable, PartialLink)) else v for k, v in kwargs.items()})
+        except Exception:
+            return None
+        if isinstance(out, Variable):
+            out = var2link(out)
+        if isinstance(out, PartialLink):
+            return PartialLink(out.vars, out.expr, out.links, string=self._get_string(*args, **kwargs))
+        return None
+
     def __call__(self, *args, **kwargs):
+        traced = self._traced(args, kwargs)
+        if traced is not None:
+            return traced
         link_args = [var2link(arg) for arg in args]
         link_kwargs = {name: var2link(arg) for name, arg in kwargs.items()}
         vars_ = set()

@@ -100,6 +100,27 @@ class BrancherClass(ABC):
     def flatten(self):
         return set(self._flatten())
 
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        """a torch function applied to a variable or a link — what happens inside a user callable wrapped by
+        ``BrancherFunction(fn)`` (`functions.py:9-45`) when it is traced with symbolic arguments: ``torch.exp(x)`` becomes the
+        link ``BF.exp(x)``, ``torch.add / sub / mul / div / pow`` the operators"""
+        from brancher_amd import functions as BF
+        name = getattr(func, "__name__", None)
+        kwargs = kwargs or {}
+        binary = {"add": "__add__", "sub": "__sub__", "mul": "__mul__", "div": "__truediv__", "true_divide": "__truediv__",
+                  "pow": "__pow__"}
+        if name in binary and len(args) == 2 and not kwargs:
+            a, b = args
+            if isinstance(a, BrancherClass):
+                return getattr(a, binary[name])(b)
+            return getattr(b, binary[name].replace("__", "__r", 1))(a)
+        if name in ("neg", "negative") and len(args) == 1:
+            return -args[0]
+        if not name or name.startswith("_"):
+            return NotImplemented
+        return getattr(BF, name)(*args, **kwargs)
+
     def get_variable(self, var_name):
         # `variables.py:68-83`: a name -> variable table over the flattened graph.  Duplicate names are legal in the
         # reference (the README model has one) and the later one in name order wins; the lowering warns once per compile.

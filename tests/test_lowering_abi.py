@@ -293,3 +293,39 @@ def test_taylor1_entropy_on_the_means_of_sampled_parents():
     assert counts["pathwise"] == (4, 0, 4)          # s, z, u, w: sample + entropy in one record
     assert counts["taylor1"] == (4, 2, 2)           # u and w: entropy-only records on the means of s (and u)
 
+
+def test_user_callables_are_traced_into_link_expressions():
+    """`BrancherFunction(python_callable)` (functions.py:9-45): the closure is called once with symbolic arguments — torch
+    functions dispatch through __torch_function__, arithmetic builds links — and compiles to the very program of the same
+    link written with BF.*; a callable that cannot be traced stays an opaque node that the lowering names"""
+    import torch
+    import brancher_amd.functions as BF
+    api = W.native_api()
+
+    def build(use_callable):
+        data = np.random.RandomState(0).normal(0.5, 1.0, size=(6, 1)).astype(np.float32)
+        z = api.NormalVariable(0., 1.5, "z")
+        s = api.LogNormalVariable(0., 0.3, "s")
+        if use_callable:
+            f = BF.BrancherFunction(lambda a, b: torch.exp(a * 0.3) * 0.5 + torch.tanh(b) / (1.0 + torch.nn.functional.softplus(a)))
+            loc = f(z, s)
+        else:
+            loc = BF.exp(z * 0.3) * 0.5 + BF.tanh(s) / (1.0 + BF.softplus(z))
+        x = api.NormalVariable(loc, 0.8, "x")
+        model = api.ProbabilisticModel([x])
+        x.observe(data)
+        model.set_posterior_model(api.ProbabilisticModel([api.NormalVariable(0., 1., "z", learnable=True),
+                                                          api.LogNormalVariable(0.1, 0.2, "s", learnable=True)]))
+        return model
+
+    pa, pb = (lowering.lower(build(flag), None, "pathwise") for flag in (True, False))
+    assert pa.summary() == pb.summary() and np.array_equal(np.asarray(pa.code), np.asarray(pb.code))
+    opaque = BF.BrancherFunction(lambda a: a.numpy() + 1.0)             # leaves torch / the operators: cannot be traced
+    z = api.NormalVariable(0., 1., "z")
+    x = api.NormalVariable(opaque(z), 1.0, "x")
+    model = api.ProbabilisticModel([x])
+    x.observe(np.zeros((3, 1), dtype=np.float32))
+    model.set_posterior_model(api.ProbabilisticModel([api.NormalVariable(0., 1., "z", learnable=True)]))
+    with pytest.raises((lowering.LoweringError, NotImplementedError)):
+        lowering.lower(model, None, "pathwise")
+
