@@ -25,7 +25,6 @@ import torch
 
 from brancher_amd import distributions as D
 from brancher_amd import lowering, native
-from brancher_amd import symbolic as sym
 from brancher_amd.lowering import LoweringError, _Lowering
 from brancher_amd.native import OUT_HEADER
 from brancher_amd.variables import RandomVariable, RootVariable

@@ -23,7 +23,6 @@ It walks the graph objects of brancher_amd (which mirror the reference's classes
 per-call dictionaries, exactly like the reference, instead of using the compiled program —
 so it also checks the lowering.
 """
-import math
 import operator
 
 import numpy as np

@@ -6,7 +6,6 @@ import os
 import socket
 import sys
 
-import numpy as np
 import pytest
 import torch
 

@@ -4,7 +4,6 @@ every scalar golden workload and for the BASELINE configurations.  What the gene
 the GPU (tests/test_gpu_parity.py runs every fixture through the specialised kernels AND the interpreter)."""
 import re
 
-import numpy as np
 import pytest
 
 from conftest import Golden, golden_cases

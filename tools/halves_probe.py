@@ -2,7 +2,6 @@
 tails of the f32 products?  Times K iterations of one 256-sample call against two concurrent 128-sample calls."""
 import ctypes as C
 import sys
-import time
 
 import torch
 
