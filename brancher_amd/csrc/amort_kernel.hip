@@ -1622,6 +1622,17 @@ struct Net {
     std::vector<size_t> val_off, grad_off;   // float offsets into the workspace, per row-block base (times R at use)
 };
 
+// the fork / join events between the two streams of one call order work on ONE device: no system-scope fence (the default
+// writes the caches back so that the host could inspect the data: ~6 us of idle stream behind every record; BSVI_AMORT_EVENT_FENCE=1
+// keeps it)
+static unsigned event_flags() {
+    static const unsigned f = [] {
+        const char* e = getenv("BSVI_AMORT_EVENT_FENCE");
+        return (unsigned)hipEventDisableTiming | ((e && e[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
+    }();
+    return f;
+}
+#define kEventFlags event_flags()
 struct bsvi_amort {
     bsvi_amort_desc d;
     Net enc, dec;
@@ -1777,9 +1788,9 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     a->overlap = !(ov && ov[0] == '0');
     if (a->overlap) {
         bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&a->joined, hipEventDisableTiming) == hipSuccess;
+                  hipEventCreateWithFlags(&a->joined, kEventFlags) == hipSuccess;
         a->ready.resize(desc->n_enc_layers + desc->n_dec_layers + 1, nullptr);      // (the last one: the encoder's forward pass is enqueued)
-        for (auto& e : a->ready) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto& e : a->ready) ok = ok && hipEventCreateWithFlags(&e, kEventFlags) == hipSuccess;
         if (!ok) {
             bsvi_amort_destroy(a);
             return bsvi_fail(BSVI_ERR_HIP, "side stream / event creation failed");
@@ -2265,7 +2276,10 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         std::vector<char> written(net.width.size(), 0);
         for (int i = (int)net.layers.size() - 1; i >= 0; --i) {
             hipStream_t wstream = stream;
-            if (a->overlap) {          // dY of this layer is complete on `stream` here
+            const auto& lw = net.layers[i];
+            // (a layer without an input-gradient product — the one that reads the data rows — has nothing on `stream` to
+            //  run beside: its weight gradient stays there and saves the event round trip, ~7 us)
+            if (a->overlap && (lw.in_value != 0 || input_grad)) {          // dY of this layer is complete on `stream` here
                 hipEvent_t e = a->ready[next_event++];
                 HIP_TRY(hipEventRecord(e, stream));
                 HIP_TRY(hipStreamWaitEvent(a->side, e, 0));
