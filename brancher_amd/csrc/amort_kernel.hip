@@ -1789,7 +1789,7 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     if (a->overlap) {
         bool ok = hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&a->joined, kEventFlags) == hipSuccess;
-        a->ready.resize(desc->n_enc_layers + desc->n_dec_layers + 1, nullptr);      // (the last one: the encoder's forward pass is enqueued)
+        a->ready.resize(desc->n_enc_layers + desc->n_dec_layers + 1, nullptr);      // (the last one: the transposed minibatch rows are written)
         for (auto& e : a->ready) ok = ok && hipEventCreateWithFlags(&e, kEventFlags) == hipSuccess;
         if (!ok) {
             bsvi_amort_destroy(a);
@@ -2272,6 +2272,11 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         return BSVI_OK;
     };
     size_t next_event = 0;
+    bool xt_pending = XT != nullptr, xt_on_side = false;
+    auto launch_xt = [&](hipStream_t ts) {
+        hipLaunchKernelGGL(xt_gather_kernel, dim3((unsigned)(Rp / 64), (unsigned)((P + 127) / 128)), dim3(256), 0, ts,
+                           a->dataset_bf16_dev, idx, a->data_kp, P, (int)R, Rp, XT);
+    };
     auto backward = [&](const Net& net, bool gather, bool input_grad) -> int {
         std::vector<char> written(net.width.size(), 0);
         for (int i = (int)net.layers.size() - 1; i >= 0; --i) {
@@ -2284,6 +2289,15 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 HIP_TRY(hipEventRecord(e, stream));
                 HIP_TRY(hipStreamWaitEvent(a->side, e, 0));
                 wstream = a->side;
+                if (xt_pending) {
+                    // the transposed minibatch rows, first thing on the side stream of the backward pass: the side stream has
+                    // ~70 us of slack there (beside the encoder's first product it cost that product 12 us, beside the
+                    // decoder's narrow first layer 16 us and an event round trip of its own)
+                    launch_xt(a->side);
+                    HIP_TRY(hipEventRecord(a->ready.back(), a->side));       // (the exact-piece weight gradient runs on `stream`)
+                    xt_on_side = true;
+                    xt_pending = false;
+                }
             }
             const auto& l = net.layers[i];
             const float* dY = grad(net, l.out_value);
@@ -2299,6 +2313,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 part += align4((size_t)(Rp / 64) * l.n_out);
                 uint16_t* T = reinterpret_cast<uint16_t*>(part);
                 part += align4(3 * (size_t)l.n_out * Rp / 2);
+                if (xt_on_side && wstream != a->side) HIP_TRY(hipStreamWaitEvent(wstream, a->ready.back(), 0));
                 hipLaunchKernelGGL(dy_split_t_kernel, dim3((unsigned)(Rp / 64), (unsigned)((l.n_out + 63) / 64)), dim3(256), 0, wstream,
                                    dY, ldy, (int)R, Rp, (int)l.n_out, T, has_bias ? colsum : nullptr);
                 launch_xdw(XT, T, (int)l.n_in, (int)l.n_out, plan, slices, wstream);
@@ -2350,18 +2365,6 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
 
     int rc = forward(a->enc, true);
     if (rc) return rc;
-    if (XT) {
-        // on the side stream, beside the decoder's f32 products (which leave the memory system idle; beside the encoder's
-        // first product, itself fed from the data rows, it cost that product 12 us)
-        hipStream_t ts = stream;
-        if (a->overlap) {
-            HIP_TRY(hipEventRecord(a->ready.back(), stream));
-            HIP_TRY(hipStreamWaitEvent(a->side, a->ready.back(), 0));
-            ts = a->side;
-        }
-        hipLaunchKernelGGL(xt_gather_kernel, dim3((unsigned)(Rp / 64), (unsigned)((P + 127) / 128)), dim3(256), 0, ts,
-                           a->dataset_bf16_dev, idx, a->data_kp, P, (int)R, Rp, XT);
-    }
     hipLaunchKernelGGL(amort_latent_fwd, row_grid, dim3(256), 0, stream, D);
     rc = forward(a->dec, false);
     if (rc) return rc;
@@ -2369,6 +2372,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     rc = backward(a->dec, false, true);
     if (rc) return rc;
     hipLaunchKernelGGL(amort_latent_bwd, row_grid, dim3(256), 0, stream, D);
+    if (xt_pending) { launch_xt(stream); xt_pending = false; }       // (no side stream: BSVI_AMORT_OVERLAP=0)
     rc = backward(a->enc, true, false);
     if (rc) return rc;
     if (a->overlap) {
