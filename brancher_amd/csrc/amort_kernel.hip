@@ -1685,6 +1685,7 @@ static int build_net(Net& net, const bsvi_mlp_layer* layers, uint32_t n_layers, 
 
 extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) {
     if (!desc || !out) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    BSVI_CHECK_STRUCT(desc, bsvi_amort_desc);
     if (desc->abi_version != BSVI_ABI_VERSION) return bsvi_fail(BSVI_ERR_INVALID, "ABI version mismatch");
     if (!desc->n_enc_layers || !desc->n_dec_layers || !desc->enc_layers || !desc->dec_layers || !desc->dataset ||
         !desc->prior_loc || !desc->prior_scale || !desc->latent_dim || !desc->batch_size || !desc->n_features)
@@ -2137,6 +2138,7 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
 }
 
 extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args) {
+    if (args) BSVI_CHECK_STRUCT(args, bsvi_amort_args);
     if (!a || !args || !args->params_dev || !args->out_dev || !args->workspace_dev || !args->n_samples_local)
         return bsvi_fail(BSVI_ERR_INVALID, "null argument");
     if (args->estimator > 1) return bsvi_fail(BSVI_ERR_UNSUPPORTED, "estimator must be 0 (pathwise) or 1 (BlackBox)");

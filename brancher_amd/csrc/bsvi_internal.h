@@ -9,6 +9,15 @@
 
 // records the thread-local message returned by bsvi_last_error() and returns `code`
 int bsvi_fail(int code, const std::string& msg);
+// every descriptor / argument struct starts with struct_size = the CALLER's sizeof (include/bsvi.h): a binding written
+// against another header revision is refused instead of being read past its end
+#define BSVI_CHECK_STRUCT(ptr, type)                                                                              \
+    do {                                                                                                          \
+        if ((ptr)->struct_size != sizeof(type))                                                                   \
+            return bsvi_fail(BSVI_ERR_INVALID, std::string(#type "::struct_size is ") + std::to_string((ptr)->struct_size) + \
+                             ", this library's sizeof is " + std::to_string(sizeof(type)) +                       \
+                             ": the binding was written against another revision of include/bsvi.h");             \
+    } while (0)
 // amort_kernel.hip: C[M][N] = X[rows[m]] W^T on the bf16 matrix cores — X exactly bf16 [..][Kp], Wp the three bf16 pieces
 // [3][N][Kp] (hi, mid, lo) of an f32 operand, Kp a multiple of 32
 int bsvi_xgemm_nt(const uint16_t* X, const int32_t* rows, const uint16_t* Wp, long plane_stride, float* C, int ldc,

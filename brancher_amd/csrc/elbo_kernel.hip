@@ -1442,6 +1442,24 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 extern "C" const char* bsvi_last_error(void) { return g_last_error.c_str(); }
 extern "C" int bsvi_abi_version(void) { return BSVI_ABI_VERSION; }
+extern "C" size_t bsvi_sizeof(int kind) {
+    switch (kind) {
+    case BSVI_SK_UNIFORM_ENTRY: return sizeof(bsvi_uniform_entry);
+    case BSVI_SK_RECORD: return sizeof(bsvi_record);
+    case BSVI_SK_PROGRAM_DESC: return sizeof(bsvi_program_desc);
+    case BSVI_SK_ELBO_ARGS: return sizeof(bsvi_elbo_args);
+    case BSVI_SK_OPT_CFG: return sizeof(bsvi_opt_cfg);
+    case BSVI_SK_DENSE_DESC: return sizeof(bsvi_dense_desc);
+    case BSVI_SK_DENSE_ARGS: return sizeof(bsvi_dense_args);
+    case BSVI_SK_MLP_LAYER: return sizeof(bsvi_mlp_layer);
+    case BSVI_SK_AMORT_DESC: return sizeof(bsvi_amort_desc);
+    case BSVI_SK_AMORT_ARGS: return sizeof(bsvi_amort_args);
+    case BSVI_SK_MVN_INSN: return sizeof(bsvi_mvn_insn);
+    case BSVI_SK_MVN_DESC: return sizeof(bsvi_mvn_desc);
+    case BSVI_SK_MVN_ARGS: return sizeof(bsvi_mvn_args);
+    default: return 0;
+    }
+}
 
 extern "C" int bsvi_device_count(void) {
     int n = 0;
@@ -1451,6 +1469,7 @@ extern "C" int bsvi_device_count(void) {
 
 static int validate(const bsvi_program_desc* d) {
     if (!d) return fail(BSVI_ERR_INVALID, "null program descriptor");
+    BSVI_CHECK_STRUCT(d, bsvi_program_desc);
     if (d->abi_version != BSVI_ABI_VERSION) return fail(BSVI_ERR_INVALID, "ABI version mismatch");
     if (d->n_uniform_grad > d->n_uniform) return fail(BSVI_ERR_INVALID, "n_uniform_grad > n_uniform");
     if (d->estimator > BSVI_EST_BLACKBOX) return fail(BSVI_ERR_INVALID, "unknown estimator");
@@ -1908,6 +1927,7 @@ static Geometry share_geometry(const bsvi_program* p, Geometry g, uint32_t n_loc
 }
 
 extern "C" int bsvi_elbo_fwd_bwd(const bsvi_program* p, const bsvi_elbo_args* a) {
+    if (a) BSVI_CHECK_STRUCT(a, bsvi_elbo_args);
     if (!p || !a) return fail(BSVI_ERR_INVALID, "null argument");
     if (!a->out_dev) return fail(BSVI_ERR_INVALID, "out_dev is null");
     if (a->q_weight_dev && p->d.estimator != BSVI_EST_BLACKBOX)
@@ -2002,6 +2022,7 @@ extern "C" int bsvi_finalize_step_counted(const bsvi_opt_cfg* cfg, float* params
 extern "C" int bsvi_svi_step(const bsvi_program* p, const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
                              float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                              float* loss_slot_dev, float* finite_slot_dev) {
+    if (a) BSVI_CHECK_STRUCT(a, bsvi_elbo_args);
     if (!p || !a) return fail(BSVI_ERR_INVALID, "null argument");
     int rc = check_cfg(cfg);
     if (rc) return rc;
@@ -2060,6 +2081,7 @@ extern "C" int bsvi_persistent_supported(const bsvi_program* p, uint32_t n_local
 extern "C" int bsvi_train_persistent(const bsvi_program* p, const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
                                      float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                                      uint32_t n_iterations, float* loss_curve_dev, float* finite_dev) {
+    if (a) BSVI_CHECK_STRUCT(a, bsvi_elbo_args);
     return bsvi_train_persistent2(p, a, cfg, params_dev, state_dev, active_mask_dev, active_mask_dev, 0,
                                   n_iterations, loss_curve_dev, finite_dev);
 }
@@ -2074,6 +2096,7 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
                                       float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                                       const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
                                       uint32_t n_iterations, float* loss_curve_dev, float* finite_dev) {
+    if (a) BSVI_CHECK_STRUCT(a, bsvi_elbo_args);
     return train_persistent_impl(p, nullptr, 0, a, cfg, params_dev, state_dev, active_mask_dev, active_mask_first_dev,
                                  pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);
 }
@@ -2118,6 +2141,7 @@ extern "C" int bsvi_train_persistent_split(const bsvi_program* p, const bsvi_pro
                                            float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                                            const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
                                            uint32_t n_iterations, float* loss_curve_dev, float* finite_dev) {
+    if (a) BSVI_CHECK_STRUCT(a, bsvi_elbo_args);
     if (!shares || n_shares < 2 || n_shares > 8) return fail(BSVI_ERR_INVALID, "2..8 program shares expected");
     for (uint32_t v = 0; v < n_shares; ++v) {
         if (!shares[v]) return fail(BSVI_ERR_INVALID, "null program share");

@@ -10,12 +10,21 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 OUT_HEADER = 4
 
 
 class NativeError(RuntimeError):
     pass
+
+
+class Sized(C.Structure):
+    """A descriptor / argument struct of the C ABI: its first member is `struct_size`, the size of the struct as THIS binding
+    declares it (include/bsvi.h: the library refuses a call whose struct_size differs from its own sizeof)."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(self)
 
 
 class UniformEntry(C.Structure):
@@ -28,17 +37,18 @@ class Record(C.Structure):
                 ("temp_base", C.c_uint32), ("n_temps", C.c_uint32), ("flags", C.c_uint32)]
 
 
-class ProgramDesc(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("n_params", C.c_uint32), ("n_consts", C.c_uint32),
+class ProgramDesc(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("n_params", C.c_uint32), ("n_consts", C.c_uint32),
                 ("n_obs", C.c_uint32), ("n_slots", C.c_uint32), ("n_noise", C.c_uint32),
                 ("n_uniform", C.c_uint32), ("n_uniform_grad", C.c_uint32), ("n_records", C.c_uint32),
-                ("n_code", C.c_uint32), ("estimator", C.c_uint32), ("reserved", C.c_uint32),
+                ("n_code", C.c_uint32), ("estimator", C.c_uint32),
                 ("uniform", C.c_void_p), ("records", C.c_void_p), ("code", C.c_void_p), ("consts", C.c_void_p),
                 ("param_uniform_ptr", C.c_void_p), ("param_uniform_idx", C.c_void_p)]
 
 
-class ElboArgs(C.Structure):
-    _fields_ = [("params_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("noise_dev", C.c_void_p),
+class ElboArgs(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("params_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("noise_dev", C.c_void_p),
                 ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
                 ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
@@ -53,8 +63,8 @@ class OptCfg(C.Structure):
                 ("eps", C.c_float), ("amsgrad", C.c_uint32), ("maximize", C.c_uint32)]
 
 
-class DenseDesc(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("n_params", C.c_uint32), ("n_consts", C.c_uint32),
+class DenseDesc(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("n_params", C.c_uint32), ("n_consts", C.c_uint32),
                 ("n_uniform", C.c_uint32), ("n_uniform_grad", C.c_uint32),
                 ("n_classes", C.c_uint32), ("n_features", C.c_uint32), ("dataset_size", C.c_uint32),
                 ("batch_size", C.c_uint32), ("likelihood", C.c_uint32),
@@ -62,13 +72,14 @@ class DenseDesc(C.Structure):
                 ("prior_scale_u", C.c_uint32), ("q_loc_stride", C.c_uint32), ("q_scale_stride", C.c_uint32),
                 ("prior_loc_stride", C.c_uint32), ("prior_scale_stride", C.c_uint32),
                 ("lik_weight", C.c_float), ("prior_weight", C.c_float), ("entropy_weight", C.c_float),
-                ("estimator", C.c_uint32),
+                ("estimator", C.c_uint32), ("reserved", C.c_uint32),
                 ("uniform", C.c_void_p), ("consts", C.c_void_p), ("param_uniform_ptr", C.c_void_p),
                 ("param_uniform_idx", C.c_void_p), ("dataset", C.c_void_p), ("labels", C.c_void_p)]
 
 
-class DenseArgs(C.Structure):
-    _fields_ = [("params_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("indices_dev", C.c_void_p),
+class DenseArgs(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("params_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("indices_dev", C.c_void_p),
                 ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
                 ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
@@ -129,6 +140,7 @@ EXPORTS = {
     "bsvi_debug_set_stamps": (None, [C.c_void_p]),
     "bsvi_last_error": (C.c_char_p, []),
     "bsvi_abi_version": (C.c_int, []),
+    "bsvi_sizeof": (C.c_size_t, [C.c_int]),
     "bsvi_device_count": (C.c_int, []),
 }
 EXPORTS.update(DENSE_EXPORTS)
@@ -141,8 +153,8 @@ class MlpLayer(C.Structure):
                 ("post_add2", C.c_float), ("reserved", C.c_uint32)]
 
 
-class AmortDesc(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("n_params", C.c_uint32),
+class AmortDesc(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("abi_version", C.c_uint32), ("n_params", C.c_uint32),
                 ("n_features", C.c_uint32), ("latent_dim", C.c_uint32), ("dataset_size", C.c_uint32),
                 ("batch_size", C.c_uint32), ("n_enc_layers", C.c_uint32), ("n_dec_layers", C.c_uint32),
                 ("enc_loc_value", C.c_uint32), ("enc_scale_value", C.c_uint32),
@@ -153,8 +165,9 @@ class AmortDesc(C.Structure):
                 ("likelihood_scale", C.c_void_p), ("prior_loc_off", C.c_uint32), ("prior_scale_off", C.c_uint32)]
 
 
-class AmortArgs(C.Structure):
-    _fields_ = [("params_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("indices_dev", C.c_void_p),
+class AmortArgs(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("params_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("indices_dev", C.c_void_p),
                 ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
                 ("sample_base", C.c_uint32), ("estimator", C.c_uint32),
@@ -191,16 +204,17 @@ class MvnInsn(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("flag", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("imm", C.c_float)]
 
 
-class MvnDesc(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("dim", C.c_uint32), ("n_code", C.c_uint32), ("n_mats", C.c_uint32),
+class MvnDesc(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("abi_version", C.c_uint32), ("dim", C.c_uint32), ("n_code", C.c_uint32), ("n_mats", C.c_uint32),
                 ("n_slot_inputs", C.c_uint32), ("n_uniform_inputs", C.c_uint32), ("value_is_latent", C.c_uint32),
                 ("loc_is_param", C.c_uint32),
                 ("code", C.POINTER(MvnInsn)), ("mats", C.c_void_p), ("loc", C.c_void_p), ("value", C.c_void_p),
                 ("uniform_inputs", C.c_void_p), ("loc_entries", C.c_void_p), ("weight", C.c_float), ("reserved2", C.c_uint32)]
 
 
-class MvnArgs(C.Structure):
-    _fields_ = [("params_dev", C.c_void_p), ("samples_dev", C.c_void_p), ("rows_out_dev", C.c_void_p),
+class MvnArgs(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("params_dev", C.c_void_p), ("samples_dev", C.c_void_p), ("rows_out_dev", C.c_void_p),
                 ("n_samples_local", C.c_uint32), ("value_row0", C.c_uint32), ("input_rows", C.c_uint32 * 8),
                 ("stream", C.c_void_p)]
 
@@ -271,6 +285,10 @@ def mvn_source(node):
     return buf.value.decode()
 
 
+# bsvi_struct_kind (include/bsvi.h) -> the ctypes mirror of the struct: load() checks every size against bsvi_sizeof()
+STRUCT_KINDS = {0: UniformEntry, 1: Record, 2: ProgramDesc, 3: ElboArgs, 4: OptCfg, 5: DenseDesc, 6: DenseArgs, 7: MlpLayer,
+                8: AmortDesc, 9: AmortArgs, 10: MvnInsn, 11: MvnDesc, 12: MvnArgs}
+
 _lib = None
 
 
@@ -293,6 +311,10 @@ def load():
         fn.argtypes = argtypes
     if lib.bsvi_abi_version() != ABI_VERSION:
         raise NativeError("libbsvi.so ABI version {} != {}".format(lib.bsvi_abi_version(), ABI_VERSION))
+    for kind, cls in STRUCT_KINDS.items():
+        if lib.bsvi_sizeof(kind) != C.sizeof(cls):
+            raise NativeError("{}: this binding declares {} bytes, libbsvi.so {} (include/bsvi.h and native.py disagree)".format(
+                cls.__name__, C.sizeof(cls), lib.bsvi_sizeof(kind)))
     _lib = lib
     return lib
 

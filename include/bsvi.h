@@ -41,7 +41,20 @@ typedef long long int64_t;
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 8
+#define BSVI_ABI_VERSION 9
+
+/* Every descriptor / argument struct a binder fills in starts with `struct_size` = sizeof of the struct AS THE BINDER
+ * DECLARES IT.  An entry point that receives a struct whose struct_size differs from the library's own sizeof returns
+ * BSVI_ERR_INVALID instead of reading past the end of a shorter struct (structs only ever grow at the tail, and a binding
+ * written against an older header is otherwise indistinguishable from a current one).  bsvi_sizeof() answers the same
+ * question ahead of time, also for the table element types that travel in arrays. */
+typedef enum bsvi_struct_kind {
+    BSVI_SK_UNIFORM_ENTRY = 0, BSVI_SK_RECORD = 1, BSVI_SK_PROGRAM_DESC = 2, BSVI_SK_ELBO_ARGS = 3, BSVI_SK_OPT_CFG = 4,
+    BSVI_SK_DENSE_DESC = 5, BSVI_SK_DENSE_ARGS = 6, BSVI_SK_MLP_LAYER = 7, BSVI_SK_AMORT_DESC = 8, BSVI_SK_AMORT_ARGS = 9,
+    BSVI_SK_MVN_INSN = 10, BSVI_SK_MVN_DESC = 11, BSVI_SK_MVN_ARGS = 12, BSVI_SK_COUNT = 13
+} bsvi_struct_kind;
+/* sizeof(struct) inside this build of the library; 0 for an unknown kind */
+size_t bsvi_sizeof(int kind);
 
 typedef enum bsvi_status {
     BSVI_OK = 0,
@@ -177,6 +190,7 @@ typedef enum bsvi_estimator {
 } bsvi_estimator;
 
 typedef struct bsvi_program_desc {
+    uint32_t struct_size;     /* sizeof(bsvi_program_desc)                          */
     uint32_t abi_version;
     uint32_t n_params;        /* length of the flat parameter buffer                */
     uint32_t n_consts;        /* length of the constant buffer                      */
@@ -188,7 +202,6 @@ typedef struct bsvi_program_desc {
     uint32_t n_records;
     uint32_t n_code;          /* 32-byte instructions                               */
     uint32_t estimator;       /* bsvi_estimator                                     */
-    uint32_t reserved;
     const bsvi_uniform_entry* uniform;
     const bsvi_record* records;
     const uint32_t* code;     /* 8 * n_code words */
@@ -221,6 +234,8 @@ size_t bsvi_workspace_bytes(const bsvi_program* prog, uint32_t n_samples_local);
 #define BSVI_OUT_HEADER 4
 
 typedef struct bsvi_elbo_args {
+    uint32_t struct_size;         /* sizeof(bsvi_elbo_args)                                 */
+    uint32_t reserved0;
     const float* params_dev;      /* [n_params]                                             */
     const float* obs_dev;         /* [n_obs]                                                */
     const float* noise_dev;       /* [n_noise][n_samples_local] or NULL -> in-kernel Philox  */
@@ -401,6 +416,7 @@ typedef enum bsvi_dense_likelihood {
 } bsvi_dense_likelihood;
 
 typedef struct bsvi_dense_desc {
+    uint32_t struct_size;                      /* sizeof(bsvi_dense_desc) */
     uint32_t abi_version;
     uint32_t n_params, n_consts, n_uniform, n_uniform_grad;
     uint32_t n_classes, n_features, dataset_size, batch_size;
@@ -411,6 +427,7 @@ typedef struct bsvi_dense_desc {
     uint32_t q_loc_stride, q_scale_stride, prior_loc_stride, prior_scale_stride;
     float lik_weight, prior_weight, entropy_weight;
     uint32_t estimator;                        /* bsvi_estimator: pathwise, or BlackBox (gradient_estimators.py:29-36) */
+    uint32_t reserved;
     const bsvi_uniform_entry* uniform;
     const float* consts;
     const uint32_t* param_uniform_ptr;
@@ -422,6 +439,8 @@ typedef struct bsvi_dense_desc {
 typedef struct bsvi_dense bsvi_dense;
 
 typedef struct bsvi_dense_args {
+    uint32_t struct_size;        /* sizeof(bsvi_dense_args)                                      */
+    uint32_t reserved0;
     const float* params_dev;     /* [n_params]                                                   */
     const float* noise_dev;      /* eps [C*P][n_samples_local] or NULL -> Philox                  */
     const int32_t* indices_dev;  /* minibatch rows [batch_size] or NULL -> drawn on the device    */
@@ -491,6 +510,7 @@ typedef struct bsvi_mlp_layer {
 } bsvi_mlp_layer;
 
 typedef struct bsvi_amort_desc {
+    uint32_t struct_size, reserved0;              /* sizeof(bsvi_amort_desc) */
     uint32_t abi_version, n_params;
     uint32_t n_features, latent_dim, dataset_size, batch_size;
     uint32_t n_enc_layers, n_dec_layers;          /* topologically ordered */
@@ -516,6 +536,8 @@ typedef struct bsvi_amort_desc {
 typedef struct bsvi_amort bsvi_amort;
 
 typedef struct bsvi_amort_args {
+    uint32_t struct_size;         /* sizeof(bsvi_amort_args)                                            */
+    uint32_t reserved0;
     const float* params_dev;      /* [n_params]                                                         */
     const float* noise_dev;       /* eps [n_samples_local * B][latent_dim] or NULL -> Philox             */
     const int32_t* indices_dev;   /* minibatch rows [n_samples_local][B] or NULL -> drawn on the device  */
@@ -604,6 +626,7 @@ typedef struct bsvi_mvn_insn {
     float imm;         /* IMM: the value; UN POWI: the exponent */
 } bsvi_mvn_insn;
 typedef struct bsvi_mvn_desc {
+    uint32_t struct_size, reserved0;           /* sizeof(bsvi_mvn_desc) */
     uint32_t abi_version, dim, n_code, n_mats;
     uint32_t n_slot_inputs, n_uniform_inputs, value_is_latent, loc_is_param;
     const bsvi_mvn_insn* code;                 /* host */
@@ -617,6 +640,7 @@ typedef struct bsvi_mvn_desc {
     uint32_t reserved2;
 } bsvi_mvn_desc;
 typedef struct bsvi_mvn_args {
+    uint32_t struct_size, reserved0;           /* sizeof(bsvi_mvn_args) */
     const float* params_dev;
     const float* samples_dev;
     float* rows_out_dev;

@@ -44,9 +44,80 @@ def test_opcodes_match_header():
     assert int(re.search(r"#define BSVI_ABI_VERSION (\d+)", HEADER).group(1)) == native.ABI_VERSION
 
 
-def test_struct_layouts():
+C_NAMES = {native.UniformEntry: "bsvi_uniform_entry", native.Record: "bsvi_record", native.ProgramDesc: "bsvi_program_desc",
+           native.ElboArgs: "bsvi_elbo_args", native.OptCfg: "bsvi_opt_cfg", native.DenseDesc: "bsvi_dense_desc",
+           native.DenseArgs: "bsvi_dense_args", native.MlpLayer: "bsvi_mlp_layer", native.AmortDesc: "bsvi_amort_desc",
+           native.AmortArgs: "bsvi_amort_args", native.MvnInsn: "bsvi_mvn_insn", native.MvnDesc: "bsvi_mvn_desc",
+           native.MvnArgs: "bsvi_mvn_args"}
+
+
+def test_struct_layouts(tmp_path):
+    """EVERY struct of the binding against the header itself: a C program compiled from include/bsvi.h alone prints sizeof and
+    the offset of each member (by the member's name, so a renamed or reordered field fails to compile or compare); the
+    library's own bsvi_sizeof() must agree with both.  (Round 3 checked two of thirteen, and a binder following
+    INTEGRATION.md handed the library a struct 24 bytes short.)"""
+    import subprocess
     assert ctypes.sizeof(native.UniformEntry) == 16 == lowering.UNIFORM_DTYPE.itemsize
     assert ctypes.sizeof(native.Record) == 24 == lowering.RECORD_DTYPE.itemsize
+    assert set(C_NAMES) == set(native.STRUCT_KINDS.values())
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "bsvi.h"', "int main(void) {"]
+    for cls, cname in C_NAMES.items():
+        lines.append('    printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field in cls._fields_:
+            lines.append('    printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, field[0], cname, field[0]))
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    seen = {}
+    for line in subprocess.check_output([str(exe)]).decode().splitlines():
+        cname, member, value = line.split()
+        seen[(cname, member)] = int(value)
+    lib = native.load()
+    kind_of = {cls: kind for kind, cls in native.STRUCT_KINDS.items()}
+    for cls, cname in C_NAMES.items():
+        assert seen[(cname, "sizeof")] == ctypes.sizeof(cls) == lib.bsvi_sizeof(kind_of[cls]), cname
+        for field in cls._fields_:
+            assert seen[(cname, field[0])] == getattr(cls, field[0]).offset, (cname, field[0])
+        # every member of the header is mirrored (count the declarators of the C struct)
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), HEADER, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        members = [m for decl in body.split(";") for m in decl.split(",") if m.strip()]
+        assert len(members) == len(cls._fields_), (cname, len(members), len(cls._fields_))
+    kinds = header_enum("BSVI_SK_")
+    assert kinds["COUNT"] == len(native.STRUCT_KINDS) and lib.bsvi_sizeof(kinds["COUNT"]) == 0
+    for cls, cname in C_NAMES.items():
+        assert kinds[cname[len("bsvi_"):].upper()] == kind_of[cls]
+
+
+def test_a_struct_of_another_size_is_refused():
+    """`struct_size` is the caller's sizeof: an argument / descriptor struct from a binding written against another revision
+    of the header must come back as BSVI_ERR_INVALID — before anything is read beyond it, and before a device is needed."""
+    lib = native.load()
+    prog = lowering.lower(W.build_readme_ar(W.native_api(), T=3))
+    d, keep = native.program_desc(prog)
+    assert d.struct_size == ctypes.sizeof(native.ProgramDesc)
+    d.struct_size -= 8
+    handle = ctypes.c_void_p()
+    assert lib.bsvi_program_create(ctypes.byref(d), ctypes.byref(handle)) == -1      # BSVI_ERR_INVALID
+    assert b"struct_size" in lib.bsvi_last_error() and not handle.value
+    assert lib.bsvi_program_source(ctypes.byref(d), 0, None, 0) == 0
+    dd = native.DenseDesc(abi_version=native.ABI_VERSION, n_classes=2, n_features=32, dataset_size=4, batch_size=2)
+    dd.struct_size += 4
+    assert lib.bsvi_dense_create(ctypes.byref(dd), ctypes.byref(handle)) == -1 and b"bsvi_dense_desc" in lib.bsvi_last_error()
+    ad = native.AmortDesc(abi_version=native.ABI_VERSION)
+    ad.struct_size = 0
+    assert lib.bsvi_amort_create(ctypes.byref(ad), ctypes.byref(handle)) == -1 and b"bsvi_amort_desc" in lib.bsvi_last_error()
+    md = native.MvnDesc(abi_version=native.ABI_VERSION, dim=4)
+    md.struct_size = 88
+    assert lib.bsvi_mvn_create(ctypes.byref(md), ctypes.byref(handle)) == -1 and b"bsvi_mvn_desc" in lib.bsvi_last_error()
+    # argument structs: the check comes before the (null) object is looked at
+    for fn, args in ((lib.bsvi_elbo_fwd_bwd, native.ElboArgs()), (lib.bsvi_dense_fwd_bwd, native.DenseArgs()),
+                     (lib.bsvi_amort_fwd_bwd, native.AmortArgs()), (lib.bsvi_mvn_eval, native.MvnArgs())):
+        args.struct_size += 8
+        assert fn(None, ctypes.byref(args)) == -1
+        assert b"struct_size" in lib.bsvi_last_error(), lib.bsvi_last_error()
 
 
 def test_library_exports_every_declared_symbol():
