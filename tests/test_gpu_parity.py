@@ -25,6 +25,27 @@ def grad_check(named, ref, tol):
         assert np.abs(named[name] - g_ref).max() <= tol * scale + 1e-7 * scale, name
 
 
+def yardstick_grad_check(named, exact, reference, tol=TOL):
+    """The bound of every check that cannot hold the flat 1e-5 of BASELINE.json's north_star: the truth is the oracle in DOUBLE
+    precision on the same draws, and the kernel must be as close to it as the reference arithmetic — single precision — is
+    itself (x4), or within 1e-5 of the largest gradient:  err <= max(4 * |reference_fp32 - oracle_fp64|, 1e-5 * scale).
+    (BlackBox gradients multiply log q by f, two sums of opposite sign: the reference's own single-precision result is
+    1e-5 ... 1e-4 of the scale away from the double-precision one.  A flat 1e-4 said nothing about WHICH of the two is off.)"""
+    scale = max(np.abs(v).max() for v in exact.values() if v is not None)
+    for name, g64 in exact.items():
+        g64 = np.zeros(1) if g64 is None else g64
+        ref = np.zeros(1) if reference.get(name) is None else reference[name]
+        err, yard = np.abs(named[name] - g64).max(), np.abs(ref - g64).max()
+        assert err <= max(4 * yard, tol * scale), (name, err, yard, scale)
+
+
+def exact_oracle(g_or_model, n, estimator, noise, minibatch=None):
+    import torch as _t
+    from oracle.svi_oracle import Oracle
+    model = g_or_model.build() if isinstance(g_or_model, Golden) else g_or_model
+    return Oracle(model, dtype=_t.float64).loss_and_grads(n, estimator, noise, minibatch)
+
+
 def is_dense(case):
     return case.startswith("logreg")
 
@@ -56,7 +77,7 @@ def test_loss_and_grads_match_reference_golden(case, estimator):
         gscale = max(np.abs(v).max() for v in exact["grads"].values())
         for name, g64 in exact["grads"].items():
             err_g, err_ref_g = np.abs(named[name] - g64).max(), np.abs(ref_g[name] - g64).max()
-            assert err_g <= max(4 * err_ref_g, (TOL if estimator == "pathwise" else 1e-4) * gscale), (name, err_g, err_ref_g)
+            assert err_g <= max(4 * err_ref_g, TOL * gscale), (name, err_g, err_ref_g)
         f64, f_ref = exact["f"].reshape(-1), (g.data["lp"] + g.data["H"]).reshape(-1)
         fscale = np.abs(f64).max()
         assert np.abs(res["f"].cpu().numpy() - f64).max() <= max(4 * np.abs(f_ref - f64).max(), TOL * fscale)
@@ -92,7 +113,11 @@ def test_loss_and_grads_match_reference_golden(case, estimator):
         assert np.abs(res["f"].cpu().numpy() - f64).max() <= 1e-6 * scale
         return
     assert abs(loss - ref) <= TOL * abs(ref), (loss, ref)
-    grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL if estimator == "pathwise" else 1e-4)
+    exact_g = exact_oracle(g, g.N, estimator, g.noise, g.minibatch)["grads"] if estimator == "blackbox" else None
+    if estimator == "pathwise":
+        grad_check(c.named_grads(), g.group("grad_pathwise/"), TOL)
+    else:
+        yardstick_grad_check(c.named_grads(), exact_g, g.group("grad_blackbox/"))
     # per-sample terms and the samples themselves
     f_ref = (g.data["lp"] + g.data["H"]).reshape(-1)
     assert rel_err(res["f"].cpu().numpy(), f_ref) <= TOL
@@ -105,7 +130,10 @@ def test_loss_and_grads_match_reference_golden(case, estimator):
     # lean build with the pre-resolved node handlers: same fixture through that one
     res2 = c.evaluate(g.N, noise=g.noise, minibatch=g.minibatch)
     assert abs(float(res2["loss"].item()) - ref) <= TOL * abs(ref)
-    grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL if estimator == "pathwise" else 1e-4)
+    if estimator == "pathwise":
+        grad_check(c.named_grads(), g.group("grad_pathwise/"), TOL)
+    else:
+        yardstick_grad_check(c.named_grads(), exact_g, g.group("grad_blackbox/"))
 
 
 @pytest.mark.parametrize("case", [c for c in golden_cases() if "loss_taylor1" in Golden(c).data.files])
@@ -187,13 +215,28 @@ def test_training_trajectory_matches_reference_golden(case, persistent):
     losses, finite = c.train(tr["iters"], tr["n"], tr["optimizer"], noise_seq=g.trajectory_noise(),
                              minibatch_seq=g.trajectory_minibatch(), allow_persistent=persistent, **g.opt_kwargs())
     assert c.last_mode == ("persistent" if persistent and not is_dense(case) and not is_batched_mvn(case) else "stepwise")
-    # (batched multivariate-normal terms: two single-precision Cholesky factorisations at a condition number of ~1e3)
-    tol, ptol = (3e-4, 3e-4) if is_batched_mvn(case) else (TOL, 2e-5)
-    assert rel_err(losses.cpu().numpy(), g.data["traj/losses"]) <= tol
     assert finite.cpu().numpy().all()
     after = g.group("traj/param_after/")
+    if is_batched_mvn(case):
+        # two single-precision Cholesky factorisations at a condition number of ~1e3 agree to ~1e-4, and the difference feeds
+        # back through the steps: the truth is the oracle's trajectory in DOUBLE precision on the same draws, the yardstick the
+        # reference's own single-precision trajectory (the fixture)
+        import torch as _t
+        from oracle.svi_oracle import Oracle
+        o = Oracle(g.build(), dtype=_t.float64)
+        exact_losses = o.train(tr["iters"], tr["n"], tr["optimizer"], noise_seq=g.trajectory_noise(),
+                               minibatch_seq=g.trajectory_minibatch(), **g.opt_kwargs()).astype(np.float64)
+        got, ref_l = losses.cpu().numpy().astype(np.float64), g.data["traj/losses"].astype(np.float64)
+        lscale = np.abs(exact_losses).max()
+        assert np.abs(got - exact_losses).max() <= max(4 * np.abs(ref_l - exact_losses).max(), TOL * lscale)
+        exact_after = {name: t.detach().numpy() for name, t in o.named_parameters().items()}
+        for name, p in c.named_params().items():
+            e64 = exact_after[name].reshape(p.shape)
+            assert np.abs(p - e64).max() <= max(4 * np.abs(after[name] - e64).max(), 2e-5 * (1 + np.abs(e64).max())), name
+        return
+    assert rel_err(losses.cpu().numpy(), g.data["traj/losses"]) <= TOL
     for name, p in c.named_params().items():
-        assert np.abs(p - after[name]).max() <= ptol * (1 + np.abs(after[name]).max()), name
+        assert np.abs(p - after[name]).max() <= 2e-5 * (1 + np.abs(after[name]).max()), name
 
 
 @pytest.mark.parametrize("builder,kwargs,n", [
@@ -227,8 +270,9 @@ def test_philox_path_matches_oracle_on_emitted_noise(builder, kwargs, n, estimat
     ref = Oracle(getattr(W, builder)(api, **kwargs)).loss_and_grads(n, estimator, named)
     loss = float(res["loss"].item())
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"]), (loss, ref["loss"])
-    grads = {k: (np.zeros(1) if v is None else v) for k, v in ref["grads"].items()}
-    grad_check(c.named_grads(), grads, 2e-5 if estimator == "pathwise" else 2e-4)
+    # gradients: the oracle in double precision is the truth, the oracle in single precision (the reference's arithmetic) the yardstick
+    exact = exact_oracle(getattr(W, builder)(api, **kwargs), n, estimator, named)
+    yardstick_grad_check(c.named_grads(), exact["grads"], ref["grads"])
     # the same seed/offset must reproduce bit-identically (no atomics anywhere)
     res2 = c.evaluate(n, seed=1234, offset=7)
     # (the lean launch may split the model's records over workgroups — program shares — so the summation order differs
@@ -264,7 +308,7 @@ def test_batched_mvn_philox_path_matches_oracle_on_emitted_noise(n_points, n, es
     gscale = max(np.abs(v).max() for v in exact["grads"].values())
     for name, g64 in exact["grads"].items():
         err, yard = np.abs(named_g[name] - g64).max(), np.abs(single["grads"][name] - g64).max()
-        assert err <= max(4 * yard, (2e-5 if estimator == "pathwise" else 2e-4) * gscale), (name, err, yard)
+        assert err <= max(4 * yard, TOL * gscale), (name, err, yard)
     # a repeat of the same call is bitwise the same
     first = c.out.cpu().numpy().copy()
     c.evaluate(n, seed=321, offset=3)

@@ -91,6 +91,17 @@ def test_struct_layouts(tmp_path):
         assert kinds[cname[len("bsvi_"):].upper()] == kind_of[cls]
 
 
+def test_integration_document_shows_the_current_struct():
+    """INTEGRATION.md prints the ctypes mirror of bsvi_elbo_args a maintainer would paste into the reference: it must be the
+    one of native.py (it was three fields stale at the end of round 3)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"class ElboArgs\(Sized\):.*?_fields_ = \[(.*?)\]\n", doc, re.S).group(1)
+    shown = re.findall(r'\("([a-z0-9_]+)", C\.(c_[a-z0-9_]+)\)', block)
+    import ctypes as C
+    assert [name for name, _ in shown] == [name for name, _ in native.ElboArgs._fields_]
+    assert [getattr(C, ctype) for _, ctype in shown] == [ctype for _, ctype in native.ElboArgs._fields_]
+
+
 def test_a_struct_of_another_size_is_refused():
     """`struct_size` is the caller's sizeof: an argument / descriptor struct from a binding written against another revision
     of the header must come back as BSVI_ERR_INVALID — before anything is read beyond it, and before a device is needed."""
