@@ -522,6 +522,7 @@ class CompiledAmortized:
         args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, offset, noise_o, idx_o, fvals, logq)
         native.check(self.lib.bsvi_amort_fwd_bwd(self.handle, C.byref(args)))
         engine.allreduce_sums(self.out)
+        engine.check_exchange(self.device)
         # sums -> loss and gradients: the ELBO estimate is a mean over N*B rows (gradient_estimators.py:36,44)
         cfg = self._identity_cfg()
         zero_mask = getattr(self, "_zero_mask", None)
@@ -611,6 +612,8 @@ class CompiledAmortized:
                 number_samples * p.batch_size, C.c_void_p(loss_curve.data_ptr() + 4 * it),
                 C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
+        if world > 1:
+            engine.check_exchange(self.device)         # (an abandoned exchange poisoned a step: say so, loudly)
         return loss_curve[:K], finite[:K]
 
 

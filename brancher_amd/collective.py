@@ -75,6 +75,17 @@ class Exchange:
         native.check(self.lib.bsvi_exchange_allreduce(self.handle, C.c_void_p(tensor.data_ptr()), tensor.numel(), C.c_void_p(st)))
         return tensor
 
+    def self_test(self):
+        """one all-reduce of known vectors right after the regions are connected: rank r contributes (r + 1) * [1, 2, ...];
+        True when this rank got the exact total in time (synchronises; run once, outside any capture)"""
+        n = min(64, int(getattr(self, "capacity", 64)))
+        ramp = torch.arange(1, n + 1, device=self.device, dtype=torch.float32)
+        buf = (ramp * float(self.rank + 1)).contiguous()
+        self.allreduce(buf)
+        torch.cuda.synchronize(self.device)
+        expected = ramp * float(self.world * (self.world + 1) // 2)
+        return self.status() == 0 and bool(torch.equal(buf, expected))
+
     def status(self):
         """0, or the sequence number of the last call that gave up waiting for a peer (synchronises with the device)"""
         return int(self.lib.bsvi_exchange_status(self.handle))

@@ -110,13 +110,24 @@ __device__ __forceinline__ float* slot_of(unsigned char* region, uint32_t parity
 
 // ONE workgroup.  Stores to the peers and the loads of what they wrote are system-scope atomics (relaxed): they bypass this
 // GPU's caches, so a slot written by a peer two calls ago cannot be served stale from L2.
+//
+// Failure is sticky and shared: a rank that gives up waiting raises the abort word of EVERY region; a rank that finds its
+// abort word raised — at the start of a call, while it waits, or after the wait — abandons the call too.  An abandoned call
+// leaves NaN in buf[0] (the loss sum) and buf[1] (the non-finite count): bsvi_finalize_step then sees a non-finite loss and
+// skips the optimizer step, on every rank, so the replicated parameters cannot drift apart silently, and the NaN in the loss
+// curve plus bsvi_exchange_status tell the host.  (Before: the rank that gave up kept its own partial sums — finite, and
+// wrong — while a late peer completed the call normally.)
 __global__ __launch_bounds__(256) void exchange_kernel(const XArgs A) {
     const uint32_t tid = threadIdx.x;
     __shared__ uint32_t gave_up, seq_s;
     uint32_t* mine = reinterpret_cast<uint32_t*>(A.peer[A.rank]);
+    uint32_t* const abort_word = mine + kMaxRanks * kFlagStride;
     // the call's sequence number lives in the region (word kCallsWord, touched by this rank's kernels only): the launch is the
     // same every time, so a HIP graph that captured it replays correctly
-    if (tid == 0) { gave_up = 0; seq_s = mine[kCallsWord] + 1u; }
+    if (tid == 0) {
+        gave_up = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ? 1u : 0u;
+        seq_s = mine[kCallsWord] + 1u;
+    }
     __syncthreads();
     const uint32_t seq = seq_s, parity = seq & 1u;
     // 1. this rank's vector into its slot of every region (its own included)
@@ -131,22 +142,29 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XArgs A) {
     if (tid < A.world)
         __hip_atomic_store(reinterpret_cast<uint32_t*>(A.peer[tid]) + A.rank * kFlagStride, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tid == 0) mine[kCallsWord] = seq;
-    // 3. wait for every rank's number in this rank's region — bounded
-    if (tid < A.world) {
+    // 3. wait for every rank's number in this rank's region — bounded, and ended by anybody's abort
+    if (tid < A.world && !gave_up) {
         const unsigned long long t0 = wall_clock64();
         // (sequence numbers only grow; a peer may already be one call ahead)
         while ((int32_t)(__hip_atomic_load(mine + tid * kFlagStride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { gave_up = 1; break; }
             if (wall_clock64() - t0 > A.timeout_ticks) {
                 gave_up = 1;
-                __hip_atomic_store(mine + kMaxRanks * kFlagStride, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // abort word: the call that gave up
-                atomicAdd(mine + kMaxRanks * kFlagStride + 1, 1u);
+                for (uint32_t p = 0; p < A.world; ++p)          // the abort word of every region: the call that gave up
+                    __hip_atomic_store(reinterpret_cast<uint32_t*>(A.peer[p]) + kMaxRanks * kFlagStride, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                atomicAdd(abort_word + 1, 1u);
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
-    if (gave_up) return;                     // buf keeps this rank's own sums; the host reads bsvi_exchange_status
+    if (tid == 0 && !gave_up && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) gave_up = 1;
+    __syncthreads();
+    if (gave_up) {                           // abandoned: poison the sums (see above); the host reads bsvi_exchange_status
+        if (tid < 2 && tid < A.n) A.buf[tid] = __int_as_float(0x7fc00000);
+        return;
+    }
     // 4. the total, slots added in rank order
     unsigned char* region = A.peer[A.rank];
     for (uint32_t i = tid; i < A.n; i += 256) {
@@ -178,10 +196,18 @@ extern "C" int bsvi_exchange_create(uint32_t rank, uint32_t world, uint32_t capa
     auto* x = new bsvi_exchange();
     x->rank = rank; x->world = world; x->capacity = (capacity_floats + 63u) / 64u * 64u;
     x->bytes = (size_t)kHeaderWords * 4 + 2 * (size_t)world * x->capacity * sizeof(float);
-    // fine-grained (uncached across devices) when the runtime has it; plain device memory serves ranks that share a GPU
+    // fine-grained memory: uncached across devices — what a region written by peers on OTHER GPUs needs while the spinning
+    // kernel is resident.  Coarse-grained device memory gives no such guarantee: it serves one rank, or ranks that share a GPU
+    // (the single-GPU tests say so with BSVI_EXCHANGE_SAME_DEVICE=1); otherwise the caller is told to use RCCL.
     void* p = nullptr;
     if (hipExtMallocWithFlags(&p, x->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
+        const char* same = getenv("BSVI_EXCHANGE_SAME_DEVICE");
+        if (world > 1 && !(same && same[0] == '1')) {
+            delete x;
+            return bsvi_fail(BSVI_ERR_UNSUPPORTED, "bsvi_exchange_create: no fine-grained device memory on this device — the one-shot exchange "
+                                                   "cannot guarantee visibility between GPUs; use bsvi_allreduce (RCCL)");
+        }
         if (hipMalloc(&p, x->bytes) != hipSuccess) { delete x; return bsvi_fail(BSVI_ERR_HIP, "bsvi_exchange_create: device allocation failed"); }
     }
     x->region = (unsigned char*)p;

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
@@ -732,12 +733,14 @@ const std::string& source(const Spec* s, int variant) { return s->variant[varian
 // ---------------------------------------------------------------------------------------------------------------
 //  hiprtc
 // ---------------------------------------------------------------------------------------------------------------
+static const char* kJitOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+static const int kJitOptionCount = (int)(sizeof(kJitOptions) / sizeof(kJitOptions[0]));
+
 int compile(const std::string& src, std::vector<char>& code, std::string& log) {
     hiprtcProgram prog = nullptr;
     hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "bsvi_spec.hip", kJitHeaderCount, kJitHeaderTexts, kJitHeaderNames);
     if (r != HIPRTC_SUCCESS) { log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r); return BSVI_ERR_HIP; }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    r = hiprtcCompileProgram(prog, 3, opts);
+    r = hiprtcCompileProgram(prog, kJitOptionCount, kJitOptions);       // (the same array keys the disk cache)
     size_t n = 0;
     if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
         log.resize(n);
@@ -785,8 +788,6 @@ static void feed(Hash128& h, const void* data, size_t n) {
 }
 static void feed(Hash128& h, const std::string& s) { const uint64_t n = s.size(); feed(h, &n, 8); feed(h, s.data(), s.size()); }
 
-static const char* kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-
 static bool enabled() {
     const char* e = getenv("BSVI_JIT_CACHE");
     return !(e && e[0] == '0');
@@ -808,11 +809,21 @@ static bool make_dirs(const std::string& path) {
     return true;
 }
 
+// The cache holds GPU code that this process will run: it is only trusted when the directory is a real directory (not a
+// link) that belongs to this user and that nobody else can write.  The fallback path under /tmp is predictable, the key is
+// a non-cryptographic hash of known text and the embedded content hash authenticates the file, not its origin — another
+// local user who got there first could otherwise plant a code object.  Anything else: no disk cache (hiprtc compiles).
+static bool trusted(const std::string& dir) {
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
 static std::string key_of(const std::string& src) {
     static const Hash128 base = [] {        // everything but the generated source: the same for every program of a process
         Hash128 h;
         for (int i = 0; i < kJitHeaderCount; ++i) { feed(h, std::string(kJitHeaderNames[i])); feed(h, std::string(kJitHeaderTexts[i])); }
-        for (const char* o : kOptions) feed(h, std::string(o));
+        for (int i = 0; i < kJitOptionCount; ++i) feed(h, std::string(kJitOptions[i]));
         int major = 0, minor = 0, runtime = 0;
         (void)hiprtcVersion(&major, &minor);
         (void)hipRuntimeGetVersion(&runtime);
@@ -828,9 +839,12 @@ struct Header { char magic[8]; uint64_t size, ha, hb; };
 static const char kMagic[8] = {'B', 'S', 'V', 'I', 'C', 'O', '0', '1'};
 
 static bool load(const std::string& key, std::vector<char>& code) {
-    const std::string path = directory() + "/" + key + ".co";
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
+    const std::string dir = directory();
+    if (!trusted(dir)) return false;
+    const std::string path = dir + "/" + key + ".co";
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    FILE* f = fd >= 0 ? fdopen(fd, "rb") : nullptr;
+    if (!f) { if (fd >= 0) close(fd); return false; }
     Header H;
     bool ok = fread(&H, sizeof H, 1, f) == 1 && memcmp(H.magic, kMagic, 8) == 0 && H.size > 0 && H.size < (1ull << 30);
     if (ok) {
@@ -849,7 +863,7 @@ static bool load(const std::string& key, std::vector<char>& code) {
 
 static void store(const std::string& key, const std::vector<char>& code) {
     const std::string dir = directory();
-    if (!make_dirs(dir)) return;
+    if (!make_dirs(dir) || !trusted(dir)) return;
     Header H;
     memcpy(H.magic, kMagic, 8);
     H.size = code.size();
@@ -857,8 +871,9 @@ static void store(const std::string& key, const std::vector<char>& code) {
     feed(h, code.data(), code.size());
     H.ha = h.a; H.hb = h.b;
     const std::string tmp = dir + "/" + key + fmt(".tmp.%d", (int)getpid());
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!f) { if (fd >= 0) close(fd); return; }
     const bool ok = fwrite(&H, sizeof H, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
     if (fclose(f) != 0 || !ok || rename(tmp.c_str(), (dir + "/" + key + ".co").c_str()) != 0) (void)remove(tmp.c_str());
 }

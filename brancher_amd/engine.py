@@ -53,33 +53,66 @@ def shard(n_global, rank, world):
     return base, n_local
 
 
-_exchanges = {}          # device index -> collective.Exchange (BSVI_COLLECTIVE=exchange)
+_exchanges = {}          # device index -> collective.Exchange, or False: decided (by all ranks together) that RCCL serves
+
+
+def _exchange_for(out):
+    """The one-shot exchange of this device for a message of out.numel() floats, or None.  Decided ONCE per device and message
+    capacity, by all ranks together and outside any stream capture: every rank creates its region and maps its peers'
+    (HIP IPC), then a self-test all-reduce of known vectors must come back exact on every rank — the ranks vote with one
+    torch.distributed all-reduce.  Anything short of that (no IPC access to a peer, no fine-grained memory, a wrong or late
+    sum) and every rank uses RCCL for the rest of the process."""
+    import torch.distributed as dist
+    from brancher_amd import collective
+    key = out.device.index
+    ex = _exchanges.get(key)
+    if ex is False:
+        return None
+    if ex is not None and ex.capacity >= out.numel():
+        return ex
+    if torch.cuda.is_current_stream_capturing():
+        return None                 # (cannot be decided inside a capture: the graph path makes an untimed call first)
+    if ex is not None:
+        ex.close()
+    capacity = max(out.numel(), 1024)
+    ok = 1.0
+    try:
+        ex = collective.Exchange(capacity, device=out.device)
+        ex.capacity = capacity
+        if not ex.self_test():
+            ok = 0.0
+    except (native.NativeError, RuntimeError):
+        ex, ok = None, 0.0
+    vote = torch.tensor([ok], device=out.device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+    if float(vote.item()) < 1.0:
+        if ex is not None:
+            ex.close()
+        _exchanges[key] = False
+        return None
+    _exchanges[key] = ex
+    return ex
 
 
 def allreduce_sums(out):
     """The ONE collective of the multi-GPU path: sum the per-rank output blocks
-    [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.  By default torch.distributed's
-    all-reduce (RCCL over xGMI when `out` is a device tensor and the backend is "nccl"; gloo in the CPU tests).
-    BSVI_COLLECTIVE=rccl: the same RCCL call through the C ABI (`bsvi_allreduce` on torch's communicator);
-    BSVI_COLLECTIVE=exchange: the library's one-shot direct-write all-reduce over IPC-mapped peer regions
-    (`bsvi_exchange_*`, messages of up to 16384 floats) — one one-workgroup kernel, no RCCL on the step's path."""
+    [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.
+
+    BSVI_COLLECTIVE=auto (the default): device messages of up to 16384 floats — every message of the scalar and dense paths,
+    188 bytes at BASELINE config 1 — go through the library's one-shot direct-write all-reduce over IPC-mapped peer regions
+    (`bsvi_exchange_*`: one one-workgroup kernel, no ring; DESIGN.md 6 puts the RCCL ring at 2-3 times its latency for these
+    sizes) when `_exchange_for` found it usable; everything else through torch.distributed's all-reduce (RCCL over xGMI when
+    the backend is "nccl"; gloo in the CPU tests).  BSVI_COLLECTIVE=torch forces that; BSVI_COLLECTIVE=rccl is the same RCCL
+    call through the C ABI (`bsvi_allreduce` on torch's communicator); BSVI_COLLECTIVE=exchange is `auto` spelled out."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return out
-    kind = os.environ.get("BSVI_COLLECTIVE", "torch")
-    if kind == "exchange" and out.is_cuda and out.numel() <= 16384 and out.dtype == torch.float32:
-        from brancher_amd import collective
-        key = out.device.index
-        ex = _exchanges.get(key)
-        if ex is None or ex.capacity < out.numel():
-            # (collective: every rank reaches this with the same message length, outside any stream capture — the graph
-            #  path makes one untimed call of the sequence first)
-            if ex is not None:
-                ex.close()
-            ex = _exchanges[key] = collective.Exchange(max(out.numel(), 1024), device=out.device)
-            ex.capacity = max(out.numel(), 1024)
-        ex.allreduce(out)
-        return out
+    kind = os.environ.get("BSVI_COLLECTIVE", "auto")
+    if kind in ("auto", "exchange") and out.is_cuda and out.numel() <= 16384 and out.dtype == torch.float32:
+        ex = _exchange_for(out)
+        if ex is not None:
+            ex.allreduce(out)
+            return out
     if kind == "rccl" and out.is_cuda and out.dtype == torch.float32:
         from brancher_amd import collective
         comm = collective.rccl_comm_ptr()
@@ -90,14 +123,16 @@ def allreduce_sums(out):
 
 
 def check_exchange(device):
-    """after a training call over the one-shot exchange: did every call meet its peers?  (a rank that gives up keeps its own
-    sums — finite, but no longer the totals — so this must be an error, not a warning)"""
-    ex = _exchanges.get(device.index)
-    if ex is not None:
+    """At the end of every public evaluation / training call of the three engines when ranks exchanged through the one-shot
+    exchange: did every call meet its peers?  An abandoned call poisons the sums (NaN loss, the optimizer step is skipped on
+    every rank — csrc/collective.hip), so nothing diverges silently; this turns it into the error it is."""
+    ex = _exchanges.get(device.index if hasattr(device, "index") else device)
+    if ex:
         gave_up = ex.status()
         if gave_up:
-            raise native.NativeError("the one-shot exchange gave up waiting for a peer at its call {} "
-                                     "(BSVI_EXCHANGE_TIMEOUT_MS); the ranks' parameters are no longer in step".format(gave_up))
+            raise native.NativeError("the one-shot exchange was abandoned at its call {} (a peer did not arrive within "
+                                     "BSVI_EXCHANGE_TIMEOUT_MS, or raised the abort word); that call's sums are NaN and its "
+                                     "optimizer step was skipped on every rank".format(gave_up))
 
 
 def estimator_name(gradient_estimator):
@@ -356,7 +391,11 @@ class CompiledELBO:
             bufs = self._base_buffers[n_local] = dict(ws=torch.empty(nbytes, dtype=torch.uint8, device=dev),
                                                       samples=torch.empty((bp.n_noise, n_local), device=dev),
                                                       noise=torch.zeros((p.n_noise, n_local), device=dev))
-        full = noise_t if noise_t is not None else bufs["noise"]
+        # (supplied noise: a COPY carries the surrogate rows — the caller's tensor may be replayed on another model or estimator)
+        full = bufs["noise"]
+        if noise_t is not None:
+            full.copy_(noise_t)
+            noise_t = full
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         args = ElboArgs(params_dev=ptr(self.params), obs_dev=ptr(self.base_obs), noise_dev=ptr(noise_t),
                         seed=self._resolved(seed), offset=int(offset), n_samples_local=n_local, n_samples_global=n_global,
@@ -406,6 +445,7 @@ class CompiledELBO:
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
+        check_exchange(self.device)
         native.check(self.lib.bsvi_finalize(self.native.handle, C.c_void_p(self.out.data_ptr()), number_samples,
                                             self._stream()))
         self.grads_valid = True
@@ -436,6 +476,7 @@ class CompiledELBO:
         args.f_weight_dev, args.q_weight_dev = a.data_ptr(), b.data_ptr()
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
+        check_exchange(self.device)
         native.check(self.lib.bsvi_finalize(self.native.handle, C.c_void_p(self.out.data_ptr()), 1, self._stream()))
         self.grads_valid = True
         return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
@@ -526,23 +567,19 @@ class CompiledELBO:
         params, mask_all, mask_first = (C.c_void_p(t.data_ptr()) for t in (self.params, self.mask_all, self.mask_first))
         params_ptr = self.params.data_ptr()
         dev = self.device
-        default_seed = None
         current_stream = torch.cuda.current_stream
         empty = torch.empty
         import torch.distributed as dist
         is_distributed = dist.is_initialized if dist.is_available() else (lambda: False)
 
         def run(K, seed):
-            nonlocal default_seed
             Ka = (K + 3) // 4 * 4
             # (a sibling estimator re-bound the parameter buffer, or a process group appeared since: the full path decides)
             if self.params.data_ptr() != params_ptr or is_distributed():
                 self._fast_train.clear()
                 return None
             if seed is None:
-                if default_seed is None:
-                    default_seed = shared_seed(None, dev)
-                seed = default_seed
+                seed = shared_seed(None, dev)      # (per call: a torch.manual_seed() since the last one counts, as on the full path)
             buf = empty(2 * Ka, device=dev)
             args.seed = int(seed) & 0x7FFFFFFFFFFFFFFF
             args.offset = self.iteration
@@ -574,9 +611,13 @@ class CompiledELBO:
         # — optimizer block, argument block, ctypes pointers, the launch plan — is kept from the first one, and the call is
         # a buffer, five stores into the argument block and ONE library call.
         if noise_seq is None and minibatch_seq is None and not _force_sharded_path and allow_persistent:
-            fast_key = (int(number_samples), optimizer if isinstance(optimizer, str) else None,
-                        int(pretraining_iterations), tuple(sorted(opt_params.items())) if opt_params else ())
-            fast = self._fast_train.get(fast_key)
+            # (option values in a hashable normal form: betas=[0.9, 0.99] is as good as the tuple)
+            fast_key = (int(number_samples), optimizer if isinstance(optimizer, str) else None, int(pretraining_iterations),
+                        tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in opt_params.items())))
+            try:
+                fast = self._fast_train.get(fast_key)
+            except TypeError:                   # an unhashable option value: no prepared repeat for this call
+                fast_key, fast = None, None
             if fast is not None and number_iterations > 0:
                 try:
                     return fast(int(number_iterations), seed)
@@ -776,10 +817,10 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
     seed = compiled._seed(None)
     offset = compiled.iteration
     compiled.iteration += 1
-    first = compiled.evaluate(N, seed=seed, offset=offset, want_fvalues=True, noise=noise)     # (noise: parity tests)
     rank, world = dist_info()
     if world > 1:
         raise NotImplementedError("user-defined gradient estimators on several ranks")
+    first = compiled.evaluate(N, seed=seed, offset=offset, want_fvalues=True, noise=noise)     # (noise: parity tests)
     F = first["f"].detach().clone().reshape(-1, 1).requires_grad_(True)
     LQ = first["lq"].detach().clone().reshape(-1, 1).requires_grad_(True)
     token = _OpaqueSamples()

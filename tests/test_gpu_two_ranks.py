@@ -29,7 +29,7 @@ def _worker(rank, world, port, workload, n_samples, iters, optimizer, opt_kw, ou
     os.environ["MASTER_PORT"] = str(port)
     os.environ["BSVI_COLLECTIVE"] = collective
     # a gloo collective cannot be captured into a HIP graph; the library's one-shot exchange is a kernel and can
-    os.environ["BSVI_GRAPH"] = "1" if collective == "exchange" else "0"
+    os.environ["BSVI_GRAPH"] = "1" if collective in ("exchange", "auto") else "0"
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -45,7 +45,7 @@ def _worker(rank, world, port, workload, n_samples, iters, optimizer, opt_kw, ou
     res = c.evaluate(n_samples, seed=5, offset=900)
     torch.cuda.synchronize()
     out_q.put((rank, losses.cpu().numpy(), c.params.detach().cpu().numpy().copy(), float(res["loss"].item()),
-               c.last_mode, bool(finite.all())))
+               c.last_mode, bool(finite.all()), bool(engine._exchanges.get(0))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,8 +84,8 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank in (0, 1):
-        losses, params, ev, mode, finite = got[rank]
-        assert finite and "allreduce" in mode, mode
+        losses, params, ev, mode, finite, used = got[rank]
+        assert finite and "allreduce" in mode and not used, mode
         np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=1e-5)
         np.testing.assert_allclose(params, ref_params, rtol=2e-5, atol=2e-6)
         assert abs(ev - ref_eval) <= 2e-5 * abs(ref_eval)
@@ -93,17 +93,25 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
     assert np.array_equal(got[0][1], got[1][1])
 
 
-def test_two_ranks_over_the_one_shot_exchange_inside_a_hip_graph():
-    """the same trajectory with the library's own exchange (bsvi_exchange_*: the ranks map each other's regions through HIP
-    IPC) in place of the host-staged all-reduce — a kernel, so the step sequence is captured in a HIP graph and replayed
-    with the exchange inside"""
+@pytest.mark.parametrize("workload,n_samples,optimizer,opt_kw,mode", [
+    (("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3), "graph+allreduce"),
+    (("build_logistic_regression", dict(dataset_size=256, batch_size=64, n_features=64, n_classes=10, q_scale=0.05)), 96, "Adam", dict(lr=5e-3),
+     "stepwise+allreduce"),
+    (("build_vae", dict(dataset_size=300, batch_size=20, n_features=40, hidden1=24, hidden2=16, seed=1)), 32, "Adam", dict(lr=1e-3),
+     "stepwise+allreduce"),
+])
+def test_two_ranks_over_the_one_shot_exchange(workload, n_samples, optimizer, opt_kw, mode):
+    """the same trajectories with the DEFAULT collective (BSVI_COLLECTIVE=auto): the library's own exchange (bsvi_exchange_*:
+    the ranks map each other's regions through HIP IPC, a self-test all-reduce and a vote decide once that it serves) in place
+    of the host-staged all-reduce, on all three engines.  It is a kernel, so the scalar path's step sequence is captured in a
+    HIP graph and replayed with the exchange inside."""
     import torch.multiprocessing as mp
-    workload, n_samples, optimizer, opt_kw, iters = ("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3), 40
+    iters = 40 if mode.startswith("graph") else 12
     ref_losses, ref_params, ref_eval = _single(workload, n_samples, iters, optimizer, opt_kw)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, workload, n_samples, iters, optimizer, opt_kw, q, "exchange")) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, workload, n_samples, iters, optimizer, opt_kw, q, "auto")) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -114,11 +122,73 @@ def test_two_ranks_over_the_one_shot_exchange_inside_a_hip_graph():
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank in (0, 1):
-        losses, params, ev, mode, finite = got[rank]
-        assert finite and mode == "graph+allreduce", mode
+        losses, params, ev, last_mode, finite, used = got[rank]
+        assert finite and last_mode == mode, last_mode
+        assert used, "the exchange was not chosen (self-test or vote failed): the test would be measuring gloo"
         np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=1e-5)
         np.testing.assert_allclose(params, ref_params, rtol=2e-5, atol=2e-6)
+        assert abs(ev - ref_eval) <= 2e-5 * abs(ref_eval)
     assert np.array_equal(got[0][1], got[1][1])
+
+
+def _abandon_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BSVI_EXCHANGE_TIMEOUT_MS="300")
+    import time
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brancher_amd import engine, native
+    dev = torch.device("cuda", 0)
+    first = torch.arange(8, device=dev, dtype=torch.float32) + rank
+    engine.allreduce_sums(first)                      # decides for the exchange (self-test + vote), then a good call
+    torch.cuda.synchronize()
+    ok_first = bool(torch.equal(first, 2 * torch.arange(8, device=dev, dtype=torch.float32) + 1)) and bool(engine._exchanges.get(0))
+    dist.barrier()
+    block = torch.full((8,), float(rank + 1), device=dev)
+    if rank == 1:
+        time.sleep(1.5)                               # rank 0 gives up after 0.3 s ...
+    engine.allreduce_sums(block)                      # ... and raises the abort word of BOTH regions: the late call is abandoned too
+    torch.cuda.synchronize()
+    raised = False
+    try:
+        engine.check_exchange(dev)
+    except native.NativeError:
+        raised = True
+    again = torch.ones(8, device=dev)                 # sticky: nothing after the failure pretends to be a total
+    engine.allreduce_sums(again)
+    torch.cuda.synchronize()
+    out_q.put((rank, ok_first, block.cpu().numpy(), raised, again.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_an_abandoned_exchange_poisons_the_sums_on_every_rank():
+    """a rank that gave up waiting used to keep its own partial sums — finite, wrong — while the late peer finished
+    the call normally, and only the scalar path's train() ever looked at the status.  Now the rank that gives up raises the
+    abort word of every region, an abandoned call leaves NaN in the loss sum and the non-finite count (so bsvi_finalize_step
+    skips the optimizer step: the ranks cannot drift apart), the failure is sticky, and `check_exchange` — called at the end
+    of every public evaluation / training call of all three engines — raises."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_abandon_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok_first, block, raised, again = got[rank]
+        assert ok_first
+        assert np.isnan(block[0]) and np.isnan(block[1]), (rank, block)
+        assert raised
+        assert np.isnan(again[0]) and np.isnan(again[1])
 
 
 def test_bench_with_two_ranks_dry_run():
