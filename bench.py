@@ -76,7 +76,8 @@ def run_traffic_probe(workloads, steps_of, warmup_of, estimator, mode, samples, 
         return None, "rocprofv3 not found on this box"
     rows = []
     spec = ",".join("%s:%d:%d" % (w, steps_of[w], warmup_of[w]) for w in workloads)
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    # (a third pass counts the vector instructions of every launch: roofline.issue of the latency-bound configs)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         out_dir = tempfile.mkdtemp(prefix="bsvi_pmc_%s_" % counter, dir="/tmp")
         cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
                sys.executable, os.path.abspath(__file__), "--traffic-probe", spec, "--estimator", estimator, "--mode", mode]
@@ -87,10 +88,14 @@ def run_traffic_probe(workloads, steps_of, warmup_of, estimator, mode, samples, 
                                  stderr=subprocess.STDOUT, timeout=timeout_s, text=True)
         except Exception as err:      # noqa: BLE001  (timeout, exec failure: the bench goes on without the counters)
             shutil.rmtree(out_dir, ignore_errors=True)
+            if counter == "SQ_INSTS_VALU":
+                break                 # (the traffic passes stand on their own)
             return None, "PMC pass %s did not finish: %s" % (counter, err)
         files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
         if res.returncode != 0 or not files:
             shutil.rmtree(out_dir, ignore_errors=True)
+            if counter == "SQ_INSTS_VALU":
+                break
             return None, "PMC pass %s failed (exit %d): %s" % (counter, res.returncode, (res.stdout or "")[-300:])
         per = {}
         for f in files:
@@ -100,7 +105,7 @@ def run_traffic_probe(workloads, steps_of, warmup_of, estimator, mode, samples, 
                 key = (int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]))
                 per[key] = per.get(key, 0.0) + float(r["Counter_Value"])          # (one row per XCD / instance)
         for (dispatch, kernel, grid), kb in sorted(per.items()):
-            rows.append(dict(counter=counter, dispatch=dispatch, kernel=kernel, grid=grid, bytes=kb * 1024.0))
+            rows.append(dict(counter=counter, dispatch=dispatch, kernel=kernel, grid=grid, bytes=kb * 1024.0, value=kb))
         shutil.rmtree(out_dir, ignore_errors=True)
     return rows, None
 
@@ -122,6 +127,28 @@ def traffic_of(rows, kernel_substrings, grid=None, last_only=False, per=1, doubl
         scale = 2.0 if (double_fetch and counter == "FETCH_SIZE") else 1.0
         total += scale * (sel[-1]["bytes"] if last_only else sum(r["bytes"] for r in sel) / max(per, 1))
     return total if hit else None
+
+
+def issue_roofline(rows, kernel_substrings, grid, n_samples, iterations, us_per_iteration, last_only):
+    """roofline.issue of a latency-bound config: the vector instructions ONE wave issues per iteration (SQ_INSTS_VALU of
+    the launch / its waves / its iterations, from this run's own counter pass) x 4 cycles of issue each
+    (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') x the waves that share the busiest SIMD, at the 2.4 GHz peak
+    clock, against the measured iteration.  The sample shard runs as ceil(n / 64) waves on ONE CU's four SIMDs."""
+    sel = [r for r in (rows or []) if r["counter"] == "SQ_INSTS_VALU" and any(k in r["kernel"] for k in kernel_substrings)
+           and (grid is None or r["grid"] == grid)]
+    if not sel:
+        return None
+    insts = sel[-1]["value"] if last_only else sum(r["value"] for r in sel) / len(sel)
+    waves = (n_samples + 63) // 64
+    per_wave_iter = insts / waves / max(iterations, 1)
+    busiest = (waves + 3) // 4
+    issue_us = per_wave_iter * 4.0 * busiest / 2400.0
+    return dict(bound="valu-issue of the busiest SIMD", valu_per_wave_iteration=per_wave_iter, waves=waves,
+                waves_on_busiest_simd=busiest, cycles_per_instruction=4, clock_ghz=2.4, issue_us_per_iteration=issue_us,
+                measured_us_per_iteration=us_per_iteration, frac=issue_us / us_per_iteration,
+                note="one workgroup of %d waves on ONE of 256 CUs: the iteration cannot be shorter than the instruction issue "
+                     "of the SIMD that hosts %d of them; the rest of the iteration is barriers, LDS exchange and dependent "
+                     "latency (DESIGN.md 4.7)" % (waves, busiest))
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA = f32 vector peak
@@ -280,6 +307,21 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     #      (the driver runs K = 20) is not measured on a GPU whose clocks have not ramped yet
     train(max(warmup, 1))
     barrier()
+    # ---- the same K steps ONCE before any spin-up: what a caller sees on a GPU whose clocks have not ramped (reported next
+    #      to the hot figure as `cold_start`; the headline stays the contract's: W warm-up steps, then K timed steps)
+    cold = None
+    if spinup_ms > 0:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        c0.record()
+        tc = time.perf_counter()
+        train(steps)
+        c1.record()
+        barrier()
+        cold_dt = time.perf_counter() - tc
+        cold = dict(ms_per_step=cold_dt * 1e3 / steps, device_ms_per_step=c0.elapsed_time(c1) / steps,
+                    value=steps / cold_dt * (n_global / 300.0), unit="it/s",
+                    note="the first %d-step call after the %d warm-up steps, before the untimed spin-up" % (steps, max(warmup, 1)))
     # no garbage collection from here to the end of the timed region: a collection inside a 200 us region would be a
     # tenth of it, and a pause between the spin-up and the region would let the clocks drop again
     gc.collect()
@@ -376,6 +418,10 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
             traffic_how = "elbo_kernel launches of the probe / its %d iterations" % (iters_probed or 0)
     achieved = alg_bytes_iter * units_per_launch / (launch_ms * 1e-3) / 1e9
     us_iter = dev_ms * 1e3 / steps
+    issue = None
+    if spec is not None and spec["n_blocks"] == 1 and probe_rows:
+        issue = issue_roofline(probe_rows, ["bsvi_spec_kernel"], spec["n_blocks"] * spec["n_threads"], n_per_gpu,
+                               steps if mode == "persistent" else 1, us_iter, last_only=(mode == "persistent"))
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                     traffic=traffic, kernel=kernel, algorithmic_bytes_per_iteration=alg_bytes_iter,
                     iterations_per_launch=units_per_launch, launch_ms=launch_ms,
@@ -384,24 +430,32 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                          "curve — what bounds it is the serial instruction stream of one wave per sample group and the "
                          "workgroup barriers of an iteration (DESIGN.md 4.7); a launch-per-step design pays ~5-10 us of "
                          "launch latency per iteration on top" % us_iter)
+    if issue is not None:
+        roofline["issue"] = issue
     if dense:
         # the whole iteration (6 launches) is timed; the two MFMA GEMMs are >80 % of it (profiles/)
         flops = dense_flops_per_iteration(program, n_per_gpu)
         tf = flops / (dev_ms * 1e-3 / steps) / 1e12
         if probe_rows:
-            traffic = traffic_of(probe_rows, ["dense_", "xgemm_nt"], per=iters_probed or 1, double_fetch=True)
-            traffic_how = "all dense_* and xgemm_nt launches of the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
+            # (the probe runs every config in one process: the products of the six-launch form, `xgemm_nt_*`, are counted only
+            #  between this config's first and last `dense_` dispatch — config 5 launches the same kernels for its first layer,
+            #  and the driver's line of round 3 carried them in config 4's figure: 510 MB against 304 MB measured alone)
+            own = [r["dispatch"] for r in probe_rows if "dense_" in r["kernel"]]
+            span = [r for r in probe_rows if own and min(own) <= r["dispatch"] <= max(own)]
+            traffic = traffic_of(span, ["dense_", "xgemm_nt"], per=iters_probed or 1, double_fetch=True)
+            traffic_how = "all dense_* (and, six-launch form, xgemm_nt) launches of this config in the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
         exact = getattr(compiled, "data_path", lambda: "f32")() == "bf16x3"
         peak = MFMA_EXACT_PEAK_TFLOPS if exact else MFMA_F32_PEAK_TFLOPS
         roofline = dict(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s",
                         frac=tf / peak, traffic=traffic,
-                        kernel=("bsvi_amort_impl::xgemm_nt_kernel<128> x2 (logits product, gradient product)" if exact
-                                else "bsvi::dense_forward<10> + bsvi::dense_backward"),
+                        kernel=("dense_xfwd (draw + logits product + cross-entropy) + dense_xbwd (gradient product + reduction "
+                                "against the redrawn normals)" if exact else "bsvi::dense_forward<10> + bsvi::dense_backward"),
                         algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps, data_path="bf16x3" if exact else "f32",
                         frac_of_f32_mfma_peak=tf / MFMA_F32_PEAK_TFLOPS,
                         note=("the minibatch is exactly bf16 (pixel counts): both products run as three bf16 MFMAs on the exact "
                               "pieces hi + mid + lo of the f32 operand; peak = dense bf16 MFMA peak / 3; achieved = GEMM flops of "
-                              "one iteration / duration of the whole iteration (9 launches); frac_of_f32_mfma_peak compares with "
+                              "one iteration / duration of the whole iteration (6 launches, the two products fused with their "
+                              "neighbours: DESIGN.md 4.8); frac_of_f32_mfma_peak compares with "
                               "the f32-input MFMA kernels that serve inexact data" if exact else
                               "f32-input MFMA; achieved = GEMM flops of one iteration / duration of the whole iteration"))
     if amort:
@@ -447,6 +501,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                 iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
                 device_ms_per_step=dev_ms / steps, all_finite=ok,
                 final_loss=float(losses[-1].item()), roofline=roofline)
+    if cold is not None:
+        part["cold_start"] = cold
     del compiled, model
     return part, dict(builder=builder, kwargs=kwargs, n=n_per_gpu, optimizer=optimizer, opt_kwargs=opt_kwargs,
                       dense=dense, amort=amort)
@@ -549,8 +605,8 @@ def main():
         try:        # the other configs never cost the headline its line
             part, _ = measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows, probe_iters)
             keep = ("value", "unit", "steps", "warmup", "ms_per_step", "device_ms_per_step", "iters_per_sec", "samples_per_sec",
-                    "all_finite", "final_loss", "config", "roofline")
-            other_lines[workload] = {k: part[k] for k in keep}
+                    "all_finite", "final_loss", "config", "roofline", "cold_start")
+            other_lines[workload] = {k: part[k] for k in keep if k in part}
         except Exception as err:      # noqa: BLE001
             other_lines[workload] = dict(error="%s: %s" % (type(err).__name__, err))
         torch.cuda.empty_cache()
