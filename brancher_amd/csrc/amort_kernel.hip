@@ -2007,6 +2007,12 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
         if (prefetch_depth(mode) == 2) hipLaunchKernelGGL((gemm_kernel<MODE_TN, 64, 2>), grid, dim3(NTHREADS), 0, stream, G);
         else hipLaunchKernelGGL((gemm_kernel<MODE_TN, 64, 1>), grid, dim3(NTHREADS), 0, stream, G);
     } else {
+        // (round 4, measured and removed: stream-K — a grid of the resident slots, equal runs of (128 x 128 tile, k step) units
+        //  per workgroup, a cut tile finished by the later workgroup in a fixed order.  cfg 5's layers at 25 600 rows: 136 /
+        //  117 / 94 / 179 us forward and 108 / 158 / 140 us input gradient against 126 / 81 / 84 / 125 and 89 / 93 / 118 here.
+        //  With K = 256 ... 784 a tile is 16 ... 49 steps: what these shapes pay for is the tile's prologue and its 64 scalar
+        //  stores per thread, which four co-resident 64-row workgroups hide from each other and three persistent 128-row ones
+        //  do not — not the uneven last round the shape count suggested.)
         // 64-row tiles when 128-row tiles would leave most CUs with one or two workgroups
         static const int half_below = [] { const char* e = getenv("BSVI_GEMM_HALF_BELOW"); return e ? atoi(e) : 1536; }();
         const bool half = tiles < half_below && G.M > 64;

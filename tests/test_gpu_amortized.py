@@ -70,10 +70,11 @@ def test_gemm_matches_torch(mode, shape):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("shape", [(25600, 256, 784), (25600, 512, 256), (17000, 200, 72)])
+@pytest.mark.parametrize("shape", [(25600, 256, 784), (25600, 512, 256), (17000, 200, 72), (25600, 784, 256), (25000, 256, 512),
+                                   (9000, 300, 48)])
 def test_gemm_tall_products_at_config5_rows(mode, shape):
-    """tall products at the row counts of BASELINE config 5 (800 / 1600 / 532 output tiles: several workgroups per CU, edge
-    tiles along M and N): against torch in double precision, and bit-identical call after call."""
+    """tall products at the row counts of BASELINE config 5 (edge tiles along M and N): against torch in double precision, and
+    bit-identical call after call."""
     from brancher_amd import native
     lib = native.load()
     dev = torch.device("cuda:0")

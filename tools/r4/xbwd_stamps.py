@@ -24,5 +24,7 @@ for w in range(16):
     if len(row) < 2:
         continue
     d = np.diff(row)
-    print("block %s wave %d: prologue %6d | " % ("0  " if w < 8 else "133", w % 8, d[0]) +
-          " ".join("[wait %5d mfma %6d epi %6d]" % tuple(d[i:i + 3]) for i in range(1, len(d) - 2, 3)), "total", row[-1] - row[0])
+    role = "product" if (w % 8) < 4 else "partner"
+    # product waves: staging | then per block (product loop, hand-over); partner waves: staging | then per block (wait, epilogue)
+    print("block %s wave %d %s: staging %6d | " % ("0  " if w < 8 else "133", w % 8, role, d[0]) +
+          " ".join("[%6d %6d]" % tuple(d[i:i + 2]) for i in range(1, len(d) - 1, 2)), "total", row[-1] - row[0])
