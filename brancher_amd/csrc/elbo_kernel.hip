@@ -1810,7 +1810,9 @@ static int try_spec(const bsvi_program* p, const bsvi_elbo_args* a, int mode, co
                     float* state, const uint8_t* mask, const uint8_t* mask_first, uint32_t pretraining, uint32_t n_iterations,
                     float* loss_slot, float* finite_slot) {
     if (!p->spec || g_debug_stamps || !bsvi_spec::applies(p->spec, a->n_samples_local, mode)) return 0;
-    if (a->f_weight_dev || a->q_weight_dev) return 0;       // caller-weighted gradients: the interpreter kernels
+    // (caller-weighted gradients — bsvi_elbo_args::f_weight_dev / q_weight_dev, the second pass of a user-defined gradient
+    //  estimator — are served by the diagnostic variant of the specialised kernel: one-launch evaluations only)
+    if ((a->f_weight_dev || a->q_weight_dev) && mode != bsvi_spec::MODE_SUMS) return 0;
     bsvi_spec::Launch L;
     L.a = a; L.mode = mode; L.cfg = cfg; L.params = params; L.state = state; L.mask = mask; L.mask_first = mask_first;
     L.pretraining_iterations = pretraining; L.n_iterations = n_iterations; L.loss_slot = loss_slot; L.finite_slot = finite_slot;

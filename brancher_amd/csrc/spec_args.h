@@ -32,6 +32,8 @@ struct SpecArgs {
     float* loss_slot;                    // step: one slot (or null); loop: the loss curve
     float* finite_slot;
     const unsigned long long* offset_dev;   // added to the Philox offset when non-null (bsvi_elbo_args::offset_dev)
+    const float* f_weight;               // diagnostic variant: caller weights of grad f_n / grad log q_n (bsvi_elbo_args::f_weight_dev,
+    const float* q_weight;               //   q_weight_dev — the second pass of a user-defined gradient estimator), or null
     uint32_t n_local, n_global, sample_base, mode;
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
     uint32_t n_iterations, pretraining_iterations, n_params, reserved;

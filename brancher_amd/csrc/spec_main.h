@@ -307,8 +307,11 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     B0.samples_out = SPEC_A->samples_out;
     B0.noise_out = SPEC_A->noise_out;
     B0.fvalue_out = SPEC_A->fvalue_out;
+    B0.f_weight = SPEC_A->f_weight;
+    B0.q_weight = SPEC_A->q_weight;
 #else
     B0.noise = nullptr; B0.samples_out = nullptr; B0.noise_out = nullptr; B0.fvalue_out = nullptr;
+    B0.f_weight = nullptr; B0.q_weight = nullptr;
 #endif
     unsigned long long off0 = ((unsigned long long)SPEC_A->offset_hi << 32) | SPEC_A->offset_lo;
     if (const unsigned long long* const offset_dev = SPEC_A->offset_dev) off0 += *offset_dev;
@@ -353,6 +356,11 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             const unsigned long long off = off0 + it;
             T.f = 0.0f;
             T.lq = 0.0f;
+#if SPEC_DIAG
+            T.gw = B.f_weight ? B.f_weight[T.nc] : 1.0f;
+#else
+            T.gw = 1.0f;
+#endif
             T.off_lo = (uint32_t)off;
             T.off_hi = (uint32_t)(off >> 32);
 #if !SPEC_EARLY_DRAW

@@ -27,12 +27,15 @@ struct SpecBody {
     float* samples_out;
     float* noise_out;
     float* fvalue_out;
+    const float* f_weight;               // caller weights (diagnostic variant), or null
+    const float* q_weight;
     uint32_t n_local, seed_lo, seed_hi;
 };
 
 // per-lane state of the generated body
 struct SpecLane {
     float f, lq;             // log p + entropy terms; log q (score term of the BlackBox estimator)
+    float gw;                // weight of this sample's grad f (1, or the caller's f_weight: diagnostic variant)
     uint32_t n, nc;          // local sample index; clamped to the shard (inactive lanes shadow the last sample)
     uint32_t nidx;           // global sample index: Philox counter
     uint32_t lane;

@@ -302,6 +302,10 @@ private:
         }
     }
 
+    // the weight of a term's GRADIENT: the record's constant — times the caller's per-sample weight in the diagnostic variant
+    // (bsvi_elbo_args::f_weight_dev: the second pass of a user-defined gradient estimator; 1 without one)
+    std::string wg(uint32_t imm) const { return diag_ ? "(" + flit(imm) + " * T.gw)" : flit(imm); }
+
     // ---- a model log-prob term N(value | A*B + C, S) finished in the forward sweep (elbo_kernel.hip naff_sink)
     void naff_sink(const Insn& I, uint32_t e) {
         ++visits_;
@@ -310,6 +314,7 @@ private:
             line("{");
             line(fmt("  float gl, gs; spec_naff_sink(%s, %s, %s * %s + %s, %s, %s, T.f, gl, gs);", flit(I.imm0).c_str(), val(I.dst, e).c_str(),
                      A.c_str(), B.c_str(), val(I.c, e).c_str(), rcp_of(I.s, e).c_str(), log_of(I.s, e).c_str()));
+            if (diag_) line("  gl *= T.gw; gs *= T.gw;");
         }
         add_adj(I.dst, e, "-gl");
         add_adj(I.a, e, "gl * " + B);
@@ -330,10 +335,10 @@ private:
                 line(fmt("  const float rS = %s, loc = %s * %s + %s;", rcp_of(I.s, e).c_str(), A.c_str(), B.c_str(), val(I.c, e).c_str()));
                 line("  float gv = 0.0f, gl = 0.0f, gs = 0.0f;");
                 if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
-                    const std::string gw = (flags & BSVI_F_WF) ? fmt("(%s + fweight)", flit(I.imm0).c_str()) : flit(I.imm0);
+                    const std::string gw = (flags & BSVI_F_WF) ? fmt("(%s + fweight)", wg(I.imm0).c_str()) : wg(I.imm0);
                     line(fmt("  spec_naff_lp_bwd(%s, %s, loc, rS, gv, gl, gs);", gw.c_str(), v.c_str()));
                 }
-                if (flags & BSVI_F_ENT) line(fmt("  gs += %s * rS;", flit(I.imm1).c_str()));
+                if (flags & BSVI_F_ENT) line(fmt("  gs += %s * rS;", wg(I.imm1).c_str()));
             }
             if (flags & BSVI_F_SAMPLE) {
                 // a sampled latent's own adjoint is its incoming gradient: folded into loc / scale, left unchanged
@@ -385,11 +390,11 @@ private:
                 line(fmt("  const float p0 = %s, p1 = %s;", val(I.a, e).c_str(), val(I.b, e).c_str()));
                 line("  float gv = 0.0f, g0 = 0.0f, g1 = 0.0f;");
                 if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
-                    const std::string gw = (flags & BSVI_F_WF) ? fmt("(%s + fweight)", flit(I.imm0).c_str()) : flit(I.imm0);
+                    const std::string gw = (flags & BSVI_F_WF) ? fmt("(%s + fweight)", wg(I.imm0).c_str()) : wg(I.imm0);
                     line(fmt("  { const float4 r = logp_bwd_generic(%u, %s, p0, p1, %s); gv += r.x; g0 += r.y; g1 += r.z; }", dist, v.c_str(), gw.c_str()));
                 }
                 if (flags & BSVI_F_ENT)
-                    line(fmt("  { const float2 r = entropy_bwd_generic(%u, p0, p1, %s); g0 += r.x; g1 += r.y; }", dist, flit(I.imm1).c_str()));
+                    line(fmt("  { const float2 r = entropy_bwd_generic(%u, p0, p1, %s); g0 += r.x; g1 += r.y; }", dist, wg(I.imm1).c_str()));
             }
             if (flags & BSVI_F_SAMPLE) {
                 if (!counting_) {
@@ -541,7 +546,9 @@ private:
             maybe_fence();
             if (visits_ > kMaxVisits) return;
         }
-        line("const float fweight = T.f; (void)fweight;");
+        // the weight of grad log q_n (BlackBox: the complete f_n; a caller's q_weight in the diagnostic variant)
+        if (diag_) line("const float fweight = A.q_weight ? A.q_weight[T.nc] : T.f * T.gw; (void)fweight;");
+        else line("const float fweight = T.f; (void)fweight;");
         if (fence) {
             // long programs: the reverse sweep recomputes a node's location from its parents' values; as a common
             // subexpression of the forward sweep's the optimiser would instead keep all of them (one register per node
@@ -994,7 +1001,7 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     if (!a->out_dev) return bsvi_fail(BSVI_ERR_INVALID, "out_dev is null");
     if (!a->n_samples_local || !a->n_samples_global) return bsvi_fail(BSVI_ERR_INVALID, "zero samples");
     Geo g = geo(s, a->n_samples_local, L.mode);
-    int v = 2 * g.geom + ((a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev) ? 1 : 0);
+    int v = 2 * g.geom + ((a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || a->f_weight_dev || a->q_weight_dev) ? 1 : 0);
     uint32_t seq;
     {
         std::lock_guard<std::mutex> lock(s->mu);
@@ -1022,6 +1029,7 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     A.seed_lo = (uint32_t)a->seed; A.seed_hi = (uint32_t)(a->seed >> 32);
     A.offset_lo = (uint32_t)a->offset; A.offset_hi = (uint32_t)(a->offset >> 32);
     A.offset_dev = (const unsigned long long*)a->offset_dev;
+    A.f_weight = a->f_weight_dev; A.q_weight = a->q_weight_dev;
     A.n_iterations = L.n_iterations; A.pretraining_iterations = L.pretraining_iterations; A.n_params = s->n_params;
     if (L.cfg) A.cfg = *L.cfg;
     size_t size = sizeof A;

@@ -152,13 +152,17 @@ def test_taylor1_estimator_matches_reference_golden(case):
     assert engine.compile_model(model, None, Taylor1Estimator) is c
 
 
+@pytest.mark.parametrize("jit", ["1", "0"], ids=["specialised", "interpreter"])
 @pytest.mark.parametrize("which", ["baseline", "softmax"])
 @pytest.mark.parametrize("case", [c for c in golden_cases() if "loss_custom_baseline" in Golden(c).data.files])
-def test_user_defined_estimator_matches_reference_golden(case, which):
+def test_user_defined_estimator_matches_reference_golden(case, which, jit, monkeypatch):
     """The GradientEstimator seam (gradient_estimators.py:17-26): the SAME subclass bodies the real reference ran
     (workloads.custom_estimators) on this engine — two passes of the fused kernel around the user's torch code
-    (engine.custom_estimator_loss) — against the reference's loss and gradients on its recorded draws."""
+    (engine.custom_estimator_loss) — against the reference's loss and gradients on its recorded draws.  On BOTH engines of
+    the scalar path: the program-specialised kernels a user gets by default (the per-sample weights of the second pass are
+    an operand of its diagnostic variant since round 4) and the interpreter kernels (BSVI_JIT=0)."""
     from brancher_amd import gradient_estimators as ge
+    monkeypatch.setenv("BSVI_JIT", jit)
     g = Golden(case)
     model = g.build()
     cls = W.custom_estimators(ge)[which]
@@ -166,6 +170,8 @@ def test_user_defined_estimator_matches_reference_golden(case, which):
     ref = float(g.data["loss_custom_" + which])             # the fixture holds the LOSS: -estimator value
     assert abs(-float(value.detach().cpu()) - ref) <= TOL * abs(ref)
     grad_check(value.compiled.named_grads(), g.group("grad_custom_%s/" % which), 1e-4)
+    served = value.compiled.native.engine(g.N, 0)["engine"]
+    assert served == ("specialised" if jit == "1" else "interpreter"), served
 
 
 def test_builtin_estimators_written_against_the_seam_reproduce_the_builtin_programs():
