@@ -13,6 +13,12 @@
 //   4  S = C^-1 = X^T X, row i by lane i                        A <- S          (both triangles)
 //   5  alpha = S d,  quad = d.alpha,  log p = -quad/2 - sum log L_ii - D/2 log 2pi
 //   6  dlogp/dC = (alpha alpha^T - S)/2  contracted with the expression's derivatives -> dlogp/ds_k;  dlogp/dx = -alpha
+// The other two parameterisations of `distributions.py:314-331` run through the same steps with the roles changed (MVN_FORM):
+//   scale_tril        the expression IS L (its lower triangle): step 2 only adds up log L_ii; with y = L^-1 d (= X d)
+//                     d log p / d L_ij = alpha_i y_j - [i = j] / L_ii   for i >= j  (alpha = L^-T y = C^-1 d as before)
+//   precision_matrix  alpha = P d and the quadratic form come first (from the expression's lower triangle); then P = M M^T is
+//                     factorised where C was, log p = -d.alpha / 2 + sum log M_ii - D/2 log 2pi, S = X^T X with X = M^-1 is
+//                     P^-1, and  d log p / d P = (S - d d^T) / 2
 // Rows are 16-byte aligned with a stride of 4 * odd words: every inner product runs on ds_read_b128 along k, conflict-free
 // across the lanes' rows; both matrices start zeroed so that aligned 4-wide blocks may overrun a triangle's edge.
 //
@@ -109,8 +115,33 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
     }
     __syncthreads();
 
+#if MVN_FORM == 2
+    // ---- precision form: alpha = P d from the lower triangle (row part along k, column part down the rows), before P is factorised
+    float quad = 0.0f;
+    for (int t = 0; t < (D + 63) / 64; ++t) {
+        const int i = lane + 64 * t;
+        if (i < D) {
+            float acc = 0.0f;
+            for (int k = 0; k <= i; ++k) acc += A[i * LD + k] * dvec[k];
+            for (int k = i + 1; k < D; ++k) acc += A[k * LD + i] * dvec[k];
+            avec[i] = acc;
+            quad += acc * dvec[i];
+        }
+    }
+    quad = mvn_wave_sum(quad);
+    __syncthreads();
+#endif
+
     // ---- 2: Cholesky (left-looking): column j from the columns before it
     float logdet = 0.0f;
+#if MVN_FORM == 1
+    // (scale_tril: the lower triangle already holds L)
+    for (int t = 0; t < (D + 63) / 64; ++t) {
+        const int i = lane + 64 * t;
+        if (i < D) logdet += logf(A[i * LD + i]);
+    }
+    logdet = mvn_wave_sum(logdet);
+#else
     for (int j = 0; j < D; ++j) {
         float s[(D + 63) / 64];
         const int jb = j & ~3;
@@ -140,6 +171,7 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
         }
         __syncthreads();
     }
+#endif
 
     // ---- 3: X = L^-1, column j by lane j, kept transposed: XT[j][i] = X[i][j] = -(sum_{j<=k<i} L[i][k] X[k][j]) / L[i][i]
     for (int t = 0; t < (D + 63) / 64; ++t) {
@@ -160,6 +192,20 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
     }
     __syncthreads();
 
+#if MVN_FORM == 1
+    // ---- scale_tril form: y = L^-1 d = X d, y_j = sum_{k <= j} X[j][k] d_k = sum_k XT[k][j] d_k (lanes along j: conflict-free)
+    __shared__ __attribute__((aligned(16))) float yvec[(D + 3) / 4 * 4 + 4];
+    for (int t = 0; t < (D + 63) / 64; ++t) {
+        const int j = lane + 64 * t;
+        if (j < D) {
+            float acc = 0.0f;
+            for (int k = 0; k <= j; ++k) acc += XT[k * LD + j] * dvec[k];
+            yvec[j] = acc;
+        }
+    }
+    __syncthreads();
+#endif
+
     // ---- 4: S = X^T X:  S[i][j] = sum_{k >= i} XT[i][k] XT[j][k]  (i >= j), written to both triangles of A
     for (int t = 0; t < (D + 63) / 64; ++t) {
         const int i = lane + 64 * t;
@@ -178,6 +224,7 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
     __syncthreads();
 
     // ---- 5: alpha = S d, the quadratic form, log p
+#if MVN_FORM != 2
     float quad = 0.0f;
     for (int t = 0; t < (D + 63) / 64; ++t) {
         const int i = lane + 64 * t;
@@ -197,6 +244,9 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
     quad = mvn_wave_sum(quad);
     __syncthreads();
     const float logp = -0.5f * quad - logdet - 0.5f * (float)D * 1.8378770664093453f;
+#else
+    const float logp = -0.5f * quad + logdet - 0.5f * (float)D * 1.8378770664093453f;      // (logdet = sum log M_ii = log det P / 2)
+#endif
 
     // ---- 6: dlogp/ds_k = sum_{i >= j} m_ij (alpha_i alpha_j - S_ij) / 2 * dC_ij/ds_k   (m_ij = 2 off the diagonal: C is symmetric)
     float gin[MVN_NIN_PAD];
@@ -210,7 +260,13 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
         const int j = e - i * (i + 1) / 2;
         float c, dc[MVN_NIN_PAD];
         mvn_cov(i, j, in, G.mats, c, dc);
+#if MVN_FORM == 0
         const float gij = (i == j ? 0.5f : 1.0f) * (avec[i] * avec[j] - A[i * LD + j]);
+#elif MVN_FORM == 1
+        const float gij = avec[i] * yvec[j] - (i == j ? XT[i * LD + i] : 0.0f);           // (X_ii = 1 / L_ii)
+#else
+        const float gij = (i == j ? 0.5f : 1.0f) * (A[i * LD + j] - dvec[i] * dvec[j]);
+#endif
 #pragma unroll
         for (int k = 0; k < MVN_NIN; ++k) gin[k] += gij * dc[k];
     }

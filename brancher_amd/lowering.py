@@ -973,20 +973,15 @@ class _Lowering:
             log N(x | m, L L^T) = sum_i log Normal(u_i | 0, L_ii).
         ~D^3 / 3 multiply-adds of ordinary link arithmetic: the reverse mode through the factorisation comes for free, shared
         entries of L become derived slots (computed once per sample)."""
-        if given == "precision_matrix":
-            raise LoweringError("a precision matrix that depends on learnable or sampled values is not lowered (covariance_matrix "
-                                "and scale_tril are)")
         links = v.link.expressions()
         mat = self.from_expr(links[given].expr, self.p_value)
         B, dim, dim2 = mat.shape
         if B != 1 or dim != dim2:
             raise LoweringError("%s of %r must be one square matrix per sample (shape %r)" % (given, v.name, mat.shape))
-        if dim > self.kMaxSymbolicMvn:
-            if given != "covariance_matrix":
-                raise LoweringError("%r: a %dx%d scale_tril that depends on learnable or sampled values (the factorisation is "
-                                    "unrolled per sample up to %d; larger nodes take a covariance_matrix: the batched "
-                                    "kernel)" % (v.name, dim, dim, self.kMaxSymbolicMvn))
-            return self.mvn_external(v, mat)
+        if dim > self.kMaxSymbolicMvn or given == "precision_matrix":
+            # the batched kernel serves all three parameterisations (bsvi_mvn_form): a scale_tril needs no factorisation there,
+            # a precision matrix is factorised in place of the covariance (its inverse is never unrolled symbolically)
+            return self.mvn_external(v, mat, given)
         value = self.p_value(v)
         loc = self.from_expr(links["loc"].expr, self.p_value)
         for what, node in (("value", value), ("loc", loc)):
@@ -1030,7 +1025,7 @@ class _Lowering:
 
     kMaxExternalMvn = 136
 
-    def mvn_external(self, v, mat):
+    def mvn_external(self, v, mat, given="covariance_matrix"):
         """A MultivariateNormal term too large to unroll (D > kMaxSymbolicMvn) whose covariance is an ELEMENTWISE expression of
         constant matrices and SCALARS that are sampled or learnable: it leaves the per-sample program for the batched kernel
         of the library (`bsvi_mvn_*`, csrc/mvn_kernel.h: one wave per sample factorises the covariance in LDS).  Here the
@@ -1139,6 +1134,7 @@ class _Lowering:
                 loc_vec = np.broadcast_to(a + b * host_g[g](raw), (dim,))
         node = ExternalMvn()
         node.name, node.dim, node.code, node.weight = v.name, dim, code, 1.0
+        node.form = given                      # covariance_matrix | scale_tril | precision_matrix (bsvi_mvn_form)
         node.mats = np.stack(mats) if mats else np.zeros((0, dim, dim), np.float32)
         node.loc = np.ascontiguousarray(loc_vec, dtype=np.float32)
         node.slot_inputs = [row for _, row in slot_inputs]

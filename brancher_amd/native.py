@@ -209,7 +209,7 @@ class MvnDesc(Sized):
                 ("n_slot_inputs", C.c_uint32), ("n_uniform_inputs", C.c_uint32), ("value_is_latent", C.c_uint32),
                 ("loc_is_param", C.c_uint32),
                 ("code", C.POINTER(MvnInsn)), ("mats", C.c_void_p), ("loc", C.c_void_p), ("value", C.c_void_p),
-                ("uniform_inputs", C.c_void_p), ("loc_entries", C.c_void_p), ("weight", C.c_float), ("reserved2", C.c_uint32)]
+                ("uniform_inputs", C.c_void_p), ("loc_entries", C.c_void_p), ("weight", C.c_float), ("form", C.c_uint32)]
 
 
 class MvnArgs(Sized):
@@ -220,6 +220,7 @@ class MvnArgs(Sized):
 
 
 MVN_KIND = dict(MAT=0, INPUT=1, IMM=2, BIN=3, UN=4)
+MVN_FORM = dict(covariance_matrix=0, scale_tril=1, precision_matrix=2)      # bsvi_mvn_form
 EXPORTS.update({
     "bsvi_mvn_create": (C.c_int, [C.POINTER(MvnDesc), C.POINTER(C.c_void_p)]),
     "bsvi_mvn_destroy": (None, [C.c_void_p]),
@@ -243,7 +244,7 @@ def mvn_desc(node):
                 n_slot_inputs=len(node.slot_inputs), n_uniform_inputs=len(uni), value_is_latent=int(node.value is None),
                 loc_is_param=int(loc_entries is not None), loc_entries=_ptr(loc_entries) if loc_entries is not None else None,
                 code=code, mats=_ptr(mats), loc=_ptr(loc), value=_ptr(value), uniform_inputs=_ptr(uni) if len(uni) else None,
-                weight=float(node.weight))
+                weight=float(node.weight), form=MVN_FORM[getattr(node, "form", "covariance_matrix")])
     return d, keep
 
 

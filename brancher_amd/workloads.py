@@ -291,6 +291,34 @@ def build_gp_hyperparameters(api, n=5, jitter=1e-2, noise=0.2, seed=0, learnable
     return model
 
 
+def build_mvn_forms(api, n=16, form="scale_tril", noise=0.3, seed=0):
+    """The other two parameterisations of `MultivariateNormalVariable` (`standard_variables.py:317-347`,
+    `distributions.py:314-331`) with a matrix that depends on a sampled scalar, as an ELEMENTWISE link expression of constant
+    matrices: `scale_tril = L0 * s + jitter I` (L0 the Cholesky factor of a squared-exponential kernel) or
+    `precision_matrix = P0 * tau + jitter I` (P0 its inverse) with a LogNormal latent scale inferred by a LogNormal
+    posterior; y ~ Normal(f, noise) observed."""
+    rng = np.random.RandomState(seed)
+    x = np.linspace(-2., 2., n)
+    K0 = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / 0.8 ** 2) + 0.05 * np.eye(n)
+    if form == "scale_tril":
+        base, jit = np.linalg.cholesky(K0), 0.02
+    elif form == "precision_matrix":
+        base, jit = np.linalg.inv(K0), 0.05
+    else:
+        base, jit = K0, 0.02
+    mat0 = api.RootVariable(base.astype(np.float32), "base_matrix")
+    eye = api.RootVariable((jit * np.eye(n)).astype(np.float32), "jitter")
+    s = api.LogNormalVariable(0.1, 0.3, "s")
+    f = api.MultivariateNormalVariable(loc=np.zeros((n,)), name="f", **{form: mat0 * s + eye})
+    y = api.NormalVariable(f, noise, name="y")
+    model = api.ProbabilisticModel([y])
+    y.observe((np.sin(2 * np.pi * 0.3 * x) + noise * rng.normal(0., 1., (1, n))).astype(np.float32))
+    Qs = api.LogNormalVariable(0.0, 0.2, "s", learnable=True)
+    Qf = api.NormalVariable(loc=np.zeros((n,)), scale=0.7, name="f", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qs, Qf]))
+    return model
+
+
 def build_map_estimate(api, n_obs=12, seed=0):
     """Point estimates (MAP, `inference.py:251-275`; `examples/MAP_logistic_regression.py:46-56`): the "posterior" is a
     model of learnable RootVariables carrying the latents' names.  No sampling and no entropy: the loss is

@@ -637,8 +637,13 @@ typedef struct bsvi_mvn_desc {
     const bsvi_uniform_entry* loc_entries;     /* host [dim]: a LEARNABLE loc (loc_is_param; by the reference's name-collision rule
                                                   the prior's loc root is often the posterior's learnable mean) */
     float weight;                              /* of log p in f */
-    uint32_t reserved2;
+    uint32_t form;                             /* bsvi_mvn_form: what the expression yields (distributions.py:314-331) */
 } bsvi_mvn_desc;
+typedef enum bsvi_mvn_form {
+    BSVI_MVN_COVARIANCE = 0,    /* MultivariateNormalVariable(covariance_matrix=...): factorised per sample              */
+    BSVI_MVN_SCALE_TRIL = 1,    /* (scale_tril=...): the expression IS the Cholesky factor (lower triangle): no factorisation */
+    BSVI_MVN_PRECISION = 2      /* (precision_matrix=...): the precision is factorised; its inverse is the covariance    */
+} bsvi_mvn_form;
 typedef struct bsvi_mvn_args {
     uint32_t struct_size, reserved0;           /* sizeof(bsvi_mvn_args) */
     const float* params_dev;

@@ -56,6 +56,11 @@ CASES = {
     # the same model with 32 / 100 inputs: the covariance no longer fits the per-sample program (batched kernel, bsvi_mvn_*)
     "gp_hyperparameters_n32_N40": ("build_gp_hyperparameters", dict(n=32, jitter=5e-2), 40, 31, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
     "gp_hyperparameters_n100_N24": ("build_gp_hyperparameters", dict(n=100, jitter=5e-2), 24, 37, dict(iters=3, n=12, optimizer="Adam", lr=1e-2)),
+    # the other two parameterisations of the MultivariateNormal node, with a matrix that depends on a sampled scale
+    # (bsvi_mvn_form: the batched kernel skips the factorisation for a scale_tril and factorises the precision in its place)
+    "mvn_scale_tril_n24_N40": ("build_mvn_forms", dict(n=24, form="scale_tril"), 40, 41, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
+    "mvn_precision_n24_N40": ("build_mvn_forms", dict(n=24, form="precision_matrix"), 40, 43, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
+    "mvn_precision_n6_N60": ("build_mvn_forms", dict(n=6, form="precision_matrix"), 60, 47, None),
     "learnable_model_N60": ("build_learnable_model", dict(n_obs=15), 60, 13, dict(iters=6, n=40, optimizer="Adam", lr=0.02)),
     "discrete_latent_N200": ("build_discrete_latent", dict(n_obs=8), 200, 12, None),
     "heavy_tails_N64": ("build_heavy_tails", dict(n_obs=12), 64, 6, dict(iters=4, n=32, optimizer="Adam", lr=1e-2)),
