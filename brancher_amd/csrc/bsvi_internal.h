@@ -80,9 +80,14 @@ struct Launch {
     float* loss_slot = nullptr;
     float* finite_slot = nullptr;
     void* workspace = nullptr;      // the spec's region of the caller's workspace
+    const void* xchg = nullptr;     // loop mode on several ranks: the device-resident descriptor of the exchange (SpecExchange), or null
 };
 int launch(Spec* s, const bsvi_program* p, const Launch& L);
 // geometry of that launch (tests / bench)
 void geometry(const Spec* s, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads, uint32_t* lds_bytes);
 
 }  // namespace bsvi_spec
+
+// collective.hip: the device-resident descriptor of a connected exchange for a message of n floats (what a generated kernel
+// that exchanges inside its training loop reads: SpecExchange, spec_args.h), or null with the reason in bsvi_last_error
+const void* bsvi_exchange_descriptor(bsvi_exchange* x, uint32_t n);

@@ -30,6 +30,7 @@
 
 #include "bsvi.h"
 #include "bsvi_internal.h"
+#include "spec_args.h"      // the region layout, shared with the generated kernels that exchange inside their training loop
 
 // ---------------------------------------------------------------------------------------------------------------
 //  RCCL through the instance the process already has
@@ -92,10 +93,10 @@ extern "C" int bsvi_allreduce(void* rccl_comm, float* buf_dev, size_t n, void* s
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t kMaxRanks = 8;           // one node: 8 GPUs, 7 xGMI peers each
-constexpr uint32_t kFlagStride = 16;        // a flag per 64-byte line
-constexpr uint32_t kHeaderWords = 256;      // flags [8 x 16] | abort | timeouts | calls | ... (1 KB)
-constexpr uint32_t kCallsWord = kMaxRanks * kFlagStride + 16;
+constexpr uint32_t kMaxRanks = bsvi::XCHG_MAX_RANKS;           // one node: 8 GPUs, 7 xGMI peers each
+constexpr uint32_t kFlagStride = bsvi::XCHG_FLAG_STRIDE;       // a flag per 64-byte line
+constexpr uint32_t kHeaderWords = bsvi::XCHG_HEADER_WORDS;     // flags [8 x 16] | abort | timeouts | calls | ... (1 KB)
+constexpr uint32_t kCallsWord = bsvi::XCHG_CALLS_WORD;
 
 struct XArgs {
     unsigned char* peer[kMaxRanks];         // every rank's region as mapped here (peer[rank] = this rank's own)
@@ -185,7 +186,27 @@ struct bsvi_exchange {
     bool opened[kMaxRanks] = {};
     bool connected = false;
     unsigned long long timeout_ticks = 0;
+    bsvi::SpecExchange* desc_dev = nullptr;     // the exchange as a kernel that runs it inside its own loop reads it (spec_main.h)
 };
+
+// device-resident copy of (peers, rank, world, capacity, timeout): written once, when every peer's region is mapped
+static int publish_descriptor(bsvi_exchange* x) {
+    bsvi::SpecExchange d;
+    memset(&d, 0, sizeof d);
+    for (uint32_t r = 0; r < x->world; ++r) d.peer[r] = x->peer[r];
+    d.rank = x->rank; d.world = x->world; d.capacity = x->capacity; d.timeout_ticks = x->timeout_ticks;
+    if (!x->desc_dev && hipMalloc((void**)&x->desc_dev, sizeof d) != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, "bsvi_exchange: descriptor allocation failed");
+    if (hipMemcpy(x->desc_dev, &d, sizeof d, hipMemcpyHostToDevice) != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, "bsvi_exchange: descriptor upload failed");
+    return BSVI_OK;
+}
+
+// (bsvi_internal.h) the descriptor for a message of n floats, or null with the reason in bsvi_last_error
+const void* bsvi_exchange_descriptor(bsvi_exchange* x, uint32_t n) {
+    if (!x || !x->connected) { (void)bsvi_fail(BSVI_ERR_INVALID, "the exchange's peers are not connected yet"); return nullptr; }
+    if (n > x->capacity) { (void)bsvi_fail(BSVI_ERR_INVALID, "message longer than the exchange's capacity"); return nullptr; }
+    if (!x->desc_dev && publish_descriptor(x) != BSVI_OK) return nullptr;
+    return x->desc_dev;
+}
 
 extern "C" size_t bsvi_exchange_handle_bytes(void) { return sizeof(hipIpcMemHandle_t); }
 
@@ -248,7 +269,7 @@ extern "C" int bsvi_exchange_connect(bsvi_exchange* x, const void* handles) {
         x->opened[r] = true;
     }
     x->connected = true;
-    return BSVI_OK;
+    return publish_descriptor(x);
 }
 
 extern "C" int bsvi_exchange_allreduce(bsvi_exchange* x, float* buf_dev, uint32_t n, void* stream) {
@@ -280,5 +301,6 @@ extern "C" void bsvi_exchange_destroy(bsvi_exchange* x) {
     for (uint32_t r = 0; r < x->world; ++r)
         if (x->opened[r] && x->peer[r]) (void)hipIpcCloseMemHandle(x->peer[r]);
     if (x->region) (void)hipFree(x->region);
+    if (x->desc_dev) (void)hipFree(x->desc_dev);
     delete x;
 }

@@ -2103,6 +2103,33 @@ extern "C" int bsvi_train_persistent2(const bsvi_program* p, const bsvi_elbo_arg
                                  pretraining_iterations, n_iterations, loss_curve_dev, finite_dev);
 }
 
+// K iterations of the SHARDED loop in one launch per rank: this rank's samples, the cross-rank sum of the loss words and the
+// per-parameter gradient sums INSIDE the loop (spec_main.h, spec_exchange: the one-shot direct-write exchange run by the
+// owners' wave), the replicated optimizer step.  Served by the program-specialised one-workgroup kernel only.
+extern "C" int bsvi_train_persistent_exchange(const bsvi_program* p, const bsvi_elbo_args* a, const bsvi_opt_cfg* cfg,
+                                              float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
+                                              const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
+                                              uint32_t n_iterations, float* loss_curve_dev, float* finite_dev, bsvi_exchange* x) {
+    if (!p || !a || !x) return fail(BSVI_ERR_INVALID, "null argument");
+    BSVI_CHECK_STRUCT(a, bsvi_elbo_args);
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!a->out_dev || !params_dev || !active_mask_dev || !active_mask_first_dev || !loss_curve_dev || !finite_dev)
+        return fail(BSVI_ERR_INVALID, "null argument");
+    if (a->offset_dev) return fail(BSVI_ERR_INVALID, "the in-kernel training loop counts its own iterations: offset_dev must be null");
+    if (a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || a->f_weight_dev || a->q_weight_dev)
+        return fail(BSVI_ERR_UNSUPPORTED, "the in-loop exchange serves Philox noise without per-sample outputs");
+    if (!p->spec || g_debug_stamps || !bsvi_spec::applies(p->spec, a->n_samples_local, bsvi_spec::MODE_LOOP))
+        return fail(BSVI_ERR_UNSUPPORTED, "this shard does not run on the program-specialised one-workgroup kernel");
+    const void* desc = bsvi_exchange_descriptor(x, BSVI_OUT_HEADER + p->d.n_params);
+    if (!desc) return BSVI_ERR_INVALID;
+    bsvi_spec::Launch L;
+    L.a = a; L.mode = bsvi_spec::MODE_LOOP; L.cfg = cfg; L.params = params_dev; L.state = state_dev; L.mask = active_mask_dev;
+    L.mask_first = active_mask_first_dev; L.pretraining_iterations = pretraining_iterations; L.n_iterations = n_iterations;
+    L.loss_slot = loss_curve_dev; L.finite_slot = finite_dev; L.workspace = spec_workspace(p, a); L.xchg = desc;
+    return bsvi_spec::launch(p->spec, p, L);
+}
+
 // Attach the shares of a program (programs created from lowering.Program.shares[n]: identical tables, own code) for the
 // multi-workgroup launches of bsvi_elbo_fwd_bwd / bsvi_svi_step.  The shares must outlive `p`'s use.
 extern "C" int bsvi_program_set_shares(bsvi_program* p, const bsvi_program* const* shares, uint32_t n_shares) {

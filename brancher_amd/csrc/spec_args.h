@@ -10,6 +10,18 @@ namespace bsvi {
 
 enum { SPEC_MODE_SUMS = 0, SPEC_MODE_STEP = 1, SPEC_MODE_LOOP = 2 };
 
+// The one-shot exchange (collective.hip) as the in-kernel training loop sees it: a rank's region is
+//   [header: XCHG_HEADER_WORDS words][slots: 2 parities x world ranks x capacity floats]
+// header words: flag of rank r at r * XCHG_FLAG_STRIDE (the sequence number of r's last complete call) | abort word at
+// XCHG_MAX_RANKS * XCHG_FLAG_STRIDE (+1: how often this rank gave up) | XCHG_CALLS_WORD: this rank's own call count.
+// ONE definition for the exchange kernel of the library and the generated kernels, which take part in the same sequence.
+enum { XCHG_MAX_RANKS = 8, XCHG_FLAG_STRIDE = 16, XCHG_HEADER_WORDS = 256, XCHG_CALLS_WORD = XCHG_MAX_RANKS * XCHG_FLAG_STRIDE + 16 };
+struct SpecExchange {                    // device-resident, written once when the peers are connected
+    unsigned char* peer[XCHG_MAX_RANKS]; // every rank's region as mapped into this process (peer[rank]: its own)
+    uint32_t rank, world, capacity, reserved;
+    unsigned long long timeout_ticks;    // of the 100 MHz wall clock
+};
+
 // kernel argument block (mirrored by the host in specialize.cpp; plain data, 8-byte aligned pointers first)
 struct SpecArgs {
     const bsvi_uniform_entry* uniform;   // [SPEC_N_UNIFORM]
@@ -34,6 +46,7 @@ struct SpecArgs {
     const unsigned long long* offset_dev;   // added to the Philox offset when non-null (bsvi_elbo_args::offset_dev)
     const float* f_weight;               // diagnostic variant: caller weights of grad f_n / grad log q_n (bsvi_elbo_args::f_weight_dev,
     const float* q_weight;               //   q_weight_dev — the second pass of a user-defined gradient estimator), or null
+    const SpecExchange* xchg;            // loop mode on several ranks: the sums of every iteration are exchanged INSIDE the loop, or null
     uint32_t n_local, n_global, sample_base, mode;
     uint32_t seed_lo, seed_hi, offset_lo, offset_hi;
     uint32_t n_iterations, pretraining_iterations, n_params, reserved;

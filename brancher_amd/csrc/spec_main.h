@@ -116,6 +116,72 @@ __device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
     return o;
 }
 
+// ---- the cross-rank sum INSIDE the in-kernel training loop (SPEC_WITH_EXCHANGE: a kernel variant of its own, compiled
+//      when a multi-rank run first asks for it).  Monte-Carlo samples are sharded over the GPUs of a node; per
+//      iteration every rank holds its loss sum, its non-finite count and, after the chain rule, one gradient sum per
+//      parameter, and all ranks need the totals before the (replicated) optimizer step.  The protocol is the one-shot
+//      direct-write exchange of collective.hip — same regions, same sequence numbers, so launches of that kernel and of this
+//      one can follow each other on the same bsvi_exchange — run by the OWNERS' WAVE alone: lane i owns parameter i
+//      (SPEC_GENERIC_OWNERS == 0: every parameter has an owner in that one wave), so
+//        1. lane i stores its parameter's sum (lane 0 also the two loss words) into this rank's slot of EVERY region,
+//        2. system-scope fence; lanes < world publish the call's sequence number in every region (release),
+//        3. lanes < world wait for their rank's number in this rank's region (acquire; bounded; anybody's abort ends it),
+//        4. lane i adds the world's slots of its parameter in rank order: bit-identical totals on every rank.
+//      No workgroup barrier: program order inside one wave orders 1-4, and the other waves go on to the next iteration's
+//      first barrier (drawing its normals on the way), where they wait for the owners to publish the new table as always.
+#if defined(SPEC_WITH_EXCHANGE) && !SPEC_GENERIC_OWNERS && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS
+#define SPEC_EXCHANGE 1
+__device__ __forceinline__ float* spec_xslot(unsigned char* region, uint32_t parity, uint32_t r, uint32_t capacity, uint32_t world) {
+    return reinterpret_cast<float*>(region + XCHG_HEADER_WORDS * 4) + ((size_t)parity * world + r) * capacity;
+}
+// returns false when the call was abandoned (this rank or a peer gave up waiting: sticky, csrc/collective.hip)
+__device__ __forceinline__ bool spec_exchange(const SpecExchange* xg, uint32_t seq, uint32_t l, bool has_param, float& vs, float& vb, float& gsum) {
+    const uint32_t world = xg->world, rank = xg->rank, cap = xg->capacity, parity = seq & 1u;
+    uint32_t* const mine = reinterpret_cast<uint32_t*>(xg->peer[rank]);
+    uint32_t* const abort_word = mine + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE;
+    bool gave_up = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    for (uint32_t p = 0; p < world; ++p) {
+        float* const slot = spec_xslot(xg->peer[p], parity, rank, cap, world);
+        if (l == 0u) {
+            __hip_atomic_store(slot, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(slot + 1, vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (has_param) __hip_atomic_store(slot + 4 + l, gsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the layout of the output block: BSVI_OUT_HEADER)
+    }
+    __threadfence_system();
+    if (l < world) __hip_atomic_store(reinterpret_cast<uint32_t*>(xg->peer[l]) + rank * XCHG_FLAG_STRIDE, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (l < world && !gave_up) {
+        const unsigned long long t0 = wall_clock64(), limit = xg->timeout_ticks;
+        while ((int32_t)(__hip_atomic_load(mine + l * XCHG_FLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { gave_up = true; break; }
+            if (wall_clock64() - t0 > limit) {
+                gave_up = true;
+                for (uint32_t p = 0; p < world; ++p)
+                    __hip_atomic_store(reinterpret_cast<uint32_t*>(xg->peer[p]) + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                atomicAdd(abort_word + 1, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    gave_up = __any((int)gave_up) != 0;
+    if (!gave_up) gave_up = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    if (gave_up) return false;
+    unsigned char* const region = xg->peer[rank];
+    float ts = 0.0f, tb = 0.0f, tg = 0.0f;
+    for (uint32_t r = 0; r < world; ++r) {
+        const float* const slot = spec_xslot(region, parity, r, cap, world);
+        ts += __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        tb += __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (has_param) tg += __hip_atomic_load(slot + 4 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    vs = ts; vb = tb; gsum = tg;
+    return true;
+}
+#else
+#define SPEC_EXCHANGE 0
+#endif
+
 #if defined(SPEC_WAVES_PER_EU)
 #define SPEC_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(SPEC_WAVES_PER_EU, SPEC_WAVES_PER_EU)))
 #elif defined(SPEC_NUM_VGPR)
@@ -317,6 +383,11 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     if (const unsigned long long* const offset_dev = SPEC_A->offset_dev) off0 += *offset_dev;
     const uint32_t n_global = SPEC_A->n_global;
     const uint32_t pretraining = SPEC_A->pretraining_iterations;
+#if SPEC_EXCHANGE
+    // (this rank's call count lives in its region and is touched by this rank's kernels only: stream order makes it current)
+    uint32_t xseq0 = 0;
+    if (const SpecExchange* const xg0 = SPEC_A->xchg) xseq0 = reinterpret_cast<const uint32_t*>(xg0->peer[xg0->rank])[XCHG_CALLS_WORD];
+#endif
 
 #if defined(SPEC_DEBUG_STAMPS)        // timing experiment (tools/spec_stamps.py): s_memtime at the phase boundaries of one iteration
     unsigned long long stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -524,6 +595,28 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             vs += w < rows ? a : 0.0f;
             vb += w < rows ? b : 0.0f;
         }
+#if SPEC_EXCHANGE
+        // several ranks: the owners' wave exchanges [loss sum, non-finite count, gradient sum per parameter] with its peers
+        // (spec_exchange above); everything below runs on the TOTALS, as bsvi_finalize_step does behind the exchange kernel
+        const SpecExchange* const xg = SPEC_A->xchg;
+        const bool xrun = xg != nullptr && mode == SPEC_MODE_LOOP && (tid >> 6) == (own_base >> 6);
+        float xgsum = 0.0f;
+        if (xrun) {
+            if (own_fast) {
+                const SpecOwn own = spec_own_load(OWN + 5 * oid);
+                float tot[2];
+#pragma unroll
+                for (uint32_t e = 0; e < 2u; ++e) tot[e] = spec_pos_total(WS, own.pos[e], rows);
+#pragma unroll
+                for (uint32_t e = 0; e < 2u; ++e) {
+                    const float term = tot[e] * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
+                    xgsum += e < own.n ? term : 0.0f;
+                }
+            }
+            if (!spec_exchange(xg, xseq0 + it + 1u, oid, own_fast, vs, vb, xgsum)) vs = __int_as_float(0x7fc00000);     // abandoned: NaN loss, no step
+            if (oid == 0u && it + 1u == n_it) reinterpret_cast<uint32_t*>(xg->peer[xg->rank])[XCHG_CALLS_WORD] = xseq0 + n_it;
+        }
+#endif
         // -vs / n is finite exactly when vs is (n >= 1): the optimizer step does not wait for the division
         const float finite = isfinite(vs) ? 1.0f : 0.0f;
         const float loss = -vs / (float)n_global;
@@ -551,6 +644,9 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 const float term = tot[e] * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
                 gsum += e < own.n ? term : 0.0f;
             }
+#if SPEC_EXCHANGE
+            if (xrun) gsum = xgsum;
+#endif
             const float grad = gsum * scale;
             SPEC_STAMP(8);
             if (last || !step) out[BSVI_OUT_HEADER + oid] = grad;

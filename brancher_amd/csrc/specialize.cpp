@@ -50,6 +50,7 @@ constexpr size_t kMaxVisits = 12000;     // unrolled instruction visits (forward
 constexpr uint32_t kKeepEpsRows = 64;    // up to this many noise rows stay in registers for the reverse sweep
 constexpr uint32_t kRescheduleAboveSlots = 40; // programs with more per-sample slots defer their sinks (register pressure)
 constexpr uint32_t kFenceAboveCode = 100;     // programs longer than this get scheduling fences ...
+constexpr const char* kJitOptionMark = "// bsvi-jit-option: ";     // a per-program hiprtc option carried in the generated source
 constexpr uint32_t kFenceEvery = 4;           // ... every this many records
 constexpr uint32_t kAccumulateEntries = 1u << 30;   // up to this many gradient-carrying uniform entries accumulate in registers
 
@@ -83,9 +84,15 @@ public:
         for (uint32_t pc = 0; pc < d.n_code; ++pc) {
             const Insn I = insn(pc);
             const uint32_t op = I.w0 & 0xFFu;
-            if ((op == BSVI_OP_NAFF || op == BSVI_OP_NODE) && (((I.w0 >> 8) & 0xFFu) & BSVI_F_WF)) reschedule_ = false;
+            if ((op == BSVI_OP_NAFF || op == BSVI_OP_NODE) && (((I.w0 >> 8) & 0xFFu) & BSVI_F_WF) && d.estimator != BSVI_EST_BLACKBOX) reschedule_ = false;
         }
-        if (d.estimator == BSVI_EST_BLACKBOX) reschedule_ = false;
+        // A score term (BlackBox) weights the reverse steps with the COMPLETE f, so the sinks cannot simply move into the
+        // reverse sweep.  Long programs run them TWICE instead: value only in the forward sweep (f complete at the turn),
+        // adjoints only — same schedule as above — in the reverse sweep.  With every sink finished in the forward sweep the
+        // adjoint of every latent is live across the turn: T = 200 is 2 x 201 long-lived registers of 512, and the register
+        // allocator's eviction search alone took 23 s of a 29 s compile (-ftime-report).
+        two_pass_ = reschedule_ && d.estimator == BSVI_EST_BLACKBOX && !(getenv("BSVI_SPEC_TWO_PASS") && getenv("BSVI_SPEC_TWO_PASS")[0] == '0');
+        if (d.estimator == BSVI_EST_BLACKBOX && !two_pass_) reschedule_ = false;
         du_total_.assign(d.n_uniform_grad, 0);
         du_seen_.assign(d.n_uniform_grad, 0);
     }
@@ -139,7 +146,8 @@ public:
 private:
     const bsvi_program_desc& d_;
     bool diag_;
-    bool keep_eps_ = true, counting_ = true, direct_du_ = false, reschedule_ = true;
+    bool keep_eps_ = true, counting_ = true, direct_du_ = false, reschedule_ = true, two_pass_ = false;
+    int sink_mode_ = 0;         // two_pass_: 1 = a sink's value only (forward sweep), 2 = its adjoints only (reverse sweep); 0 = both
     size_t visits_ = 0;
     std::string body_;
     std::vector<uint32_t> du_total_, du_seen_, order_;
@@ -248,11 +256,11 @@ private:
                 diag_outputs(row, v, eps);
             }
             if (flags & (BSVI_F_ENT | BSVI_F_LOGP | BSVI_F_WF)) line(fmt("  const float lS = %s;", log_of(I.s, e).c_str()));
-            if (flags & BSVI_F_ENT) line(fmt("  T.f += %s * (kHalfLog2PiE + lS);", flit(I.imm1).c_str()));
+            if (flags & BSVI_F_ENT) line(fmt("  %s += %s * (kHalfLog2PiE + lS);", ftarget(), flit(I.imm1).c_str()));
             if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
                 line(fmt("  const float lp = spec_naff_lp(%s, loc, %s, lS);", v.c_str(), rcp_of(I.s, e).c_str()));
-                line(fmt("  T.f += %s * lp;", flit(I.imm0).c_str()));
-                if (flags & BSVI_F_WF) line("  T.lq += lp;");
+                line(fmt("  %s += %s * lp;", ftarget(), flit(I.imm0).c_str()));
+                if ((flags & BSVI_F_WF) && sink_mode_ != 2) line("  T.lq += lp;");
             }
             line("}");
         } else if (op == BSVI_OP_BIN) {
@@ -292,15 +300,18 @@ private:
                 }
                 diag_outputs(row, v, fmt("ns_%u", row));
             }
-            if (flags & BSVI_F_ENT) line(fmt("  T.f += %s * entropy_generic(%u, p0, p1);", flit(I.imm1).c_str(), dist));
+            if (flags & BSVI_F_ENT) line(fmt("  %s += %s * entropy_generic(%u, p0, p1);", ftarget(), flit(I.imm1).c_str(), dist));
             if (flags & (BSVI_F_LOGP | BSVI_F_WF)) {
                 line(fmt("  const float lp = logp_generic(%u, %s, p0, p1);", dist, v.c_str()));
-                line(fmt("  T.f += %s * lp;", flit(I.imm0).c_str()));
-                if (flags & BSVI_F_WF) line("  T.lq += lp;");
+                line(fmt("  %s += %s * lp;", ftarget(), flit(I.imm0).c_str()));
+                if ((flags & BSVI_F_WF) && sink_mode_ != 2) line("  T.lq += lp;");
             }
             line("}");
         }
     }
+
+    // where a term's VALUE goes: the sample's f — or nowhere, when the term runs a second time for its adjoints (two_pass_)
+    const char* ftarget() const { return sink_mode_ == 2 ? "f_dead" : "T.f"; }
 
     // the weight of a term's GRADIENT: the record's constant — times the caller's per-sample weight in the diagnostic variant
     // (bsvi_elbo_args::f_weight_dev: the second pass of a user-defined gradient estimator; 1 without one)
@@ -310,10 +321,15 @@ private:
     void naff_sink(const Insn& I, uint32_t e) {
         ++visits_;
         const std::string A = val(I.a, e), B = val(I.b, e);
+        if (sink_mode_ == 1) {      // the value alone
+            line(fmt("T.f += %s * spec_naff_lp(%s, %s * %s + %s, %s, %s);", flit(I.imm0).c_str(), val(I.dst, e).c_str(), A.c_str(), B.c_str(),
+                     val(I.c, e).c_str(), rcp_of(I.s, e).c_str(), log_of(I.s, e).c_str()));
+            return;
+        }
         if (!counting_) {
             line("{");
-            line(fmt("  float gl, gs; spec_naff_sink(%s, %s, %s * %s + %s, %s, %s, T.f, gl, gs);", flit(I.imm0).c_str(), val(I.dst, e).c_str(),
-                     A.c_str(), B.c_str(), val(I.c, e).c_str(), rcp_of(I.s, e).c_str(), log_of(I.s, e).c_str()));
+            line(fmt("  float gl, gs; spec_naff_sink(%s, %s, %s * %s + %s, %s, %s, %s, gl, gs);", flit(I.imm0).c_str(), val(I.dst, e).c_str(),
+                     A.c_str(), B.c_str(), val(I.c, e).c_str(), rcp_of(I.s, e).c_str(), log_of(I.s, e).c_str(), ftarget()));
             if (diag_) line("  gl *= T.gw; gs *= T.gw;");
         }
         add_adj(I.dst, e, "-gl");
@@ -439,12 +455,12 @@ private:
             const Insn I = insn(R.first);
             if (R.sink && (I.w0 & 0xFFu) == BSVI_OP_NAFF) { naff_sink(I, 0); return; }
             forward(I, 0, true);
-            if (R.sink) backward(I, 0);
+            if (R.sink && sink_mode_ != 1) backward(I, 0);
             return;
         }
         for (uint32_t e = 0; e < R.n_elems && visits_ <= kMaxVisits; ++e) {
             for (uint32_t j = 0; j < R.n; ++j) forward(insn(R.first + j), e, true);
-            if (R.sink) {
+            if (R.sink && sink_mode_ != 1) {
                 zero_temps(R.temp_base, R.n_temps);
                 for (uint32_t j = R.n; j-- > 0;) backward(insn(R.first + j), e);
             }
@@ -540,9 +556,12 @@ private:
         const bool fence = d_.n_code > kFenceAboveCode;
         uint32_t since = 0;
         auto maybe_fence = [&]() { if (fence && ++since >= kFenceEvery) { since = 0; line("asm volatile(\"\" ::: \"memory\"); __builtin_amdgcn_sched_barrier(0);"); } };
+        if (two_pass_) line("float f_dead = 0.0f; (void)f_dead;");
         for (uint32_t r = 0; r < recs.size(); ++r) {
-            if (home[r] >= 0) continue;
+            if (home[r] >= 0 && !two_pass_) continue;
+            sink_mode_ = home[r] >= 0 ? 1 : 0;
             emit_forward(recs[r]);
+            sink_mode_ = 0;
             maybe_fence();
             if (visits_ > kMaxVisits) return;
         }
@@ -561,7 +580,9 @@ private:
             }
         }
         for (uint32_t r : rorder) {
+            sink_mode_ = two_pass_ ? 2 : 0;
             for (uint32_t sidx : deferred[r]) emit_forward(recs[sidx]);
+            sink_mode_ = 0;
             emit_reverse(recs[r]);
             maybe_fence();
             if (visits_ > kMaxVisits) return;
@@ -594,7 +615,9 @@ struct Spec {
     uint32_t n_pos = 0;                                   // positions of the transpose tile (>= n_ugrad)
     Geom geom[2];
     std::vector<uint32_t> pu_ptr_host, pu_pos_host, pu_idx_host;   // CSR theta -> (position, uniform entry)
-    Variant variant[5];                                   // [geometry][0 lean, 1 diagnostic]; 4: lean one-workgroup kernel with the draw wave
+    Variant variant[6];                                   // [geometry][0 lean, 1 diagnostic]; 4: lean one-workgroup kernel with the draw wave;
+                                                          // 5: the same with the cross-rank exchange inside the training loop (spec_main.h)
+    bool exchange_ok = false;                             // every parameter has its owner in one wave: the in-loop exchange serves
     void* dev = nullptr;                                  // [tickets: 256 B][pu_ptr][pu_pos][pu_idx]
     unsigned int* tickets = nullptr;
     const uint32_t* pu_ptr = nullptr;
@@ -673,6 +696,14 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
             std::string src;
             src += "// generated by libbsvi (specialize.cpp) from a model program: do not edit\n";
             src += "#define BSVI_SPECIALIZED 1\n";
+            // long BlackBox programs: no SLP vectorizer.  gfx950 has packed f32 arithmetic, so the vectorizer pairs the
+            // isomorphic terms of DISTANT records of the unrolled stream into <2 x float> operations placed at the later one
+            // — every such pair holds the earlier record's operands across the records in between (T = 200: 2 158 spilled
+            // registers and 52 s of compile time with it, 231 and 29 s without; the rest went with the two-pass sinks: 12
+            // and 9 s; 199 -> 90 us per iteration at 1 024 samples).  Long Pathwise programs keep it: their deferred sinks
+            // leave it nothing distant to pair (7 spills with, 0 without, and 69.7 against 70.9 us).
+            if (d.n_code > kFenceAboveCode && d.estimator == BSVI_EST_BLACKBOX && !(getenv("BSVI_JIT_SLP") && getenv("BSVI_JIT_SLP")[0] == '1'))
+                src += std::string(kJitOptionMark) + "-fno-slp-vectorize\n";
             src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
                        d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
             src += fmt("#define SPEC_N_POS %u\n", s->n_pos);
@@ -702,6 +733,8 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     }
     // (a kernel of its own: the extra roles cost the plain loop 3 % when they are merely compiled in)
     s->variant[4].src = "#define SPEC_WITH_DRAW_WAVE 1\n" + s->variant[0].src;
+    s->exchange_ok = all_fast;
+    s->variant[5].src = std::string("#define SPEC_WITH_EXCHANGE 1\n") + (s->draw_wave_ok ? "#define SPEC_WITH_DRAW_WAVE 1\n" : "") + s->variant[0].src;
     return s;
 }
 
@@ -735,7 +768,7 @@ int upload(Spec* s) {
 }
 
 // variant: 0 training kernel, 1 diagnostic kernel of the one-workgroup geometry; 2, 3 the same of the many-workgroup one
-const std::string& source(const Spec* s, int variant) { return s->variant[variant & 3].src; }
+const std::string& source(const Spec* s, int variant) { return s->variant[(variant == 4 || variant == 5) ? variant : (variant & 3)].src; }
 
 // ---------------------------------------------------------------------------------------------------------------
 //  hiprtc
@@ -747,7 +780,16 @@ int compile(const std::string& src, std::vector<char>& code, std::string& log) {
     hiprtcProgram prog = nullptr;
     hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "bsvi_spec.hip", kJitHeaderCount, kJitHeaderTexts, kJitHeaderNames);
     if (r != HIPRTC_SUCCESS) { log = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r); return BSVI_ERR_HIP; }
-    r = hiprtcCompileProgram(prog, kJitOptionCount, kJitOptions);       // (the same array keys the disk cache)
+    // per-program options ride in the source as "// bsvi-jit-option: <opt>" lines (so the disk cache's key, which hashes
+    // the source and the common array, covers them)
+    std::vector<std::string> extra;
+    for (size_t at = src.find(kJitOptionMark); at != std::string::npos; at = src.find(kJitOptionMark, at + 1)) {
+        const size_t b = at + strlen(kJitOptionMark), e = src.find('\n', b);
+        extra.push_back(src.substr(b, e == std::string::npos ? std::string::npos : e - b));
+    }
+    std::vector<const char*> opts(kJitOptions, kJitOptions + kJitOptionCount);
+    for (const std::string& o : extra) opts.push_back(o.c_str());
+    r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t n = 0;
     if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
         log.resize(n);
@@ -954,12 +996,12 @@ static bool draw_wave() {
     const char* e = getenv("BSVI_SPEC_DRAW_WAVE");        // (read per call: the tests switch it within a process)
     return !(e && e[0] == '0');
 }
-static Geo geo(const Spec* s, uint32_t n_local, int mode = MODE_SUMS) {
+static Geo geo(const Spec* s, uint32_t n_local, int mode = MODE_SUMS, bool exchange = false) {
     const uint32_t waves = (n_local + 63) / 64;
     if (waves <= s->geom[GEOM_ONE].max_threads / 64) {
         // (up to four sample waves — one per SIMD: beyond that two of them share a SIMD and their draws set the pace, not the owners' chain)
         const bool extra = mode == MODE_LOOP && s->draw_wave_ok && draw_wave() && waves <= 4 && waves + 1 <= s->geom[GEOM_ONE].max_threads / 64
-                           && !s->variant[4].failed;
+                           && !s->variant[exchange ? 5 : 4].failed;
         return Geo{1, (waves + (extra ? 1u : 0u)) * 64, GEOM_ONE, extra};
     }
     // many samples: 256-thread workgroups (one wave per SIMD), two per CU at most; beyond that every workgroup walks
@@ -1000,12 +1042,20 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     if (!a->obs_dev && s->n_obs) return bsvi_fail(BSVI_ERR_INVALID, "obs_dev is null");
     if (!a->out_dev) return bsvi_fail(BSVI_ERR_INVALID, "out_dev is null");
     if (!a->n_samples_local || !a->n_samples_global) return bsvi_fail(BSVI_ERR_INVALID, "zero samples");
-    Geo g = geo(s, a->n_samples_local, L.mode);
+    Geo g = geo(s, a->n_samples_local, L.mode, L.xchg != nullptr);
     int v = 2 * g.geom + ((a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || a->f_weight_dev || a->q_weight_dev) ? 1 : 0);
+    if (L.xchg && !(L.mode == MODE_LOOP && g.blocks == 1 && v == 0 && s->exchange_ok))
+        return bsvi_fail(BSVI_ERR_UNSUPPORTED, "the in-loop exchange serves the one-workgroup training loop of programs whose parameters all have "
+                                               "an owner thread in one wave (<= 64 parameters, <= 2 uniform entries each), Philox noise");
     uint32_t seq;
     {
         std::lock_guard<std::mutex> lock(s->mu);
-        if (g.draw_wave && v == 0 && ensure_compiled(s, 4) == BSVI_OK) v = 4;
+        if (L.xchg) {
+            const int rc5 = ensure_compiled(s, 5);
+            if (rc5) return rc5;
+            v = 5;
+        }
+        else if (g.draw_wave && v == 0 && ensure_compiled(s, 4) == BSVI_OK) v = 4;
         else if (g.draw_wave) { g.threads -= 64; g.draw_wave = false; }        // (diagnostic kernel, or the variant did not compile)
         const int rc = ensure_compiled(s, v);
         if (rc) return rc;
@@ -1030,6 +1080,7 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     A.offset_lo = (uint32_t)a->offset; A.offset_hi = (uint32_t)(a->offset >> 32);
     A.offset_dev = (const unsigned long long*)a->offset_dev;
     A.f_weight = a->f_weight_dev; A.q_weight = a->q_weight_dev;
+    A.xchg = (const bsvi::SpecExchange*)L.xchg;
     A.n_iterations = L.n_iterations; A.pretraining_iterations = L.pretraining_iterations; A.n_params = s->n_params;
     if (L.cfg) A.cfg = *L.cfg;
     size_t size = sizeof A;

@@ -94,6 +94,32 @@ def _exchange_for(out):
     return ex
 
 
+def loop_exchange(out):
+    """The exchange for the in-kernel training loop of a sharded run (`bsvi_train_persistent_exchange`), or None: the one
+    `allreduce_sums` uses between launches — decided once, by all ranks together — or, for ONE rank walking the sharded path
+    (`_force_sharded_path` with BSVI_LOOP_EXCHANGE=force: tests), an exchange of its own.  BSVI_LOOP_EXCHANGE=0 keeps the
+    launch-per-step sequence."""
+    if os.environ.get("BSVI_LOOP_EXCHANGE", "1") == "0" or os.environ.get("BSVI_COLLECTIVE", "auto") not in ("auto", "exchange"):
+        return None
+    if not out.is_cuda or out.numel() > 16384:
+        return None
+    if dist_info()[1] > 1:
+        return _exchange_for(out)
+    if os.environ.get("BSVI_LOOP_EXCHANGE") != "force":       # (one rank: the HIP-graph replay of the step sequence is the default)
+        return None
+    key = out.device.index
+    ex = _exchanges.get(key)
+    if ex is None or (ex and ex.capacity < out.numel()):
+        from brancher_amd import collective
+        try:
+            ex = collective.Exchange(max(out.numel(), 1024), device=out.device)
+            ex.capacity = max(out.numel(), 1024)
+        except (native.NativeError, RuntimeError):
+            ex = False
+        _exchanges[key] = ex
+    return ex or None
+
+
 def allreduce_sums(out):
     """The ONE collective of the multi-GPU path: sum the per-rank output blocks
     [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.
@@ -695,6 +721,31 @@ class CompiledELBO:
             return loss_curve, finite
 
         sharded = world > 1 or _force_sharded_path
+        if sharded and noise_t is None and not self._externals:
+            # several ranks, ONE launch each: the cross-rank sums are exchanged inside the in-kernel loop (spec_main.h,
+            # spec_exchange).  Whether it serves — the shard on the specialised one-workgroup kernel, every parameter
+            # owned by a thread of one wave, the exchange usable — is probed once per plan with an empty call (which
+            # also compiles the kernel variant) and VOTED: a rank on another path would leave its peers waiting.
+            xkey = plan_key + ("loop exchange",)
+            xplan = self._train_plans.get(xkey)
+            ex = loop_exchange(self.out)
+            args = self._elbo_args(n_local, number_samples, base, None, seed, offset0)
+            xcall = lambda k: self.lib.bsvi_train_persistent_exchange(
+                self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(self.mask_all),
+                ptr(self.mask_first), int(pretraining_iterations), k, ptr(loss_curve), ptr(finite), ex.handle)
+            if xplan is None:
+                ok = 1.0 if (ex is not None and xcall(0) == 0) else 0.0
+                if world > 1:
+                    import torch.distributed as dist
+                    vote = torch.tensor([ok], device=dev if dist.get_backend() == "nccl" else "cpu")
+                    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+                    ok = float(vote.item())
+                xplan = self._train_plans[xkey] = ok > 0.0
+            if xplan and ex is not None:
+                native.check(xcall(K))
+                self.last_mode = "persistent+exchange"
+                check_exchange(dev)
+                return loss_curve, finite
         if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0" and not self._externals:
             # multi-GPU: the step sequence is captured once in a HIP graph and replayed — no Python between the launches
             try:

@@ -119,6 +119,8 @@ EXPORTS = {
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bsvi_train_persistent2": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bsvi_train_persistent_exchange": (C.c_int, [C.c_void_p, C.POINTER(ElboArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsvi_persistent_supported": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bsvi_persistent_split_shares": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bsvi_program_set_shares": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32]),

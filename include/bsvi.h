@@ -336,6 +336,26 @@ int bsvi_train_persistent2(const bsvi_program* prog, const bsvi_elbo_args* args,
                            uint32_t pretraining_iterations, uint32_t n_iterations,
                            float* loss_curve_dev, float* finite_dev);
 
+/* The same loop on SEVERAL ranks (the Monte-Carlo samples of an iteration are sharded over the GPUs of a node):
+ * every rank calls this with its shard (args->n_samples_local / sample_base; n_samples_global = the whole draw) and the
+ * bsvi_exchange it shares with its peers (below), and runs n_iterations iterations in ONE launch — per iteration the
+ * loss sum, the non-finite count and one gradient sum per parameter are exchanged INSIDE the kernel (the protocol of
+ * bsvi_exchange_allreduce, run by the wave that owns the parameters: direct stores into every peer's region, sequence
+ * numbers, slots added in rank order — bit-identical totals, so the replicated optimizer steps stay in lockstep), where
+ * bsvi_elbo_fwd_bwd + bsvi_exchange_allreduce + bsvi_finalize_step_counted are three launches per iteration.  An
+ * abandoned exchange (a peer did not arrive within the bound) leaves NaN in that iteration's loss, skips its optimizer
+ * step on every rank and is sticky (bsvi_exchange_status).  Replaces the Python loop of inference.py:95-108 on N GPUs.
+ * BSVI_ERR_UNSUPPORTED unless the shard runs on the program-specialised one-workgroup kernel (bsvi_program_engine, mode
+ * 2), every parameter has at most two uniform-table entries and there are at most 64 of them (one owner thread each in
+ * one wave), noise is Philox and no per-sample output is asked for: callers then fall back to the three-launch sequence.
+ * state_dev may be NULL (a fresh optimizer inside the kernel), as for bsvi_train_persistent2. */
+struct bsvi_exchange;
+int bsvi_train_persistent_exchange(const bsvi_program* prog, const bsvi_elbo_args* args, const bsvi_opt_cfg* cfg,
+                                   float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
+                                   const uint8_t* active_mask_first_dev, uint32_t pretraining_iterations,
+                                   uint32_t n_iterations, float* loss_curve_dev, float* finite_dev,
+                                   struct bsvi_exchange* exchange);
+
 /* 1 if bsvi_train_persistent supports (prog, n_samples_local), else 0. */
 int bsvi_persistent_supported(const bsvi_program* prog, uint32_t n_samples_local);
 /* The multi-workgroup persistent trainer (5..16 waves: one wave per workgroup, one exchange of partial sums per

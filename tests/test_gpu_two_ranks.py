@@ -23,11 +23,12 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, workload, n_samples, iters, optimizer, opt_kw, out_q, collective="torch"):
+def _worker(rank, world, port, workload, n_samples, iters, optimizer, opt_kw, out_q, collective="torch", loop_exchange="1"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["BSVI_COLLECTIVE"] = collective
+    os.environ["BSVI_LOOP_EXCHANGE"] = loop_exchange
     # a gloo collective cannot be captured into a HIP graph; the library's one-shot exchange is a kernel and can
     os.environ["BSVI_GRAPH"] = "1" if collective in ("exchange", "auto") else "0"
     import torch.distributed as dist
@@ -94,6 +95,9 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
 
 
 @pytest.mark.parametrize("workload,n_samples,optimizer,opt_kw,mode", [
+    (("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3), "persistent+exchange"),
+    (("build_readme_ar", dict(T=20)), 600, "Adam", dict(lr=2e-3), "persistent+exchange"),
+    (("build_readme_ar", dict(T=20)), 200, "SGD", dict(lr=1e-3), "persistent+exchange"),      # two sample waves + the draw wave per rank
     (("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3), "graph+allreduce"),
     (("build_logistic_regression", dict(dataset_size=256, batch_size=64, n_features=64, n_classes=10, q_scale=0.05)), 96, "Adam", dict(lr=5e-3),
      "stepwise+allreduce"),
@@ -103,15 +107,17 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
 def test_two_ranks_over_the_one_shot_exchange(workload, n_samples, optimizer, opt_kw, mode):
     """the same trajectories with the DEFAULT collective (BSVI_COLLECTIVE=auto): the library's own exchange (bsvi_exchange_*:
     the ranks map each other's regions through HIP IPC, a self-test all-reduce and a vote decide once that it serves) in place
-    of the host-staged all-reduce, on all three engines.  It is a kernel, so the scalar path's step sequence is captured in a
-    HIP graph and replayed with the exchange inside."""
+    of the host-staged all-reduce, on all three engines.  On the scalar path the whole loop is ONE launch per rank with the
+    exchange inside the kernel's iteration (bsvi_train_persistent_exchange; "persistent+exchange"); with BSVI_LOOP_EXCHANGE=0
+    the step sequence — kernel, exchange kernel, finalize — is captured in a HIP graph and replayed ("graph+allreduce")."""
     import torch.multiprocessing as mp
-    iters = 40 if mode.startswith("graph") else 12
+    iters = 12 if mode.startswith("stepwise") else 40
+    loop = "0" if mode == "graph+allreduce" else "1"
     ref_losses, ref_params, ref_eval = _single(workload, n_samples, iters, optimizer, opt_kw)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, workload, n_samples, iters, optimizer, opt_kw, q, "auto")) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, workload, n_samples, iters, optimizer, opt_kw, q, "auto", loop)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
@@ -207,5 +213,30 @@ def test_bench_with_two_ranks_dry_run():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["steps"] == 40 and line["scaling"] == "weak" and line["all_finite"]
     assert line["config"]["number_samples_global"] == 2 * line["config"]["number_samples_per_gpu"] == 600
-    assert "allreduce" in line["config"]["mode"] and line["value"] > 0
+    # (the one-shot exchange serves here: the whole loop of a step call is one launch per rank with the exchange inside)
+    assert ("allreduce" in line["config"]["mode"] or line["config"]["mode"] == "persistent+exchange") and line["value"] > 0
     assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
+
+
+def test_loop_exchange_on_one_rank_is_the_in_kernel_loop_bit_for_bit(monkeypatch):
+    """`bsvi_train_persistent_exchange` with ONE rank: the owners' wave stores its sums into its own region, publishes and
+    meets its own sequence number, and reads the same numbers back — so the loss curve and the parameters must be those of
+    the plain in-kernel loop, bit for bit, SGD and Adam, with and without the draw wave, across two calls on one exchange
+    (the sequence numbers continue), and the exchange must report no abandoned call."""
+    sys.path.insert(0, ROOT)
+    from brancher_amd import engine, workloads as W
+    monkeypatch.setenv("BSVI_LOOP_EXCHANGE", "force")
+    for n_samples in (300, 128):
+        for optimizer, kw in (("SGD", dict(lr=1e-3)), ("Adam", dict(lr=2e-3))):
+            ref = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+            r1, _ = ref.train(25, n_samples, optimizer, seed=3, **kw)
+            r2, _ = ref.train(10, n_samples, optimizer, seed=3, **kw)
+            assert ref.last_mode == "persistent"
+            c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+            l1, f1 = c.train(25, n_samples, optimizer, seed=3, _force_sharded_path=True, **kw)
+            l2, f2 = c.train(10, n_samples, optimizer, seed=3, _force_sharded_path=True, **kw)
+            assert c.last_mode == "persistent+exchange", c.last_mode
+            assert bool(f1.all()) and bool(f2.all())
+            assert torch.equal(l1, r1) and torch.equal(l2, r2), (n_samples, optimizer, (l1 - r1).abs().max().item())
+            assert torch.equal(c.params, ref.params)
+    engine.check_exchange(torch.device("cuda", 0))

@@ -64,6 +64,40 @@ def test_long_chain_keeps_fewer_registers():
     assert body[:turn].count("spec_naff_sink(") == 0 and body[turn:].count("spec_naff_sink(") == 401
 
 
+def test_long_blackbox_program_runs_its_sinks_twice_and_compiles_without_spilling(tmp_path, monkeypatch):
+    """BlackBox at T = 200 (~1 min of hiprtc, ~2 000 spilled registers).  The score term weights the
+    reverse steps with the complete f, so the model terms run TWICE: value only in the forward sweep, adjoints only — at the
+    deferred positions of the Pathwise schedule — in the reverse sweep; and the translation unit asks for no SLP
+    vectorization (the vectorizer paired terms of distant records).  The code object must keep (nearly) every value in
+    registers; the compile time follows (9 s in the build container against 52)."""
+    import os
+    import subprocess
+    import time
+    model = W.build_readme_ar(W.native_api(), T=200)
+    program = lowering.lower(model, model.posterior_model, "blackbox")
+    src = native.specialised_source(program, 0)
+    body = src.split("void spec_body")[1]
+    turn = body.index("const float fweight")
+    # forward sweep: 401 values and no sink adjoints; reverse sweep: the 401 sinks again, their values going nowhere
+    assert body[:turn].count("spec_naff_sink(") == 0 and body[:turn].count("T.f += 1.0f * spec_naff_lp(") == 401
+    assert body[turn:].count("spec_naff_sink(") == 401 and body[turn:].count(", f_dead, gl, gs)") == 401
+    assert "// bsvi-jit-option: -fno-slp-vectorize" in src
+    pathwise = native.specialised_source(lowering.lower(model, model.posterior_model, "pathwise"), 0)
+    assert "bsvi-jit-option" not in pathwise and "f_dead" not in pathwise
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("no llvm-readelf in this image")
+    dump = str(tmp_path / "kernel.co")
+    monkeypatch.setenv("BSVI_JIT_DUMP", dump)
+    t0 = time.perf_counter()
+    assert native.jit_compile(src + "\n// (unique: not served from the code cache)\n") > 0
+    seconds = time.perf_counter() - t0
+    notes = subprocess.run([readelf, "--notes", dump], capture_output=True, text=True).stdout
+    meta = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_spill_count|vgpr_count):\s+(\d+)", notes)}
+    assert meta["vgpr_spill_count"] <= 64, meta            # (12 here; 2 158 before)
+    assert seconds < 40.0, seconds                         # (9 s here; 52 s before — a loose bound: shared CI cores)
+
+
 def test_unrolling_limit_declines():
     """a program whose unrolled stream exceeds the generator's limit is left to the interpreter (not an error)"""
     api = W.native_api()
