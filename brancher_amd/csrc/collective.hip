@@ -216,7 +216,8 @@ extern "C" int bsvi_exchange_create(uint32_t rank, uint32_t world, uint32_t capa
                                            "larger ones belong to bsvi_allreduce)");
     auto* x = new bsvi_exchange();
     x->rank = rank; x->world = world; x->capacity = (capacity_floats + 63u) / 64u * 64u;
-    x->bytes = (size_t)kHeaderWords * 4 + 2 * (size_t)world * x->capacity * sizeof(float);
+    // header | the flagged slots of exchange_kernel | the tagged 8-byte entries of the in-loop exchange (spec_args.h)
+    x->bytes = (size_t)kHeaderWords * 4 + 2 * (size_t)world * x->capacity * sizeof(float) + 2 * (size_t)world * x->capacity * 8;
     // fine-grained memory: uncached across devices — what a region written by peers on OTHER GPUs needs while the spinning
     // kernel is resident.  Coarse-grained device memory gives no such guarantee: it serves one rank, or ranks that share a GPU
     // (the single-GPU tests say so with BSVI_EXCHANGE_SAME_DEVICE=1); otherwise the caller is told to use RCCL.

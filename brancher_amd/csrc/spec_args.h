@@ -12,8 +12,10 @@ enum { SPEC_MODE_SUMS = 0, SPEC_MODE_STEP = 1, SPEC_MODE_LOOP = 2 };
 
 // The one-shot exchange (collective.hip) as the in-kernel training loop sees it: a rank's region is
 //   [header: XCHG_HEADER_WORDS words][slots: 2 parities x world ranks x capacity floats]
+//   [entries: 2 parities x world ranks x capacity 8-byte words, (call number << 32) | value bits — the in-loop exchange's]
 // header words: flag of rank r at r * XCHG_FLAG_STRIDE (the sequence number of r's last complete call) | abort word at
-// XCHG_MAX_RANKS * XCHG_FLAG_STRIDE (+1: how often this rank gave up) | XCHG_CALLS_WORD: this rank's own call count.
+// XCHG_MAX_RANKS * XCHG_FLAG_STRIDE (+1: how often this rank gave up) | XCHG_CALLS_WORD: this rank's own call count
+// (+1: the count of its in-loop exchanges, which number their calls separately).
 // ONE definition for the exchange kernel of the library and the generated kernels, which take part in the same sequence.
 enum { XCHG_MAX_RANKS = 8, XCHG_FLAG_STRIDE = 16, XCHG_HEADER_WORDS = 256, XCHG_CALLS_WORD = XCHG_MAX_RANKS * XCHG_FLAG_STRIDE + 16 };
 struct SpecExchange {                    // device-resident, written once when the peers are connected

@@ -120,61 +120,76 @@ __device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
 //      when a multi-rank run first asks for it).  Monte-Carlo samples are sharded over the GPUs of a node; per
 //      iteration every rank holds its loss sum, its non-finite count and, after the chain rule, one gradient sum per
 //      parameter, and all ranks need the totals before the (replicated) optimizer step.  The protocol is the one-shot
-//      direct-write exchange of collective.hip — same regions, same sequence numbers, so launches of that kernel and of this
-//      one can follow each other on the same bsvi_exchange — run by the OWNERS' WAVE alone: lane i owns parameter i
+//      direct-write exchange of collective.hip — same regions and abort word, its own area and call count, so launches of
+//      that kernel and of this one can follow each other on the same bsvi_exchange — run by the OWNERS' WAVE alone: lane i owns parameter i
 //      (SPEC_GENERIC_OWNERS == 0: every parameter has an owner in that one wave), so
-//        1. lane i stores its parameter's sum (lane 0 also the two loss words) into this rank's slot of EVERY region,
-//        2. system-scope fence; lanes < world publish the call's sequence number in every region (release),
-//        3. lanes < world wait for their rank's number in this rank's region (acquire; bounded; anybody's abort ends it),
-//        4. lane i adds the world's slots of its parameter in rank order: bit-identical totals on every rank.
-//      No workgroup barrier: program order inside one wave orders 1-4, and the other waves go on to the next iteration's
-//      first barrier (drawing its normals on the way), where they wait for the owners to publish the new table as always.
+//        1. lane i stores its parameter's sum (lane 0 also the two loss words) into this rank's row of EVERY region,
+//        2. lane i reads every rank's entry of its parameter (and the loss words) in this rank's region until all carry the
+//           call's number (bounded; anybody's abort ends it) and adds them in rank order: bit-identical totals on every rank.
+//      No workgroup barrier: the other waves go on to the next iteration's first barrier (drawing its normals on the way),
+//      where they wait for the owners to publish the new table as always.
 #if defined(SPEC_WITH_EXCHANGE) && !SPEC_GENERIC_OWNERS && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS
 #define SPEC_EXCHANGE 1
-__device__ __forceinline__ float* spec_xslot(unsigned char* region, uint32_t parity, uint32_t r, uint32_t capacity, uint32_t world) {
-    return reinterpret_cast<float*>(region + XCHG_HEADER_WORDS * 4) + ((size_t)parity * world + r) * capacity;
+// An entry of the region's second area carries its value AND the number of the call that wrote it in one 8-byte word
+// (xchg_ll_entry), stored with a single 64-bit store: a reader that finds the call's number has the value — no fence and no
+// separate flag between "data written" and "data may be read", one store -> one load across the link instead of store, fence,
+// flag, poll, load.  (Measured with one rank exchanging with itself, fine-grained memory: the flagged form of
+// collective.hip's kernel added 2.5 us to a 4.8 us iteration.)
+__device__ __forceinline__ unsigned long long* spec_xentry(unsigned char* region, uint32_t parity, uint32_t r, uint32_t capacity, uint32_t world) {
+    return reinterpret_cast<unsigned long long*>(region + XCHG_HEADER_WORDS * 4 + (size_t)2 * world * capacity * 4) + ((size_t)parity * world + r) * capacity;
 }
 // returns false when the call was abandoned (this rank or a peer gave up waiting: sticky, csrc/collective.hip)
 __device__ __forceinline__ bool spec_exchange(const SpecExchange* xg, uint32_t seq, uint32_t l, bool has_param, float& vs, float& vb, float& gsum) {
     const uint32_t world = xg->world, rank = xg->rank, cap = xg->capacity, parity = seq & 1u;
-    uint32_t* const mine = reinterpret_cast<uint32_t*>(xg->peer[rank]);
-    uint32_t* const abort_word = mine + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE;
-    bool gave_up = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    uint32_t* const abort_word = reinterpret_cast<uint32_t*>(xg->peer[rank]) + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE;
+    const uint32_t aborted = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (needed at the end only)
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    // 1. this rank's sums into its row of EVERY region (its own included): lane l its parameter's, lane 0 the loss words too
     for (uint32_t p = 0; p < world; ++p) {
-        float* const slot = spec_xslot(xg->peer[p], parity, rank, cap, world);
+        unsigned long long* const row = spec_xentry(xg->peer[p], parity, rank, cap, world);
         if (l == 0u) {
-            __hip_atomic_store(slot, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(slot + 1, vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(row, tag | __float_as_uint(vs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(row + 1, tag | __float_as_uint(vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (has_param) __hip_atomic_store(slot + 4 + l, gsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the layout of the output block: BSVI_OUT_HEADER)
+        if (has_param) __hip_atomic_store(row + BSVI_OUT_HEADER + l, tag | __float_as_uint(gsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
-    if (l < world) __hip_atomic_store(reinterpret_cast<uint32_t*>(xg->peer[l]) + rank * XCHG_FLAG_STRIDE, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (l < world && !gave_up) {
-        const unsigned long long t0 = wall_clock64(), limit = xg->timeout_ticks;
-        while ((int32_t)(__hip_atomic_load(mine + l * XCHG_FLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { gave_up = true; break; }
-            if (wall_clock64() - t0 > limit) {
-                gave_up = true;
-                for (uint32_t p = 0; p < world; ++p)
-                    __hip_atomic_store(reinterpret_cast<uint32_t*>(xg->peer[p]) + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                atomicAdd(abort_word + 1, 1u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    gave_up = __any((int)gave_up) != 0;
-    if (!gave_up) gave_up = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-    if (gave_up) return false;
+    // 2. every rank's row of THIS region, until all of them carry the call's number; added in rank order
     unsigned char* const region = xg->peer[rank];
-    float ts = 0.0f, tb = 0.0f, tg = 0.0f;
-    for (uint32_t r = 0; r < world; ++r) {
-        const float* const slot = spec_xslot(region, parity, r, cap, world);
-        ts += __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        tb += __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (has_param) tg += __hip_atomic_load(slot + 4 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long t0 = 0;
+    bool gave_up = false;
+    float ts, tb, tg;
+    for (uint32_t round = 0;; ++round) {
+        unsigned long long e0[XCHG_MAX_RANKS], e1[XCHG_MAX_RANKS], eg[XCHG_MAX_RANKS];
+#pragma unroll
+        for (uint32_t r = 0; r < XCHG_MAX_RANKS; ++r) {
+            e0[r] = e1[r] = eg[r] = tag;
+            if (r < world) {
+                const unsigned long long* const row = spec_xentry(region, parity, r, cap, world);
+                e0[r] = __hip_atomic_load(row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                e1[r] = __hip_atomic_load(row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (has_param) eg[r] = __hip_atomic_load(row + BSVI_OUT_HEADER + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        bool all = true;
+        ts = 0.0f; tb = 0.0f; tg = 0.0f;
+#pragma unroll
+        for (uint32_t r = 0; r < XCHG_MAX_RANKS; ++r) {
+            all = all && (uint32_t)(e0[r] >> 32) == seq && (uint32_t)(e1[r] >> 32) == seq && (uint32_t)(eg[r] >> 32) == seq;
+            if (r < world) { ts += __uint_as_float((uint32_t)e0[r]); tb += __uint_as_float((uint32_t)e1[r]); tg += __uint_as_float((uint32_t)eg[r]); }
+        }
+        if (__all((int)all)) break;
+        // somebody is late: bounded, and ended by anybody's abort
+        if (round == 0u) t0 = wall_clock64();
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { gave_up = true; break; }
+        if (wall_clock64() - t0 > xg->timeout_ticks) {
+            gave_up = true;
+            if (l < world) __hip_atomic_store(reinterpret_cast<uint32_t*>(xg->peer[l]) + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (l == 0u) atomicAdd(abort_word + 1, 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
+    if (gave_up || aborted != 0u) return false;
     vs = ts; vb = tb; gsum = tg;
     return true;
 }
@@ -386,7 +401,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #if SPEC_EXCHANGE
     // (this rank's call count lives in its region and is touched by this rank's kernels only: stream order makes it current)
     uint32_t xseq0 = 0;
-    if (const SpecExchange* const xg0 = SPEC_A->xchg) xseq0 = reinterpret_cast<const uint32_t*>(xg0->peer[xg0->rank])[XCHG_CALLS_WORD];
+    if (const SpecExchange* const xg0 = SPEC_A->xchg) xseq0 = reinterpret_cast<const uint32_t*>(xg0->peer[xg0->rank])[XCHG_CALLS_WORD + 1];
 #endif
 
 #if defined(SPEC_DEBUG_STAMPS)        // timing experiment (tools/spec_stamps.py): s_memtime at the phase boundaries of one iteration
@@ -614,7 +629,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 }
             }
             if (!spec_exchange(xg, xseq0 + it + 1u, oid, own_fast, vs, vb, xgsum)) vs = __int_as_float(0x7fc00000);     // abandoned: NaN loss, no step
-            if (oid == 0u && it + 1u == n_it) reinterpret_cast<uint32_t*>(xg->peer[xg->rank])[XCHG_CALLS_WORD] = xseq0 + n_it;
+            if (oid == 0u && it + 1u == n_it) reinterpret_cast<uint32_t*>(xg->peer[xg->rank])[XCHG_CALLS_WORD + 1] = xseq0 + n_it;
         }
 #endif
         // -vs / n is finite exactly when vs is (n >= 1): the optimizer step does not wait for the division

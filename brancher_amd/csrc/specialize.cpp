@@ -702,7 +702,9 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
             // registers and 52 s of compile time with it, 231 and 29 s without; the rest went with the two-pass sinks: 12
             // and 9 s; 199 -> 90 us per iteration at 1 024 samples).  Long Pathwise programs keep it: their deferred sinks
             // leave it nothing distant to pair (7 spills with, 0 without, and 69.7 against 70.9 us).
-            if (d.n_code > kFenceAboveCode && d.estimator == BSVI_EST_BLACKBOX && !(getenv("BSVI_JIT_SLP") && getenv("BSVI_JIT_SLP")[0] == '1'))
+            // (BSVI_JIT_SLP=1 / 0 forces it on / off for every program: measurements)
+            const char* const slp = getenv("BSVI_JIT_SLP");
+            if (slp ? slp[0] == '0' : (d.n_code > kFenceAboveCode && d.estimator == BSVI_EST_BLACKBOX))
                 src += std::string(kJitOptionMark) + "-fno-slp-vectorize\n";
             src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
                        d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
