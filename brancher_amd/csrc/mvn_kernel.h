@@ -57,29 +57,115 @@ __device__ __forceinline__ float mvn_wave_sum(float v) {
 }
 __device__ __forceinline__ float mvn_dot4(mvn_f4 a, mvn_f4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
-extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G) {
-    constexpr int D = MVN_D, LD = MVN_LD;
-    __shared__ __attribute__((aligned(16))) float A[D * LD];
-    __shared__ __attribute__((aligned(16))) float XT[D * LD];
-    __shared__ __attribute__((aligned(16))) float dvec[(D + 3) / 4 * 4 + 4];
-    __shared__ __attribute__((aligned(16))) float avec[(D + 3) / 4 * 4 + 4];
+// timing experiments (BSVI_SPEC_DEFINES="#define MVN_STOP_AFTER k", tools/r4/mvn_steps.sh): the kernel ends behind step k
+#if defined(MVN_STOP_AFTER)
+#define MVN_STEP_END(k) if (MVN_STOP_AFTER == (k)) { if (tid == 0) G.rows_out[n] = A[0] + XT[1] + avec[0]; return; }
+#else
+#define MVN_STEP_END(k)
+#endif
+
+constexpr int MVN_THREADS = 256;
+
+// sum over the workgroup's four waves; `red` is free again when it returns
+__device__ __forceinline__ float mvn_block_sum(float v, float* red, int tid) {
+    v = mvn_wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+}
+// (i, j) of the e-th element of the lower triangle, row by row
+__device__ __forceinline__ void mvn_tri(int e, int& i, int& j) {
+    i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > e) --i;
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    j = e - i * (i + 1) / 2;
+}
+// sum over the 16-byte blocks b0, b0 + step, ... < b1 of two LDS rows, four blocks in flight (one wave per SIMD has nobody to
+// hide an LDS round trip behind but its own other loads: with one block per trip these loops ran at a tenth of the LDS rate).
+// (Measured and dropped: eight blocks per trip with the tail replaced by zeros instead of a remainder loop — the selects and
+// index arithmetic of the predication cost more issue slots than the round trips they save: D = 128 444 -> 514 us.)
+__device__ __forceinline__ float mvn_rowdot(const mvn_f4* x, const mvn_f4* y, int b0, int b1, int step) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int b = b0;
+    for (; b + 3 * step < b1; b += 4 * step) {
+        const mvn_f4 x0 = x[b], x1 = x[b + step], x2 = x[b + 2 * step], x3 = x[b + 3 * step];
+        const mvn_f4 y0 = y[b], y1 = y[b + step], y2 = y[b + 2 * step], y3 = y[b + 3 * step];
+        a0 += mvn_dot4(x0, y0); a1 += mvn_dot4(x1, y1); a2 += mvn_dot4(x2, y2); a3 += mvn_dot4(x3, y3);
+    }
+    for (; b < b1; b += step) a0 += mvn_dot4(x[b], y[b]);
+    return (a0 + a1) + (a2 + a3);
+}
+
+// the other lane of the pair (lane ^ 1): one DPP move, no LDS round trip (ds_bpermute, which __shfl_xor compiles to, is one)
+__device__ __forceinline__ float mvn_pair(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1, 0, 3, 2]
+#else
+    return v;
+#endif
+}
+// x.y and y.y over the same blocks in ONE loop (the pivot of a Cholesky column rides on the loads of the row's own product)
+__device__ __forceinline__ void mvn_rowdot2(const mvn_f4* x, const mvn_f4* y, int b0, int b1, int step, float& xy, float& yy) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+    int b = b0;
+    for (; b + 3 * step < b1; b += 4 * step) {
+        const mvn_f4 x0 = x[b], x1 = x[b + step], x2 = x[b + 2 * step], x3 = x[b + 3 * step];
+        const mvn_f4 y0 = y[b], y1 = y[b + step], y2 = y[b + 2 * step], y3 = y[b + 3 * step];
+        a0 += mvn_dot4(x0, y0); a1 += mvn_dot4(x1, y1); a2 += mvn_dot4(x2, y2); a3 += mvn_dot4(x3, y3);
+        p0 += mvn_dot4(y0, y0); p1 += mvn_dot4(y1, y1); p2 += mvn_dot4(y2, y2); p3 += mvn_dot4(y3, y3);
+    }
+    for (; b < b1; b += step) { const mvn_f4 x0 = x[b], y0 = y[b]; a0 += mvn_dot4(x0, y0); p0 += mvn_dot4(y0, y0); }
+    xy = (a0 + a1) + (a2 + a3);
+    yy = (p0 + p1) + (p2 + p3);
+}
+// 1 / sqrt(p): the hardware estimate and one Newton step (the IEEE sqrt and divide of the library are ~40 dependent instructions
+// in the middle of the one chain a Cholesky column is); NaN for p < 0 like sqrtf, so a non-positive pivot still poisons the step
+__device__ __forceinline__ float mvn_rsqrt(float p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rsqf(p);
+#else
+    const float r = 1.0f / sqrtf(p);
+#endif
+    return p > 0.0f ? r * (1.5f - 0.5f * p * r * r) : __int_as_float(0x7fc00000);
+}
+
+// Round 4: FOUR waves per sample (round 3: one; tools/r4/mvn_steps.sh has the step times of both).  A row of the factorisation and
+// a column of the triangular inverse belong to a PAIR of neighbouring lanes that split the inner product's 16-byte blocks
+// between them (even / odd) and add their halves with one DPP exchange; the elements of C, of S = X^T X and of the gradient
+// contraction are dealt out over all 256 threads.  One barrier per Cholesky column: every thread forms the pivot itself, from
+// the blocks of row j it reads anyway, in the same order as everybody else — no broadcast of the pivot through LDS.
+extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const MvnArgs G) {
+    // DP: D rounded up to whole 16-byte blocks of rows and columns.  The pad is an IDENTITY block (C_kk = 1 behind row D - 1): it
+    // factorises to itself, contributes log 1 to the determinant and nothing to alpha or S, and lets every panel of four
+    // columns below be a whole one.
+    constexpr int D = MVN_D, LD = MVN_LD, DP = (D + 3) / 4 * 4, VP = DP + 4;
+    __shared__ __attribute__((aligned(16))) float A[DP * LD];
+    __shared__ __attribute__((aligned(16))) float XT[DP * LD];
+    __shared__ __attribute__((aligned(16))) float Tblk[16];          // the panel's updated 4 x 4 diagonal block
+    __shared__ __attribute__((aligned(16))) float dvec[VP];
+    __shared__ __attribute__((aligned(16))) float avec[VP];
+    __shared__ __attribute__((aligned(16))) float diag[VP];          // L_ii and 1 / L_ii (the diagonal of A keeps C_ii)
+    __shared__ __attribute__((aligned(16))) float rdiag[VP];
     __shared__ float inputs[MVN_NIN_PAD];
-    const int lane = threadIdx.x;
+    __shared__ float red[4];
+    const int tid = threadIdx.x, h = tid & 1, pr = tid >> 1;
     const uint32_t n = blockIdx.x;
     if (n >= G.n_local) return;
 
     // ---- inputs of the covariance expression, d = x - m, zeroed matrices
-    if (lane < MVN_NIN) {
+    if (tid < MVN_NIN) {
         float v;
-        if (lane < MVN_NSI) {
-            v = G.samples[(size_t)G.input_rows[lane] * G.n_local + n];
+        if (tid < MVN_NSI) {
+            v = G.samples[(size_t)G.input_rows[tid] * G.n_local + n];
         } else {
-            const bsvi_uniform_entry e = G.uniform_inputs[lane - MVN_NSI];
+            const bsvi_uniform_entry e = G.uniform_inputs[tid - MVN_NSI];
             v = e.a + e.b * utransform(e.transform, G.params[e.src]);
         }
-        inputs[lane] = v;
+        inputs[tid] = v;
     }
-    for (int i = lane; i < (D + 3) / 4 * 4 + 4; i += 64) {
+    for (int i = tid; i < VP; i += MVN_THREADS) {
         float v = 0.0f;
         if (i < D) {
             const float x = MVN_VALUE_LATENT ? G.samples[(size_t)(G.value_row0 + i) * G.n_local + n] : G.vecs[D + i];
@@ -92,8 +178,10 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
         }
         dvec[i] = v;
         avec[i] = 0.0f;
+        diag[i] = 1.0f;
+        rdiag[i] = 1.0f;
     }
-    for (int i = lane; i < D * LD / 4; i += 64) {
+    for (int i = tid; i < DP * LD / 4; i += MVN_THREADS) {
         reinterpret_cast<mvn_f4*>(A)[i] = mvn_f4{0.0f, 0.0f, 0.0f, 0.0f};
         reinterpret_cast<mvn_f4*>(XT)[i] = mvn_f4{0.0f, 0.0f, 0.0f, 0.0f};
     }
@@ -104,160 +192,215 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
 
     // ---- 1: the lower triangle of C
     constexpr int NTRI = D * (D + 1) / 2;
-    for (int e = lane; e < NTRI; e += 64) {
-        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while (i * (i + 1) / 2 > e) --i;
-        while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        const int j = e - i * (i + 1) / 2;
+    for (int e = tid; e < NTRI; e += MVN_THREADS) {
+        int i, j;
+        mvn_tri(e, i, j);
         float c, dc[MVN_NIN_PAD];
         mvn_cov(i, j, in, G.mats, c, dc);
         A[i * LD + j] = c;
     }
+    if (tid < DP - D) A[(D + tid) * LD + D + tid] = 1.0f;
     __syncthreads();
+    MVN_STEP_END(1)
 
 #if MVN_FORM == 2
     // ---- precision form: alpha = P d from the lower triangle (row part along k, column part down the rows), before P is factorised
     float quad = 0.0f;
-    for (int t = 0; t < (D + 63) / 64; ++t) {
-        const int i = lane + 64 * t;
-        if (i < D) {
-            float acc = 0.0f;
-            for (int k = 0; k <= i; ++k) acc += A[i * LD + k] * dvec[k];
-            for (int k = i + 1; k < D; ++k) acc += A[k * LD + i] * dvec[k];
-            avec[i] = acc;
-            quad += acc * dvec[i];
-        }
+    for (int i = tid; i < D; i += MVN_THREADS) {
+        float acc = 0.0f;
+        for (int k = 0; k <= i; ++k) acc += A[i * LD + k] * dvec[k];
+        for (int k = i + 1; k < D; ++k) acc += A[k * LD + i] * dvec[k];
+        avec[i] = acc;
+        quad += acc * dvec[i];
     }
-    quad = mvn_wave_sum(quad);
-    __syncthreads();
+    quad = mvn_block_sum(quad, red, tid);
 #endif
 
     // ---- 2: Cholesky (left-looking): column j from the columns before it
     float logdet = 0.0f;
 #if MVN_FORM == 1
     // (scale_tril: the lower triangle already holds L)
-    for (int t = 0; t < (D + 63) / 64; ++t) {
-        const int i = lane + 64 * t;
-        if (i < D) logdet += logf(A[i * LD + i]);
-    }
-    logdet = mvn_wave_sum(logdet);
-#else
-    for (int j = 0; j < D; ++j) {
-        float s[(D + 63) / 64];
-        const int jb = j & ~3;
-#pragma unroll
-        for (int t = 0; t < (D + 63) / 64; ++t) {
-            const int i = j + lane + 64 * t;
-            float acc = 0.0f;
-            if (i < D) {
-                const mvn_f4* ri = reinterpret_cast<const mvn_f4*>(A + i * LD);
-                const mvn_f4* rj = reinterpret_cast<const mvn_f4*>(A + j * LD);
-                for (int k = 0; k < jb; k += 4) acc += mvn_dot4(ri[k >> 2], rj[k >> 2]);
-                // the block that holds column j itself: only the components in front of it
-                const mvn_f4 a = ri[jb >> 2], b = rj[jb >> 2];
-                const int r = j - jb;
-                acc += (r > 0 ? a.x * b.x : 0.0f) + (r > 1 ? a.y * b.y : 0.0f) + (r > 2 ? a.z * b.z : 0.0f);
-                acc = A[i * LD + j] - acc;
-            }
-            s[t] = acc;
+    {
+        float part = 0.0f;
+        for (int i = tid; i < D; i += MVN_THREADS) {
+            const float l = A[i * LD + i];
+            diag[i] = l;
+            rdiag[i] = 1.0f / l;
+            part += logf(l);
         }
-        const float pivot = __shfl(s[0], 0, 64);          // row j is lane 0 of the first pass
-        const float ljj = sqrtf(pivot), inv = 1.0f / ljj;  // (a pivot <= 0 gives NaN: the step is then skipped as non-finite)
-        logdet += logf(ljj);
+        logdet = mvn_block_sum(part, red, tid);
+    }
+#else
+    // Panels of FOUR columns (one 16-byte block): per panel ONE pass over the row's blocks in front of it — the row's block against
+    // the same blocks of the panel's four rows, 16 multiply-adds per five loads where the column-by-column form had 8 per two —
+    // then the 4 x 4 diagonal block goes through LDS, every thread factorises it in registers and solves its own row's four
+    // entries.  Two barriers per panel = D / 2 in all, and D / 4 dependent passes, where one column at a time took D of each
+    // (tools/r4/mvn_steps.sh: 1 875 cycles per column, nearly all of it the latency of that one chain).
+    constexpr int TRIPS = (DP + MVN_THREADS / 2 - 1) / (MVN_THREADS / 2);      // rows per pair: 1, or 2 when DP > 128
+    for (int c0 = 0; c0 < DP; c0 += 4) {
+        const int nb = c0 >> 2;
+        const mvn_f4* const y0 = reinterpret_cast<const mvn_f4*>(A + (c0 + 0) * LD);
+        const mvn_f4* const y1 = reinterpret_cast<const mvn_f4*>(A + (c0 + 1) * LD);
+        const mvn_f4* const y2 = reinterpret_cast<const mvn_f4*>(A + (c0 + 2) * LD);
+        const mvn_f4* const y3 = reinterpret_cast<const mvn_f4*>(A + (c0 + 3) * LD);
+        float t[TRIPS][4];
 #pragma unroll
-        for (int t = 0; t < (D + 63) / 64; ++t) {
-            const int i = j + lane + 64 * t;
-            if (i < D) A[i * LD + j] = (i == j) ? ljj : s[t] * inv;
+        for (int tt = 0; tt < TRIPS; ++tt) {
+            const int i = c0 + pr + tt * (MVN_THREADS / 2);
+            t[tt][0] = t[tt][1] = t[tt][2] = t[tt][3] = 0.0f;
+            if (i < DP) {                                     // (a pair's lanes share i)
+                const mvn_f4* const ri = reinterpret_cast<const mvn_f4*>(A + i * LD);
+                const mvn_f4 own = ri[nb];                   // C_i,c0..c0+3 (zeros above the diagonal)
+                float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;
+                int b = h;
+                for (; b + 2 < nb; b += 4) {
+                    const mvn_f4 xa = ri[b], xb = ri[b + 2];
+                    const mvn_f4 a0 = y0[b], a1 = y1[b], a2 = y2[b], a3 = y3[b];
+                    const mvn_f4 b0 = y0[b + 2], b1 = y1[b + 2], b2 = y2[b + 2], b3 = y3[b + 2];
+                    t0 += mvn_dot4(xa, a0); t1 += mvn_dot4(xa, a1); t2 += mvn_dot4(xa, a2); t3 += mvn_dot4(xa, a3);
+                    u0 += mvn_dot4(xb, b0); u1 += mvn_dot4(xb, b1); u2 += mvn_dot4(xb, b2); u3 += mvn_dot4(xb, b3);
+                }
+                if (b < nb) {
+                    const mvn_f4 xa = ri[b];
+                    t0 += mvn_dot4(xa, y0[b]); t1 += mvn_dot4(xa, y1[b]); t2 += mvn_dot4(xa, y2[b]); t3 += mvn_dot4(xa, y3[b]);
+                }
+                t0 += u0; t1 += u1; t2 += u2; t3 += u3;
+                t0 += mvn_pair(t0); t1 += mvn_pair(t1); t2 += mvn_pair(t2); t3 += mvn_pair(t3);
+                t[tt][0] = own.x - t0; t[tt][1] = own.y - t1; t[tt][2] = own.z - t2; t[tt][3] = own.w - t3;
+                if (h == 0 && i - c0 < 4) *reinterpret_cast<mvn_f4*>(Tblk + 4 * (i - c0)) = mvn_f4{t[tt][0], t[tt][1], t[tt][2], t[tt][3]};
+            }
+        }
+        __syncthreads();
+        // the diagonal block T = L_pp L_pp^T, by every thread alike
+        const mvn_f4 T0 = reinterpret_cast<const mvn_f4*>(Tblk)[0], T1 = reinterpret_cast<const mvn_f4*>(Tblk)[1],
+                     T2 = reinterpret_cast<const mvn_f4*>(Tblk)[2], T3 = reinterpret_cast<const mvn_f4*>(Tblk)[3];
+        const float r0 = mvn_rsqrt(T0.x), l00 = T0.x * r0;           // (a pivot <= 0 gives NaN: the step is then skipped as non-finite)
+        const float l10 = T1.x * r0;
+        const float p1 = T1.y - l10 * l10, r1 = mvn_rsqrt(p1), l11 = p1 * r1;
+        const float l20 = T2.x * r0, l21 = (T2.y - l20 * l10) * r1;
+        const float p2 = T2.z - l20 * l20 - l21 * l21, r2 = mvn_rsqrt(p2), l22 = p2 * r2;
+        const float l30 = T3.x * r0, l31 = (T3.y - l30 * l10) * r1, l32 = (T3.z - l30 * l20 - l31 * l21) * r2;
+        const float p3 = T3.w - l30 * l30 - l31 * l31 - l32 * l32, r3 = mvn_rsqrt(p3), l33 = p3 * r3;
+#pragma unroll
+        for (int tt = 0; tt < TRIPS; ++tt) {
+            const int i = c0 + pr + tt * (MVN_THREADS / 2), r = i - c0;
+            // this row's four entries: L_i,c0.. = t L_pp^-T (the rows of the block itself: the block's own row, zeros above the diagonal)
+            float x0 = t[tt][0] * r0;
+            float x1 = (t[tt][1] - x0 * l10) * r1;
+            float x2 = (t[tt][2] - x0 * l20 - x1 * l21) * r2;
+            float x3 = (t[tt][3] - x0 * l30 - x1 * l31 - x2 * l32) * r3;
+            if (r == 0) { x0 = l00; x1 = 0.0f; x2 = 0.0f; x3 = 0.0f; }
+            if (r == 1) { x0 = l10; x1 = l11; x2 = 0.0f; x3 = 0.0f; }
+            if (r == 2) { x0 = l20; x1 = l21; x2 = l22; x3 = 0.0f; }
+            if (r == 3) { x0 = l30; x1 = l31; x2 = l32; x3 = l33; }
+            if (h == 0 && i < DP) *reinterpret_cast<mvn_f4*>(A + i * LD + c0) = mvn_f4{x0, x1, x2, x3};
+        }
+        if (tid == 0) {
+            *reinterpret_cast<mvn_f4*>(diag + c0) = mvn_f4{l00, l11, l22, l33};
+            *reinterpret_cast<mvn_f4*>(rdiag + c0) = mvn_f4{r0, r1, r2, r3};
         }
         __syncthreads();
     }
+    {   // log det L from the diagonal, once
+        float part = 0.0f;
+        for (int i = tid; i < D; i += MVN_THREADS) part += logf(diag[i]);
+        logdet = mvn_block_sum(part, red, tid);
+    }
 #endif
+    MVN_STEP_END(2)
 
-    // ---- 3: X = L^-1, column j by lane j, kept transposed: XT[j][i] = X[i][j] = -(sum_{j<=k<i} L[i][k] X[k][j]) / L[i][i]
-    for (int t = 0; t < (D + 63) / 64; ++t) {
-        const int j = lane + 64 * t;
-        if (j < D) {
-            float* xj = XT + j * LD;
-            xj[j] = 1.0f / A[j * LD + j];
-            const int jb = j & ~3;
-            for (int i = j + 1; i < D; ++i) {
-                const mvn_f4* li = reinterpret_cast<const mvn_f4*>(A + i * LD);
-                const mvn_f4* xr = reinterpret_cast<const mvn_f4*>(xj);
-                float acc = 0.0f;
-                // (aligned blocks: XT[j][k < j] and XT[j][k >= i] are still zero, A above its diagonal is zero)
-                for (int k = jb; k < i; k += 4) acc += mvn_dot4(li[k >> 2], xr[k >> 2]);
-                xj[i] = -acc / A[i * LD + i];
+    // ---- 3: X = L^-1, column j by lane pair j, kept transposed: XT[j][i] = X[i][j] = -(sum_{j<=k<i} L[i][k] X[k][j]) / L[i][i]
+    // Row blocks of FOUR: the sums over the blocks in front of a row block are four products sharing the column's loads, the
+    // block's own triangle runs in registers, the four results leave as one 16-byte store — D / 4 dependent steps per column.
+    for (int j = pr; j < D; j += MVN_THREADS / 2) {
+        float* const xj = XT + j * LD;
+        const mvn_f4* const xr = reinterpret_cast<const mvn_f4*>(xj);
+        const int jb = j >> 2;
+        for (int I = jb; I < DP / 4; ++I) {
+            const int i0 = 4 * I;
+            const mvn_f4* const l0 = reinterpret_cast<const mvn_f4*>(A + (i0 + 0) * LD);
+            const mvn_f4* const l1 = reinterpret_cast<const mvn_f4*>(A + (i0 + 1) * LD);
+            const mvn_f4* const l2 = reinterpret_cast<const mvn_f4*>(A + (i0 + 2) * LD);
+            const mvn_f4* const l3 = reinterpret_cast<const mvn_f4*>(A + (i0 + 3) * LD);
+            // the block's own triangle of L and the reciprocals of its diagonal: requested in front of the pass
+            const mvn_f4 d0 = l0[I], d1 = l1[I], d2 = l2[I], d3 = l3[I];
+            const mvn_f4 rd = *reinterpret_cast<const mvn_f4*>(rdiag + i0);
+            (void)d0;
+            // s_r = sum_{4 jb <= k < 4 I} L[i0 + r][k] X[k][j]   (XT[j][k < j] is zero)
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;
+            int b = jb + h;
+            for (; b + 2 < I; b += 4) {
+                const mvn_f4 xa = xr[b], xb = xr[b + 2];
+                const mvn_f4 a0 = l0[b], a1 = l1[b], a2 = l2[b], a3 = l3[b];
+                const mvn_f4 b0 = l0[b + 2], b1 = l1[b + 2], b2 = l2[b + 2], b3 = l3[b + 2];
+                s0 += mvn_dot4(xa, a0); s1 += mvn_dot4(xa, a1); s2 += mvn_dot4(xa, a2); s3 += mvn_dot4(xa, a3);
+                u0 += mvn_dot4(xb, b0); u1 += mvn_dot4(xb, b1); u2 += mvn_dot4(xb, b2); u3 += mvn_dot4(xb, b3);
             }
+            if (b < I) {
+                const mvn_f4 xa = xr[b];
+                s0 += mvn_dot4(xa, l0[b]); s1 += mvn_dot4(xa, l1[b]); s2 += mvn_dot4(xa, l2[b]); s3 += mvn_dot4(xa, l3[b]);
+            }
+            s0 += u0; s1 += u1; s2 += u2; s3 += u3;
+            s0 += mvn_pair(s0); s1 += mvn_pair(s1); s2 += mvn_pair(s2); s3 += mvn_pair(s3);
+            // rows i0 .. i0 + 3 in order: X[i][j] = -(s + the block's own part) / L_ii; rows in front of j are zero, row j is 1 / L_jj
+            const int q = j - i0;                             // (>= 0 only in the column's first block)
+            float x0 = q > 0 ? 0.0f : (q == 0 ? rd.x : -s0 * rd.x);
+            float x1 = q > 1 ? 0.0f : (q == 1 ? rd.y : -(s1 + d1.x * x0) * rd.y);
+            float x2 = q > 2 ? 0.0f : (q == 2 ? rd.z : -(s2 + d2.x * x0 + d2.y * x1) * rd.z);
+            float x3 = q == 3 ? rd.w : -(s3 + d3.x * x0 + d3.y * x1 + d3.z * x2) * rd.w;
+            if (h == 0) *reinterpret_cast<mvn_f4*>(xj + i0) = mvn_f4{x0, x1, x2, x3};
         }
     }
     __syncthreads();
+    MVN_STEP_END(3)
 
 #if MVN_FORM == 1
     // ---- scale_tril form: y = L^-1 d = X d, y_j = sum_{k <= j} X[j][k] d_k = sum_k XT[k][j] d_k (lanes along j: conflict-free)
-    __shared__ __attribute__((aligned(16))) float yvec[(D + 3) / 4 * 4 + 4];
-    for (int t = 0; t < (D + 63) / 64; ++t) {
-        const int j = lane + 64 * t;
-        if (j < D) {
-            float acc = 0.0f;
-            for (int k = 0; k <= j; ++k) acc += XT[k * LD + j] * dvec[k];
-            yvec[j] = acc;
-        }
+    __shared__ __attribute__((aligned(16))) float yvec[VP];
+    for (int j = tid; j < D; j += MVN_THREADS) {
+        float acc = 0.0f;
+        for (int k = 0; k <= j; ++k) acc += XT[k * LD + j] * dvec[k];
+        yvec[j] = acc;
     }
     __syncthreads();
 #endif
 
     // ---- 4: S = X^T X:  S[i][j] = sum_{k >= i} XT[i][k] XT[j][k]  (i >= j), written to both triangles of A
-    for (int t = 0; t < (D + 63) / 64; ++t) {
-        const int i = lane + 64 * t;
-        if (i < D) {
-            const int ib = i & ~3;
-            const mvn_f4* xi = reinterpret_cast<const mvn_f4*>(XT + i * LD);
-            for (int j = 0; j <= i; ++j) {
-                const mvn_f4* xj = reinterpret_cast<const mvn_f4*>(XT + j * LD);
-                float acc = 0.0f;
-                for (int k = ib; k < D; k += 4) acc += mvn_dot4(xi[k >> 2], xj[k >> 2]);      // (XT[i][k < i] = 0; columns >= D are zero)
-                A[i * LD + j] = acc;
-                A[j * LD + i] = acc;
-            }
-        }
+    for (int e = tid; e < NTRI; e += MVN_THREADS) {
+        int i, j;
+        mvn_tri(e, i, j);
+        // (XT[i][k < i] = 0; columns >= D are zero)
+        const float acc = mvn_rowdot(reinterpret_cast<const mvn_f4*>(XT + i * LD), reinterpret_cast<const mvn_f4*>(XT + j * LD), i >> 2, LD / 4, 1);
+        A[i * LD + j] = acc;
+        A[j * LD + i] = acc;
     }
     __syncthreads();
+    MVN_STEP_END(4)
 
     // ---- 5: alpha = S d, the quadratic form, log p
 #if MVN_FORM != 2
     float quad = 0.0f;
-    for (int t = 0; t < (D + 63) / 64; ++t) {
-        const int i = lane + 64 * t;
-        if (i < D) {
-            const mvn_f4* si = reinterpret_cast<const mvn_f4*>(A + i * LD);
-            const mvn_f4* dv = reinterpret_cast<const mvn_f4*>(dvec);
-            float acc = 0.0f;
-            for (int k = 0; k < D; k += 4) {
-                mvn_f4 row = si[k >> 2];
-                // (the row's tail beyond column D-1 may hold nothing of S: d is zero there)
-                acc += mvn_dot4(row, dv[k >> 2]);
-            }
-            avec[i] = acc;
-            quad += acc * dvec[i];
-        }
+    for (int i = tid; i < D; i += MVN_THREADS) {
+        // (the row's tail beyond column D-1 may hold nothing of S: d is zero there)
+        const float acc = mvn_rowdot(reinterpret_cast<const mvn_f4*>(A + i * LD), reinterpret_cast<const mvn_f4*>(dvec), 0, (D + 3) / 4, 1);
+        avec[i] = acc;
+        quad += acc * dvec[i];
     }
-    quad = mvn_wave_sum(quad);
-    __syncthreads();
+    quad = mvn_block_sum(quad, red, tid);
     const float logp = -0.5f * quad - logdet - 0.5f * (float)D * 1.8378770664093453f;
 #else
     const float logp = -0.5f * quad + logdet - 0.5f * (float)D * 1.8378770664093453f;      // (logdet = sum log M_ii = log det P / 2)
 #endif
+    MVN_STEP_END(5)
 
     // ---- 6: dlogp/ds_k = sum_{i >= j} m_ij (alpha_i alpha_j - S_ij) / 2 * dC_ij/ds_k   (m_ij = 2 off the diagonal: C is symmetric)
     float gin[MVN_NIN_PAD];
 #pragma unroll
     for (int k = 0; k < MVN_NIN_PAD; ++k) gin[k] = 0.0f;
 #if MVN_NIN > 0
-    for (int e = lane; e < NTRI; e += 64) {
-        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while (i * (i + 1) / 2 > e) --i;
-        while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        const int j = e - i * (i + 1) / 2;
+    for (int e = tid; e < NTRI; e += MVN_THREADS) {
+        int i, j;
+        mvn_tri(e, i, j);
         float c, dc[MVN_NIN_PAD];
         mvn_cov(i, j, in, G.mats, c, dc);
 #if MVN_FORM == 0
@@ -271,7 +414,7 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
         for (int k = 0; k < MVN_NIN; ++k) gin[k] += gij * dc[k];
     }
 #pragma unroll
-    for (int k = 0; k < MVN_NIN; ++k) gin[k] = mvn_wave_sum(gin[k]);
+    for (int k = 0; k < MVN_NIN; ++k) gin[k] = mvn_block_sum(gin[k], red, tid);
 #endif
 
     // ---- the surrogate's rows: coefficients of the slot inputs, of x (when latent), of the uniform inputs, then e
@@ -281,43 +424,37 @@ extern "C" __global__ void __launch_bounds__(64) bsvi_mvn_kernel(const MvnArgs G
     for (int k = 0; k < MVN_NIN; ++k) lin += w * gin[k] * in[k];
     float linx = 0.0f;
     uint32_t row = 0;
-    if (lane == 0) {
+    if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < MVN_NSI; ++k) G.rows_out[(size_t)(row + k) * G.n_local + n] = w * gin[k];
     }
     row += MVN_NSI;
     if (MVN_VALUE_LATENT) {
-        for (int t = 0; t < (D + 63) / 64; ++t) {
-            const int i = lane + 64 * t;
-            if (i < D) {
-                const float gx = -w * avec[i];
-                G.rows_out[(size_t)(row + i) * G.n_local + n] = gx;
-                linx += gx * G.samples[(size_t)(G.value_row0 + i) * G.n_local + n];
-            }
+        for (int i = tid; i < D; i += MVN_THREADS) {
+            const float gx = -w * avec[i];
+            G.rows_out[(size_t)(row + i) * G.n_local + n] = gx;
+            linx += gx * G.samples[(size_t)(G.value_row0 + i) * G.n_local + n];
         }
-        linx = mvn_wave_sum(linx);
+        linx = mvn_block_sum(linx, red, tid);
         row += D;
     }
-    if (lane == 0) {
+    if (tid == 0) {
 #pragma unroll
         for (int k = MVN_NSI; k < MVN_NIN; ++k) G.rows_out[(size_t)(row + k - MVN_NSI) * G.n_local + n] = w * gin[k];
     }
     row += MVN_NIN - MVN_NSI;
     float linm = 0.0f;
     if (MVN_LOC_PARAM) {           // d log p / d m = +alpha
-        for (int t = 0; t < (D + 63) / 64; ++t) {
-            const int i = lane + 64 * t;
-            if (i < D) {
-                const float gm = w * avec[i];
-                G.rows_out[(size_t)(row + i) * G.n_local + n] = gm;
-                const bsvi_uniform_entry e = G.loc_entries[i];
-                linm += gm * (e.a + e.b * utransform(e.transform, G.params[e.src]));
-            }
+        for (int i = tid; i < D; i += MVN_THREADS) {
+            const float gm = w * avec[i];
+            G.rows_out[(size_t)(row + i) * G.n_local + n] = gm;
+            const bsvi_uniform_entry e = G.loc_entries[i];
+            linm += gm * (e.a + e.b * utransform(e.transform, G.params[e.src]));
         }
-        linm = mvn_wave_sum(linm);
+        linm = mvn_block_sum(linm, red, tid);
         row += D;
     }
-    if (lane == 0) G.rows_out[(size_t)row * G.n_local + n] = w * logp - lin - linx - linm;
+    if (tid == 0) G.rows_out[(size_t)row * G.n_local + n] = w * logp - lin - linx - linm;
 }
 
 }  // namespace bsvi
