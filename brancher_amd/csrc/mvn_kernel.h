@@ -59,7 +59,7 @@ __device__ __forceinline__ float mvn_dot4(mvn_f4 a, mvn_f4 b) { return (a.x * b.
 
 // timing experiments (BSVI_SPEC_DEFINES="#define MVN_STOP_AFTER k", tools/r4/mvn_steps.sh): the kernel ends behind step k
 #if defined(MVN_STOP_AFTER)
-#define MVN_STEP_END(k) if (MVN_STOP_AFTER == (k)) { if (tid == 0) G.rows_out[n] = A[0] + XT[1] + avec[0]; return; }
+#define MVN_STEP_END(k) if (MVN_STOP_AFTER == (k)) { if (tid == 0) G.rows_out[n] = A[0] + A[1] + avec[0]; return; }
 #else
 #define MVN_STEP_END(k)
 #endif
@@ -141,9 +141,15 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
     // factorises to itself, contributes log 1 to the determinant and nothing to alpha or S, and lets every panel of four
     // columns below be a whole one.
     constexpr int D = MVN_D, LD = MVN_LD, DP = (D + 3) / 4 * 4, VP = DP + 4;
+    // ONE matrix (round 3 and the first version of this kernel kept two: 136 x 136 at most, and one sample per CU from D = 100):
+    //   below the diagonal   C, then L, at the end S = C^-1 (strictly lower part; its diagonal in sdiag)
+    //   above the diagonal   zero until step 3, then X^T:  A[j][i] = X[i][j] for i > j   (X = L^-1)
+    //   the diagonal         C_jj, L_jj, from step 3 on X_jj = 1 / L_jj
+    // The diagonals of L live in diag / rdiag.  Readers of a row that mixes the two (the first block of a column of X, the
+    // first block of a row in S = X^T X) mask the components that belong to the other triangle.
     __shared__ __attribute__((aligned(16))) float A[DP * LD];
-    __shared__ __attribute__((aligned(16))) float XT[DP * LD];
     __shared__ __attribute__((aligned(16))) float Tblk[16];          // the panel's updated 4 x 4 diagonal block
+    __shared__ __attribute__((aligned(16))) float sdiag[VP];
     __shared__ __attribute__((aligned(16))) float dvec[VP];
     __shared__ __attribute__((aligned(16))) float avec[VP];
     __shared__ __attribute__((aligned(16))) float diag[VP];          // L_ii and 1 / L_ii (the diagonal of A keeps C_ii)
@@ -183,7 +189,6 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
     }
     for (int i = tid; i < DP * LD / 4; i += MVN_THREADS) {
         reinterpret_cast<mvn_f4*>(A)[i] = mvn_f4{0.0f, 0.0f, 0.0f, 0.0f};
-        reinterpret_cast<mvn_f4*>(XT)[i] = mvn_f4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     __syncthreads();
     float in[MVN_NIN_PAD];
@@ -312,10 +317,11 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
     // ---- 3: X = L^-1, column j by lane pair j, kept transposed: XT[j][i] = X[i][j] = -(sum_{j<=k<i} L[i][k] X[k][j]) / L[i][i]
     // Row blocks of FOUR: the sums over the blocks in front of a row block are four products sharing the column's loads, the
     // block's own triangle runs in registers, the four results leave as one 16-byte store — D / 4 dependent steps per column.
+    // Column j of X is ROW j of A behind its diagonal; the row's entries in front of it are still L.
     for (int j = pr; j < D; j += MVN_THREADS / 2) {
-        float* const xj = XT + j * LD;
+        float* const xj = A + j * LD;
         const mvn_f4* const xr = reinterpret_cast<const mvn_f4*>(xj);
-        const int jb = j >> 2;
+        const int jb = j >> 2, q0 = j & 3;
         for (int I = jb; I < DP / 4; ++I) {
             const int i0 = 4 * I;
             const mvn_f4* const l0 = reinterpret_cast<const mvn_f4*>(A + (i0 + 0) * LD);
@@ -323,12 +329,16 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
             const mvn_f4* const l2 = reinterpret_cast<const mvn_f4*>(A + (i0 + 2) * LD);
             const mvn_f4* const l3 = reinterpret_cast<const mvn_f4*>(A + (i0 + 3) * LD);
             // the block's own triangle of L and the reciprocals of its diagonal: requested in front of the pass
-            const mvn_f4 d0 = l0[I], d1 = l1[I], d2 = l2[I], d3 = l3[I];
+            const mvn_f4 d1 = l1[I], d2 = l2[I], d3 = l3[I];
             const mvn_f4 rd = *reinterpret_cast<const mvn_f4*>(rdiag + i0);
-            (void)d0;
-            // s_r = sum_{4 jb <= k < 4 I} L[i0 + r][k] X[k][j]   (XT[j][k < j] is zero)
+            // s_r = sum_{j <= k < 4 I} L[i0 + r][k] X[k][j]: the column's first block (lane h = 0) without what is L in it
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;
-            int b = jb + h;
+            if (h == 0 && jb < I) {
+                mvn_f4 xa = xr[jb];
+                xa.x = q0 > 0 ? 0.0f : xa.x; xa.y = q0 > 1 ? 0.0f : xa.y; xa.z = q0 > 2 ? 0.0f : xa.z;
+                s0 = mvn_dot4(xa, l0[jb]); s1 = mvn_dot4(xa, l1[jb]); s2 = mvn_dot4(xa, l2[jb]); s3 = mvn_dot4(xa, l3[jb]);
+            }
+            int b = jb + 1 + h;
             for (; b + 2 < I; b += 4) {
                 const mvn_f4 xa = xr[b], xb = xr[b + 2];
                 const mvn_f4 a0 = l0[b], a1 = l1[b], a2 = l2[b], a3 = l3[b];
@@ -342,13 +352,22 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
             }
             s0 += u0; s1 += u1; s2 += u2; s3 += u3;
             s0 += mvn_pair(s0); s1 += mvn_pair(s1); s2 += mvn_pair(s2); s3 += mvn_pair(s3);
-            // rows i0 .. i0 + 3 in order: X[i][j] = -(s + the block's own part) / L_ii; rows in front of j are zero, row j is 1 / L_jj
+            // rows i0 .. i0 + 3 in order: X[i][j] = -(s + the block's own part) / L_ii; row j itself is 1 / L_jj
             const int q = j - i0;                             // (>= 0 only in the column's first block)
-            float x0 = q > 0 ? 0.0f : (q == 0 ? rd.x : -s0 * rd.x);
-            float x1 = q > 1 ? 0.0f : (q == 1 ? rd.y : -(s1 + d1.x * x0) * rd.y);
-            float x2 = q > 2 ? 0.0f : (q == 2 ? rd.z : -(s2 + d2.x * x0 + d2.y * x1) * rd.z);
-            float x3 = q == 3 ? rd.w : -(s3 + d3.x * x0 + d3.y * x1 + d3.z * x2) * rd.w;
-            if (h == 0) *reinterpret_cast<mvn_f4*>(xj + i0) = mvn_f4{x0, x1, x2, x3};
+            const float x0 = q > 0 ? 0.0f : (q == 0 ? rd.x : -s0 * rd.x);
+            const float x1 = q > 1 ? 0.0f : (q == 1 ? rd.y : -(s1 + d1.x * x0) * rd.y);
+            const float x2 = q > 2 ? 0.0f : (q == 2 ? rd.z : -(s2 + d2.x * x0 + d2.y * x1) * rd.z);
+            const float x3 = q == 3 ? rd.w : -(s3 + d3.x * x0 + d3.y * x1 + d3.z * x2) * rd.w;
+            if (h == 0) {
+                if (I > jb) {
+                    *reinterpret_cast<mvn_f4*>(xj + i0) = mvn_f4{x0, x1, x2, x3};
+                } else {                                       // the first block: what lies in front of the diagonal stays L
+                    if (q <= 0) xj[i0] = x0;
+                    if (q <= 1) xj[i0 + 1] = x1;
+                    if (q <= 2) xj[i0 + 2] = x2;
+                    xj[i0 + 3] = x3;
+                }
+            }
         }
     }
     __syncthreads();
@@ -359,20 +378,24 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
     __shared__ __attribute__((aligned(16))) float yvec[VP];
     for (int j = tid; j < D; j += MVN_THREADS) {
         float acc = 0.0f;
-        for (int k = 0; k <= j; ++k) acc += XT[k * LD + j] * dvec[k];
+        for (int k = 0; k <= j; ++k) acc += A[k * LD + j] * dvec[k];               // (X[j][k] = A[k][j] above the diagonal, X_jj on it)
         yvec[j] = acc;
     }
     __syncthreads();
 #endif
 
-    // ---- 4: S = X^T X:  S[i][j] = sum_{k >= i} XT[i][k] XT[j][k]  (i >= j), written to both triangles of A
+    // ---- 4: S = X^T X:  S[i][j] = sum_{k >= i} X[k][i] X[k][j]  (i >= j): rows i and j of A from block i / 4 on, row i without what is
+    //         L in its first block.  S goes where L was (nobody reads L any more); its diagonal, which X_ii still occupies, to sdiag.
     for (int e = tid; e < NTRI; e += MVN_THREADS) {
         int i, j;
         mvn_tri(e, i, j);
-        // (XT[i][k < i] = 0; columns >= D are zero)
-        const float acc = mvn_rowdot(reinterpret_cast<const mvn_f4*>(XT + i * LD), reinterpret_cast<const mvn_f4*>(XT + j * LD), i >> 2, LD / 4, 1);
-        A[i * LD + j] = acc;
-        A[j * LD + i] = acc;
+        const mvn_f4* const xi = reinterpret_cast<const mvn_f4*>(A + i * LD);
+        const mvn_f4* const xq = reinterpret_cast<const mvn_f4*>(A + j * LD);
+        const int ib = i >> 2, q0 = i & 3;
+        mvn_f4 first = xi[ib];
+        first.x = q0 > 0 ? 0.0f : first.x; first.y = q0 > 1 ? 0.0f : first.y; first.z = q0 > 2 ? 0.0f : first.z;
+        const float acc = mvn_dot4(first, xq[ib]) + mvn_rowdot(xi, xq, ib + 1, DP / 4, 1);
+        if (i == j) sdiag[i] = acc; else A[i * LD + j] = acc;
     }
     __syncthreads();
     MVN_STEP_END(4)
@@ -381,8 +404,21 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
 #if MVN_FORM != 2
     float quad = 0.0f;
     for (int i = tid; i < D; i += MVN_THREADS) {
-        // (the row's tail beyond column D-1 may hold nothing of S: d is zero there)
-        const float acc = mvn_rowdot(reinterpret_cast<const mvn_f4*>(A + i * LD), reinterpret_cast<const mvn_f4*>(dvec), 0, (D + 3) / 4, 1);
+        // S is symmetric and only its lower triangle is stored: the row in front of the diagonal, the column behind it
+        float a0 = sdiag[i] * dvec[i], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int k = 0;
+        for (; k + 3 < i; k += 4) {
+            const float* const row = A + i * LD + k;
+            a0 += row[0] * dvec[k]; a1 += row[1] * dvec[k + 1]; a2 += row[2] * dvec[k + 2]; a3 += row[3] * dvec[k + 3];
+        }
+        for (; k < i; ++k) a0 += A[i * LD + k] * dvec[k];
+        k = i + 1;
+        for (; k + 3 < D; k += 4) {
+            a0 += A[k * LD + i] * dvec[k]; a1 += A[(k + 1) * LD + i] * dvec[k + 1];
+            a2 += A[(k + 2) * LD + i] * dvec[k + 2]; a3 += A[(k + 3) * LD + i] * dvec[k + 3];
+        }
+        for (; k < D; ++k) a0 += A[k * LD + i] * dvec[k];
+        const float acc = (a0 + a1) + (a2 + a3);
         avec[i] = acc;
         quad += acc * dvec[i];
     }
@@ -404,11 +440,13 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
         float c, dc[MVN_NIN_PAD];
         mvn_cov(i, j, in, G.mats, c, dc);
 #if MVN_FORM == 0
-        const float gij = (i == j ? 0.5f : 1.0f) * (avec[i] * avec[j] - A[i * LD + j]);
+        const float sij = i == j ? sdiag[i] : A[i * LD + j];
+        const float gij = (i == j ? 0.5f : 1.0f) * (avec[i] * avec[j] - sij);
 #elif MVN_FORM == 1
-        const float gij = avec[i] * yvec[j] - (i == j ? XT[i * LD + i] : 0.0f);           // (X_ii = 1 / L_ii)
+        const float gij = avec[i] * yvec[j] - (i == j ? rdiag[i] : 0.0f);                 // (X_ii = 1 / L_ii)
 #else
-        const float gij = (i == j ? 0.5f : 1.0f) * (A[i * LD + j] - dvec[i] * dvec[j]);
+        const float sij = i == j ? sdiag[i] : A[i * LD + j];
+        const float gij = (i == j ? 0.5f : 1.0f) * (sij - dvec[i] * dvec[j]);
 #endif
 #pragma unroll
         for (int k = 0; k < MVN_NIN; ++k) gin[k] += gij * dc[k];

@@ -491,11 +491,13 @@ class CompiledELBO:
         a_n = dg/df_n, b_n = dg/dlog q_n (bsvi_elbo_args::f_weight_dev / q_weight_dev; the program must be a BlackBox one)."""
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
-        if self._externals:
-            raise NotImplementedError("user-defined gradient estimators on models with batched multivariate-normal terms")
         a = f_weight.reshape(-1)[base:base + n_local].contiguous().float()
         b = q_weight.reshape(-1)[base:base + n_local].contiguous().float()
         noise_t = self._noise_tensor(noise, number_samples, base, n_local)
+        if self._externals:
+            # batched multivariate-normal terms re-enter the program as linear surrogate records — model terms like any other,
+            # so a_n weights them too; their rows come from the same three-launch sequence as in `evaluate`
+            noise_t = self._external_rows(n_local, number_samples, base, noise_t, self._seed(seed), int(offset))
         args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, number_samples, base, None, self._seed(seed), int(offset)))
         args.stream = self._stream()
         args.noise_dev = noise_t.data_ptr() if noise_t is not None else None

@@ -1023,7 +1023,7 @@ class _Lowering:
             terms.append((_Term(v, i), u, [mk("imm", (), 0.0), L[i][i]], (1, 1, 1)))
         return terms
 
-    kMaxExternalMvn = 136
+    kMaxExternalMvn = 192
 
     def mvn_external(self, v, mat, given="covariance_matrix"):
         """A MultivariateNormal term too large to unroll (D > kMaxSymbolicMvn) whose covariance is an ELEMENTWISE expression of
@@ -1034,13 +1034,17 @@ class _Lowering:
         coefficients are GIVEN rows the kernel fills — value and gradient of log p at the sample, so the program's reverse
         sweep carries d log p / d inputs on to the posterior's parameters.  (`distributions.py:314-331`,
         `standard_variables.py:317-347`.)"""
-        if self.estimator in ("taylor1", "importance"):
-            raise LoweringError("%r: the batched multivariate-normal kernel serves the Pathwise and BlackBox estimators (the %s "
-                                "program evaluates the model at values other than the posterior's draws)" % (v.name, self.estimator))
+        # (the importance program — log p and log q at caller-supplied values, variables.py:821-841 — is served: its base
+        #  program reports the supplied values as the "draw", the kernel evaluates the term there.  Taylor1 is not: it reads
+        #  the model at the posterior's MEANS, which no program reports row by row)
+        if self.estimator == "taylor1":
+            raise LoweringError("%r: the batched multivariate-normal kernel serves the Pathwise and BlackBox estimators and the "
+                                "importance program (the taylor1 program evaluates the model at the posterior's means, not at its "
+                                "draws)" % v.name)
         links = v.link.expressions()
         _, dim, _ = mat.shape
         if dim > self.kMaxExternalMvn:
-            raise LoweringError("%r: a %dx%d covariance (the batched kernel keeps two matrices in LDS: limit %d)"
+            raise LoweringError("%r: a %dx%d covariance (the batched kernel keeps the matrix in LDS: limit %d)"
                                 % (v.name, dim, dim, self.kMaxExternalMvn))
         host_g = dict(identity=lambda x: x, softplus=lambda x: np.logaddexp(0.0, x), sigmoid=lambda x: 1.0 / (1.0 + np.exp(-x)),
                       exp=np.exp, log=np.log, tanh=np.tanh, sqrt=np.sqrt, square=np.square)

@@ -196,8 +196,13 @@ def test_builtin_estimators_written_against_the_seam_reproduce_the_builtin_progr
             return self.function(samples).mean()
 
     N = 96
-    for cls, builtin in ((MyBlackBox, "blackbox"), (MyPathwise, "pathwise")):
-        model = W.build_readme_ar(W.native_api(), T=6)
+    builders = [lambda: W.build_readme_ar(W.native_api(), T=6),
+                # ... and on a model whose MultivariateNormal term runs on the batched kernel family (its surrogate records are
+                # model terms like any other: the per-sample weights of the second pass apply to them too)
+                lambda: W.build_gp_hyperparameters(W.native_api(), n=24, jitter=5e-2)]
+    for cls, builtin, build in ((MyBlackBox, "blackbox", builders[0]), (MyPathwise, "pathwise", builders[0]),
+                                (MyBlackBox, "blackbox", builders[1]), (MyPathwise, "pathwise", builders[1])):
+        model = build()
         c = engine.compile_model(model, None, "blackbox")
         offset = c.iteration
         value = engine.custom_estimator_loss(model, model.posterior_model, cls, N)
@@ -617,10 +622,14 @@ def test_dense_sharded_step_sequence_equals_the_fused_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["readme_ar_T5_N7", "readme_ar_T20_N300", "beta_binomial_N512", "heavy_tails_N64"])
+@pytest.mark.parametrize("case", ["readme_ar_T5_N7", "readme_ar_T20_N300", "beta_binomial_N512", "heavy_tails_N64",
+                                  "gp_hyperparameters_n5_N80", "gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24",
+                                  "mvn_scale_tril_n24_N40", "mvn_precision_n24_N40"])
 def test_importance_weights_match_reference_log_densities(case):
     """`ProbabilisticModel.get_importance_weights` (variables.py:821-841) on the posterior samples the reference
-    drew: the fixtures hold log p(z, y) ("lp") and log q(z) ("lq") computed by the reference itself."""
+    drew: the fixtures hold log p(z, y) ("lp") and log q(z) ("lq") computed by the reference itself.  The Gaussian-process
+    cases above 10 inputs evaluate their MultivariateNormal term on the batched kernel family at the SUPPLIED values (the
+    importance program's base program reports them as its draw), in all three parameterisations."""
     g = Golden(case)
     model = g.build(W.native_api())
     q_samples = {name: g.data["z/" + name] for name in [k[2:] for k in g.data.files if k.startswith("z/")]}
