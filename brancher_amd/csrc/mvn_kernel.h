@@ -5,22 +5,26 @@
 // (`stochastic_processes.py:29-40`, `standard_variables.py:317-347`).  mvn.cpp generates `mvn_cov` (the expression with its
 // forward-mode derivatives in the m scalars) in front of this header and hiprtc compiles the two together.
 //
-// ONE WAVE per Monte-Carlo sample, everything in LDS, no barrier between dependent steps (a wave's LDS operations complete
-// in program order; __syncthreads() of a one-wave workgroup is a wait + a free barrier and only fences the compiler):
-//   1  C (lower triangle) from mvn_cov                          A <- C
-//   2  Cholesky, left-looking, in place                         A <- L          (sum log L_ii on the way)
-//   3  X = L^-1, column j by lane j, stored transposed          XT[j][k] = X[k][j]
-//   4  S = C^-1 = X^T X, row i by lane i                        A <- S          (both triangles)
+// ONE WORKGROUP of four waves per Monte-Carlo sample, ONE D x LD matrix in LDS that L, X^T and S share (round 4; round 3: one wave,
+// two matrices — profiles/r4/mvn_steps.txt has the step times of every stage: D = 128 1179 -> 158 us per launch at 512 samples):
+//   1  C (lower triangle) from mvn_cov, dealt out over the 256 threads             A(lower) <- C
+//   2  Cholesky, left-looking, in PANELS of four columns: a row belongs to a pair    A(lower) <- L, diag / rdiag <- L_ii, 1 / L_ii
+//      of lanes that split its 16-byte blocks; the 4 x 4 diagonal block goes through
+//      LDS and every thread factorises it in registers: two barriers per panel
+//   3  X = L^-1, column j by lane pair j in ROW BLOCKS of four, stored transposed    A(upper)[j][i] <- X[i][j], A[j][j] <- 1 / L_jj
+//      in the triangle L does not use
+//   4  S = C^-1 = X^T X, its D (D + 1) / 2 elements dealt out over the threads       A(strictly lower) <- S, sdiag <- S_ii
 //   5  alpha = S d,  quad = d.alpha,  log p = -quad/2 - sum log L_ii - D/2 log 2pi
 //   6  dlogp/dC = (alpha alpha^T - S)/2  contracted with the expression's derivatives -> dlogp/ds_k;  dlogp/dx = -alpha
+// D is padded to whole blocks of four rows with an identity block (it factorises to itself and contributes nothing).
 // The other two parameterisations of `distributions.py:314-331` run through the same steps with the roles changed (MVN_FORM):
 //   scale_tril        the expression IS L (its lower triangle): step 2 only adds up log L_ii; with y = L^-1 d (= X d)
 //                     d log p / d L_ij = alpha_i y_j - [i = j] / L_ii   for i >= j  (alpha = L^-T y = C^-1 d as before)
 //   precision_matrix  alpha = P d and the quadratic form come first (from the expression's lower triangle); then P = M M^T is
 //                     factorised where C was, log p = -d.alpha / 2 + sum log M_ii - D/2 log 2pi, S = X^T X with X = M^-1 is
 //                     P^-1, and  d log p / d P = (S - d d^T) / 2
-// Rows are 16-byte aligned with a stride of 4 * odd words: every inner product runs on ds_read_b128 along k, conflict-free
-// across the lanes' rows; both matrices start zeroed so that aligned 4-wide blocks may overrun a triangle's edge.
+// Rows are 16-byte aligned with a stride of 4 * odd words: every inner product runs on ds_read_b128 along k; the matrix starts
+// zeroed, and a reader of a row that holds two triangles masks the components of the other one.
 //
 // Rows out: coefficients of the slot inputs | of x (when latent) | of the uniform inputs | of m (when learnable) | e.
 // The results leave as the rows of a LINEAR surrogate (lowering.ExternalMvn): g_k = dlogp/d(input k) and

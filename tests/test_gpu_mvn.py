@@ -31,7 +31,7 @@ def gp_node(D, latent_x, weight=1.0, jitter=1e-2, seed=0):
                                  slot_inputs=[0], weight=weight), sq, eye
 
 
-@pytest.mark.parametrize("D,latent_x", [(5, True), (12, True), (32, True), (33, False), (64, True), (100, True), (100, False), (128, True)])
+@pytest.mark.parametrize("D,latent_x", [(5, True), (12, True), (32, True), (33, False), (64, True), (100, True), (100, False), (128, True), (131, False), (160, True), (192, True)])
 def test_log_density_and_gradients_match_torch_double(D, latent_x):
     from brancher_amd import native
     lib = native.load()

@@ -320,7 +320,7 @@ def test_multivariate_normal_with_a_sampled_covariance_is_unrolled():
     source = native.mvn_source(ext)
     assert "#define MVN_D 12" in source and "mvn_cov" in source and native.jit_compile(source) > 0
     with pytest.raises(lowering.LoweringError, match="limit"):
-        huge = W.build_gp_hyperparameters(api, n=140)
+        huge = W.build_gp_hyperparameters(api, n=200)
         lowering.lower(huge, huge.posterior_model, "pathwise")
     with pytest.raises(lowering.LoweringError, match="Pathwise and BlackBox"):
         lowering.lower(W.build_gp_hyperparameters(api, n=12), None, "taylor1")
