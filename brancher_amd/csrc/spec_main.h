@@ -398,6 +398,10 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     if (const unsigned long long* const offset_dev = SPEC_A->offset_dev) off0 += *offset_dev;
     const uint32_t n_global = SPEC_A->n_global;
     const uint32_t pretraining = SPEC_A->pretraining_iterations;
+    // several workgroups in loop mode: the generation number the launch starts from (read before anybody can advance it:
+    // workgroup 0 releases the first one only after every workgroup has published its first row)
+    unsigned int gen0 = 0;
+    if (G > 1 && mode == SPEC_MODE_LOOP) gen0 = __hip_atomic_load(SPEC_A->ticket + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if SPEC_EXCHANGE
     // (this rank's call count lives in its region and is touched by this rank's kernels only: stream order makes it current)
     uint32_t xseq0 = 0;
@@ -547,12 +551,57 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 mine[1] = c;
             }
             __syncthreads();                                   // every wave's stores issued and drained
-            if (tid == 0) {
-                const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                RED[2] = (t == G - 1u) ? 1.0f : 0.0f;
+            if (mode == SPEC_MODE_LOOP) {
+                // The loop of inference.py:95-108 over SEVERAL workgroups in one launch (round 4; before: one launch per
+                // iteration, every workgroup staging the tables again — 70 x the algorithmic traffic at BASELINE config 2).
+                // Workgroup 0 is the iteration's owner: it waits for the other G - 1 rows, adds them, runs the epilogue on ITS
+                // copy of the parameters and the optimizer state, writes the new parameters to memory and releases the
+                // iteration's generation number; the others wait for that number, read the parameters back and rebuild their
+                // copy of the uniform table.  Generation numbers only grow (base read at the start of the launch), the waits
+                // are bounded (a launch whose workgroups are not all resident must not hang: it ends with a NaN loss).
+                unsigned int* const gen = ticket + 64;
+                const unsigned int target = gen0 + it + 1u;
+                if (blockIdx.x != 0) {
+                    if (tid == 0) {
+                        __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long t0 = wall_clock64();
+                        while ((int)(__hip_atomic_load(gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                            if (wall_clock64() - t0 > 400000000ull) break;          // 4 s of the 100 MHz clock
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    __syncthreads();
+                    if (it + 1u == n_it) return;
+                    float* const params = SPEC_A->params;
+                    for (uint32_t i = tid; i < SPEC_N_PARAMS; i += nthreads)
+                        PS[i] = __hip_atomic_load(params + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    const float* const consts = SPEC_A->consts;
+                    (void)consts;
+                    for (uint32_t k = tid; k < SPEC_N_UNIFORM; k += nthreads) {
+                        const uint32_t src = TAB[4 * k], w1 = TAB[4 * k + 1];
+                        if ((w1 >> 8) & 0xFFu) spec_publish_uniform(TAB, k, PS[src]);
+                    }
+                    continue;                                  // (the next iteration's first barrier publishes the table)
+                }
+                if (tid == 0) {
+                    const unsigned long long t0 = wall_clock64();
+                    bool late = false;
+                    while (__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != G - 1u) {
+                        if (wall_clock64() - t0 > 400000000ull) { late = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    RED[3] = late ? 1.0f : 0.0f;
+                }
+                __syncthreads();
+            } else {
+                if (tid == 0) {
+                    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    RED[2] = (t == G - 1u) ? 1.0f : 0.0f;
+                }
+                __syncthreads();
+                if (RED[2] == 0.0f) return;
             }
-            __syncthreads();
-            if (RED[2] == 0.0f) return;
             // column c of the G rows: four interleaved slices per column (G can be hundreds of workgroups), then the slices
             float* const SL = spec_lds + SPEC_OFF_SCR;
             for (uint32_t i = tid; i < 4u * stride; i += nthreads) {
@@ -586,7 +635,10 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #endif
                 }
             }
-            if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (mode == SPEC_MODE_LOOP && RED[3] != 0.0f) RED[8] = __int_as_float(0x7fc00000);      // a workgroup never arrived: no step
+            }
             __syncthreads();
             rows = 1;
         }
@@ -669,6 +721,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 if (finite != 0.0f && (own.mask & mask_bit))
                     optimizer_apply_running(cfg, own.theta, own.s0, own.s1, own.s2, own.st, grad, own.p1, own.p2);
                 SPEC_STAMP(9);
+                if (G > 1 && !last) __hip_atomic_store(SPEC_A->params + oid, own.theta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (last) {
                     float* const params = SPEC_A->params;
                     float* const state = SPEC_A->state;
@@ -715,9 +768,15 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             } else {
                 const float theta2 = PS[i];
                 for (uint32_t j = j0; j < j1; ++j) spec_publish_uniform(TAB, TAB[SPEC_TAB_IDX + j], theta2);
+                if (G > 1) __hip_atomic_store(SPEC_A->params + i, theta2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #endif
+        if (G > 1 && mode == SPEC_MODE_LOOP) {                  // (only workgroup 0 gets here) the new parameters are out: release the iteration
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(SPEC_A->ticket + 64, gen0 + it + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         SPEC_STAMP(6);
     }
 #if defined(SPEC_DEBUG_STAMPS)

@@ -749,18 +749,18 @@ void destroy(Spec* s) {
 
 int upload(Spec* s) {
     const size_t n_ptr = s->pu_ptr_host.size(), n_pos = s->pu_pos_host.size();
-    const size_t bytes = 256 + (n_ptr + 2 * n_pos) * 4 + 256;
+    const size_t bytes = 512 + (n_ptr + 2 * n_pos) * 4 + 256;      // [arrival tickets: 64 words][generation numbers: 64 words][CSR tables]
     hipError_t e = hipMalloc(&s->dev, bytes);
     if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("hipMalloc (specialiser tables): ") + hipGetErrorString(e));
-    std::vector<uint32_t> host(64 + n_ptr + 2 * n_pos, 0u);
-    std::copy(s->pu_ptr_host.begin(), s->pu_ptr_host.end(), host.begin() + 64);
-    std::copy(s->pu_pos_host.begin(), s->pu_pos_host.end(), host.begin() + 64 + n_ptr);
-    std::copy(s->pu_idx_host.begin(), s->pu_idx_host.end(), host.begin() + 64 + n_ptr + n_pos);
+    std::vector<uint32_t> host(128 + n_ptr + 2 * n_pos, 0u);
+    std::copy(s->pu_ptr_host.begin(), s->pu_ptr_host.end(), host.begin() + 128);
+    std::copy(s->pu_pos_host.begin(), s->pu_pos_host.end(), host.begin() + 128 + n_ptr);
+    std::copy(s->pu_idx_host.begin(), s->pu_idx_host.end(), host.begin() + 128 + n_ptr + n_pos);
     e = hipMemset(s->dev, 0, bytes);
     if (e == hipSuccess) e = hipMemcpy(s->dev, host.data(), host.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("specialiser tables: ") + hipGetErrorString(e));
     s->tickets = (unsigned int*)s->dev;
-    s->pu_ptr = (const uint32_t*)s->dev + 64;
+    s->pu_ptr = (const uint32_t*)s->dev + 128;
     s->pu_pos = s->pu_ptr + n_ptr;
     s->pu_idx = s->pu_pos + n_pos;
     int dev = 0, cus = 0;
@@ -1034,7 +1034,12 @@ bool applies(const Spec* s, uint32_t n_local, int mode) {
     if (e && e[0] == '0') return false;
     const Geo g = geo(s, n_local);
     if (s->variant[2 * g.geom].failed || s->variant[2 * g.geom + 1].failed) return false;
-    if (mode == MODE_LOOP && g.blocks != 1) return false;
+    // several workgroups in loop mode: workgroup 0 owns the iteration, the others wait on its generation number (spec_main.h);
+    // every workgroup must be resident — geo() never asks for more than fit the chip (BSVI_SPEC_LOOP_MANY=0: launch per iteration)
+    if (mode == MODE_LOOP && g.blocks != 1) {
+        const char* m = getenv("BSVI_SPEC_LOOP_MANY");
+        return !(m && m[0] == '0');
+    }
     return true;
 }
 

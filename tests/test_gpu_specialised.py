@@ -113,6 +113,33 @@ def test_draw_wave_loop_equals_plain_loop(n, optimizer, kw, monkeypatch):
     assert rel_err(curves[2], curves[0]) <= 2e-6
 
 
+@pytest.mark.parametrize("builder,kwargs,n,optimizer,kw", [
+    ("build_readme_ar", dict(T=20), 1024, "SGD", dict(lr=1e-3)),            # 4 workgroups
+    ("build_readme_ar", dict(T=20), 1500, "Adam", dict(lr=2e-3)),           # 6 workgroups, a ragged last one
+    ("build_beta_binomial", dict(), 4096, "SGD", dict(lr=0.1)),             # BASELINE config 2: 16 workgroups
+    ("build_readme_ar", dict(T=200), 1024, "SGD", dict(lr=1e-4)),           # BASELINE config 3's shard
+])
+def test_loop_over_several_workgroups_equals_launch_per_iteration(builder, kwargs, n, optimizer, kw, monkeypatch):
+    """a shard of several workgroups trained in ONE launch (workgroup 0 owns the iteration: it adds the rows, steps, writes the
+    parameters and releases the generation number the others wait on) against one launch per iteration — the rows are added in
+    the same order by the same code, so under SGD the curves agree to the bit — and against BSVI_SPEC_LOOP_MANY=0"""
+    curves, params, modes = [], [], []
+    for env, opts in (("1", dict()), ("1", dict(allow_persistent=False)), ("0", dict())):
+        monkeypatch.setenv("BSVI_SPEC_LOOP_MANY", env)
+        c = engine.compile_model(getattr(W, builder)(W.native_api(), **kwargs), None, "pathwise")
+        a, fa = c.train(17, n, optimizer, seed=4, **opts, **kw)
+        b, fb = c.train(8, n, optimizer, seed=4, **opts, **kw)             # (a second call: the generation numbers go on)
+        assert bool(fa.all()) and bool(fb.all())
+        curves.append(np.concatenate([a.cpu().numpy(), b.cpu().numpy()]))
+        params.append(c.params.cpu().numpy().copy())
+        modes.append(c.last_mode)
+    assert modes[0] == "persistent" and modes[1] == "stepwise", modes
+    # (Adam's bias corrections are running products inside a launch and powers at its start: equal to rounding)
+    if optimizer == "SGD":
+        assert np.array_equal(curves[0], curves[1]) and np.array_equal(params[0], params[1])
+    assert rel_err(curves[1], curves[0]) <= 2e-6 and rel_err(curves[2], curves[0]) <= 2e-6
+
+
 def test_pretraining_iterations_in_the_loop_kernel(monkeypatch):
     """model parameters are stepped only after `pretraining_iterations` (inference.py:102-104): in-kernel loop vs the
     interpreter's persistent trainer"""
