@@ -41,7 +41,9 @@ def test_default_engine_is_the_specialised_kernel():
         assert c.native.engine(n, 1)["n_threads"] == 64 * waves and c.native.engine(n, 2)["n_threads"] == 64 * (waves + 1)
     many = c.native.engine(262144, 1)
     assert many["engine"] == "specialised" and many["n_threads"] == 256 and many["n_blocks"] <= 512
-    assert c.native.engine(262144, 2)["engine"] == "interpreter"      # the in-kernel loop is a one-workgroup mode
+    # (round 4: the in-kernel loop also runs over several workgroups — workgroup 0 owns the iteration)
+    loop = c.native.engine(262144, 2)
+    assert loop["engine"] == "specialised" and loop["n_blocks"] == many["n_blocks"]
 
 
 @pytest.mark.parametrize("case", SCALAR)
