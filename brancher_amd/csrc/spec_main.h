@@ -128,7 +128,7 @@ __device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
 //           call's number (bounded; anybody's abort ends it) and adds them in rank order: bit-identical totals on every rank.
 //      No workgroup barrier: the other waves go on to the next iteration's first barrier (drawing its normals on the way),
 //      where they wait for the owners to publish the new table as always.
-#if defined(SPEC_WITH_EXCHANGE) && !SPEC_GENERIC_OWNERS && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS
+#if defined(SPEC_WITH_EXCHANGE) && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS
 #define SPEC_EXCHANGE 1
 // An entry of the region's second area carries its value AND the number of the call that wrote it in one 8-byte word
 // (xchg_ll_entry), stored with a single 64-bit store: a reader that finds the call's number has the value — no fence and no
@@ -138,6 +138,50 @@ __device__ __forceinline__ SpecOwn spec_own_load(const spec_f4* row) {
 __device__ __forceinline__ unsigned long long* spec_xentry(unsigned char* region, uint32_t parity, uint32_t r, uint32_t capacity, uint32_t world) {
     return reinterpret_cast<unsigned long long*>(region + XCHG_HEADER_WORDS * 4 + (size_t)2 * world * capacity * 4) + ((size_t)parity * world + r) * capacity;
 }
+// Programs whose parameters do not all have an owner in one wave (more than 64 of them, or more than two table entries each:
+// SPEC_GENERIC_OWNERS): the same entries, written and awaited PER THREAD — a tagged entry needs no rendezvous, so the thread
+// that forms a parameter's sum stores it to every region and later polls that one entry of every rank, wherever in the
+// workgroup it sits.  Every thread also polls the loss words: each owner gates its own step on the total's finiteness.
+__device__ __forceinline__ void spec_xput(const SpecExchange* xg, uint32_t seq, uint32_t k, float v) {
+    const uint32_t world = xg->world, rank = xg->rank, cap = xg->capacity, parity = seq & 1u;
+    const unsigned long long e = ((unsigned long long)seq << 32) | __float_as_uint(v);
+    for (uint32_t p = 0; p < world; ++p)
+        __hip_atomic_store(spec_xentry(xg->peer[p], parity, rank, cap, world) + k, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool spec_xget(const SpecExchange* xg, uint32_t seq, uint32_t k, float& v) {
+    const uint32_t world = xg->world, rank = xg->rank, cap = xg->capacity, parity = seq & 1u;
+    unsigned char* const region = xg->peer[rank];
+    uint32_t* const abort_word = reinterpret_cast<uint32_t*>(region) + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE;
+    unsigned long long t0 = 0;
+    for (uint32_t round = 0;; ++round) {
+        unsigned long long e[XCHG_MAX_RANKS];
+#pragma unroll
+        for (uint32_t r = 0; r < XCHG_MAX_RANKS; ++r) {
+            e[r] = (unsigned long long)seq << 32;
+            if (r < world) e[r] = __hip_atomic_load(spec_xentry(region, parity, r, cap, world) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        bool all = true;
+        float t = 0.0f;
+#pragma unroll
+        for (uint32_t r = 0; r < XCHG_MAX_RANKS; ++r) {
+            all = all && (uint32_t)(e[r] >> 32) == seq;
+            if (r < world) t += __uint_as_float((uint32_t)e[r]);
+        }
+        if (all) {
+            v = t;
+            return __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
+        }
+        if (round == 0u) t0 = wall_clock64();
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
+        if (wall_clock64() - t0 > xg->timeout_ticks) {
+            for (uint32_t p = 0; p < world; ++p)
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(xg->peer[p]) + XCHG_MAX_RANKS * XCHG_FLAG_STRIDE, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+#if !SPEC_GENERIC_OWNERS
 // returns false when the call was abandoned (this rank or a peer gave up waiting: sticky, csrc/collective.hip)
 __device__ __forceinline__ bool spec_exchange(const SpecExchange* xg, uint32_t seq, uint32_t l, bool has_param, float& vs, float& vb, float& gsum) {
     const uint32_t world = xg->world, rank = xg->rank, cap = xg->capacity, parity = seq & 1u;
@@ -193,6 +237,7 @@ __device__ __forceinline__ bool spec_exchange(const SpecExchange* xg, uint32_t s
     vs = ts; vb = tb; gsum = tg;
     return true;
 }
+#endif
 #else
 #define SPEC_EXCHANGE 0
 #endif
@@ -666,6 +711,40 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
         // several ranks: the owners' wave exchanges [loss sum, non-finite count, gradient sum per parameter] with its peers
         // (spec_exchange above); everything below runs on the TOTALS, as bsvi_finalize_step does behind the exchange kernel
         const SpecExchange* const xg = SPEC_A->xchg;
+#if SPEC_GENERIC_OWNERS
+        const bool xrun = xg != nullptr && mode == SPEC_MODE_LOOP;
+        float xgsum = 0.0f;
+        if (xrun) {                                            // per thread: see spec_xput / spec_xget
+            const uint32_t xseq = xseq0 + it + 1u;
+            if (tid == own_base) { spec_xput(xg, xseq, 0u, vs); spec_xput(xg, xseq, 1u, vb); }
+            if (own_fast) {
+                const SpecOwn own = spec_own_load(OWN + 5 * oid);
+                float g = 0.0f;
+#pragma unroll
+                for (uint32_t e = 0; e < 2u; ++e) {
+                    const float term = spec_pos_total(WS, own.pos[e], rows) * (own.b[e] * spec_utransform_grad(own.tr[e], own.theta));
+                    g += e < own.n ? term : 0.0f;
+                }
+                spec_xput(xg, xseq, BSVI_OUT_HEADER + oid, g);
+            }
+            for (uint32_t i = tid; i < SPEC_N_PARAMS; i += nthreads) {
+                if (i == oid && own_fast) continue;
+                const float theta = PS[i];
+                const uint32_t j0 = TAB[SPEC_TAB_PTR + i], j1 = TAB[SPEC_TAB_PTR + i + 1];
+                float g = 0.0f;
+                for (uint32_t j = j0; j < j1; ++j) {
+                    const uint32_t pos = TAB[SPEC_TAB_POS + j], k = TAB[SPEC_TAB_IDX + j];
+                    g += spec_pos_total(WS, pos, rows) * (__uint_as_float(TAB[4 * k + 3]) * spec_utransform_grad(TAB[4 * k + 1] & 0xFFu, theta));
+                }
+                spec_xput(xg, xseq, BSVI_OUT_HEADER + i, g);
+            }
+            bool ok = spec_xget(xg, xseq, 0u, vs);
+            ok = spec_xget(xg, xseq, 1u, vb) && ok;
+            if (own_fast) ok = spec_xget(xg, xseq, BSVI_OUT_HEADER + oid, xgsum) && ok;
+            if (!ok) vs = __int_as_float(0x7fc00000);         // abandoned: NaN loss, no step
+            if (tid == own_base && it + 1u == n_it) reinterpret_cast<uint32_t*>(xg->peer[xg->rank])[XCHG_CALLS_WORD + 1] = xseq0 + n_it;
+        }
+#else
         const bool xrun = xg != nullptr && mode == SPEC_MODE_LOOP && (tid >> 6) == (own_base >> 6);
         float xgsum = 0.0f;
         if (xrun) {
@@ -683,6 +762,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             if (!spec_exchange(xg, xseq0 + it + 1u, oid, own_fast, vs, vb, xgsum)) vs = __int_as_float(0x7fc00000);     // abandoned: NaN loss, no step
             if (oid == 0u && it + 1u == n_it) reinterpret_cast<uint32_t*>(xg->peer[xg->rank])[XCHG_CALLS_WORD + 1] = xseq0 + n_it;
         }
+#endif
 #endif
         // -vs / n is finite exactly when vs is (n >= 1): the optimizer step does not wait for the division
         const float finite = isfinite(vs) ? 1.0f : 0.0f;
@@ -752,9 +832,15 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 const uint32_t pos = TAB[SPEC_TAB_POS + j], k = TAB[SPEC_TAB_IDX + j];
                 gsum += spec_pos_total(WS, pos, rows) * (__uint_as_float(TAB[4 * k + 3]) * spec_utransform_grad(TAB[4 * k + 1] & 0xFFu, theta));
             }
+#if SPEC_EXCHANGE
+            bool xok = true;
+            if (xrun) xok = spec_xget(xg, xseq0 + it + 1u, BSVI_OUT_HEADER + i, gsum);      // the ranks' sums of this parameter, in rank order
+#else
+            const bool xok = true;
+#endif
             const float grad = gsum * scale;
             if (last || !step) out[BSVI_OUT_HEADER + i] = grad;
-            if (step && finite != 0.0f && (TAB[SPEC_TAB_MASK + i] & mask_bit))
+            if (step && xok && finite != 0.0f && (TAB[SPEC_TAB_MASK + i] & mask_bit))
                 optimizer_update(cfg, PS, PS + SPEC_NP_PAD, SPEC_NP_PAD, i, grad);
             if (!step) continue;
             if (last) {

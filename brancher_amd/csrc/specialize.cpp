@@ -735,7 +735,7 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
     }
     // (a kernel of its own: the extra roles cost the plain loop 3 % when they are merely compiled in)
     s->variant[4].src = "#define SPEC_WITH_DRAW_WAVE 1\n" + s->variant[0].src;
-    s->exchange_ok = all_fast;
+    s->exchange_ok = true;       // (owners in one wave: the wave exchanges; otherwise every thread exchanges its own parameters' entries)
     s->variant[5].src = std::string("#define SPEC_WITH_EXCHANGE 1\n") + (s->draw_wave_ok ? "#define SPEC_WITH_DRAW_WAVE 1\n" : "") + s->variant[0].src;
     return s;
 }
@@ -1052,8 +1052,7 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     Geo g = geo(s, a->n_samples_local, L.mode, L.xchg != nullptr);
     int v = 2 * g.geom + ((a->noise_dev || a->samples_out_dev || a->noise_out_dev || a->fvalue_out_dev || a->f_weight_dev || a->q_weight_dev) ? 1 : 0);
     if (L.xchg && !(L.mode == MODE_LOOP && g.blocks == 1 && v == 0 && s->exchange_ok))
-        return bsvi_fail(BSVI_ERR_UNSUPPORTED, "the in-loop exchange serves the one-workgroup training loop of programs whose parameters all have "
-                                               "an owner thread in one wave (<= 64 parameters, <= 2 uniform entries each), Philox noise");
+        return bsvi_fail(BSVI_ERR_UNSUPPORTED, "the in-loop exchange serves the one-workgroup training loop with Philox noise and no per-sample outputs");
     uint32_t seq;
     {
         std::lock_guard<std::mutex> lock(s->mu);

@@ -346,8 +346,9 @@ int bsvi_train_persistent2(const bsvi_program* prog, const bsvi_elbo_args* args,
  * abandoned exchange (a peer did not arrive within the bound) leaves NaN in that iteration's loss, skips its optimizer
  * step on every rank and is sticky (bsvi_exchange_status).  Replaces the Python loop of inference.py:95-108 on N GPUs.
  * BSVI_ERR_UNSUPPORTED unless the shard runs on the program-specialised one-workgroup kernel (bsvi_program_engine, mode
- * 2), every parameter has at most two uniform-table entries and there are at most 64 of them (one owner thread each in
- * one wave), noise is Philox and no per-sample output is asked for: callers then fall back to the three-launch sequence.
+ * 2), noise is Philox and no per-sample output is asked for: callers then fall back to the three-launch sequence.  (With at
+ * most 64 parameters of at most two uniform-table entries each the wave that owns them exchanges; otherwise every thread
+ * exchanges the entries of the parameters it steps.)
  * state_dev may be NULL (a fresh optimizer inside the kernel), as for bsvi_train_persistent2. */
 struct bsvi_exchange;
 int bsvi_train_persistent_exchange(const bsvi_program* prog, const bsvi_elbo_args* args, const bsvi_opt_cfg* cfg,

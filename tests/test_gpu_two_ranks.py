@@ -98,6 +98,7 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
     (("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3), "persistent+exchange"),
     (("build_readme_ar", dict(T=20)), 600, "Adam", dict(lr=2e-3), "persistent+exchange"),
     (("build_readme_ar", dict(T=20)), 200, "SGD", dict(lr=1e-3), "persistent+exchange"),      # two sample waves + the draw wave per rank
+    (("build_readme_ar", dict(T=40)), 400, "Adam", dict(lr=2e-3), "persistent+exchange"),     # 83 parameters: every thread exchanges its own
     (("build_readme_ar", dict(T=20)), 600, "SGD", dict(lr=1e-3), "graph+allreduce"),
     (("build_logistic_regression", dict(dataset_size=256, batch_size=64, n_features=64, n_classes=10, q_scale=0.05)), 96, "Adam", dict(lr=5e-3),
      "stepwise+allreduce"),
@@ -226,13 +227,13 @@ def test_loop_exchange_on_one_rank_is_the_in_kernel_loop_bit_for_bit(monkeypatch
     sys.path.insert(0, ROOT)
     from brancher_amd import engine, workloads as W
     monkeypatch.setenv("BSVI_LOOP_EXCHANGE", "force")
-    for n_samples in (300, 128):
+    for n_samples, T in ((300, 20), (128, 20), (200, 40)):      # (T = 40: 83 parameters, exchanged per thread instead of by the owners' wave)
         for optimizer, kw in (("SGD", dict(lr=1e-3)), ("Adam", dict(lr=2e-3))):
-            ref = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+            ref = engine.compile_model(W.build_readme_ar(W.native_api(), T=T), None, "pathwise")
             r1, _ = ref.train(25, n_samples, optimizer, seed=3, **kw)
             r2, _ = ref.train(10, n_samples, optimizer, seed=3, **kw)
             assert ref.last_mode == "persistent"
-            c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
+            c = engine.compile_model(W.build_readme_ar(W.native_api(), T=T), None, "pathwise")
             l1, f1 = c.train(25, n_samples, optimizer, seed=3, _force_sharded_path=True, **kw)
             l2, f2 = c.train(10, n_samples, optimizer, seed=3, _force_sharded_path=True, **kw)
             assert c.last_mode == "persistent+exchange", c.last_mode
