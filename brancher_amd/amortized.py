@@ -272,12 +272,14 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
         raise LoweringError("amortised path: the latent prior must be Normal")
     if x.distribution.kind not in (D.DIST_BINOMIAL, D.DIST_BERNOULLI, D.DIST_NORMAL):
         raise LoweringError("amortised path: the likelihood must be Binomial(1, logits) / Bernulli(logits) or "
-                            "Normal(decoder output, constant scale)")
+                            "Normal(decoder output, scale given as numbers — constant or learnable)")
     xl = x.link.expressions()
-    likelihood, lik_scale = "binomial", None
+    likelihood, lik_scale, lik_scale_par = "binomial", None, None
     if x.distribution.kind == D.DIST_NORMAL:
         likelihood = "normal"
-        lik_scale = _constant_parameter(x, "scale", positive=True)
+        # a number / array: a constant, or — `NormalVariable(decoder value, scale, learnable=True)` — a parameter of the joint
+        # model behind softplus (standard_variables.py:57-68)
+        lik_scale, lik_scale_par = _root_parameter(x, "scale", positive=True, learnable_ok=True)
         if lik_scale.size not in (1, P):
             raise LoweringError("amortised path: the likelihood's scale must be one number or one per feature")
         lik_scale = np.ascontiguousarray(np.broadcast_to(lik_scale, (P,)), dtype=np.float32)
@@ -335,6 +337,11 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
             setattr(prog, which, off)
             prog.parameters.append((par, off, par.size, 1))
             off += par.size
+    prog.lik_scale_off, prog.lik_scale_size = NO_BIAS, 0
+    if lik_scale_par is not None:
+        prog.lik_scale_off, prog.lik_scale_size = off, lik_scale_par.size
+        prog.parameters.append((lik_scale_par, off, lik_scale_par.size, 1))
+        off += lik_scale_par.size
     prog.n_params = off
     prog.param_active = np.zeros(off, dtype=np.uint8)
     for par, o, size, g in prog.parameters:
@@ -402,7 +409,8 @@ class CompiledAmortized:
                       dec_logits_value=p.dec_logits_value, enc_layers=k["enc"], dec_layers=k["dec"],
                       prior_loc=ptr(k["loc"]), prior_scale=ptr(k["scale"]), dataset=ptr(k["dataset"]),
                       likelihood=1 if p.likelihood == "normal" else 0, likelihood_scale=ptr(k["lik_scale"]),
-                      prior_loc_off=p.prior_loc_off, prior_scale_off=p.prior_scale_off)
+                      prior_loc_off=p.prior_loc_off, prior_scale_off=p.prior_scale_off,
+                      lik_scale_off=p.lik_scale_off, lik_scale_size=p.lik_scale_size)
         handle = C.c_void_p()
         native.check(lib.bsvi_amort_create(C.byref(d), C.byref(handle)))
         self.handle = handle

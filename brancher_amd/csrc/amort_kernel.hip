@@ -1388,6 +1388,9 @@ struct RowParams {
     const float* params; uint32_t prior_loc_off, prior_scale_off;
     float* prior_loc_part; float* prior_scale_part;      // [workgroups of amort_latent_bwd][Dz] partial gradient sums, or null
     int likelihood; const float* lik_scale;              // BSVI_AMORT_LIK_*; [P] scale of the Normal likelihood
+    // ... or learnable: raw values in the parameter buffer (scale = softplus(raw); 1 of them, or P); kNoOffset: the constants above
+    uint32_t lik_scale_off, lik_scale_size;
+    float* lik_scale_part;                               // [row slices][P] partial sums of d log p / d raw, or null
     float* rowf;             // [R] f per row
     float* rowlq;            // [R] log q per row
     float* logits; int ld_logits;
@@ -1479,6 +1482,36 @@ __global__ void amort_latent_fwd(const RowParams D) {
     D.rowlq[r] = lq;
 }
 
+// the Normal likelihood's scale for feature j: a constant, or softplus of its learnable raw value (one for all features, or one each)
+__device__ __forceinline__ float lik_scale_of(const RowParams& D, int j) {
+    if (D.lik_scale_off == kNoOffset) return D.lik_scale[j];
+    const float raw = D.params[D.lik_scale_off + (D.lik_scale_size == 1u ? 0 : j)];
+    return raw > 20.0f ? raw : log1pf(expf(raw));
+}
+
+// A learnable likelihood scale (ABI 10): d log p / d raw_j = dsoftplus(raw_j) * sum_rows (u^2 - 1) / s_j with u = (x - mean) / s_j.
+// amort_lik left d log p / d mean = u / s_j where the means stood, so (u^2 - 1) / s = (u / s)^2 s - 1 / s needs no second pass over
+// the data.  Thread j walks one slice of the rows (consecutive threads: consecutive columns of the row-major matrix); the slices
+// are added by the iteration's one reduction launch in a fixed order.
+__global__ __launch_bounds__(256) void amort_lik_scale_grad(const RowParams D, int rows_per_slice) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= D.P) return;
+    const float s = lik_scale_of(D, j);
+    const float raw = D.params[D.lik_scale_off + (D.lik_scale_size == 1u ? 0 : j)];
+    const float ds = raw > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-raw));
+    const int r0 = blockIdx.y * rows_per_slice, r1 = min(D.R, r0 + rows_per_slice);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        const float g0 = D.logits[(long)r * D.ld_logits + j], g1 = D.logits[(long)(r + 1) * D.ld_logits + j];
+        const float g2 = D.logits[(long)(r + 2) * D.ld_logits + j], g3 = D.logits[(long)(r + 3) * D.ld_logits + j];
+        a0 += g0 * g0; a1 += g1 * g1; a2 += g2 * g2; a3 += g3 * g3;
+    }
+    for (; r < r1; ++r) { const float g = D.logits[(long)r * D.ld_logits + j]; a0 += g * g; }
+    const float sum_g2 = (a0 + a1) + (a2 + a3);
+    D.lik_scale_part[(long)blockIdx.y * D.P + j] = ds * (sum_g2 * s - (float)(r1 - r0) / s);
+}
+
 // log p(x | z) = sum_j x_j l_j - softplus(l_j)  (torch binomial.py:140-160 with total_count = 1) and
 // dlogits = x - sigmoid(l), written over the logits.  One wave per row.
 __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
@@ -1491,7 +1524,7 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
         // x ~ Normal(mean = decoder value, scale_j): log p = -u^2/2 - log(scale) - log(2 pi)/2, u = (x - mean)/scale;
         // d log p / d mean = u / scale, written over the means   (torch normal.py:83-90)
         for (int j = lane; j < D.P; j += 64) {
-            const float sj = D.lik_scale[j], u = (x[j] - l[j]) / sj;
+            const float sj = lik_scale_of(D, j), u = (x[j] - l[j]) / sj;
             lp += -0.5f * u * u - logf(sj) - kHalfLog2Pi;
             l[j] = u / sj;
         }
@@ -1700,6 +1733,13 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     for (uint32_t off : {desc->prior_loc_off, desc->prior_scale_off})
         if (off != BSVI_AMORT_CONSTANT && (size_t)off + desc->latent_dim > desc->n_params)
             return bsvi_fail(BSVI_ERR_INVALID, "learnable prior exceeds the parameter buffer");
+    if (desc->lik_scale_off != BSVI_AMORT_CONSTANT) {
+        if (desc->likelihood != BSVI_AMORT_LIK_NORMAL) return bsvi_fail(BSVI_ERR_INVALID, "a learnable likelihood scale needs the Normal likelihood");
+        if (desc->lik_scale_size != 1u && desc->lik_scale_size != desc->n_features)
+            return bsvi_fail(BSVI_ERR_INVALID, "a learnable likelihood scale has one value, or one per feature");
+        if ((size_t)desc->lik_scale_off + desc->lik_scale_size > desc->n_params)
+            return bsvi_fail(BSVI_ERR_INVALID, "learnable likelihood scale exceeds the parameter buffer");
+    }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return bsvi_fail(BSVI_ERR_NO_DEVICE, "no HIP device");
     auto* a = new bsvi_amort();
@@ -1806,6 +1846,7 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
             }
         for (uint32_t off : {desc->prior_loc_off, desc->prior_scale_off})
             if (off != BSVI_AMORT_CONSTANT) spans.emplace_back((size_t)off, (size_t)Dz);
+        if (desc->lik_scale_off != BSVI_AMORT_CONSTANT) spans.emplace_back((size_t)desc->lik_scale_off, (size_t)desc->lik_scale_size);
         std::sort(spans.begin(), spans.end());
         size_t at = 0;
         bool exact = true;
@@ -1894,6 +1935,12 @@ static size_t xdw_floats(const bsvi_amort* a, size_t li, size_t R) {      // sli
     const XdwPlan p = xdw_plan((int)l.n_in, (int)l.n_out, R);
     return align4((size_t)p.slices * l.n_out * l.n_in) + align4((size_t)(p.Rp / 64) * l.n_out) + align4(3 * (size_t)l.n_out * p.Rp / 2);
 }
+// row slices of amort_lik_scale_grad: enough workgroups to fill the chip, at least 64 rows each
+static uint32_t lik_scale_slices(size_t R) {
+    const size_t s = (R + 63) / 64;
+    return (uint32_t)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
 static size_t partial_floats(const bsvi_amort* a, size_t R) {
     size_t n = align4(2 * ((R + 255) / 256));
     bool any_xdw = false;
@@ -1906,6 +1953,8 @@ static size_t partial_floats(const bsvi_amort* a, size_t R) {
     if (any_xdw) n += align4((size_t)a->d.n_features * ((R + 63) / 64 * 64) / 2);      // the transposed minibatch rows (bf16)
     if (a->d.prior_loc_off != BSVI_AMORT_CONSTANT || a->d.prior_scale_off != BSVI_AMORT_CONSTANT)
         n += 2 * align4(((R + 255) / 256) * (size_t)a->d.latent_dim);                  // a learnable prior's gradient partials
+    if (a->d.lik_scale_off != BSVI_AMORT_CONSTANT)
+        n += align4((size_t)lik_scale_slices(R) * a->d.n_features);                    // a learnable likelihood scale's
     return n + 16;
 }
 
@@ -2213,6 +2262,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.prior_loc = a->prior_dev; D.prior_scale = a->prior_dev + Dz;
     D.params = params; D.prior_loc_off = d.prior_loc_off; D.prior_scale_off = d.prior_scale_off;
     D.likelihood = (int)d.likelihood; D.lik_scale = a->lik_scale_dev;
+    D.lik_scale_off = d.lik_scale_off; D.lik_scale_size = d.lik_scale_size; D.lik_scale_part = nullptr;
     D.rowf = rowf; D.rowlq = rowlq;
     D.logits = val(a->dec, d.dec_logits_value); D.ld_logits = a->dec.ld[d.dec_logits_value];
     D.out = out; D.fvalue_out = args->fvalue_out_dev; D.logq_out = args->logq_out_dev;
@@ -2377,6 +2427,18 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     rc = forward(a->dec, false);
     if (rc) return rc;
     hipLaunchKernelGGL(amort_lik, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, D);
+    if (d.lik_scale_off != BSVI_AMORT_CONSTANT) {
+        // d log p / d (raw scale): column sums over the d log p / d mean that amort_lik left, per slice of the rows
+        const uint32_t slices = lik_scale_slices(R);
+        const int per = (int)((R + slices - 1) / slices);
+        D.lik_scale_part = part;
+        part += align4((size_t)slices * P);
+        hipLaunchKernelGGL(amort_lik_scale_grad, dim3((unsigned)((P + 255) / 256), slices), dim3(256), 0, stream, D, per);
+        // one value for every feature: its gradient is the sum over the features too (slices x P partials of ONE element)
+        rc = d.lik_scale_size == 1u ? add_segment(grads + d.lik_scale_off, D.lik_scale_part, 1, 1, slices * (uint32_t)P)
+                                    : add_segment(grads + d.lik_scale_off, D.lik_scale_part, 1, (uint32_t)P, slices);
+        if (rc) return rc;
+    }
     rc = backward(a->dec, false, true);
     if (rc) return rc;
     hipLaunchKernelGGL(amort_latent_bwd, row_grid, dim3(256), 0, stream, D);

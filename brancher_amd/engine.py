@@ -1014,8 +1014,12 @@ def _amortized_sample(model, compiled, number_samples, input_values):
         x = torch.from_numpy(np.array(np.broadcast_to(given_x.reshape(-1, p.n_features)[:N], (N, p.n_features)),
                                       dtype=np.float32)).to(dev)
     elif p.likelihood == "normal":
-        x = decoded[p.logits_key] + torch.from_numpy(p.likelihood_scale).to(dev) * \
-            torch.randn((N, p.n_features), device=dev, generator=gen)
+        if getattr(p, "lik_scale_size", 0):       # learnable: softplus of the raw values the optimizer steps (one, or one per feature)
+            raw = compiled.params[p.lik_scale_off:p.lik_scale_off + p.lik_scale_size]
+            lik_scale = torch.nn.functional.softplus(raw).expand(p.n_features) if p.lik_scale_size == 1 else torch.nn.functional.softplus(raw)
+        else:
+            lik_scale = torch.from_numpy(p.likelihood_scale).to(dev)
+        x = decoded[p.logits_key] + lik_scale * torch.randn((N, p.n_features), device=dev, generator=gen)
     else:
         x = torch.bernoulli(torch.sigmoid(decoded[p.logits_key]), generator=gen)
     out[x_var] = x.reshape(N, 1, p.n_features, 1)

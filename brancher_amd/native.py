@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 OUT_HEADER = 4
 
 
@@ -164,7 +164,8 @@ class AmortDesc(Sized):
                 ("dec_logits_value", C.c_uint32), ("likelihood", C.c_uint32),
                 ("enc_layers", C.POINTER(MlpLayer)), ("dec_layers", C.POINTER(MlpLayer)),
                 ("prior_loc", C.c_void_p), ("prior_scale", C.c_void_p), ("dataset", C.c_void_p),
-                ("likelihood_scale", C.c_void_p), ("prior_loc_off", C.c_uint32), ("prior_scale_off", C.c_uint32)]
+                ("likelihood_scale", C.c_void_p), ("prior_loc_off", C.c_uint32), ("prior_scale_off", C.c_uint32),
+                ("lik_scale_off", C.c_uint32), ("lik_scale_size", C.c_uint32)]
 
 
 class AmortArgs(Sized):

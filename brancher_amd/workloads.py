@@ -622,12 +622,13 @@ def vae_data(dataset_size, n_features, seed=0, real=False):
 
 
 def build_vae(api, dataset_size=64, batch_size=16, n_features=784, latent_size=2, hidden1=512, hidden2=256, seed=0,
-              likelihood="binomial", likelihood_scale=0.5, learnable_prior=False):
+              likelihood="binomial", likelihood_scale=0.5, learnable_prior=False, learnable_likelihood_scale=False):
     """BASELINE config 5: `examples/VAE_playground.py:64-79` — amortised Normal posterior over a latent code,
     Binomial(1, logits = decoder(z)) likelihood, every Monte-Carlo sample drawing its own minibatch.
     Variants of the same pattern: `likelihood="normal"` (real-valued rows, Normal(decoder(z), likelihood_scale) — a number
-    or one value per feature), `learnable_prior=True` (the prior's loc and scale are learnable parameters of the joint
-    model, `standard_variables.py:57-68`)."""
+    or one value per feature; `learnable_likelihood_scale=True`: a learnable parameter of the joint model),
+    `learnable_prior=True` (the prior's loc and scale are learnable parameters of the joint model,
+    `standard_variables.py:57-68`)."""
     BF = api.BF
     dataset = vae_data(dataset_size, n_features, seed, real=(likelihood == "normal"))
     enc, dec = vae_modules(n_features, latent_size, hidden1, hidden2, seed)
@@ -638,7 +639,8 @@ def build_vae(api, dataset_size=64, batch_size=16, n_features=784, latent_size=2
     if likelihood == "normal":
         if not np.isscalar(likelihood_scale):
             likelihood_scale = np.asarray(likelihood_scale, dtype=np.float64)
-        x = api.NormalVariable(decoder_output["mean"], likelihood_scale, name="x")
+        # (learnable=True turns the numeric argument — the scale — into a learnable root of the joint model behind softplus)
+        x = api.NormalVariable(decoder_output["mean"], likelihood_scale, name="x", learnable=bool(learnable_likelihood_scale))
     else:
         x = api.BinomialVariable(total_count=1, logits=decoder_output["mean"], name="x")
     model = api.ProbabilisticModel([x, z])

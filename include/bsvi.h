@@ -41,7 +41,7 @@ typedef long long int64_t;
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 9
+#define BSVI_ABI_VERSION 10
 
 /* Every descriptor / argument struct a binder fills in starts with `struct_size` = sizeof of the struct AS THE BINDER
  * DECLARES IT.  An entry point that receives a struct whose struct_size differs from the library's own sizeof returns
@@ -549,6 +549,10 @@ typedef struct bsvi_amort_desc {
      * the parameter buffer — loc as stored, scale = softplus(raw) (geometric_ranges.py RightHalfLine) — or
      * BSVI_AMORT_CONSTANT: the constants above */
     uint32_t prior_loc_off, prior_scale_off;
+    /* ABI 10: a learnable scale of the Normal likelihood (`NormalVariable(decoder value, scale, learnable=True)`): offset of
+     * its raw values in the parameter buffer — scale = softplus(raw) — and their count (1: one scale for every feature, or
+     * n_features); BSVI_AMORT_CONSTANT: the constants of likelihood_scale (which still carries the initial values) */
+    uint32_t lik_scale_off, lik_scale_size;
 } bsvi_amort_desc;
 #define BSVI_AMORT_LIK_BINOMIAL1 0u               /* Binomial(1, logits = decoder value)  (examples/VAE_playground.py:71) */
 #define BSVI_AMORT_LIK_NORMAL 1u

@@ -46,6 +46,15 @@ CASES = {
         dict(dataset_size=40, batch_size=12, n_features=140, hidden1=72, hidden2=40, latent_size=4, likelihood="normal",
              likelihood_scale=[0.4 + 0.01 * j for j in range(140)], learnable_prior=True), 6, 26,
         dict(iters=4, n=6, optimizer="SGD", lr=1e-3)),
+    # ... and a LEARNABLE likelihood scale (NormalVariable(decoder value, scale, learnable=True): a root of the joint model behind
+    # softplus): one value for every feature, and one per feature
+    "vae_normal_learnable_scale_P24_H12_H8_DS30_B6_N5": (
+        dict(dataset_size=30, batch_size=6, n_features=24, hidden1=12, hidden2=8, likelihood="normal", likelihood_scale=0.8,
+             learnable_likelihood_scale=True), 5, 27, dict(iters=5, n=5, optimizer="Adam", lr=1e-2)),
+    "vae_normal_learnable_scales_P132_H40_H24_DS36_B10_N7": (
+        dict(dataset_size=36, batch_size=10, n_features=132, hidden1=40, hidden2=24, latent_size=3, likelihood="normal",
+             likelihood_scale=[0.5 + 0.004 * j for j in range(132)], learnable_likelihood_scale=True, learnable_prior=True), 7, 28,
+        dict(iters=4, n=7, optimizer="Adam", lr=5e-3)),
 }
 
 

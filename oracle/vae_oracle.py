@@ -47,6 +47,12 @@ class VaeOracle:
         # behind softplus — standard_variables.py:57-68, geometric_ranges.py RightHalfLine)
         self.likelihood = prog.likelihood
         self.lik_scale = None if prog.likelihood_scale is None else torch.from_numpy(prog.likelihood_scale).to(dtype)
+        # ... or learnable: NormalVariable(decoder value, scale, learnable=True) keeps softplus^-1(scale) as a root of the joint model
+        self.lik_raw, self._lik_name = None, None
+        for par, off, size, group in prog.parameters:
+            if getattr(prog, "lik_scale_size", 0) and off == prog.lik_scale_off:
+                self.lik_raw = torch.nn.Parameter(torch.from_numpy(np.asarray(par.numpy(), dtype=np.float64)).to(dtype))
+                self._lik_name = par.name
         self.prior_raw = {}
         for par, off, size, group in prog.parameters:
             if off in (prog.prior_loc_off, prog.prior_scale_off):
@@ -65,6 +71,8 @@ class VaeOracle:
                 out["%s/%s" % (tag, k)] = p
         for k, p in self.prior_raw.items():
             out["prior/" + k] = p
+        if self.lik_raw is not None:
+            out["prior/" + self._lik_name] = self.lik_raw        # ("prior/": the fixtures' prefix for every learnable root of the joint model)
         return out
 
     def prior(self):
@@ -83,7 +91,8 @@ class VaeOracle:
         logits = self.dec(z)["mean"]
         ploc, pscale = self.prior()
         if self.likelihood == "normal":
-            lik = td.Normal(logits, self.lik_scale).log_prob(x).sum(-1)
+            scale = self.lik_scale if self.lik_raw is None else torch.nn.functional.softplus(self.lik_raw.reshape(-1))
+            lik = td.Normal(logits, scale).log_prob(x).sum(-1)
         else:
             lik = td.Binomial(total_count=1, logits=logits).log_prob(x).sum(-1)
         lp = lik + td.Normal(ploc, pscale).log_prob(z).sum(-1)
@@ -112,7 +121,8 @@ class VaeOracle:
     def train(self, iters, rows_seq, eps_seq, optimizer="Adam", **opt_kwargs):
         cls = getattr(torch.optim, optimizer)
         opts = [cls(self.enc.parameters(), **opt_kwargs),
-                cls(list(self.dec.parameters()) + list(self.prior_raw.values()), **opt_kwargs)]
+                cls(list(self.dec.parameters()) + list(self.prior_raw.values()) + ([self.lik_raw] if self.lik_raw is not None else []),
+                    **opt_kwargs)]
         losses = []
         for it in range(iters):
             loss, _ = self.loss(rows_seq[it], eps_seq[it], "pathwise")
