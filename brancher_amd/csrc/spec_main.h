@@ -443,10 +443,17 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     if (const unsigned long long* const offset_dev = SPEC_A->offset_dev) off0 += *offset_dev;
     const uint32_t n_global = SPEC_A->n_global;
     const uint32_t pretraining = SPEC_A->pretraining_iterations;
-    // several workgroups in loop mode: the generation number the launch starts from (read before anybody can advance it:
-    // workgroup 0 releases the first one only after every workgroup has published its first row)
+    // several workgroups in loop mode (the many-workgroup geometry only: the one-workgroup kernels are never launched with
+    // more, and the extra live scalars cost BASELINE config 1's kernel 30 more spilled scalar registers): the generation number
+    // the launch starts from (read before anybody can advance it: workgroup 0 releases the first one only after every
+    // workgroup has published its first row)
+#if SPEC_ACCUMULATE_CHUNKS
+#define SPEC_LOOP_MANY 1
     unsigned int gen0 = 0;
     if (G > 1 && mode == SPEC_MODE_LOOP) gen0 = __hip_atomic_load(SPEC_A->ticket + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+#define SPEC_LOOP_MANY 0
+#endif
 #if SPEC_EXCHANGE
     // (this rank's call count lives in its region and is touched by this rank's kernels only: stream order makes it current)
     uint32_t xseq0 = 0;
@@ -596,6 +603,7 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 mine[1] = c;
             }
             __syncthreads();                                   // every wave's stores issued and drained
+#if SPEC_LOOP_MANY
             if (mode == SPEC_MODE_LOOP) {
                 // The loop of inference.py:95-108 over SEVERAL workgroups in one launch (round 4; before: one launch per
                 // iteration, every workgroup staging the tables again — 70 x the algorithmic traffic at BASELINE config 2).
@@ -639,7 +647,9 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                     RED[3] = late ? 1.0f : 0.0f;
                 }
                 __syncthreads();
-            } else {
+            } else
+#endif
+            {
                 if (tid == 0) {
                     const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                     RED[2] = (t == G - 1u) ? 1.0f : 0.0f;
@@ -682,7 +692,9 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             }
             if (tid == 0) {
                 __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if SPEC_LOOP_MANY
                 if (mode == SPEC_MODE_LOOP && RED[3] != 0.0f) RED[8] = __int_as_float(0x7fc00000);      // a workgroup never arrived: no step
+#endif
             }
             __syncthreads();
             rows = 1;
@@ -801,7 +813,9 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                 if (finite != 0.0f && (own.mask & mask_bit))
                     optimizer_apply_running(cfg, own.theta, own.s0, own.s1, own.s2, own.st, grad, own.p1, own.p2);
                 SPEC_STAMP(9);
+#if SPEC_LOOP_MANY
                 if (G > 1 && !last) __hip_atomic_store(SPEC_A->params + oid, own.theta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                 if (last) {
                     float* const params = SPEC_A->params;
                     float* const state = SPEC_A->state;
@@ -854,15 +868,19 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             } else {
                 const float theta2 = PS[i];
                 for (uint32_t j = j0; j < j1; ++j) spec_publish_uniform(TAB, TAB[SPEC_TAB_IDX + j], theta2);
+#if SPEC_LOOP_MANY
                 if (G > 1) __hip_atomic_store(SPEC_A->params + i, theta2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             }
         }
 #endif
+#if SPEC_LOOP_MANY
         if (G > 1 && mode == SPEC_MODE_LOOP) {                  // (only workgroup 0 gets here) the new parameters are out: release the iteration
             __threadfence();
             __syncthreads();
             if (tid == 0) __hip_atomic_store(SPEC_A->ticket + 64, gen0 + it + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+#endif
         SPEC_STAMP(6);
     }
 #if defined(SPEC_DEBUG_STAMPS)

@@ -128,8 +128,17 @@ def test_graphs_outside_the_pattern_are_rejected():
     eo = api.DeterministicVariable(BF.BrancherFunction(enc)(Qx), name="encoder_output")
     Qz = api.NormalVariable(eo["mean"], eo["sd"], name="z")
     model.set_posterior_model(api.ProbabilisticModel([Qx, Qz]))
+    # (round 4: served — the scale's raw value joins the joint model's group behind the networks' tensors, ABI 10)
+    p = amortized.lower_amortized(model, model.posterior_model, "pathwise")
+    names = {par.name: (off, size, group) for par, off, size, group in p.parameters}
+    assert names["x_scale"] == (p.lik_scale_off, 1, 1) and p.lik_scale_size == 1 and p.n_params == p.lik_scale_off + 1
+    assert np.allclose(p.likelihood_scale, 1.0, atol=1e-6)                # the initial value, behind softplus
+    # a decoder HEAD as the scale is still outside the pattern
+    x2 = api.NormalVariable(out["mean"], BF.exp(out["mean"]), name="x")
+    model2 = api.ProbabilisticModel([x2, z])
+    model2.set_posterior_model(api.ProbabilisticModel([Qx, Qz]))
     with pytest.raises(LoweringError):
-        amortized.lower_amortized(model, model.posterior_model, "pathwise")
+        amortized.lower_amortized(model2, model2.posterior_model, "pathwise")
     with pytest.raises(LoweringError):
         amortized.lower_amortized(W.build_vae(api, dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6),
                                   None if False else W.build_vae(api, dataset_size=20, batch_size=5, n_features=12,
