@@ -99,6 +99,67 @@ def test_log_density_and_gradients_match_torch_double(D, latent_x):
     close(got[row] + lin, "lp")
 
 
+@pytest.mark.parametrize("form", ["scale_tril", "precision_matrix"])
+@pytest.mark.parametrize("D", [7, 33, 61, 130, 190])
+def test_other_parameterisations_match_torch_double(form, D):
+    """`scale_tril` and `precision_matrix` (distributions.py:314-331) on the kernel family, at sizes that are NOT whole blocks of
+    four (the matrix in LDS is padded with an identity block) and beyond one pass of 128 lane pairs: log p and the coefficient of
+    the one scalar input against torch in double precision, torch's own float32 error as the yardstick."""
+    from brancher_amd import lowering, native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    N = 29
+    rng = np.random.RandomState(D)
+    B = lowering.BINOP
+    if form == "scale_tril":
+        # L = M0 * s + M1: M0 strictly lower and small, M1 a positive diagonal
+        m0 = (np.tril(rng.normal(0.0, 0.3 / np.sqrt(D), (D, D)), -1)).astype(np.float32)
+        m1 = np.diag(rng.uniform(0.7, 1.3, D)).astype(np.float32)
+    else:
+        # P = M0 * s + M1: M0 a squared-exponential kernel matrix (PSD), M1 = 0.5 I
+        x = np.sort(rng.uniform(-2.0, 2.0, D))
+        m0 = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / 0.3 ** 2).astype(np.float32)
+        m1 = (0.5 * np.eye(D)).astype(np.float32)
+    code = [("MAT", 0, 0, 0, 0.0), ("INPUT", 0, 0, 0, 0.0), ("BIN", B["mul"], 0, 1, 0.0), ("MAT", 0, 1, 0, 0.0), ("BIN", B["add"], 2, 3, 0.0)]
+    loc = rng.normal(0.0, 0.3, D).astype(np.float32)
+    value = rng.normal(0.0, 1.0, D).astype(np.float32)
+    node = types.SimpleNamespace(code=code, mats=np.stack([m0, m1]), loc=loc, value=value, dim=D,
+                                 uniform_inputs=np.zeros(0, dtype=lowering.UNIFORM_DTYPE), slot_inputs=[0], weight=1.0, form=form)
+    d, keep = native.mvn_desc(node)
+    handle = C.c_void_p()
+    native.check(lib.bsvi_mvn_create(C.byref(d), C.byref(handle)))
+    n_out = int(lib.bsvi_mvn_rows_out(C.byref(d)))
+    assert n_out == 2
+    g = torch.Generator().manual_seed(D)
+    sc = (0.6 + 0.8 * torch.rand(N, generator=g)).float()
+    samples = torch.zeros(4, N)
+    samples[2] = sc
+    samples_d = samples.to(dev)
+    out = torch.full((n_out, N), float("nan"), device=dev)
+    params_d = torch.zeros(4, device=dev)
+    args = native.MvnArgs(params_dev=params_d.data_ptr(), samples_dev=samples_d.data_ptr(), rows_out_dev=out.data_ptr(),
+                          n_samples_local=N, value_row0=0, stream=None)
+    args.input_rows[0] = 2
+    native.check(lib.bsvi_mvn_eval(handle, C.byref(args)))
+    torch.cuda.synchronize()
+    got = out.cpu().double().numpy()
+    lib.bsvi_mvn_destroy(handle)
+
+    def torch_run(dtype):
+        s_t = sc.to(dtype).clone().requires_grad_(True)
+        M = torch.tensor(m0).to(dtype)[None] * s_t[:, None, None] + torch.tensor(m1).to(dtype)[None]
+        kw = dict(scale_tril=torch.tril(M)) if form == "scale_tril" else dict(precision_matrix=M)
+        lp = torch.distributions.MultivariateNormal(torch.tensor(loc).to(dtype), **kw).log_prob(torch.tensor(value).to(dtype).expand(N, D))
+        lp.sum().backward()
+        return lp.detach().double().numpy(), s_t.grad.double().numpy()
+
+    (lp64, g64), (lp32, g32) = torch_run(torch.float64), torch_run(torch.float32)
+    for mine, ref, f32, key in ((got[0], g64, g32, "d/ds"), (got[1] + got[0] * sc.double().numpy(), lp64, lp32, "log p")):
+        scale = np.abs(ref).max() + 1e-30
+        err, yard = np.abs(mine - ref).max() / scale, np.abs(f32 - ref).max() / scale
+        assert err <= max(4.0 * yard, 2e-6), (form, D, key, err, yard)
+
+
 def test_not_positive_definite_gives_non_finite_rows():
     from brancher_amd import native
     lib = native.load()
