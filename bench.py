@@ -56,7 +56,10 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 OTHER_CONFIGS = ("cfg2", "cfg3", "cfg4", "cfg5")     # timed after the headline in the same process (N = 1)
-OTHER_STEPS, OTHER_WARMUP, OTHER_SPINUP_MS = 50, 5, 100.0
+# (the same untimed spin-up as the headline: the clocks of an idle MI355X take longer than 100 ms to ramp — cfg 2, a pure
+#  latency chain, measured 49.9 / 34.7 / 28.8 / 27.1 us per iteration after 0 / 100 / 300 / 1000 ms; every config's `cold_start`
+#  is in the line beside its hot figure)
+OTHER_STEPS, OTHER_WARMUP, OTHER_SPINUP_MS = 50, 5, 300.0
 
 
 # ---- HBM traffic, measured live ----------------------------------------------------------------------------------
