@@ -41,6 +41,7 @@ struct MvnArgs {
     const float* vecs;                    // [2][D]: loc, observed value
     const bsvi_uniform_entry* uniform_inputs;
     const bsvi_uniform_entry* loc_entries;    // [D] when the loc is learnable (MVN_LOC_PARAM), else null
+    const bsvi_uniform_entry* value_entries;  // [D] when the value is learnable parameters (MVN_VALUE_PARAM: the taylor1 program), else null
     float* rows_out;                      // the surrogate's rows: [n_rows_out][n_local], row 0 = first input's coefficient
     uint32_t n_local, value_row0;
     uint32_t input_rows[8];
@@ -48,6 +49,9 @@ struct MvnArgs {
     uint32_t reserved;
 };
 
+#ifndef MVN_VALUE_PARAM
+#define MVN_VALUE_PARAM 0
+#endif
 #ifndef MVN_NIN_PAD
 #define MVN_NIN_PAD (MVN_NIN > 0 ? MVN_NIN : 1)
 #endif
@@ -178,7 +182,11 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
     for (int i = tid; i < VP; i += MVN_THREADS) {
         float v = 0.0f;
         if (i < D) {
-            const float x = MVN_VALUE_LATENT ? G.samples[(size_t)(G.value_row0 + i) * G.n_local + n] : G.vecs[D + i];
+            float x = MVN_VALUE_LATENT ? G.samples[(size_t)(G.value_row0 + i) * G.n_local + n] : G.vecs[D + i];
+            if (MVN_VALUE_PARAM) {
+                const bsvi_uniform_entry e = G.value_entries[i];
+                x = e.a + e.b * utransform(e.transform, G.params[e.src]);
+            }
             float m = G.vecs[i];
             if (MVN_LOC_PARAM) {
                 const bsvi_uniform_entry e = G.loc_entries[i];
@@ -471,11 +479,18 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
         for (int k = 0; k < MVN_NSI; ++k) G.rows_out[(size_t)(row + k) * G.n_local + n] = w * gin[k];
     }
     row += MVN_NSI;
-    if (MVN_VALUE_LATENT) {
+    if (MVN_VALUE_LATENT || MVN_VALUE_PARAM) {
         for (int i = tid; i < D; i += MVN_THREADS) {
             const float gx = -w * avec[i];
             G.rows_out[(size_t)(row + i) * G.n_local + n] = gx;
-            linx += gx * G.samples[(size_t)(G.value_row0 + i) * G.n_local + n];
+            float x;
+            if (MVN_VALUE_PARAM) {
+                const bsvi_uniform_entry e = G.value_entries[i];
+                x = e.a + e.b * utransform(e.transform, G.params[e.src]);
+            } else {
+                x = G.samples[(size_t)(G.value_row0 + i) * G.n_local + n];
+            }
+            linx += gx * x;
         }
         linx = mvn_block_sum(linx, red, tid);
         row += D;

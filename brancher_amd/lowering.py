@@ -28,6 +28,8 @@ tests/golden and DESIGN.md §2):
 """
 import warnings
 
+import os
+
 import numpy as np
 
 from brancher_amd import distributions as D
@@ -1037,10 +1039,8 @@ class _Lowering:
         # (the importance program — log p and log q at caller-supplied values, variables.py:821-841 — is served: its base
         #  program reports the supplied values as the "draw", the kernel evaluates the term there.  Taylor1 is not: it reads
         #  the model at the posterior's MEANS, which no program reports row by row)
-        if self.estimator == "taylor1":
-            raise LoweringError("%r: the batched multivariate-normal kernel serves the Pathwise and BlackBox estimators and the "
-                                "importance program (the taylor1 program evaluates the model at the posterior's means, not at its "
-                                "draws)" % v.name)
+        if self.estimator == "taylor1" and os.environ.get("BSVI_TAYLOR1_MVN", "1") == "0":
+            raise LoweringError("%r: taylor1 through the batched multivariate-normal kernel is switched off" % v.name)
         links = v.link.expressions()
         _, dim, _ = mat.shape
         if dim > self.kMaxExternalMvn:
@@ -1153,6 +1153,22 @@ class _Lowering:
             node.value, node.value_row0 = data, 0
         elif value.op == "z" and int(np.prod(value.shape)) == dim:
             node.value, node.value_row0 = None, self.slots[value.attr].base
+            partners += [self.mk("elem", (value,), j, (1, 1, 1)) for j in range(dim)]
+        elif self.match_uniform(value) is not None:
+            # the value is itself [dim] transformed PARAMETERS — the taylor1 program reads the model at the posterior's mean
+            # (gradient_estimators.py:47-56), and the mean of Normal(loc, scale) is its learnable loc: uniform entries like a
+            # learnable loc's, with the coefficient rows -alpha where a latent value's stand
+            leaf, g, a, b = self.match_uniform(value)
+            size = int(np.prod(leaf.shape))
+            if not (leaf.op == "root" and leaf.attr.learnable) or size != dim:
+                raise LoweringError("%r: the batched kernel takes an observed value, the draw of ONE posterior variable of %d elements "
+                                    "or %d learnable values" % (v.name, dim, dim))
+            is_param, k0 = self.uniform_entries(leaf, g, a, b)
+            node.value_entries = np.zeros(dim, dtype=UNIFORM_DTYPE)
+            for i in range(dim):
+                src, tr, isp, aa, bb = self.uni_param[k0 + i]
+                node.value_entries[i] = (src, tr, isp, 0, aa, bb)
+            node.value, node.value_row0 = np.zeros(dim, dtype=np.float32), 0
             partners += [self.mk("elem", (value,), j, (1, 1, 1)) for j in range(dim)]
         else:
             raise LoweringError("%r: the batched kernel takes an observed value or the draw of ONE posterior variable of %d elements"
@@ -1647,7 +1663,7 @@ class _Lowering:
 class ExternalMvn:
     """A multivariate-normal term evaluated by the batched kernel of the library (lowering.mvn_external): the description
     `native.mvn_desc` turns into a bsvi_mvn_desc, and where its rows live in the program's noise tensor."""
-    name = dim = code = mats = loc = value = uniform_inputs = slot_inputs = weight = loc_entries = None
+    name = dim = code = mats = loc = value = uniform_inputs = slot_inputs = weight = loc_entries = value_entries = None
     value_row0 = row0 = n_rows_out = 0
 
 

@@ -212,7 +212,8 @@ class MvnDesc(Sized):
                 ("n_slot_inputs", C.c_uint32), ("n_uniform_inputs", C.c_uint32), ("value_is_latent", C.c_uint32),
                 ("loc_is_param", C.c_uint32),
                 ("code", C.POINTER(MvnInsn)), ("mats", C.c_void_p), ("loc", C.c_void_p), ("value", C.c_void_p),
-                ("uniform_inputs", C.c_void_p), ("loc_entries", C.c_void_p), ("weight", C.c_float), ("form", C.c_uint32)]
+                ("uniform_inputs", C.c_void_p), ("loc_entries", C.c_void_p), ("weight", C.c_float), ("form", C.c_uint32),
+                ("value_entries", C.c_void_p), ("value_is_param", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class MvnArgs(Sized):
@@ -242,9 +243,12 @@ def mvn_desc(node):
     uni = np.ascontiguousarray(node.uniform_inputs)
     loc_entries = getattr(node, "loc_entries", None)
     loc_entries = np.ascontiguousarray(loc_entries) if loc_entries is not None else None
-    keep = dict(code=code, mats=mats, loc=loc, value=value, uni=uni, loc_entries=loc_entries)
+    value_entries = getattr(node, "value_entries", None)
+    value_entries = np.ascontiguousarray(value_entries) if value_entries is not None else None
+    keep = dict(code=code, mats=mats, loc=loc, value=value, uni=uni, loc_entries=loc_entries, value_entries=value_entries)
     d = MvnDesc(abi_version=ABI_VERSION, dim=node.dim, n_code=len(node.code), n_mats=mats.shape[0] if mats.size else 0,
                 n_slot_inputs=len(node.slot_inputs), n_uniform_inputs=len(uni), value_is_latent=int(node.value is None),
+                value_is_param=int(value_entries is not None), value_entries=_ptr(value_entries) if value_entries is not None else None,
                 loc_is_param=int(loc_entries is not None), loc_entries=_ptr(loc_entries) if loc_entries is not None else None,
                 code=code, mats=_ptr(mats), loc=_ptr(loc), value=_ptr(value), uniform_inputs=_ptr(uni) if len(uni) else None,
                 weight=float(node.weight), form=MVN_FORM[getattr(node, "form", "covariance_matrix")])

@@ -663,6 +663,11 @@ typedef struct bsvi_mvn_desc {
                                                   the prior's loc root is often the posterior's learnable mean) */
     float weight;                              /* of log p in f */
     uint32_t form;                             /* bsvi_mvn_form: what the expression yields (distributions.py:314-331) */
+    /* ABI 10: a value that is itself [dim] transformed PARAMETERS (value_is_latent == 0, value_is_param != 0) — the taylor1
+     * program reads the model at the posterior's means (gradient_estimators.py:47-56), and the mean of Normal(loc, scale) is
+     * its learnable loc; `value` may then be NULL.  Its coefficient rows -alpha stand where a latent value's would. */
+    const bsvi_uniform_entry* value_entries;   /* host [dim] */
+    uint32_t value_is_param, reserved1;
 } bsvi_mvn_desc;
 typedef enum bsvi_mvn_form {
     BSVI_MVN_COVARIANCE = 0,    /* MultivariateNormalVariable(covariance_matrix=...): factorised per sample              */

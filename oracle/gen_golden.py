@@ -87,7 +87,10 @@ CASES = {
 
 # workloads whose posterior is made of Normal variables: the Taylor1 estimator is recorded for them too
 TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_learnable_model", "build_vector_latent", "build_scale_from_latent",
-                    "build_beta_binomial", "build_observed_ar", "build_lognormal_normal")
+                    "build_beta_binomial", "build_observed_ar", "build_lognormal_normal",
+                    # (round 4: models with a MultivariateNormal term whose matrix depends on a latent — the taylor1 program reads it
+                    #  at the posterior's means)
+                    "build_gp_hyperparameters", "build_mvn_forms")
 
 
 # ... and two user-defined estimators (workloads.custom_estimators) for these

@@ -322,8 +322,11 @@ def test_multivariate_normal_with_a_sampled_covariance_is_unrolled():
     with pytest.raises(lowering.LoweringError, match="limit"):
         huge = W.build_gp_hyperparameters(api, n=200)
         lowering.lower(huge, huge.posterior_model, "pathwise")
-    with pytest.raises(lowering.LoweringError, match="Pathwise and BlackBox"):
-        lowering.lower(W.build_gp_hyperparameters(api, n=12), None, "taylor1")
+    # (round 4) the taylor1 program reads the term at the posterior's MEANS: no slot inputs at all — the length-scale's mean is
+    # an expression of two parameters, the value is the posterior's learnable loc (parameter entries where a latent value's rows stand)
+    t1 = lowering.lower(W.build_gp_hyperparameters(api, n=12), None, "taylor1").externals[0]
+    assert t1.slot_inputs == [] and len(t1.uniform_inputs) == 3 and t1.value_entries is not None and len(t1.value_entries) == 12
+    assert t1.n_rows_out == 12 + 3 + 12 + 1 and "#define MVN_VALUE_PARAM 1" in native.mvn_source(t1)
     # a constant covariance still takes the host-side factorisation (no derived slots for L)
     const = W.build_gp_regression(api, n=5)
     assert lowering.lower(const, const.posterior_model, "pathwise").summary()["n_derived"] < 5
