@@ -281,7 +281,7 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     import gc
     import torch
     import torch.distributed as dist
-    from brancher_amd import engine, workloads as W
+    from brancher_amd import engine, native, workloads as W
     builder, kwargs, n_per_gpu, optimizer, opt_kwargs, desc = WORKLOADS[workload]
     if args.samples:
         n_per_gpu = args.samples
@@ -308,7 +308,26 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     # ---- warm-up (untimed): W steps through exactly the path that is timed (this is also where hiprtc compiles the
     #      program-specialised kernel), then — still untimed — the same path for spinup_ms so that a short timed region
     #      (the driver runs K = 20) is not measured on a GPU whose clocks have not ramped yet
-    train(max(warmup, 1))
+    fallback = None
+    try:
+        train(max(warmup, 1))
+        if world > 1 and os.environ.get("BSVI_BENCH_INJECT_EXCHANGE_FAILURE") == "1" and engine._exchanges:
+            raise native.NativeError("injected by BSVI_BENCH_INJECT_EXCHANGE_FAILURE (tests: the fallback below)")
+    except native.NativeError as err:
+        if world == 1:
+            raise
+        # Several ranks: the one-shot exchange was chosen (self-test + vote) and then abandoned in use — this is the first time
+        # the path meets this node's topology.  An abandoned call poisons every rank (csrc/collective.hip), so every rank is
+        # here: all switch to RCCL through torch.distributed and say so in the line.
+        fallback = "one-shot exchange abandoned (%s): RCCL through torch.distributed" % str(err)[:120]
+        os.environ["BSVI_COLLECTIVE"] = "torch"
+        os.environ["BSVI_LOOP_EXCHANGE"] = "0"
+        for ex in list(engine._exchanges.values()):
+            if ex:
+                ex.close()
+        engine._exchanges.clear()
+        getattr(compiled, "_train_plans", {}).clear()
+        train(max(warmup, 1))
     barrier()
     # ---- the same K steps ONCE before any spin-up: what a caller sees on a GPU whose clocks have not ramped (reported next
     #      to the hot figure as `cold_start`; the headline stays the contract's: W warm-up steps, then K timed steps)
@@ -506,6 +525,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                 final_loss=float(losses[-1].item()), roofline=roofline)
     if cold is not None:
         part["cold_start"] = cold
+    if fallback:
+        part["config"]["collective_fallback"] = fallback
     del compiled, model
     return part, dict(builder=builder, kwargs=kwargs, n=n_per_gpu, optimizer=optimizer, opt_kwargs=opt_kwargs,
                       dense=dense, amort=amort)

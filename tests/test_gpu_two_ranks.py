@@ -219,6 +219,21 @@ def test_bench_with_two_ranks_dry_run():
     assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
 
 
+def test_bench_falls_back_to_the_host_collective_when_the_exchange_fails_in_use():
+    """`bench.py --gpus N` meets a node's topology for the first time at the driver's scaling run: when the one-shot exchange was
+    chosen and then abandons a call, every rank sees it (an abandoned call poisons all ranks) and all switch to
+    torch.distributed's all-reduce, saying so in the line.  The failure is injected here (both ranks, after a good warm-up)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BSVI_BENCH_BACKEND="gloo", BSVI_BENCH_SHARE_GPU="1", BSVI_BENCH_INJECT_EXCHANGE_FAILURE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                          "--spinup-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]
+    assert "collective_fallback" in line["config"] and "allreduce" in line["config"]["mode"] and line["all_finite"]
+
+
 def test_loop_exchange_on_one_rank_is_the_in_kernel_loop_bit_for_bit(monkeypatch):
     """`bsvi_train_persistent_exchange` with ONE rank: the owners' wave stores its sums into its own region, publishes and
     meets its own sequence number, and reads the same numbers back — so the loss curve and the parameters must be those of
