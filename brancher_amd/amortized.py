@@ -274,16 +274,25 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
         raise LoweringError("amortised path: the likelihood must be Binomial(1, logits) / Bernulli(logits) or "
                             "Normal(decoder output, scale given as numbers — constant or learnable)")
     xl = x.link.expressions()
-    likelihood, lik_scale, lik_scale_par = "binomial", None, None
+    likelihood, lik_scale, lik_scale_par, scale_head_key = "binomial", None, None, None
     if x.distribution.kind == D.DIST_NORMAL:
         likelihood = "normal"
-        # a number / array: a constant, or — `NormalVariable(decoder value, scale, learnable=True)` — a parameter of the joint
-        # model behind softplus (standard_variables.py:57-68)
-        lik_scale, lik_scale_par = _root_parameter(x, "scale", positive=True, learnable_ok=True)
-        if lik_scale.size not in (1, P):
-            raise LoweringError("amortised path: the likelihood's scale must be one number or one per feature")
-        lik_scale = np.ascontiguousarray(np.broadcast_to(lik_scale, (P,)), dtype=np.float32)
         dec_link, dec_in, logits_key = _network_output(xl["loc"].expr, "the likelihood's loc")
+        try:
+            # a second HEAD of the decoder: NormalVariable(decoder(z)["mean"], decoder(z)["sd"])
+            sd_link, sd_in, scale_head_key = _network_output(xl["scale"].expr, "the likelihood's scale")
+            if sd_link is not dec_link or sd_in is not dec_in or scale_head_key is None or scale_head_key == logits_key:
+                raise LoweringError("amortised path: the likelihood's loc and scale must be two outputs of ONE decoder")
+            lik_scale = np.ones(P, dtype=np.float32)          # (unused by the kernels: the head's values are)
+        except LoweringError as head_error:
+            if scale_head_key is not None:
+                raise head_error
+            # a number / array: a constant, or — `NormalVariable(decoder value, scale, learnable=True)` — a parameter of the joint
+            # model behind softplus (standard_variables.py:57-68)
+            lik_scale, lik_scale_par = _root_parameter(x, "scale", positive=True, learnable_ok=True)
+            if lik_scale.size not in (1, P):
+                raise LoweringError("amortised path: the likelihood's scale must be one number or one per feature")
+            lik_scale = np.ascontiguousarray(np.broadcast_to(lik_scale, (P,)), dtype=np.float32)
     else:
         if "logits" not in xl:
             raise LoweringError("amortised path: the likelihood must be parameterised by logits")
@@ -304,7 +313,8 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
 
     enc_layers, enc_out = trace_network(enc_link)
     dec_layers, dec_out = trace_network(dec_link)
-    for key, outs, what in ((loc_key, enc_out, "encoder"), (scale_key, enc_out, "encoder"), (logits_key, dec_out, "decoder")):
+    for key, outs, what in ((loc_key, enc_out, "encoder"), (scale_key, enc_out, "encoder"), (logits_key, dec_out, "decoder")) + \
+            (((scale_head_key, dec_out, "decoder"),) if scale_head_key is not None else ()):
         if key not in outs:
             raise LoweringError("amortised path: the %s has no output %r" % (what, key))
     enc_layers, enc_cols, adjacent = merge_sibling_heads(enc_layers, enc_out)
@@ -361,6 +371,8 @@ def lower_amortized(joint, posterior, estimator="pathwise"):
     prog.enc_outputs, prog.dec_outputs, prog.logits_key = enc_cols, {k: (v, 0) for k, v in dec_out.items()}, logits_key
     (prog.enc_loc_value, prog.enc_loc_col), (prog.enc_scale_value, prog.enc_scale_col) = enc_cols[loc_key], enc_cols[scale_key]
     prog.dec_logits_value = dec_out[logits_key]
+    prog.dec_scale_key = scale_head_key
+    prog.dec_scale_value = dec_out[scale_head_key] if scale_head_key is not None else 0
     prog.n_features, prog.latent_dim, prog.dataset_size, prog.batch_size = P, Dz, DS, B
     prog.prior_loc = np.ascontiguousarray(prior_loc, dtype=np.float32)
     prog.prior_scale = np.ascontiguousarray(prior_scale, dtype=np.float32)
@@ -410,7 +422,7 @@ class CompiledAmortized:
                       prior_loc=ptr(k["loc"]), prior_scale=ptr(k["scale"]), dataset=ptr(k["dataset"]),
                       likelihood=1 if p.likelihood == "normal" else 0, likelihood_scale=ptr(k["lik_scale"]),
                       prior_loc_off=p.prior_loc_off, prior_scale_off=p.prior_scale_off,
-                      lik_scale_off=p.lik_scale_off, lik_scale_size=p.lik_scale_size)
+                      lik_scale_off=p.lik_scale_off, lik_scale_size=p.lik_scale_size, dec_scale_value=p.dec_scale_value)
         handle = C.c_void_p()
         native.check(lib.bsvi_amort_create(C.byref(d), C.byref(handle)))
         self.handle = handle

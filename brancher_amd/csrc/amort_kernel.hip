@@ -1391,6 +1391,8 @@ struct RowParams {
     // ... or learnable: raw values in the parameter buffer (scale = softplus(raw); 1 of them, or P); kNoOffset: the constants above
     uint32_t lik_scale_off, lik_scale_size;
     float* lik_scale_part;                               // [row slices][P] partial sums of d log p / d raw, or null
+    // ... or a decoder head: per row and feature (post-activation), its gradient buffer (pre-activation), the head's activation
+    const float* lik_sd; float* dlik_sd; int ld_lik_sd, act_lik_sd; float add_lik_sd;
     float* rowf;             // [R] f per row
     float* rowlq;            // [R] log q per row
     float* logits; int ld_logits;
@@ -1523,6 +1525,19 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
     if (D.likelihood == 1) {
         // x ~ Normal(mean = decoder value, scale_j): log p = -u^2/2 - log(scale) - log(2 pi)/2, u = (x - mean)/scale;
         // d log p / d mean = u / scale, written over the means   (torch normal.py:83-90)
+        if (D.lik_sd) {          // the scale is a second head of the decoder: d log p / d scale = (u^2 - 1) / scale, through the head's activation
+            const float* sd = D.lik_sd + (long)r * D.ld_lik_sd;
+            float* dsd = D.dlik_sd + (long)r * D.ld_lik_sd;
+            for (int j = lane; j < D.P; j += 64) {
+                const float sj = sd[j], u = (x[j] - l[j]) / sj;
+                lp += -0.5f * u * u - logf(sj) - kHalfLog2Pi;
+                l[j] = u / sj;
+                dsd[j] = (u * u - 1.0f) / sj * act_derivative(D.act_lik_sd, sj, D.add_lik_sd);
+            }
+            lp = wave_sum64(lp);
+            if (lane == 0) D.rowf[r] += lp;
+            return;
+        }
         for (int j = lane; j < D.P; j += 64) {
             const float sj = lik_scale_of(D, j), u = (x[j] - l[j]) / sj;
             lp += -0.5f * u * u - logf(sj) - kHalfLog2Pi;
@@ -1764,6 +1779,15 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
         if (l.in_value == desc->enc_loc_value || l.in_value == desc->enc_scale_value) return bad("encoder heads must not feed further layers");
     for (const auto& l : a->dec.layers)
         if (l.in_value == desc->dec_logits_value) return bad("decoder logits must not feed further layers");
+    if (desc->dec_scale_value) {
+        if (desc->likelihood != BSVI_AMORT_LIK_NORMAL || desc->lik_scale_off != BSVI_AMORT_CONSTANT)
+            return bad("a decoder-head scale needs the Normal likelihood and no learnable constant scale");
+        if (desc->dec_scale_value >= a->dec.width.size() || desc->dec_scale_value == desc->dec_logits_value ||
+            a->dec.width[desc->dec_scale_value] != (int)desc->n_features || a->dec.producer[desc->dec_scale_value] < 0)
+            return bad("the decoder's scale head must be a layer output of width n_features");
+        for (const auto& l : a->dec.layers)
+            if (l.in_value == desc->dec_scale_value) return bad("the decoder's scale head must not feed further layers");
+    }
     // workspace layout per row: values and gradients of every non-input value, z / dz, eps, rowf, rowlq, idx
     size_t off = 0;
     int alias_grad = -1;
@@ -2263,6 +2287,11 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.params = params; D.prior_loc_off = d.prior_loc_off; D.prior_scale_off = d.prior_scale_off;
     D.likelihood = (int)d.likelihood; D.lik_scale = a->lik_scale_dev;
     D.lik_scale_off = d.lik_scale_off; D.lik_scale_size = d.lik_scale_size; D.lik_scale_part = nullptr;
+    D.lik_sd = nullptr; D.dlik_sd = nullptr;
+    if (d.dec_scale_value) {
+        D.lik_sd = val(a->dec, d.dec_scale_value); D.dlik_sd = grad(a->dec, d.dec_scale_value); D.ld_lik_sd = a->dec.ld[d.dec_scale_value];
+        head_act(a->dec.layers[a->dec.producer[d.dec_scale_value]], 0, D.act_lik_sd, D.add_lik_sd);
+    }
     D.rowf = rowf; D.rowlq = rowlq;
     D.logits = val(a->dec, d.dec_logits_value); D.ld_logits = a->dec.ld[d.dec_logits_value];
     D.out = out; D.fvalue_out = args->fvalue_out_dev; D.logq_out = args->logq_out_dev;

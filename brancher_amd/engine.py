@@ -1014,7 +1014,9 @@ def _amortized_sample(model, compiled, number_samples, input_values):
         x = torch.from_numpy(np.array(np.broadcast_to(given_x.reshape(-1, p.n_features)[:N], (N, p.n_features)),
                                       dtype=np.float32)).to(dev)
     elif p.likelihood == "normal":
-        if getattr(p, "lik_scale_size", 0):       # learnable: softplus of the raw values the optimizer steps (one, or one per feature)
+        if getattr(p, "dec_scale_key", None) is not None:      # a second head of the decoder
+            lik_scale = decoded[p.dec_scale_key]
+        elif getattr(p, "lik_scale_size", 0):     # learnable: softplus of the raw values the optimizer steps (one, or one per feature)
             raw = compiled.params[p.lik_scale_off:p.lik_scale_off + p.lik_scale_size]
             lik_scale = torch.nn.functional.softplus(raw).expand(p.n_features) if p.lik_scale_size == 1 else torch.nn.functional.softplus(raw)
         else:

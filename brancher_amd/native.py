@@ -165,7 +165,7 @@ class AmortDesc(Sized):
                 ("enc_layers", C.POINTER(MlpLayer)), ("dec_layers", C.POINTER(MlpLayer)),
                 ("prior_loc", C.c_void_p), ("prior_scale", C.c_void_p), ("dataset", C.c_void_p),
                 ("likelihood_scale", C.c_void_p), ("prior_loc_off", C.c_uint32), ("prior_scale_off", C.c_uint32),
-                ("lik_scale_off", C.c_uint32), ("lik_scale_size", C.c_uint32)]
+                ("lik_scale_off", C.c_uint32), ("lik_scale_size", C.c_uint32), ("dec_scale_value", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class AmortArgs(Sized):

@@ -574,7 +574,7 @@ def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=78
     return model
 
 
-def vae_modules(n_features, latent_size, hidden1, hidden2, seed=0):
+def vae_modules(n_features, latent_size, hidden1, hidden2, seed=0, decoder_sd_head=False):
     """Encoder / decoder networks with the layer plan of `examples/VAE_playground.py:27-62` (there: 784-256-512-(2,2)
     and 2-512-256-784): two ReLU layers, then a mean head and a softplus(+0.1) scale head; the decoder mirrors the
     trunk and ends in the logits.  Plain torch modules with a seeded initialisation, returning dicts keyed like the
@@ -601,9 +601,14 @@ def vae_modules(n_features, latent_size, hidden1, hidden2, seed=0):
             self.l1 = nn.Linear(latent_size, widths[0])
             self.l2 = nn.Linear(widths[0], widths[1])
             self.l3 = nn.Linear(widths[1], widths[2])
+            if decoder_sd_head:                              # a heteroscedastic decoder: a second head for the likelihood's scale
+                self.l4 = nn.Linear(widths[1], widths[2])
 
         def forward(self, code):
-            return {"mean": self.l3(torch.relu(self.l2(torch.relu(self.l1(code)))))}
+            hidden = torch.relu(self.l2(torch.relu(self.l1(code))))
+            if decoder_sd_head:
+                return {"mean": self.l3(hidden), "sd": F.softplus(self.l4(hidden)) + 0.05}
+            return {"mean": self.l3(hidden)}
 
     state = torch.random.get_rng_state()
     torch.manual_seed(seed)
@@ -631,12 +636,15 @@ def build_vae(api, dataset_size=64, batch_size=16, n_features=784, latent_size=2
     `standard_variables.py:57-68`)."""
     BF = api.BF
     dataset = vae_data(dataset_size, n_features, seed, real=(likelihood == "normal"))
-    enc, dec = vae_modules(n_features, latent_size, hidden1, hidden2, seed)
+    enc, dec = vae_modules(n_features, latent_size, hidden1, hidden2, seed, decoder_sd_head=(likelihood == "normal" and
+                                                                                          isinstance(likelihood_scale, str)))
     encoder = BF.BrancherFunction(enc)
     decoder = BF.BrancherFunction(dec)
     z = api.NormalVariable(np.zeros((latent_size,)), np.ones((latent_size,)), name="z", learnable=learnable_prior)
     decoder_output = api.DeterministicVariable(decoder(z), name="decoder_output")
-    if likelihood == "normal":
+    if likelihood == "normal" and isinstance(likelihood_scale, str):      # "decoder": the scale is the decoder's second head
+        x = api.NormalVariable(decoder_output["mean"], decoder_output["sd"], name="x")
+    elif likelihood == "normal":
         if not np.isscalar(likelihood_scale):
             likelihood_scale = np.asarray(likelihood_scale, dtype=np.float64)
         # (learnable=True turns the numeric argument — the scale — into a learnable root of the joint model behind softplus)

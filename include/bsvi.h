@@ -553,6 +553,10 @@ typedef struct bsvi_amort_desc {
      * its raw values in the parameter buffer — scale = softplus(raw) — and their count (1: one scale for every feature, or
      * n_features); BSVI_AMORT_CONSTANT: the constants of likelihood_scale (which still carries the initial values) */
     uint32_t lik_scale_off, lik_scale_size;
+    /* ... or a second HEAD of the decoder (`NormalVariable(decoder(z)["mean"], decoder(z)["sd"])`): the decoder value that holds
+     * the scale (width n_features, a leaf, positive through its layer's activation), 0: none.  The row kernel leaves
+     * d log p / d (pre-activation) in that value's gradient buffer, the decoder's backward pass takes it from there. */
+    uint32_t dec_scale_value, reserved1;
 } bsvi_amort_desc;
 #define BSVI_AMORT_LIK_BINOMIAL1 0u               /* Binomial(1, logits = decoder value)  (examples/VAE_playground.py:71) */
 #define BSVI_AMORT_LIK_NORMAL 1u

@@ -55,6 +55,13 @@ CASES = {
         dict(dataset_size=36, batch_size=10, n_features=132, hidden1=40, hidden2=24, latent_size=3, likelihood="normal",
              likelihood_scale=[0.5 + 0.004 * j for j in range(132)], learnable_likelihood_scale=True, learnable_prior=True), 7, 28,
         dict(iters=4, n=7, optimizer="Adam", lr=5e-3)),
+    # ... or a second HEAD of the decoder (a heteroscedastic decoder: NormalVariable(decoder(z)["mean"], decoder(z)["sd"]))
+    "vae_normal_decoder_scale_P28_H16_H10_DS30_B6_N5": (
+        dict(dataset_size=30, batch_size=6, n_features=28, hidden1=16, hidden2=10, likelihood="normal", likelihood_scale="decoder"),
+        5, 29, dict(iters=5, n=5, optimizer="Adam", lr=1e-2)),
+    "vae_normal_decoder_scale_P136_H72_H40_DS40_B12_N6": (
+        dict(dataset_size=40, batch_size=12, n_features=136, hidden1=72, hidden2=40, latent_size=3, likelihood="normal",
+             likelihood_scale="decoder", learnable_prior=True), 6, 30, dict(iters=4, n=6, optimizer="Adam", lr=5e-3)),
 }
 
 

@@ -49,6 +49,7 @@ class VaeOracle:
         self.lik_scale = None if prog.likelihood_scale is None else torch.from_numpy(prog.likelihood_scale).to(dtype)
         # ... or learnable: NormalVariable(decoder value, scale, learnable=True) keeps softplus^-1(scale) as a root of the joint model
         self.lik_raw, self._lik_name = None, None
+        self.scale_head_key = getattr(prog, "dec_scale_key", None)
         for par, off, size, group in prog.parameters:
             if getattr(prog, "lik_scale_size", 0) and off == prog.lik_scale_off:
                 self.lik_raw = torch.nn.Parameter(torch.from_numpy(np.asarray(par.numpy(), dtype=np.float64)).to(dtype))
@@ -88,10 +89,13 @@ class VaeOracle:
         out = self.enc(x.unsqueeze(-1))                          # the reference hands rows over as [.., P, 1]
         loc, sd = out["mean"], out["sd"]
         z = loc + sd * eps
-        logits = self.dec(z)["mean"]
+        dec_out = self.dec(z)
+        logits = dec_out["mean"]
         ploc, pscale = self.prior()
         if self.likelihood == "normal":
             scale = self.lik_scale if self.lik_raw is None else torch.nn.functional.softplus(self.lik_raw.reshape(-1))
+            if self.scale_head_key is not None:              # NormalVariable(decoder(z)["mean"], decoder(z)["sd"]): a second head
+                scale = dec_out[self.scale_head_key]
             lik = td.Normal(logits, scale).log_prob(x).sum(-1)
         else:
             lik = td.Binomial(total_count=1, logits=logits).log_prob(x).sum(-1)

@@ -133,12 +133,18 @@ def test_graphs_outside_the_pattern_are_rejected():
     names = {par.name: (off, size, group) for par, off, size, group in p.parameters}
     assert names["x_scale"] == (p.lik_scale_off, 1, 1) and p.lik_scale_size == 1 and p.n_params == p.lik_scale_off + 1
     assert np.allclose(p.likelihood_scale, 1.0, atol=1e-6)                # the initial value, behind softplus
-    # a decoder HEAD as the scale is still outside the pattern
+    # an ARITHMETIC expression of a decoder output as the scale is still outside the pattern (a second head is inside: below)
     x2 = api.NormalVariable(out["mean"], BF.exp(out["mean"]), name="x")
     model2 = api.ProbabilisticModel([x2, z])
     model2.set_posterior_model(api.ProbabilisticModel([Qx, Qz]))
     with pytest.raises(LoweringError):
         amortized.lower_amortized(model2, model2.posterior_model, "pathwise")
+    # (round 4) NormalVariable(decoder(z)["mean"], decoder(z)["sd"]): the scale is a second head of the decoder
+    m3 = W.build_vae(api, dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6, likelihood="normal", likelihood_scale="decoder")
+    p3 = amortized.lower_amortized(m3, m3.posterior_model, "blackbox")
+    heads = [l for l in p3.dec_layers if l.out_value in (p3.dec_logits_value, p3.dec_scale_value)]
+    assert p3.dec_scale_key == "sd" and p3.dec_scale_value not in (0, p3.dec_logits_value) and len(heads) == 2
+    assert heads[0].in_value == heads[1].in_value and p3.lik_scale_size == 0
     with pytest.raises(LoweringError):
         amortized.lower_amortized(W.build_vae(api, dataset_size=20, batch_size=5, n_features=12, hidden1=8, hidden2=6),
                                   None if False else W.build_vae(api, dataset_size=20, batch_size=5, n_features=12,
