@@ -273,14 +273,18 @@ class CompiledDense:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _seed(self, seed):
+        return _engine.shared_seed(seed, self.device)
+
     def _args(self, n_local, n_global, base, noise=None, indices=None, seed=None, offset=0, noise_out=None,
-              indices_out=None, fvalue_out=None):
+              indices_out=None, fvalue_out=None, f_weight=None, q_weight=None, logq_out=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         seed = _engine.shared_seed(seed, self.device)
         return DenseArgs(params_dev=ptr(self.params), noise_dev=ptr(noise), indices_dev=ptr(indices), seed=seed,
                          offset=int(offset), n_samples_local=n_local, n_samples_global=n_global, sample_base=base,
                          out_dev=ptr(self.out), noise_out_dev=ptr(noise_out), indices_out_dev=ptr(indices_out),
-                         fvalue_out_dev=ptr(fvalue_out), workspace_dev=ptr(self.workspace(n_local)), stream=self._stream())
+                         fvalue_out_dev=ptr(fvalue_out), workspace_dev=ptr(self.workspace(n_local)), stream=self._stream(),
+                         f_weight_dev=ptr(f_weight), q_weight_dev=ptr(q_weight), logq_out_dev=ptr(logq_out))
 
     def _noise_tensor(self, noise, n_global, base, n_local):
         if noise is None:
@@ -317,7 +321,9 @@ class CompiledDense:
         noise_o = torch.empty((p.n_noise, n_local), device=dev) if want_noise else None
         idx_o = torch.empty(p.batch_size, device=dev, dtype=torch.int32) if want_indices else None
         fvals = torch.empty(n_local, device=dev) if want_fvalues else None
-        args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, offset, noise_o, idx_o, fvals)
+        # (per-sample log q next to per-sample f: what a BlackBox-style estimator multiplies — a point estimate has no q)
+        logq = torch.zeros(n_local, device=dev) if want_fvalues and getattr(p, "estimator", "pathwise") == "blackbox" else None
+        args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, offset, noise_o, idx_o, fvals, logq_out=logq)
         native.check(self.lib.bsvi_dense_fwd_bwd(self.handle, C.byref(args)))
         engine.allreduce_sums(self.out)
         engine.check_exchange(self.device)
@@ -331,7 +337,29 @@ class CompiledDense:
             res["indices"] = idx_o
         if want_fvalues:
             res["f"] = fvals
+            if logq is not None:
+                res["lq"] = logq
         return res
+
+    def evaluate_weighted(self, number_samples, f_weight, q_weight, seed, offset, noise=None, minibatch=None):
+        """The second pass of a user-defined gradient estimator (`engine.custom_estimator_loss`), as
+        `CompiledELBO.evaluate_weighted`: the draw and the minibatch of (seed, offset) again, and
+        -(sum_n a_n grad f_n + b_n grad log q_n) in the output block (bsvi_dense_args::f_weight_dev / q_weight_dev; the
+        model must have been created with the BlackBox estimator)."""
+        from brancher_amd import engine
+        rank, world = engine.dist_info()
+        base, n_local = engine.shard(number_samples, rank, world)
+        a = f_weight.reshape(-1)[base:base + n_local].contiguous().float()
+        b = q_weight.reshape(-1)[base:base + n_local].contiguous().float()
+        noise_t = self._noise_tensor(noise, number_samples, base, n_local)
+        idx_t = self._indices_tensor(minibatch)
+        args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, int(offset), f_weight=a, q_weight=b)
+        native.check(self.lib.bsvi_dense_fwd_bwd(self.handle, C.byref(args)))
+        engine.allreduce_sums(self.out)
+        engine.check_exchange(self.device)
+        native.check(self.lib.bsvi_dense_finalize(self.handle, C.c_void_p(self.out.data_ptr()), 1, self._stream()))
+        self.grads_valid = True
+        return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
 
     def named_grads(self):
         g = self.out[OUT_HEADER:].detach().cpu().numpy()

@@ -849,7 +849,7 @@ class _OpaqueSamples(dict):
     the estimator passes it on to `function` / `calculate_log_probability` unchanged (`samples.update(empirical)` is fine)"""
 
 
-def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_samples, noise=None):
+def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_samples, noise=None, minibatch=None):
     """A user-defined gradient estimator (`gradient_estimators.py:17-26`, instantiated at `variables.py:856-857`): a torch
     scalar g built from `self.function(samples)` — f_n = log p + entropy per sample — and
     `self.sampler.calculate_log_probability(samples)` — log q_n — of ONE draw `self.sampler._get_sample(n)`.
@@ -858,14 +858,17 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
     (2) the same draw again with the weights: the output block receives d(-g)/d theta = -(sum_n a_n grad f_n + b_n grad log q_n),
     reparameterisation path included (the reference drops `differentiable=False`, `variables.py:567`).  Returns +g as a
     FusedLoss.  The estimator must hand the sample object on untouched — a Taylor1-style substitution of values is a
-    different program (and built in)."""
+    different program (and built in).  Served on the scalar path and on the dense-link path (whose gradient of log q_n is
+    -1 / scale for every sample, so b enters as its sum: dense_kernel.inc); `minibatch`: the rows of a dense-link model's
+    shared minibatch (parity tests), else both passes draw the same rows from (seed, offset)."""
     if isinstance(estimator_cls, type):
         make = estimator_cls
     else:
         make = type(estimator_cls)
     compiled = compile_model(joint_model, posterior_model, "blackbox")
-    if type(compiled).__name__ != "CompiledELBO":
-        raise NotImplementedError("user-defined gradient estimators are served on the scalar path")
+    if type(compiled).__name__ not in ("CompiledELBO", "CompiledDense"):
+        raise NotImplementedError("user-defined gradient estimators are served on the scalar and dense-link paths")
+    extra = dict(minibatch=minibatch) if type(compiled).__name__ == "CompiledDense" else {}
     N = int(number_samples)
     seed = compiled._seed(None)
     offset = compiled.iteration
@@ -873,9 +876,10 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
     rank, world = dist_info()
     if world > 1:
         raise NotImplementedError("user-defined gradient estimators on several ranks")
-    first = compiled.evaluate(N, seed=seed, offset=offset, want_fvalues=True, noise=noise)     # (noise: parity tests)
+    first = compiled.evaluate(N, seed=seed, offset=offset, want_fvalues=True, noise=noise, **extra)     # (noise: parity tests)
     F = first["f"].detach().clone().reshape(-1, 1).requires_grad_(True)
-    LQ = first["lq"].detach().clone().reshape(-1, 1).requires_grad_(True)
+    lq = first.get("lq")               # (a dense-link point estimate has no q: log q = 0, as the reference's RootVariable gives)
+    LQ = (lq if lq is not None else torch.zeros_like(first["f"])).detach().clone().reshape(-1, 1).requires_grad_(True)
     token = _OpaqueSamples()
     drawn = []
 
@@ -908,7 +912,7 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
         value.backward()
     a = F.grad if F.grad is not None else torch.zeros_like(F)
     b = LQ.grad if LQ.grad is not None else torch.zeros_like(LQ)
-    compiled.evaluate_weighted(N, a, b, seed, offset, noise=noise)
+    compiled.evaluate_weighted(N, a, b, seed, offset, noise=noise, **extra)
     return FusedLoss(compiled, value.detach().reshape(()), grad_scale=-1.0)
 
 

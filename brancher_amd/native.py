@@ -84,7 +84,8 @@ class DenseArgs(Sized):
                 ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32),
                 ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
                 ("out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p), ("indices_out_dev", C.c_void_p),
-                ("fvalue_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p)]
+                ("fvalue_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p),
+                ("f_weight_dev", C.c_void_p), ("q_weight_dev", C.c_void_p), ("logq_out_dev", C.c_void_p)]
 
 
 DENSE_EXPORTS = {

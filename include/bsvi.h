@@ -473,6 +473,14 @@ typedef struct bsvi_dense_args {
     float* fvalue_out_dev;       /* per-sample f [n_samples_local] or NULL                        */
     void* workspace_dev;
     void* stream;
+    /* Caller-weighted gradients, as bsvi_elbo_args::f_weight_dev / q_weight_dev (the two passes of a user-defined
+     * GradientEstimator, gradient_estimators.py:17-26): with both given the output block receives
+     * sum_n a_n grad f_n + b_n grad log q_n of the same draw (seed, offset).  NULL: the estimator's own weights
+     * (a_n = 1; BlackBox: b_n = f_n).  q_weight_dev and logq_out_dev need a model created with the BlackBox
+     * estimator, which takes the two weights together or not at all.  Not accepted by bsvi_dense_step. */
+    const float* f_weight_dev;   /* [n_samples_local] or NULL                                     */
+    const float* q_weight_dev;   /* [n_samples_local] or NULL                                     */
+    float* logq_out_dev;         /* per-sample log q(W_n) [n_samples_local] or NULL               */
 } bsvi_dense_args;
 
 int bsvi_dense_create(const bsvi_dense_desc* desc, bsvi_dense** out);

@@ -94,7 +94,9 @@ TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_l
 
 
 # ... and two user-defined estimators (workloads.custom_estimators) for these
-CUSTOM_ESTIMATOR_BUILDERS = ("build_readme_ar", "build_vector_latent", "build_heavy_tails")
+CUSTOM_ESTIMATOR_BUILDERS = ("build_readme_ar", "build_vector_latent", "build_heavy_tails",
+                             # ... and the dense-link path (BASELINE config 4 at reduced sizes)
+                             "build_logistic_regression", "build_binary_logistic_regression")
 
 
 def reference_api():
