@@ -507,8 +507,11 @@ class CompiledAmortized:
             raise ValueError("minibatch rows must lie in [0, %d)" % p.dataset_size)
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
 
+    def _seed(self, seed):
+        return _engine.shared_seed(seed, self.device)
+
     def _args(self, n_local, n_global, base, noise=None, indices=None, seed=None, offset=0, noise_out=None,
-              indices_out=None, fvalue_out=None, logq_out=None):
+              indices_out=None, fvalue_out=None, logq_out=None, f_weight=None, q_weight=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         seed = _engine.shared_seed(seed, self.device)
         return AmortArgs(params_dev=ptr(self.params), noise_dev=ptr(noise), indices_dev=ptr(indices), seed=seed,
@@ -516,7 +519,8 @@ class CompiledAmortized:
                          estimator=1 if self.program.estimator == "blackbox" else 0,
                          out_dev=ptr(self.out), noise_out_dev=ptr(noise_out), indices_out_dev=ptr(indices_out),
                          fvalue_out_dev=ptr(fvalue_out), logq_out_dev=ptr(logq_out),
-                         workspace_dev=ptr(self.workspace(n_local)), stream=self._stream())
+                         workspace_dev=ptr(self.workspace(n_local)), stream=self._stream(),
+                         f_weight_dev=ptr(f_weight), q_weight_dev=ptr(q_weight))
 
     def _identity_cfg(self):
         return native.make_opt_cfg("SGD", lr=0.0)
@@ -544,16 +548,7 @@ class CompiledAmortized:
         engine.allreduce_sums(self.out)
         engine.check_exchange(self.device)
         # sums -> loss and gradients: the ELBO estimate is a mean over N*B rows (gradient_estimators.py:36,44)
-        cfg = self._identity_cfg()
-        zero_mask = getattr(self, "_zero_mask", None)
-        if zero_mask is None:
-            zero_mask = self._zero_mask = torch.zeros(max(p.n_params, 1), dtype=torch.uint8, device=dev)
-            self._state0 = torch.zeros(4 * max(p.n_params, 1), device=dev)
-        ptr = lambda t: C.c_void_p(t.data_ptr())
-        native.check(self.lib.bsvi_finalize_step(C.byref(cfg), ptr(self.params), ptr(self.out), ptr(self._state0),
-                                                 ptr(zero_mask), p.n_params, number_samples * p.batch_size, None, None,
-                                                 self._stream()))
-        self.grads_valid = True
+        self._finalize(number_samples * p.batch_size)
         res = dict(loss=self.out[2], finite=self.out[3], nonfinite_count=self.out[1],
                    grads=self.out[OUT_HEADER:OUT_HEADER + p.n_params], n_local=n_local, sample_base=base)
         if want_noise:
@@ -562,8 +557,41 @@ class CompiledAmortized:
             res["indices"] = idx_o
         if want_fvalues:
             res["f"] = fvals
-            res["logq"] = logq
+            res["logq"] = res["lq"] = logq
         return res
+
+    def _finalize(self, divisor):
+        """sums -> loss and gradients (an optimizer step with an empty mask: nothing moves)"""
+        dev, p = self.device, self.program
+        cfg = self._identity_cfg()
+        zero_mask = getattr(self, "_zero_mask", None)
+        if zero_mask is None:
+            zero_mask = self._zero_mask = torch.zeros(max(p.n_params, 1), dtype=torch.uint8, device=dev)
+            self._state0 = torch.zeros(4 * max(p.n_params, 1), device=dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        native.check(self.lib.bsvi_finalize_step(C.byref(cfg), ptr(self.params), ptr(self.out), ptr(self._state0),
+                                                 ptr(zero_mask), p.n_params, int(divisor), None, None, self._stream()))
+        self.grads_valid = True
+
+    def evaluate_weighted(self, number_samples, f_weight, q_weight, seed, offset, noise=None, minibatch=None):
+        """The second pass of a user-defined gradient estimator (`engine.custom_estimator_loss`), as
+        `CompiledELBO.evaluate_weighted` with one weight per ROW ([number_samples, batch_size]): the draw and the minibatches of
+        (seed, offset) again, -(sum_r a_r grad f_r + b_r grad log q_r) in the output block (bsvi_amort_args::f_weight_dev /
+        q_weight_dev)."""
+        from brancher_amd import engine
+        rank, world = engine.dist_info()
+        base, n_local = engine.shard(number_samples, rank, world)
+        B = self.program.batch_size
+        a = f_weight.reshape(-1)[base * B:(base + n_local) * B].contiguous().float()
+        b = q_weight.reshape(-1)[base * B:(base + n_local) * B].contiguous().float()
+        noise_t = self._noise_tensor(noise, base, n_local)
+        idx_t = self._indices_tensor(minibatch, base, n_local)
+        args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, int(offset), f_weight=a, q_weight=b)
+        native.check(self.lib.bsvi_amort_fwd_bwd(self.handle, C.byref(args)))
+        engine.allreduce_sums(self.out)
+        engine.check_exchange(self.device)
+        self._finalize(1)
+        return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
 
     def _apply(self, network, rows, key, outputs):
         p = self.program

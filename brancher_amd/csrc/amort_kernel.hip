@@ -1399,6 +1399,10 @@ struct RowParams {
     float* out;
     float* sum_part;         // [workgroups of amort_latent_bwd][2]: partial sums of the estimator value / non-finite count
     float* fvalue_out; float* logq_out;
+    // caller-weighted gradients (bsvi_amort_args::f_weight_dev / q_weight_dev — the second pass of a user-defined gradient
+    // estimator): row r's gradient seeds are a_r grad f_r + b_r grad log q_r; every launch behind the row kernels is linear
+    // in the seeds, so the weights enter where the seeds are written (amort_lik, amort_latent_bwd) and nowhere else
+    const float* f_weight; const float* q_weight;      // [R] each, or null (a = 1; BlackBox: b = f)
 };
 
 // minibatch of sample s: a keyed bijection of [0, DS) per (seed, iteration, sample) — 4-round Feistel on the next
@@ -1502,6 +1506,16 @@ __global__ __launch_bounds__(256) void amort_lik_scale_grad(const RowParams D, i
     const float raw = D.params[D.lik_scale_off + (D.lik_scale_size == 1u ? 0 : j)];
     const float ds = raw > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-raw));
     const int r0 = blockIdx.y * rows_per_slice, r1 = min(D.R, r0 + rows_per_slice);
+    if (D.f_weight) {
+        // amort_lik left a_r u / s: a_r (u^2 - 1) / s = g'^2 s / a_r - a_r / s   (a_r = 0: the row contributes nothing)
+        float acc = 0.0f;
+        for (int r = r0; r < r1; ++r) {
+            const float a = D.f_weight[r], g = D.logits[(long)r * D.ld_logits + j];
+            acc += a != 0.0f ? g * g * s / a - a / s : 0.0f;
+        }
+        D.lik_scale_part[(long)blockIdx.y * D.P + j] = ds * acc;
+        return;
+    }
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
     int r = r0;
     for (; r + 3 < r1; r += 4) {
@@ -1522,6 +1536,7 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
     const float* x = D.dataset + (long)D.idx[r] * D.P;
     float* l = D.logits + (long)r * D.ld_logits;
     float lp = 0.0f;
+    const float aw = D.f_weight ? D.f_weight[r] : 1.0f;       // (weight of this row's gradient seeds)
     if (D.likelihood == 1) {
         // x ~ Normal(mean = decoder value, scale_j): log p = -u^2/2 - log(scale) - log(2 pi)/2, u = (x - mean)/scale;
         // d log p / d mean = u / scale, written over the means   (torch normal.py:83-90)
@@ -1531,8 +1546,8 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
             for (int j = lane; j < D.P; j += 64) {
                 const float sj = sd[j], u = (x[j] - l[j]) / sj;
                 lp += -0.5f * u * u - logf(sj) - kHalfLog2Pi;
-                l[j] = u / sj;
-                dsd[j] = (u * u - 1.0f) / sj * act_derivative(D.act_lik_sd, sj, D.add_lik_sd);
+                l[j] = aw * (u / sj);
+                dsd[j] = aw * ((u * u - 1.0f) / sj * act_derivative(D.act_lik_sd, sj, D.add_lik_sd));
             }
             lp = wave_sum64(lp);
             if (lane == 0) D.rowf[r] += lp;
@@ -1541,7 +1556,7 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
         for (int j = lane; j < D.P; j += 64) {
             const float sj = lik_scale_of(D, j), u = (x[j] - l[j]) / sj;
             lp += -0.5f * u * u - logf(sj) - kHalfLog2Pi;
-            l[j] = u / sj;
+            l[j] = aw * (u / sj);
         }
         lp = wave_sum64(lp);
         if (lane == 0) D.rowf[r] += lp;
@@ -1554,7 +1569,7 @@ __global__ __launch_bounds__(256) void amort_lik(const RowParams D) {
         const float one_e = 1.0f + e, r = __builtin_amdgcn_rcpf(one_e);
         lp += xj * lj - (fmaxf(lj, 0.0f) + __logf(one_e));
         const float sig = lj >= 0.0f ? r : e * r;
-        return xj - sig;
+        return aw * (xj - sig);
     };
     if (D.dataset_bf16 && ((D.P | D.ld_logits) & 3) == 0) {      // the exact bf16 copy of the data: half the bytes of the gather
         const uint16_t* xb = D.dataset_bf16 + (long)D.idx[r] * D.data_kp;
@@ -1592,15 +1607,17 @@ __global__ __launch_bounds__(256) void amort_latent_bwd(const RowParams D) {
         if (!isfinite(value)) bad = 1.0f;
         if (D.fvalue_out) D.fvalue_out[r] = f;
         if (D.logq_out) D.logq_out[r] = lq;
-        const float score = D.estimator == 1 ? f : 0.0f;
+        // (a caller's weights: a_r on every term of f_r — the decoder's dz carries it already —, b_r where stopgrad(f_r) stands)
+        const float aw = D.f_weight ? D.f_weight[r] : 1.0f;
+        const float score = D.q_weight ? D.q_weight[r] : (D.estimator == 1 ? f : 0.0f);
         for (int d = 0; d < D.Dz; ++d) {
             const float e = D.eps[(long)r * D.Dz + d];
             const float m = D.loc[(long)r * D.ld_loc + d], sd = D.scale[(long)r * D.ld_scale + d];
             const float z = D.z[(long)r * D.ld_z + d];
             float pl, ps, dps;
             prior_of(D, d, pl, ps, dps);
-            const float gz = D.dz[(long)r * D.ld_z + d] - (z - pl) / (ps * ps);
-            const float gsd = gz * e + (1.0f - score) / sd;
+            const float gz = D.dz[(long)r * D.ld_z + d] - aw * ((z - pl) / (ps * ps));
+            const float gsd = gz * e + (aw - score) / sd;
             D.dloc[(long)r * D.ld_loc + d] = gz * act_derivative(D.act_loc, m, D.add_loc);
             D.dscale[(long)r * D.ld_scale + d] = gsd * act_derivative(D.act_scale, sd, D.add_scale);
         }
@@ -1615,8 +1632,9 @@ __global__ __launch_bounds__(256) void amort_latent_bwd(const RowParams D) {
                 float pl, ps, dps;
                 prior_of(D, d, pl, ps, dps);
                 const float u = (D.z[(long)r * D.ld_z + d] - pl) / ps;
-                gl = u / ps;
-                gs = (u * u - 1.0f) / ps * dps;
+                const float aw = D.f_weight ? D.f_weight[r] : 1.0f;
+                gl = aw * (u / ps);
+                gs = aw * ((u * u - 1.0f) / ps * dps);
             }
             gl = wave_sum64(gl);
             gs = wave_sum64(gs);
@@ -2295,6 +2313,9 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     D.rowf = rowf; D.rowlq = rowlq;
     D.logits = val(a->dec, d.dec_logits_value); D.ld_logits = a->dec.ld[d.dec_logits_value];
     D.out = out; D.fvalue_out = args->fvalue_out_dev; D.logq_out = args->logq_out_dev;
+    if (!args->f_weight_dev != !args->q_weight_dev)
+        return bsvi_fail(BSVI_ERR_INVALID, "f_weight_dev and q_weight_dev come together (the weights of grad f and grad log q per row), or not at all");
+    D.f_weight = args->f_weight_dev; D.q_weight = args->q_weight_dev;
 
     const dim3 row_grid((unsigned)((R + 255) / 256));
     D.sum_part = part;

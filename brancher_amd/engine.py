@@ -858,17 +858,20 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
     (2) the same draw again with the weights: the output block receives d(-g)/d theta = -(sum_n a_n grad f_n + b_n grad log q_n),
     reparameterisation path included (the reference drops `differentiable=False`, `variables.py:567`).  Returns +g as a
     FusedLoss.  The estimator must hand the sample object on untouched — a Taylor1-style substitution of values is a
-    different program (and built in).  Served on the scalar path and on the dense-link path (whose gradient of log q_n is
-    -1 / scale for every sample, so b enters as its sum: dense_kernel.inc); `minibatch`: the rows of a dense-link model's
-    shared minibatch (parity tests), else both passes draw the same rows from (seed, offset)."""
+    different program (and built in).  Served on all three paths: the scalar path, the dense-link path (whose gradient of
+    log q_n is -1 / scale for every sample, so b enters as its sum: dense_kernel.inc) and the amortised path (one weight per
+    (sample, minibatch row): the row kernels scale the gradient seeds, every launch behind them is linear in the seeds);
+    `minibatch`: the rows of the model's minibatch variable (parity tests), else both passes draw the same rows from
+    (seed, offset)."""
     if isinstance(estimator_cls, type):
         make = estimator_cls
     else:
         make = type(estimator_cls)
     compiled = compile_model(joint_model, posterior_model, "blackbox")
-    if type(compiled).__name__ not in ("CompiledELBO", "CompiledDense"):
-        raise NotImplementedError("user-defined gradient estimators are served on the scalar and dense-link paths")
-    extra = dict(minibatch=minibatch) if type(compiled).__name__ == "CompiledDense" else {}
+    kind = type(compiled).__name__
+    if kind not in ("CompiledELBO", "CompiledDense", "CompiledAmortized"):
+        raise NotImplementedError("user-defined gradient estimators: unknown engine " + kind)
+    extra = dict(minibatch=minibatch) if kind != "CompiledELBO" else {}
     N = int(number_samples)
     seed = compiled._seed(None)
     offset = compiled.iteration
@@ -877,9 +880,11 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
     if world > 1:
         raise NotImplementedError("user-defined gradient estimators on several ranks")
     first = compiled.evaluate(N, seed=seed, offset=offset, want_fvalues=True, noise=noise, **extra)     # (noise: parity tests)
-    F = first["f"].detach().clone().reshape(-1, 1).requires_grad_(True)
+    # (the amortised path: one value per (sample, minibatch row), the reference's [number_samples, batch_size])
+    shape = (N, compiled.program.batch_size) if kind == "CompiledAmortized" else (-1, 1)
+    F = first["f"].detach().clone().reshape(shape).requires_grad_(True)
     lq = first.get("lq")               # (a dense-link point estimate has no q: log q = 0, as the reference's RootVariable gives)
-    LQ = (lq if lq is not None else torch.zeros_like(first["f"])).detach().clone().reshape(-1, 1).requires_grad_(True)
+    LQ = (lq if lq is not None else torch.zeros_like(first["f"])).detach().clone().reshape(shape).requires_grad_(True)
     token = _OpaqueSamples()
     drawn = []
 

@@ -177,7 +177,7 @@ class AmortArgs(Sized):
                 ("sample_base", C.c_uint32), ("estimator", C.c_uint32),
                 ("out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p), ("indices_out_dev", C.c_void_p),
                 ("fvalue_out_dev", C.c_void_p), ("logq_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("f_weight_dev", C.c_void_p), ("q_weight_dev", C.c_void_p)]
 
 
 EXPORTS.update({

@@ -589,6 +589,12 @@ typedef struct bsvi_amort_args {
     float* logq_out_dev;          /* log q(z | x) per row, or NULL        */
     void* workspace_dev;
     void* stream;
+    /* Caller-weighted gradients (the two passes of a user-defined GradientEstimator, gradient_estimators.py:17-26, as
+     * bsvi_elbo_args::f_weight_dev / q_weight_dev): with both given — one value per ROW, [n_samples_local * B] — the
+     * output block receives sum_r a_r grad f_r + b_r grad log q_r of the same draw and minibatches (seed, offset);
+     * `estimator` then only selects the value summed into out[0].  Both or neither. */
+    const float* f_weight_dev;
+    const float* q_weight_dev;
 } bsvi_amort_args;
 
 int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out);

@@ -164,6 +164,21 @@ def run_case(name, api):
         for k, p in params.items():
             out["grad_%s/%s" % (est_name, k)] = p.grad.detach().numpy().copy()
 
+    # user-defined estimators (the GradientEstimator seam, gradient_estimators.py:17-26; workloads.custom_estimators) on the
+    # same draws and minibatches
+    for est_name, est in sorted(W.custom_estimators(ge).items()):
+        for p in params.values():
+            p.grad = None
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        loss, idx, eps, _ = evaluate(model, q, est, N, capture)
+        loss.backward()
+        assert np.array_equal(out["minibatch/x"], idx) and np.array_equal(out["noise/z"], eps), "estimators drew different noise"
+        out["loss_custom_" + est_name] = np.float32(loss.detach().numpy())
+        for k, p in params.items():
+            out["grad_custom_%s/%s" % (est_name, k)] = (np.zeros_like(out["param/" + k]) if p.grad is None
+                                                        else p.grad.detach().numpy().copy())
+
     if traj is not None:
         # the loop of inference.py:77-108: posterior optimizer every iteration, model optimizer from the second on
         method = inference.ReverseKL(gradient_estimator=ge.PathwiseDerivativeEstimator)

@@ -110,6 +110,10 @@ class VaeOracle:
     def loss(self, rows, eps, estimator="pathwise"):
         t = self.terms(rows, eps)
         f = t["lp"] + t["H"]
+        if callable(estimator):
+            # a user-defined GradientEstimator (gradient_estimators.py:17-26) restated as its scalar g(f, log q) of the
+            # [N, B] per-row values
+            return -estimator(f, t["lq"]), t
         value = f if estimator == "pathwise" else t["lq"] * f.detach() + f
         return -value.mean(), t
 

@@ -233,6 +233,97 @@ def test_vae_golden_loss_and_grads(vae_golden, estimator):
     assert rel_err(res["logq"].cpu().numpy(), g.data["lq"].reshape(-1)) <= TOL
 
 
+@pytest.mark.parametrize("which", ["baseline", "softmax"])
+def test_vae_golden_user_defined_estimators(vae_golden, which):
+    """The GradientEstimator seam (gradient_estimators.py:17-26) on the amortised path: the SAME subclass bodies the real
+    reference ran (workloads.custom_estimators, oracle/gen_golden_vae.py) around two passes of the path — per-row f and
+    log q, then one weight per row on the gradient seeds (bsvi_amort_args::f_weight_dev / q_weight_dev) — against the
+    reference's loss and gradients on its recorded draws and minibatches."""
+    from brancher_amd import engine, gradient_estimators as ge, workloads as W
+    g = vae_golden
+    model = g.build()
+    cls = W.custom_estimators(ge)[which]
+    value = engine.custom_estimator_loss(model, model.posterior_model, cls, g.N, noise=g.data["noise/z"],
+                                         minibatch=g.data["minibatch/x"])
+    compiled = value.compiled
+    assert type(compiled).__name__ == "CompiledAmortized"
+    ref_loss = float(g.data["loss_custom_" + which])
+    assert abs(-float(value.detach().cpu()) - ref_loss) <= TOL * abs(ref_loss)
+    grads = _module_view(compiled, compiled.named_grads())
+    ref_grads = g.group("grad_custom_%s/" % which)
+    # the baseline estimator multiplies grad log q by f - mean(f): rows whose f is ~500 and whose differences are ~10, so the
+    # reference's own fp32 gradients sit a few 1e-5 from the fp64 ones.  Yardstick: as close to the fp64 oracle as the fp32
+    # reference is (x4), or the 1e-5 of every other workload.
+    from oracle.vae_oracle import VaeOracle
+    fn = {"baseline": lambda f, lq: (lq * (f - f.mean()).detach() + f).mean(),
+          "softmax": lambda f, lq: (torch.softmax(0.1 * f.detach().reshape(-1), dim=0).reshape(f.shape) * f).sum()}[which]
+    exact = VaeOracle(g.build(), dtype=torch.float64).loss_and_grads(g.data["minibatch/x"], g.data["noise/z"], fn)["grads"]
+    scale = max(np.abs(v).max() for v in exact.values())
+    for name, g_ref in ref_grads.items():
+        err, err_ref = np.abs(grads[name] - exact[name]).max(), np.abs(g_ref - exact[name]).max()
+        assert err <= max(4 * err_ref, TOL * scale), (name, err, err_ref)
+
+
+def test_vae_seam_estimators_reproduce_the_builtin_programs_at_config5_size():
+    """BASELINE config 5 at full size (784-512-256-2 / 2-256-512-784, minibatch 100, 8 samples): BlackBox and Pathwise spelled
+    out by a USER as GradientEstimator subclasses (the reference's own bodies, gradient_estimators.py:29-44) give the loss
+    and every gradient of the built-in programs on the same in-kernel draw and minibatches; the weighted pass is linear in
+    its weights; half a pair of weights is refused at the boundary."""
+    import ctypes as C
+    from brancher_amd import engine, gradient_estimators as ge, native, workloads as W
+
+    class MyBlackBox(ge.GradientEstimator):
+        def __call__(self, n_samples):
+            samples = self.sampler._get_sample(n_samples, differentiable=False)
+            samples.update(self.empirical_samples)
+            variational_loss = self.sampler.calculate_log_probability(samples) * (self.function(samples).detach())
+            return (variational_loss + self.function(samples)).mean()
+
+    class MyPathwise(ge.GradientEstimator):
+        def __call__(self, n_samples):
+            samples = self.sampler._get_sample(n_samples, differentiable=True)
+            samples.update(self.empirical_samples)
+            return self.function(samples).mean()
+
+    N, B = 8, 100
+    for cls, builtin in ((MyBlackBox, "blackbox"), (MyPathwise, "pathwise")):
+        model = W.build_vae(W.native_api(), dataset_size=3000, batch_size=B, n_features=784, hidden1=512, hidden2=256, seed=3)
+        c = engine.compile_model(model, None, "blackbox")
+        offset = c.iteration
+        value = engine.custom_estimator_loss(model, model.posterior_model, cls, N)
+        got = value.compiled.out[engine.OUT_HEADER:].cpu().numpy().copy()
+        ref_c = engine.compile_model(model, None, builtin)
+        ref = ref_c.evaluate(N, seed=None, offset=offset)
+        assert abs(-float(value.detach().cpu()) - float(ref["loss"])) <= TOL * abs(float(ref["loss"]))
+        want = ref_c.out[engine.OUT_HEADER:].cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    gen = torch.Generator().manual_seed(5)
+    a1, a2, b1, b2 = (torch.randn(N, B, generator=gen).to(c.device) for _ in range(4))
+    blocks = []
+    for a, b in ((a1, b1), (a2, b2), (a1 + a2, b1 + b2)):
+        c.evaluate_weighted(N, a, b, 21, 5)
+        torch.cuda.synchronize()
+        blocks.append(c.out[engine.OUT_HEADER:].cpu().numpy().astype(np.float64))
+    scale = np.abs(blocks[2]).max()
+    assert scale > 0 and np.abs(blocks[0] + blocks[1] - blocks[2]).max() <= 2e-5 * scale
+    args = c._args(N, N, 0, None, None, 21, 5, f_weight=a1.reshape(-1).contiguous())
+    assert c.lib.bsvi_amort_fwd_bwd(c.handle, C.byref(args)) == -1           # BSVI_ERR_INVALID
+
+
+def test_public_loop_with_a_user_defined_estimator_on_the_dense_and_amortised_paths():
+    """`perform_inference(..., ReverseKL(gradient_estimator=<user class>))` (inference.py:52-111) on a dense-link model and
+    on a VAE: every iteration is two passes of the path around the user's torch code, the optimizer step on the device."""
+    from brancher_amd import gradient_estimators as ge, inference, workloads as W
+    est = W.custom_estimators(ge)["baseline"]
+    api = W.native_api()
+    for model, n, lr in ((W.build_logistic_regression(api, dataset_size=200, batch_size=50, n_features=16, n_classes=3), 32, 0.05),
+                         (W.build_vae(api, dataset_size=200, batch_size=20, n_features=40, hidden1=24, hidden2=16, seed=1), 8, 0.01)):
+        inference.perform_inference(model, inference_method=inference.ReverseKL(gradient_estimator=est),
+                                    number_iterations=80, number_samples=n, optimizer="Adam", lr=lr)
+        curve = model.diagnostics["loss curve"]
+        assert len(curve) == 80 and np.all(np.isfinite(curve)) and curve[-10:].mean() < curve[:10].mean(), curve[::10]
+
+
 def test_vae_golden_trajectory(vae_golden):
     from brancher_amd import engine
     g = vae_golden
