@@ -771,6 +771,201 @@ static XdwPlan xdw_plan(int P, int n_out, size_t R) {
     return p;
 }
 
+// ---- f32 x f32 products on the bf16 matrix cores: six products of exact pieces ("bf16x6") ------------------------------------
+// Every f32 is EXACTLY the sum of three bf16 numbers hi + mid + lo (8 + 8 + 8 significant bits, xw_split_kernel above), and a
+// product of two bf16 numbers is exact in the f32 accumulator.  a * b = sum_ij a_i b_j over nine piece products; the three
+// smallest (mid lo, lo mid, lo lo: <= 2^-24 |a b| each) are dropped, the other six — (hi hi), (hi mid), (mid hi), (hi lo), (lo hi),
+// (mid mid) — run as six v_mfma_f32_32x32x16_bf16 per tile and k chunk: 6 / 16 of the f32-input MFMA's time (the bf16 one has 16x
+// its rate), with the rounding behaviour of an f32 fma chain to within the dropped terms (~1.5 ulp of each product before
+// accumulation, of random sign).  The WEIGHT operand's pieces are split once per iteration (x6_split_kernel: both orientations
+// of every wide layer in one launch), so the kernel stages them with plain 16-byte copies; the ACTIVATION operand is read as
+// f32 and split on the way into LDS (11 VALU instructions per pair of values, packed converts).
+//   forward        C[M][N] = act(A[M][K] W[N][K]^T + bias)                      Bp = pieces of W   [3][N][Kp]
+//   input gradient C[M][N] = (dY[M][K] W[K][N]) * act'(Y[M][N])  (+= C)        Bp = pieces of W^T [3][N][Kp]
+struct X6Args {
+    const float* A; int lda;                               // [M][K] f32: rows 16-byte aligned, K a multiple of 4
+    const uint16_t* Bp; long plane_stride; int Kp;         // [3][N][Kp] bf16 pieces, zero beyond K; Kp a multiple of 32
+    float* C; int ldc;
+    int M, N, K;
+    const float* bias;
+    const float* Y; int ldy;
+    int act; float post_add; int split; int act2; float post_add2;
+    int accumulate;
+};
+
+typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float x6_f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t x6_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t x6_pack(float a, float b) {       // (v_cvt_pk_bf16_f32: round to nearest even)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x6_f32x2{a, b}, x6_bf16x2));
+}
+// two f32 -> their pieces as packed pairs; hi + mid + lo == the value exactly
+__device__ __forceinline__ void x6_split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = x6_pack(a, b);
+    const float a1 = a - __uint_as_float(hi << 16), b1 = b - __uint_as_float(hi & 0xFFFF0000u);
+    mid = x6_pack(a1, b1);
+    lo = x6_pack(a1 - __uint_as_float(mid << 16), b1 - __uint_as_float(mid & 0xFFFF0000u));
+}
+
+struct X6SplitTable {
+    struct Entry { const float* W; uint16_t* dst; int N, K, Kp, transposed; uint32_t first_block; } e[8];
+    int n;
+};
+// pieces [3][N][Kp] of W [N][K] (transposed = 0) or of the transpose of W [K][N] (transposed = 1), zero beyond K: every wide
+// layer's two orientations in ONE launch at the start of an iteration
+__device__ __forceinline__ void x6_split_body(const X6SplitTable& T, uint32_t block) {
+    int s = 0;
+    while (s + 1 < T.n && block >= T.e[s + 1].first_block) ++s;
+    const X6SplitTable::Entry E = T.e[s];
+    const long i = (long)(block - E.first_block) * 256 + threadIdx.x;
+    if (i >= (long)E.N * E.Kp) return;
+    const int n = (int)(i / E.Kp), k = (int)(i - (long)n * E.Kp);
+    const float w = k < E.K ? (E.transposed ? E.W[(long)k * E.N + n] : E.W[(long)n * E.K + k]) : 0.0f;
+    const uint16_t hi = bf16_bits(w);
+    const float r1 = w - bf16_value(hi);
+    const uint16_t mid = bf16_bits(r1);
+    const long plane = (long)E.N * E.Kp;
+    E.dst[i] = hi; E.dst[plane + i] = mid; E.dst[2 * plane + i] = bf16_bits(r1 - bf16_value(mid));
+}
+__global__ __launch_bounds__(256) void x6_split_kernel(const X6SplitTable T) { x6_split_body(T, blockIdx.x); }
+
+// Workgroup tile 128 x 128 (four waves of 64 x 64), k step 32, one LDS stage (six piece planes of 128 rows x 80 bytes: 60 KB,
+// two workgroups per CU) with the next step's global loads in flight behind the MFMAs.
+template <bool NN, int DBG = 0>      // DBG (BSVI_X6_DEBUG, timing only, wrong results): 1 no split, 2 no stores, 3 no MFMAs, 4 no LDS fragment reads
+__global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {
+    constexpr int TBM = 128, FA = 2, APL = TBM * XLD;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * APL + 3 * XPLANE];      // A hi | mid | lo | B hi | mid | lo
+    const int tiles_n = (G.N + 127) / 128;
+    int bid = blockIdx.x;
+    const int n_blocks = gridDim.x;
+    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // an XCD takes a contiguous range of tiles
+    const int m0 = (bid / tiles_n) * TBM, n0 = (bid % tiles_n) * 128;              // (neighbours share the rows of A)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
+
+    // staging.  A: 128 rows x 8 quads of f32 per step, four per thread (eight threads read 128 contiguous bytes of a row);
+    // B: 3 x 128 x 4 pieces of 16 bytes, six per thread
+    const float* pa[4];
+    int sa[4], ka[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, kq = c & 7;
+        pa[i] = G.A + (long)min(m0 + row, G.M - 1) * G.lda + kq * 4;
+        sa[i] = row * XLD + kq * 8;
+        ka[i] = kq * 4;
+    }
+    const unsigned char* const wbase = reinterpret_cast<const unsigned char*>(G.Bp);
+    uint32_t pb[6];
+    int sb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = tid + 256 * i, plane = c >> 9, w = c & 511, col = w >> 2, kq = w & 3;
+        pb[i] = (uint32_t)((plane * G.plane_stride + (long)min(n0 + col, G.N - 1) * G.Kp + kq * 8) * 2);
+        sb[i] = 3 * APL + plane * XPLANE + col * XLD + kq * 16;
+    }
+    const int n_steps = G.Kp / XBK;
+    // (the last step of a K that is not a multiple of 32 reads quads beyond the row: those come from a valid address and are zeroed)
+    auto lda4 = [&](int i, int step) {
+        const bool ok = step * XBK + ka[i] < G.K;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ok ? pa[i] + step * XBK : pa[i]);
+        if (!ok) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        return v;
+    };
+    auto ldw = [&](uint32_t off, int step) { return *reinterpret_cast<const xu4*>(wbase + off + (size_t)step * (XBK * 2)); };
+
+    f32x16 acc[FA][2];
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra[4];
+    xu4 rb[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = lda4(i, 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rb[i] = ldw(pb[i], 0);
+    const unsigned char* at = lds + (wm + lm) * XLD + lk * 16;
+    const unsigned char* bt = lds + 3 * APL + (wn + lm) * XLD + lk * 16;
+    for (int step = 0; step < n_steps; ++step) {
+        __syncthreads();                                   // the last step's reads of the stage are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t h0, m0_, l0, h1, m1, l1;
+            if (DBG == 1) {
+                h0 = m0_ = l0 = __float_as_uint(ra[i][0]); h1 = m1 = l1 = __float_as_uint(ra[i][2]);
+            } else {
+                x6_split2(ra[i][0], ra[i][1], h0, m0_, l0);
+                x6_split2(ra[i][2], ra[i][3], h1, m1, l1);
+            }
+            *reinterpret_cast<x6_u2*>(lds + sa[i]) = x6_u2{h0, h1};
+            *reinterpret_cast<x6_u2*>(lds + APL + sa[i]) = x6_u2{m0_, m1};
+            *reinterpret_cast<x6_u2*>(lds + 2 * APL + sa[i]) = x6_u2{l0, l1};
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<xu4*>(lds + sb[i]) = rb[i];
+        __syncthreads();
+        if (step + 1 < n_steps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = lda4(i, step + 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rb[i] = ldw(pb[i], step + 1);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 a[3][FA], b[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < FA; ++i) a[p][i] = *reinterpret_cast<const bf16x8*>(at + (DBG == 4 ? 0 : p * APL + 32 * i * XLD + kc * 32));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const bf16x8*>(bt + (DBG == 4 ? 0 : p * XPLANE + 32 * j * XLD + kc * 32));
+            }
+            if (DBG == 3) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { acc[i][0][p] += (float)a[p][i][0]; acc[i][1][p] += (float)b[p][i][0]; }
+                continue;
+            }
+            // smallest products first: (lo hi), (hi lo), (mid mid), (mid hi), (hi mid), (hi hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < FA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: acc[i][j][r] is C[m][n] with m = 32i + 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31)   (as gemm_kernel)
+#pragma unroll
+    for (int i = 0; i < FA; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lm;
+            if (n >= G.N) continue;
+            const float bias = (!NN && G.bias) ? G.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * lk + (r & 3);
+                if (m >= G.M) continue;
+                float v = acc[i][j][r];
+                float* c = G.C + (long)m * G.ldc + n;
+                if (DBG == 2) { if (v == 1.2345f) *c = v; continue; }
+                if (!NN) {
+                    *c = act_forward(ACT_OF(G, n), v + bias, ADD_OF(G, n));
+                } else {
+                    if (G.Y) v *= act_derivative(ACT_OF(G, n), G.Y[(long)m * G.ldy + n], ADD_OF(G, n));
+                    *c = G.accumulate ? *c + v : v;
+                }
+            }
+        }
+}
+
 // dY [R][ld] f32 -> T [3][N][Rp] bf16 pieces, and the column sums of every 64-row block (the bias gradient's partials)
 __global__ __launch_bounds__(256) void dy_split_t_kernel(const float* dY, int ld, int R, int Rp, int N, uint16_t* T, float* colsum) {
     __shared__ float tile[64][65];
@@ -1427,13 +1622,19 @@ __device__ __forceinline__ uint32_t minibatch_row(const RowParams& D, uint32_t s
     return b % (uint32_t)D.DS;
 }
 
-__global__ void amort_rows(const RowParams D) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void amort_rows_body(const RowParams& D, int r) {
     if (r >= D.R) return;
     const int s = r / D.B, b = r - s * D.B;
     const int32_t i = D.indices_in ? D.indices_in[r] : (int32_t)minibatch_row(D, (uint32_t)(D.sample_base + s), (uint32_t)b);
     D.idx[r] = i;
     if (D.indices_out) D.indices_out[r] = i;
+}
+__global__ void amort_rows(const RowParams D) { amort_rows_body(D, blockIdx.x * blockDim.x + threadIdx.x); }
+// the heads of an iteration in ONE launch of heterogeneous workgroups: the minibatch rows, and behind them the bf16 pieces of
+// every weight matrix the matrix-core products read (three launches of 6 - 8 us each, back to back on an idle chip, before)
+__global__ __launch_bounds__(256) void amort_head(const RowParams D, const X6SplitTable T, uint32_t row_blocks) {
+    if (blockIdx.x < row_blocks) amort_rows_body(D, blockIdx.x * 256 + threadIdx.x);
+    else x6_split_body(T, blockIdx.x - row_blocks);
 }
 
 // p(z)'s parameters for latent dimension d: constants, or the learnable raw values behind the constructor's transforms
@@ -1722,6 +1923,12 @@ struct bsvi_amort {
     hipEvent_t joined = nullptr;
     bool overlap = true;
     bool layers_cover_params = false;   // every parameter is a weight or bias of some layer: reduce_partials writes the whole block
+    // the wide f32 layers on the bf16 matrix cores as six products of exact pieces (x6gemm_kernel): per layer the pieces of the
+    // weights in both orientations, [3][n_out][kp_nt] for the forward product and [3][n_in][kp_nn] for the input gradient,
+    // refreshed by ONE launch at the start of every iteration (BSVI_AMORT_X6=0: the f32-input MFMA kernel serves them)
+    struct X6Layer { uint16_t* nt = nullptr; uint16_t* nn = nullptr; int kp_nt = 0, kp_nn = 0; };
+    std::vector<X6Layer> x6[2];         // [0] encoder, [1] decoder
+    bool x6_any = false;
 };
 
 static int pad4(int n) { return (n + 3) / 4 * 4; }
@@ -1867,6 +2074,29 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
     }
     (void)hipMemcpy(a->prior_dev, desc->prior_loc, Dz * sizeof(float), hipMemcpyHostToDevice);
     (void)hipMemcpy(a->prior_dev + Dz, desc->prior_scale, Dz * sizeof(float), hipMemcpyHostToDevice);
+    {   // wide layers whose input is a network value: six products of exact pieces on the bf16 matrix cores (x6gemm_kernel)
+        const char* x6e = getenv("BSVI_AMORT_X6");
+        const bool want = !(x6e && x6e[0] == '0');
+        const Net* nets[2] = {&a->enc, &a->dec};
+        for (int t = 0; t < 2 && want; ++t) {
+            a->x6[t].assign(nets[t]->layers.size(), bsvi_amort::X6Layer{});
+            for (size_t l = 0; l < nets[t]->layers.size(); ++l) {
+                const auto& L = nets[t]->layers[l];
+                const bool data_layer = t == 0 && L.in_value == 0;            // (gathered rows: the exact-data kernels or the f32 one)
+                if (data_layer || L.n_in < 64 || L.n_out < 64 || (L.n_in & 3) || (L.n_out & 3)) continue;
+                auto& X = a->x6[t][l];
+                X.kp_nt = ((int)L.n_in + XBK - 1) / XBK * XBK;
+                X.kp_nn = ((int)L.n_out + XBK - 1) / XBK * XBK;
+                const bool ok = hipMalloc(&X.nt, 3 * (size_t)L.n_out * X.kp_nt * sizeof(uint16_t)) == hipSuccess &&
+                                hipMalloc(&X.nn, 3 * (size_t)L.n_in * X.kp_nn * sizeof(uint16_t)) == hipSuccess;
+                if (!ok) {
+                    bsvi_amort_destroy(a);
+                    return bsvi_fail(BSVI_ERR_HIP, "hipMalloc of the weight pieces failed");
+                }
+                a->x6_any = true;
+            }
+        }
+    }
     const char* ov = getenv("BSVI_AMORT_OVERLAP");
     a->overlap = !(ov && ov[0] == '0');
     if (a->overlap) {
@@ -1926,6 +2156,11 @@ extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
         if (p) (void)hipFree(p);
     if (a->prior_dev) (void)hipFree(a->prior_dev);
     if (a->lik_scale_dev) (void)hipFree(a->lik_scale_dev);
+    for (auto& v : a->x6)
+        for (auto& l : v) {
+            if (l.nt) (void)hipFree(l.nt);
+            if (l.nn) (void)hipFree(l.nn);
+        }
     for (auto e : a->ready)
         if (e) (void)hipEventDestroy(e);
     if (a->joined) (void)hipEventDestroy(a->joined);
@@ -2010,6 +2245,26 @@ extern "C" size_t bsvi_amort_workspace_bytes(const bsvi_amort* a, uint32_t n_sam
 static int prefetch_depth(int mode) {
     static const std::string cfg = [] { const char* e = getenv("BSVI_GEMM_PF"); return std::string(e && strlen(e) == 3 ? e : "222"); }();
     return cfg[mode] == '2' ? 2 : 1;
+}
+
+// rows from which the 128-row tiles of x6gemm_kernel fill the chip better than the f32 kernel's 64-row ones
+constexpr int kX6MinRows = 256;
+static int launch_x6(bool nn, const X6Args& X, hipStream_t stream) {
+    const int tiles = ((X.M + 127) / 128) * ((X.N + 127) / 128);
+    static const int dbg = [] { const char* e = getenv("BSVI_X6_DEBUG"); return e ? atoi(e) : 0; }();
+    if (dbg && !nn && dbg != 12 && dbg != 13) {
+        switch (dbg) {
+        case 1: hipLaunchKernelGGL((x6gemm_kernel<false, 1>), dim3(tiles), dim3(256), 0, stream, X); break;
+        case 2: hipLaunchKernelGGL((x6gemm_kernel<false, 2>), dim3(tiles), dim3(256), 0, stream, X); break;
+        case 3: hipLaunchKernelGGL((x6gemm_kernel<false, 3>), dim3(tiles), dim3(256), 0, stream, X); break;
+        default: hipLaunchKernelGGL((x6gemm_kernel<false, 4>), dim3(tiles), dim3(256), 0, stream, X);
+        }
+    } else if (nn && dbg == 12) hipLaunchKernelGGL((x6gemm_kernel<true, 2>), dim3(tiles), dim3(256), 0, stream, X);
+    else if (nn && dbg == 13) hipLaunchKernelGGL((x6gemm_kernel<true, 3>), dim3(tiles), dim3(256), 0, stream, X);
+    else if (nn) hipLaunchKernelGGL((x6gemm_kernel<true>), dim3(tiles), dim3(256), 0, stream, X);
+    else hipLaunchKernelGGL((x6gemm_kernel<false>), dim3(tiles), dim3(256), 0, stream, X);
+    HIP_TRY(hipGetLastError());
+    return BSVI_OK;
 }
 
 static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
@@ -2194,6 +2449,26 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
         HIP_TRY(hipGetLastError());
         return BSVI_OK;
     }
+    if (mode == 5 || mode == 6) {
+        // modes 0 / 1 through x6gemm_kernel: six products of exact bf16 pieces (B's pieces split here, in a buffer the hook keeps)
+        if (!a_dev || !b_dev || !c_dev || rows_dev || (k & 3) || (lda & 3)) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
+        const int Kp = ((int)k + XBK - 1) / XBK * XBK;
+        static uint16_t* wp = nullptr; static size_t wp_n = 0;
+        const size_t need_w = 3 * (size_t)n * Kp;
+        if (need_w > wp_n) { (void)hipDeviceSynchronize(); if (wp) (void)hipFree(wp); wp = nullptr; wp_n = 0; HIP_TRY(hipMalloc(&wp, need_w * 2)); wp_n = need_w; }
+        hipStream_t st = (hipStream_t)stream;
+        if (mode == 5 ? ldb != k : ldb != n) return bsvi_fail(BSVI_ERR_INVALID, "modes 5 / 6 take a densely stored B");
+        X6SplitTable T{};
+        T.e[0] = {b_dev, wp, (int)n, (int)k, Kp, mode == 6 ? 1 : 0, 0u};
+        T.n = 1;
+        hipLaunchKernelGGL(x6_split_kernel, dim3((unsigned)(((size_t)n * Kp + 255) / 256)), dim3(256), 0, st, T);
+        X6Args X{};
+        X.A = a_dev; X.lda = (int)lda; X.Bp = wp; X.Kp = Kp; X.plane_stride = (long)n * Kp;
+        X.C = c_dev; X.ldc = (int)ldc; X.M = (int)m; X.N = (int)n; X.K = (int)k;
+        X.act = (int)activation; X.post_add = post_add; X.accumulate = (int)accumulate;
+        if (mode == 5) X.bias = bias_or_y_dev; else { X.Y = bias_or_y_dev; X.ldy = (int)ldy; }
+        return launch_x6(mode == 6, X, st);
+    }
     if (mode < 0 || mode > 2 || !a_dev || !b_dev || !c_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
     GemmArgs G{};
     G.A = a_dev; G.B = b_dev; G.C = c_dev; G.rows = rows_dev;
@@ -2331,7 +2606,50 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         if (!rc && d.prior_scale_off != BSVI_AMORT_CONSTANT) rc = add_segment(grads + d.prior_scale_off, D.prior_scale_part, 1, (uint32_t)Dz, row_grid.x);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(amort_rows, row_grid, dim3(256), 0, stream, D);
+    // the pieces of the weights the matrix-core products read — the wide layers' in both orientations (x6gemm_kernel), the data
+    // layer's (xgemm_nt_kernel) — ride in the launch that draws the minibatch rows, when they fit its table of eight
+    const bool x6_on = a->x6_any && R >= (size_t)kX6MinRows;
+    bool data_pieces_done = false;
+    {
+        std::vector<X6SplitTable::Entry> entries;
+        uint32_t blocks = 0;
+        auto add = [&](const float* W, uint16_t* dst, int N, int K, int Kp, int transposed) {
+            entries.push_back({W, dst, N, K, Kp, transposed, blocks});
+            blocks += (uint32_t)(((size_t)N * Kp + 255) / 256);
+        };
+        if (a->data_exact)
+            for (size_t l = 0; l < a->enc.layers.size() && l < a->weight_pieces.size(); ++l)
+                if (a->enc.layers[l].in_value == 0 && a->weight_pieces[l])
+                    add(params + a->enc.layers[l].weight_off, a->weight_pieces[l], (int)a->enc.layers[l].n_out, (int)a->enc.layers[l].n_in, a->data_kp, 0);
+        const size_t n_data = entries.size();
+        const Net* nets[2] = {&a->enc, &a->dec};
+        for (int t = 0; t < 2 && x6_on; ++t)
+            for (size_t l = 0; l < a->x6[t].size(); ++l) {
+                const auto& X = a->x6[t][l];
+                if (!X.nt) continue;
+                const auto& L = nets[t]->layers[l];
+                add(params + L.weight_off, X.nt, (int)L.n_out, (int)L.n_in, X.kp_nt, 0);
+                add(params + L.weight_off, X.nn, (int)L.n_in, (int)L.n_out, X.kp_nn, 1);
+            }
+        if (!entries.empty() && entries.size() <= 8) {
+            X6SplitTable T{};
+            for (const auto& e : entries) T.e[T.n++] = e;
+            hipLaunchKernelGGL(amort_head, dim3(row_grid.x + blocks), dim3(256), 0, stream, D, T, row_grid.x);
+            data_pieces_done = n_data > 0;
+        } else {
+            hipLaunchKernelGGL(amort_rows, row_grid, dim3(256), 0, stream, D);
+            // (a deeper network: the wide layers' pieces eight matrices per launch; the data layer's where it is multiplied)
+            for (size_t at = n_data; at < entries.size(); at += 8) {
+                X6SplitTable T{};
+                const uint32_t first = entries[at].first_block;
+                uint32_t last = blocks;
+                for (size_t j = at; j < entries.size() && j < at + 8; ++j) { T.e[T.n] = entries[j]; T.e[T.n++].first_block -= first; }
+                if (at + 8 < entries.size()) last = entries[at + 8].first_block;
+                hipLaunchKernelGGL(x6_split_kernel, dim3(last - first), dim3(256), 0, stream, T);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+    }
 
     // the transposed minibatch rows for the exact-data weight gradients (launched after the encoder's forward pass, below)
     uint16_t* XT = nullptr;
@@ -2352,8 +2670,9 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 const int Kp = a->data_kp;
                 uint16_t* pieces = a->weight_pieces[li];
                 const long total = (long)l.n_out * Kp;
-                hipLaunchKernelGGL(xw_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                                   params + l.weight_off, (int)l.n_out, (int)l.n_in, Kp, pieces);
+                if (!data_pieces_done)
+                    hipLaunchKernelGGL(xw_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                                       params + l.weight_off, (int)l.n_out, (int)l.n_in, Kp, pieces);
                 XGemmArgs X{};
                 X.X = a->dataset_bf16_dev; X.rows = idx; X.Wp = pieces; X.plane_stride = total;
                 X.C = val(net, l.out_value); X.ldc = net.ld[l.out_value];
@@ -2363,6 +2682,20 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 if (l.split_col > 0 && l.split_col < l.n_out) { X.split = (int)l.split_col; X.act2 = (int)l.activation2; X.post_add2 = l.post_add2; }
                 launch_xgemm(X, stream);
                 HIP_TRY(hipGetLastError());
+                continue;
+            }
+            const auto& x6 = a->x6[&net == &a->dec ? 1 : 0];
+            static const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();      // (bit 0: forward, bit 1: input gradient — see backward)
+            if (x6_on && (x6_modes & 1) && !from_data && li < x6.size() && x6[li].nt) {
+                X6Args X{};
+                X.A = val(net, l.in_value); X.lda = net.ld[l.in_value];
+                X.Bp = x6[li].nt; X.Kp = x6[li].kp_nt; X.plane_stride = (long)l.n_out * X.Kp;
+                X.C = val(net, l.out_value); X.ldc = net.ld[l.out_value];
+                X.M = (int)R; X.N = (int)l.n_out; X.K = (int)l.n_in;
+                X.bias = l.bias_off != 0xFFFFFFFFu ? params + l.bias_off : nullptr;
+                X.act = (int)l.activation; X.post_add = l.post_add;
+                if (l.split_col > 0 && l.split_col < l.n_out) { X.split = (int)l.split_col; X.act2 = (int)l.activation2; X.post_add2 = l.post_add2; }
+                if (int rc = launch_x6(false, X, stream)) return rc;
                 continue;
             }
             G.A = from_data ? a->dataset_dev : val(net, l.in_value);
@@ -2464,6 +2797,26 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 }
                 G.accumulate = written[l.in_value];
                 written[l.in_value] = 1;
+                const auto& x6 = a->x6[&net == &a->dec ? 1 : 0];
+                // The input gradients stay on the f32-input MFMA kernel by default (BSVI_X6_MODES=3 switches them over): they run
+                // BESIDE the side stream's weight-gradient launches, and with x6gemm_kernel<true> on this stream the narrow layers'
+                // outer_kernel on the other one returned ~50 of 1024 values different from call to call at cfg 5's size (always
+                // lanes 48-63, the x / z halves of one packed-f32 accumulator; also with this kernel's stores compiled out, never
+                // with its MFMAs compiled out, never with the f32-input kernel here or without the side stream) — a co-residency
+                // effect that is not understood, so the combination is not used.  The forward products never run beside the side
+                // stream.  (profiles/r4/x6_notes.txt)
+                static const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();
+                static const int x6_only = [] { const char* e = getenv("BSVI_X6_NN_ONLY"); return e ? atoi(e) : -1; }();     // (diagnostics: 10 * net + layer)
+                if (x6_on && (x6_modes & 2) && (size_t)i < x6.size() && x6[i].nn && (x6_only < 0 || x6_only == 10 * (&net == &a->dec ? 1 : 0) + i)) {
+                    X6Args X{};
+                    X.A = dY; X.lda = ldy;
+                    X.Bp = x6[i].nn; X.Kp = x6[i].kp_nn; X.plane_stride = (long)l.n_in * X.Kp;
+                    X.C = G.C; X.ldc = G.ldc; X.M = G.M; X.N = G.N; X.K = G.K;
+                    X.Y = G.Y; X.ldy = G.ldy; X.act = G.act; X.post_add = G.post_add;
+                    X.split = G.split; X.act2 = G.act2; X.post_add2 = G.post_add2; X.accumulate = G.accumulate;
+                    if (int rc = launch_x6(true, X, stream)) return rc;
+                    continue;
+                }
                 int rc = launch_gemm(MODE_NN, G, stream);
                 if (rc) return rc;
             }

@@ -621,6 +621,8 @@ int bsvi_amort_apply(const bsvi_amort* a, int network, const float* params_dev, 
  * mode 1: C[M][N] = A[M][K] B[K][N]     (* activation'(Y[m][n]))      backward-data
  * mode 2: C[M][N] += A[K][M]^T B[K][N]  (K split over workgroups: per-slice partials in a buffer the hook owns, added
  *         in slice order by a second launch) backward-weight
+ * modes 5 / 6: modes 0 / 1 as six products of exact bf16 pieces on the bf16 matrix cores (the wide layers' product path
+ *         from 256 rows; K and lda multiples of 4, no gather)
  * rows_dev (or NULL) gathers the rows of A (modes 0, 1) / of B (mode 2).
  * bias_or_y_dev: mode 0 bias[N]; mode 1 Y[M][ldy]; mode 2 an [M] accumulator that receives += column sums of A. */
 int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev, float* c_dev, const int32_t* rows_dev,

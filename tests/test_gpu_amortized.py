@@ -69,6 +69,43 @@ def test_gemm_matches_torch(mode, shape):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("mode", [5, 6])
+@pytest.mark.parametrize("shape", [(256, 128, 64), (300, 200, 100), (1000, 784, 512), (25600, 512, 256), (25600, 256, 784),
+                                   (25600, 784, 512), (4100, 72, 260)])
+def test_six_piece_products_on_the_bf16_matrix_cores_match_f32_accuracy(mode, shape):
+    """x6gemm_kernel (the wide layers of the amortised path from 256 rows): an f32 x f32 product as six bf16 MFMAs on the exact
+    pieces hi + mid + lo of both operands.  Against the product in double precision, with torch's own f32 matmul as the
+    yardstick: at most twice its error (or 2e-6 of the largest output) — shapes with tails in every dimension (K = 100, 260,
+    784 are not multiples of the k step 32; N = 200, 72, 784 not of the tile; M = 300, 4100 not either)."""
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K + mode)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    if mode == 5:
+        A, Bm, bias = rnd(M, K), rnd(N, K), rnd(N)
+        Cm = torch.full((M, N + 4), 7.0, device=dev)
+        native.check(lib.bsvi_debug_gemm(5, ptr(A), ptr(Bm), ptr(Cm), None, M, N, K, K, K, N + 4, ptr(bias), 0, 0, 0.0, 0, None))
+        ref = A.double() @ Bm.double().T + bias.double()
+        f32 = A @ Bm.T + bias
+        got = Cm[:, :N]
+        assert torch.all(Cm[:, N:] == 7.0)
+    else:
+        A, Bm, Y, C0 = rnd(M, K), rnd(K, N), rnd(M, N), rnd(M, N)
+        Cm = C0.clone()
+        native.check(lib.bsvi_debug_gemm(6, ptr(A), ptr(Bm), ptr(Cm), None, M, N, K, K, N, N, ptr(Y), N, 1, 0.0, 1, None))
+        ref = C0.double() + (A.double() @ Bm.double()) * (Y > 0).double()
+        f32 = C0 + (A @ Bm) * (Y > 0).float()
+        got = Cm
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item() / scale
+    yard = (f32.double() - ref).abs().max().item() / scale
+    assert err <= max(2.0 * yard, 2e-6), (err, yard)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("shape", [(25600, 256, 784), (25600, 512, 256), (17000, 200, 72), (25600, 784, 256), (25000, 256, 512),
                                    (9000, 300, 48)])
