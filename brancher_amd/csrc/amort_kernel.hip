@@ -830,7 +830,9 @@ __device__ __forceinline__ void x6_split_body(const X6SplitTable& T, uint32_t bl
 __global__ __launch_bounds__(256) void x6_split_kernel(const X6SplitTable T) { x6_split_body(T, blockIdx.x); }
 
 // Workgroup tile 128 x 128 (four waves of 64 x 64), k step 32, one LDS stage (six piece planes of 128 rows x 80 bytes: 60 KB,
-// two workgroups per CU) with the next step's global loads in flight behind the MFMAs.
+// two workgroups per CU) with the next step's global loads in flight behind the MFMAs.  (Measured and dropped: the f32 operand's
+// loads TWO steps ahead in a second register set — 240 VGPRs, the same times to the microsecond on every cfg 5 shape: the
+// kernel does not wait for its loads.  profiles/r4/x6_notes.txt has what it does wait for.)
 template <bool NN, int DBG = 0>      // DBG (BSVI_X6_DEBUG, timing only, wrong results): 1 no split, 2 no stores, 3 no MFMAs, 4 no LDS fragment reads
 __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {
     constexpr int TBM = 128, FA = 2, APL = TBM * XLD;
@@ -2755,6 +2757,10 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 uint16_t* T = reinterpret_cast<uint16_t*>(part);
                 part += align4(3 * (size_t)l.n_out * Rp / 2);
                 if (xt_on_side && wstream != a->side) HIP_TRY(hipStreamWaitEvent(wstream, a->ready.back(), 0));
+                // (round 4, measured and removed: the pieces and column sums written by the EPILOGUE of the input-gradient product that
+                //  computes dY — 64 x 128 tile through LDS, no dy_split_t launch, dY not read back: 1.0276 against 1.0278 ms per cfg 5
+                //  iteration.  The end of the backward pass is bound by the work of both streams together — that product grew from
+                //  118 to 133 us beside the side stream's weight gradient — not by the length of this stream's chain.)
                 hipLaunchKernelGGL(dy_split_t_kernel, dim3((unsigned)(Rp / 64), (unsigned)((l.n_out + 63) / 64)), dim3(256), 0, wstream,
                                    dY, ldy, (int)R, Rp, (int)l.n_out, T, has_bias ? colsum : nullptr);
                 launch_xdw(XT, T, (int)l.n_in, (int)l.n_out, plan, slices, wstream);

@@ -11,7 +11,7 @@ f = glob.glob('/tmp/tl/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # the last complete iteration: from an amort_rows launch to the next
-starts = [i for i, r in enumerate(rows) if 'amort_rows' in r['Kernel_Name']]
+starts = [i for i, r in enumerate(rows) if 'amort_rows' in r['Kernel_Name'] or 'amort_head' in r['Kernel_Name']]
 a, b = starts[-3], starts[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 out = open('gpurun_out/r4/cfg5_timeline.txt', 'w')
