@@ -2804,13 +2804,13 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 G.accumulate = written[l.in_value];
                 written[l.in_value] = 1;
                 const auto& x6 = a->x6[&net == &a->dec ? 1 : 0];
-                // The input gradients stay on the f32-input MFMA kernel by default (BSVI_X6_MODES=3 switches them over): they run
-                // BESIDE the side stream's weight-gradient launches, and with x6gemm_kernel<true> on this stream the narrow layers'
-                // outer_kernel on the other one returned ~50 of 1024 values different from call to call at cfg 5's size (always
-                // lanes 48-63, the x / z halves of one packed-f32 accumulator; also with this kernel's stores compiled out, never
-                // with its MFMAs compiled out, never with the f32-input kernel here or without the side stream) — a co-residency
-                // effect that is not understood, so the combination is not used.  The forward products never run beside the side
-                // stream.  (profiles/r4/x6_notes.txt)
+                // The input gradients stay on the f32-input MFMA kernel by default (BSVI_X6_MODES=3 switches them over): beside the
+                // side stream's f32-input weight gradients they gained nothing (cfg 5: 1.009 against 1.003 ms).  What that
+                // experiment found is why this file is compiled without packed-f32 instructions (Makefile): with
+                // x6gemm_kernel<true> on this stream the narrow layers' outer_kernel on the other one returned ~50 of 1024 values
+                // different from call to call — lanes 48-63, the x / z halves of one packed-f32 accumulator — and so it does
+                // beside EVERY bf16-MFMA kernel, the exact-data ones included (tools/r4/coresidency_probe.py,
+                // profiles/r4/x6_notes.txt section 4).
                 static const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();
                 static const int x6_only = [] { const char* e = getenv("BSVI_X6_NN_ONLY"); return e ? atoi(e) : -1; }();     // (diagnostics: 10 * net + layer)
                 if (x6_on && (x6_modes & 2) && (size_t)i < x6.size() && x6[i].nn && (x6_only < 0 || x6_only == 10 * (&net == &a->dec ? 1 : 0) + i)) {

@@ -353,12 +353,14 @@ def test_public_loop_with_a_user_defined_estimator_on_the_dense_and_amortised_pa
     from brancher_amd import gradient_estimators as ge, inference, workloads as W
     est = W.custom_estimators(ge)["baseline"]
     api = W.native_api()
+    torch.manual_seed(1234)                  # (the Philox key of the draws is torch's initial seed: not whatever an earlier test left)
+    np.random.seed(1234)
     for model, n, lr in ((W.build_logistic_regression(api, dataset_size=200, batch_size=50, n_features=16, n_classes=3), 32, 0.05),
                          (W.build_vae(api, dataset_size=200, batch_size=20, n_features=40, hidden1=24, hidden2=16, seed=1), 8, 0.01)):
         inference.perform_inference(model, inference_method=inference.ReverseKL(gradient_estimator=est),
-                                    number_iterations=80, number_samples=n, optimizer="Adam", lr=lr)
+                                    number_iterations=120, number_samples=n, optimizer="Adam", lr=lr)
         curve = model.diagnostics["loss curve"]
-        assert len(curve) == 80 and np.all(np.isfinite(curve)) and curve[-10:].mean() < curve[:10].mean(), curve[::10]
+        assert len(curve) == 120 and np.all(np.isfinite(curve)) and curve[-20:].mean() < curve[:20].mean(), curve[::10]
 
 
 def test_vae_golden_trajectory(vae_golden):
