@@ -2687,7 +2687,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 continue;
             }
             const auto& x6 = a->x6[&net == &a->dec ? 1 : 0];
-            static const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();      // (bit 0: forward, bit 1: input gradient — see backward)
+            const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();      // (bit 0: forward, bit 1: input gradient — see backward; read per call: tests switch it)
             if (x6_on && (x6_modes & 1) && !from_data && li < x6.size() && x6[li].nt) {
                 X6Args X{};
                 X.A = val(net, l.in_value); X.lda = net.ld[l.in_value];
@@ -2811,7 +2811,7 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 // different from call to call — lanes 48-63, the x / z halves of one packed-f32 accumulator — and so it does
                 // beside EVERY bf16-MFMA kernel, the exact-data ones included (tools/r4/coresidency_probe.py,
                 // profiles/r4/x6_notes.txt section 4).
-                static const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();
+                const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();
                 static const int x6_only = [] { const char* e = getenv("BSVI_X6_NN_ONLY"); return e ? atoi(e) : -1; }();     // (diagnostics: 10 * net + layer)
                 if (x6_on && (x6_modes & 2) && (size_t)i < x6.size() && x6[i].nn && (x6_only < 0 || x6_only == 10 * (&net == &a->dec ? 1 : 0) + i)) {
                     X6Args X{};

@@ -594,6 +594,63 @@ def _custom_vae(api, enc_module, dec_module, dataset, batch_size, latent, prior_
     return model
 
 
+@pytest.mark.parametrize("x6_modes", ["1", "3"])
+def test_deep_networks_on_the_six_piece_products_match_oracle(x6_modes, monkeypatch):
+    """Five wide layers at 384 rows: every one of them multiplies on x6gemm_kernel (forward; with BSVI_X6_MODES=3 the input
+    gradients too), with widths that leave tails in every tile dimension (68, 132, 200, 72 are multiples of 4 only), and their
+    ten weight splits + the data layer's do not fit the head launch's table of eight — the separate split launches serve them.
+    Against the fp64 oracle, both estimators; the engine's gradients are bit-identical call to call."""
+    import torch.nn as nn
+    from brancher_amd import engine, workloads as W
+    from oracle.vae_oracle import VaeOracle
+    monkeypatch.setenv("BSVI_X6_MODES", x6_modes)
+    rng = np.random.RandomState(77)
+    P, latent, DS, B, N = 96, 3, 120, 48, 8
+    torch.manual_seed(5)
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2, self.l3 = nn.Linear(P, 132), nn.Linear(132, 68), nn.Linear(68, 200)
+            self.mean, self.sd, self.sp = nn.Linear(200, latent), nn.Linear(200, latent), nn.Softplus()
+
+        def forward(self, x):
+            h = torch.relu(self.l3(torch.relu(self.l2(torch.relu(self.l1(x.squeeze(-1)))))))
+            return {"mean": self.mean(h), "sd": self.sp(self.sd(h)) + 0.05}
+
+    class Dec(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.l2, self.l3, self.out = nn.Linear(latent, 72), nn.Linear(72, 200), nn.Linear(200, 132), nn.Linear(132, P)
+
+        def forward(self, z):
+            return {"mean": self.out(torch.relu(self.l3(torch.relu(self.l2(torch.relu(self.l1(z)))))))}
+
+    enc, dec = Enc(), Dec()
+    data = (rng.rand(DS, P, 1) > 0.5).astype("int32")
+    rows = np.stack([rng.choice(DS, B, replace=False) for _ in range(N)])
+    eps = rng.randn(N, B, latent).astype(np.float32)
+    for estimator in ("pathwise", "blackbox"):
+        model = _custom_vae(W.native_api(), enc, dec, data, B, latent)
+        ref = VaeOracle(model, dtype=torch.float64).loss_and_grads(rows, eps, estimator)
+        c = engine.compile_model(model, model.posterior_model, estimator)
+        res = c.evaluate(N, noise=eps, minibatch=rows)
+        first = c.out.clone()
+        assert abs(float(res["loss"]) - ref["loss"]) <= TOL * max(abs(ref["loss"]), 1.0), (estimator, float(res["loss"]), ref["loss"])
+        grads = _module_view(c, c.named_grads())
+        scale = max(np.abs(v).max() for v in ref["grads"].values())
+        for name, g_ref in ref["grads"].items():
+            assert np.abs(grads[name] - g_ref).max() <= 2e-5 * scale, (estimator, name)
+        for _ in range(3):
+            c.evaluate(N, noise=eps, minibatch=rows)
+            assert torch.equal(c.out, first)
+    # the two settings are different launch sequences: their gradients agree to rounding, not to the bit
+    monkeypatch.setenv("BSVI_X6_MODES", "1" if x6_modes == "3" else "3")
+    c.evaluate(N, noise=eps, minibatch=rows)
+    assert not torch.equal(c.out, first)
+    assert float((c.out - first).abs().max()) <= 2e-5 * float(first.abs().max())
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BSVI_TEST_SEEDS", "20"))))
 def test_random_architectures_match_oracle(seed):
     """less-travelled shapes: heads straight off the data rows (gathered narrow layers), single-layer decoders, no
