@@ -2804,14 +2804,17 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 G.accumulate = written[l.in_value];
                 written[l.in_value] = 1;
                 const auto& x6 = a->x6[&net == &a->dec ? 1 : 0];
-                // The input gradients stay on the f32-input MFMA kernel by default (BSVI_X6_MODES=3 switches them over): beside the
-                // side stream's f32-input weight gradients they gained nothing (cfg 5: 1.009 against 1.003 ms).  What that
-                // experiment found is why this file is compiled without packed-f32 instructions (Makefile): with
+                // Most input gradients stay on the f32-input MFMA kernel (the rule is below): beside the side stream's f32-input
+                // weight gradients the six-piece form gains little.  What trying them found is why this file is compiled without
+                // packed-f32 instructions (Makefile): with
                 // x6gemm_kernel<true> on this stream the narrow layers' outer_kernel on the other one returned ~50 of 1024 values
                 // different from call to call — lanes 48-63, the x / z halves of one packed-f32 accumulator — and so it does
                 // beside EVERY bf16-MFMA kernel, the exact-data ones included (tools/r4/coresidency_probe.py,
                 // profiles/r4/x6_notes.txt section 4).
-                const int x6_modes = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();
+                // cfg 5, one input gradient at a time on x6gemm_kernel beside the f32-input weight gradients (0.984 ms with none):
+                // K = 784 -> 0.976, K = 512 -> 0.984, K = 256 -> 1.020 — a tile's prologue / epilogue against 8 ... 25 k steps.
+                // Unset: the ones with at least 512 columns to contract; BSVI_X6_MODES=1 none, 3 all.
+                const int x6_modes = [&] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : (G.K >= 512 ? 3 : 1); }();
                 static const int x6_only = [] { const char* e = getenv("BSVI_X6_NN_ONLY"); return e ? atoi(e) : -1; }();     // (diagnostics: 10 * net + layer)
                 if (x6_on && (x6_modes & 2) && (size_t)i < x6.size() && x6[i].nn && (x6_only < 0 || x6_only == 10 * (&net == &a->dec ? 1 : 0) + i)) {
                     X6Args X{};
