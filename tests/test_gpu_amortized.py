@@ -594,6 +594,64 @@ def _custom_vae(api, enc_module, dec_module, dataset, batch_size, latent, prior_
     return model
 
 
+@pytest.mark.parametrize("partner", [1, 3, 5, 6])
+def test_narrow_weight_gradient_is_bit_exact_beside_matrix_core_products_on_a_second_stream(partner):
+    """The amortised path runs its weight gradients on a side stream beside the input gradients.  Round 4 found that a kernel
+    with packed-f32 VALU instructions (outer_kernel, the narrow layers' weight gradient) returned wrong values in lanes 48-63
+    while a bf16-MFMA kernel was resident on the same CUs from the other stream (10 of 24 launches, up to 4 % of a value;
+    profiles/r4/x6_notes.txt section 4) — the translation unit is compiled without those instructions since.  Here: the
+    encoder heads' weight gradient of cfg 5 (dW[4][512] over 25 600 rows) alone, then 16 times beside a partner product looping
+    on another stream (mode 1 the f32-input MFMA kernel, 3 the exact-data bf16 x3 kernel, 5 / 6 the six-piece products):
+    every launch must return the bits of the solo launch."""
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    K, M, N = 25600, 4, 512
+    A, B = rnd(K, M), rnd(K, N)
+    s_main, s_side = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def outer(out):
+        out.zero_()
+        native.check(lib.bsvi_debug_gemm(2, ptr(A), ptr(B), ptr(out), None, M, N, K, M, N, N, None, 0, 0, 0.0, 0, C.c_void_p(s_side.cuda_stream)))
+
+    Mg, Ng, Kg = 25600, 256, 512
+    Ag, Bnn, Bnt, Yg, bias = rnd(Mg, Kg), rnd(Kg, Ng), rnd(Ng, Kg), rnd(Mg, Ng), rnd(Ng)
+    Xexact = (torch.rand(Mg, Kg, generator=g) > 0.5).float().to(dev)
+    Cg = torch.zeros(Mg, Ng, device=dev)
+
+    def product():
+        st = C.c_void_p(s_main.cuda_stream)
+        if partner == 1:
+            native.check(lib.bsvi_debug_gemm(1, ptr(Ag), ptr(Bnn), ptr(Cg), None, Mg, Ng, Kg, Kg, Ng, Ng, ptr(Yg), Ng, 1, 0.0, 0, st))
+        elif partner == 6:
+            native.check(lib.bsvi_debug_gemm(6, ptr(Ag), ptr(Bnn), ptr(Cg), None, Mg, Ng, Kg, Kg, Ng, Ng, ptr(Yg), Ng, 1, 0.0, 0, st))
+        elif partner == 5:
+            native.check(lib.bsvi_debug_gemm(5, ptr(Ag), ptr(Bnt), ptr(Cg), None, Mg, Ng, Kg, Kg, Kg, Ng, ptr(bias), 0, 1, 0.0, 0, st))
+        else:
+            native.check(lib.bsvi_debug_gemm(3, ptr(Xexact), ptr(Bnt), ptr(Cg), None, Mg, Ng, Kg, Kg, Kg, Ng, ptr(bias), 0, 1, 0.0, 0, st))
+
+    torch.cuda.synchronize()
+    solo = torch.zeros(M, N, device=dev)
+    with torch.cuda.stream(s_side):
+        outer(solo)
+    torch.cuda.synchronize()
+    ref = A.double().T @ B.double()
+    assert float((solo.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    outs = [torch.zeros(M, N, device=dev) for _ in range(16)]
+    for o in outs:
+        with torch.cuda.stream(s_main):
+            product()
+            product()
+        with torch.cuda.stream(s_side):
+            outer(o)
+    torch.cuda.synchronize()
+    bad = [int((o != solo).sum()) for o in outs]
+    assert sum(bad) == 0, bad
+
+
 @pytest.mark.parametrize("x6_modes", ["1", "3"])
 def test_deep_networks_on_the_six_piece_products_match_oracle(x6_modes, monkeypatch):
     """Five wide layers at 384 rows: every one of them multiplies on x6gemm_kernel (forward; with BSVI_X6_MODES=3 the input
