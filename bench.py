@@ -309,25 +309,36 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     #      program-specialised kernel), then — still untimed — the same path for spinup_ms so that a short timed region
     #      (the driver runs K = 20) is not measured on a GPU whose clocks have not ramped yet
     fallback = None
+    failed = None
     try:
         train(max(warmup, 1))
-        if world > 1 and os.environ.get("BSVI_BENCH_INJECT_EXCHANGE_FAILURE") == "1" and engine._exchanges:
+        # (test-only: both switches must be set, so that nothing in a production environment can trip the fallback by accident)
+        if world > 1 and os.environ.get("BSVI_TEST_HOOKS") == "1" and os.environ.get("BSVI_BENCH_INJECT_EXCHANGE_FAILURE") == "1" \
+                and engine._exchanges:
             raise native.NativeError("injected by BSVI_BENCH_INJECT_EXCHANGE_FAILURE (tests: the fallback below)")
     except native.NativeError as err:
         if world == 1:
             raise
-        # Several ranks: the one-shot exchange was chosen (self-test + vote) and then abandoned in use — this is the first time
-        # the path meets this node's topology.  An abandoned call poisons every rank (csrc/collective.hip), so every rank is
-        # here: all switch to RCCL through torch.distributed and say so in the line.
-        fallback = "one-shot exchange abandoned (%s): RCCL through torch.distributed" % str(err)[:120]
-        os.environ["BSVI_COLLECTIVE"] = "torch"
-        os.environ["BSVI_LOOP_EXCHANGE"] = "0"
-        for ex in list(engine._exchanges.values()):
-            if ex:
-                ex.close()
-        engine._exchanges.clear()
-        getattr(compiled, "_train_plans", {}).clear()
-        train(max(warmup, 1))
+        failed = err
+    if world > 1 and engine.collective_kind() in ("auto", "exchange"):
+        # Several ranks with the one-shot exchange opted in (BSVI_COLLECTIVE=auto|exchange; the default is torch.distributed):
+        # the ranks VOTE on what happened — an error on one rank only must not send that rank into other collectives than its
+        # peers.  Any failure: every rank switches to RCCL through torch.distributed, says so in the line, and starts again
+        # (`train` takes rank 0's parameters at every call, so the replicas restart from identical values).
+        ok = torch.tensor([0.0 if failed is not None else 1.0], device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            fallback = "one-shot exchange abandoned (%s): RCCL through torch.distributed" % str(failed or "on another rank")[:120]
+            os.environ["BSVI_COLLECTIVE"] = "torch"
+            os.environ["BSVI_LOOP_EXCHANGE"] = "0"
+            for ex in list(engine._exchanges.values()):
+                if ex:
+                    ex.close()
+            engine._exchanges.clear()
+            getattr(compiled, "_train_plans", {}).clear()
+            train(max(warmup, 1))
+    elif failed is not None:
+        raise failed
     barrier()
     # ---- the same K steps ONCE before any spin-up: what a caller sees on a GPU whose clocks have not ramped (reported next
     #      to the hot figure as `cold_start`; the headline stays the contract's: W warm-up steps, then K timed steps)
@@ -537,6 +548,12 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                 final_loss=float(losses[-1].item()), roofline=roofline)
     if cold is not None:
         part["cold_start"] = cold
+    if world > 1:
+        # which all-reduce every rank took (the first SCALE run says it): torch.distributed's (RCCL under the nccl backend) unless
+        # the one-shot exchange was opted in AND chosen by the self-test + vote
+        used = bool(engine._exchanges.get(torch.cuda.current_device()))
+        part["config"]["collective"] = ("one-shot exchange (bsvi_exchange_*)" if used else
+                                        "torch.distributed all_reduce, backend %s" % dist.get_backend())
     if fallback:
         part["config"]["collective_fallback"] = fallback
     del compiled, model

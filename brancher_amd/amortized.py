@@ -546,7 +546,7 @@ class CompiledAmortized:
         args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, offset, noise_o, idx_o, fvals, logq)
         native.check(self.lib.bsvi_amort_fwd_bwd(self.handle, C.byref(args)))
         engine.allreduce_sums(self.out)
-        engine.check_exchange(self.device)
+        engine.check_exchange(self.device, self.params)
         # sums -> loss and gradients: the ELBO estimate is a mean over N*B rows (gradient_estimators.py:36,44)
         self._finalize(number_samples * p.batch_size)
         res = dict(loss=self.out[2], finite=self.out[3], nonfinite_count=self.out[1],
@@ -589,7 +589,7 @@ class CompiledAmortized:
         args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, int(offset), f_weight=a, q_weight=b)
         native.check(self.lib.bsvi_amort_fwd_bwd(self.handle, C.byref(args)))
         engine.allreduce_sums(self.out)
-        engine.check_exchange(self.device)
+        engine.check_exchange(self.device, self.params)
         self._finalize(1)
         return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
 
@@ -661,7 +661,7 @@ class CompiledAmortized:
                 C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         if world > 1:
-            engine.check_exchange(self.device)         # (an abandoned exchange poisoned a step: say so, loudly)
+            engine.check_exchange(self.device, self.params)         # (an abandoned exchange poisoned a step: say so, loudly)
         return loss_curve[:K], finite[:K]
 
 

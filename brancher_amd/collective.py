@@ -53,20 +53,35 @@ class Exchange:
         else:
             self.rank, self.world = 0, 1
         handle = C.c_void_p()
+        self.handle = None
         with torch.cuda.device(self.device):
-            native.check(self.lib.bsvi_exchange_create(self.rank, self.world, int(capacity_floats), C.byref(handle)))
-            self.handle = handle
+            # A rank whose region cannot be created still takes part in the all_gather below (with a zero handle): were it to
+            # raise first, its peers would sit in the all_gather while it went on to the next collective — mismatched, a hang.
+            # Every rank sees the zero handle and every rank raises.
+            rc = self.lib.bsvi_exchange_create(self.rank, self.world, int(capacity_floats), C.byref(handle))
+            if rc == 0:
+                self.handle = handle
             if self.world > 1:
                 nbytes = int(self.lib.bsvi_exchange_handle_bytes())
                 mine = (C.c_ubyte * nbytes)()
-                native.check(self.lib.bsvi_exchange_export(self.handle, mine))
+                if rc == 0:
+                    rc = self.lib.bsvi_exchange_export(self.handle, mine)
+                    if rc:
+                        mine = (C.c_ubyte * nbytes)()
                 local = torch.tensor(list(bytes(mine)), dtype=torch.uint8)
                 if dist.get_backend(group) == "nccl":
                     local = local.to(self.device)
                 gathered = [torch.empty_like(local) for _ in range(self.world)]
                 dist.all_gather(gathered, local, group=group)
-                blob = np.concatenate([g.cpu().numpy() for g in gathered]).astype(np.uint8)
+                rows = [g.cpu().numpy() for g in gathered]
+                missing = [r for r, g in enumerate(rows) if not g.any()]
+                if missing:
+                    self.close()
+                    raise native.NativeError("bsvi_exchange_create / export failed on rank(s) {}: no rank uses the exchange".format(missing))
+                blob = np.concatenate(rows).astype(np.uint8)
                 native.check(self.lib.bsvi_exchange_connect(self.handle, blob.ctypes.data_as(C.c_void_p)))
+            else:
+                native.check(rc)
 
     def allreduce(self, tensor, stream=None):
         if tensor.dtype != torch.float32 or not tensor.is_contiguous():
@@ -75,16 +90,20 @@ class Exchange:
         native.check(self.lib.bsvi_exchange_allreduce(self.handle, C.c_void_p(tensor.data_ptr()), tensor.numel(), C.c_void_p(st)))
         return tensor
 
-    def self_test(self):
-        """one all-reduce of known vectors right after the regions are connected: rank r contributes (r + 1) * [1, 2, ...];
-        True when this rank got the exact total in time (synchronises; run once, outside any capture)"""
+    def self_test(self, calls=4):
+        """`calls` all-reduces of known vectors right after the regions are connected (both parities of the slot area and the
+        reuse of a slot two calls later): in call k rank r contributes (r + 1 + k) * [1, 2, ...]; True when this rank got
+        every exact total in time (synchronises; run once, outside any capture)"""
         n = min(64, int(getattr(self, "capacity", 64)))
         ramp = torch.arange(1, n + 1, device=self.device, dtype=torch.float32)
-        buf = (ramp * float(self.rank + 1)).contiguous()
-        self.allreduce(buf)
-        torch.cuda.synchronize(self.device)
-        expected = ramp * float(self.world * (self.world + 1) // 2)
-        return self.status() == 0 and bool(torch.equal(buf, expected))
+        ok = True
+        for k in range(int(calls)):
+            buf = (ramp * float(self.rank + 1 + k)).contiguous()
+            self.allreduce(buf)
+            torch.cuda.synchronize(self.device)
+            expected = ramp * float(self.world * (self.world + 1) // 2 + k * self.world)
+            ok = ok and self.status() == 0 and bool(torch.equal(buf, expected))
+        return ok
 
     def status(self):
         """0, or the sequence number of the last call that gave up waiting for a peer (synchronises with the device)"""

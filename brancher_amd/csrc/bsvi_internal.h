@@ -64,6 +64,7 @@ int compile(const std::string& src, std::vector<char>& code, std::string& log);
 int obtain(const std::string& src, std::vector<char>& code, std::string& log, int* origin);
 int last_origin();
 std::string cache_directory();
+std::string compiler_identity();
 // bytes of workspace a launch over n_local samples needs behind the interpreter's region
 size_t workspace_bytes(const Spec* s, uint32_t n_local);
 // true when a launch in `mode` over n_local samples is served by the specialised kernel

@@ -2307,6 +2307,12 @@ extern "C" size_t bsvi_jit_cache_dir(char* buf, size_t capacity) {
     return dir.size() + 1;
 }
 
+extern "C" size_t bsvi_jit_compiler_identity(char* buf, size_t capacity) {
+    const std::string id = bsvi_spec::compiler_identity();
+    if (buf && capacity > id.size()) memcpy(buf, id.c_str(), id.size() + 1);
+    return id.size() + 1;
+}
+
 extern "C" int bsvi_program_engine(const bsvi_program* p, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads,
                                    uint32_t* lds_bytes) {
     if (!p) return 0;

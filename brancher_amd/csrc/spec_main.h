@@ -444,13 +444,16 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     const uint32_t n_global = SPEC_A->n_global;
     const uint32_t pretraining = SPEC_A->pretraining_iterations;
     // several workgroups in loop mode (the many-workgroup geometry only: the one-workgroup kernels are never launched with
-    // more, and the extra live scalars cost BASELINE config 1's kernel 30 more spilled scalar registers): the generation number
-    // the launch starts from (read before anybody can advance it: workgroup 0 releases the first one only after every
-    // workgroup has published its first row)
+    // more, and the extra live scalars cost BASELINE config 1's kernel 30 more spilled scalar registers).  The arrival ticket
+    // and the generation number of the launch are ZERO when it starts (the host clears both words on the launch's stream,
+    // specialize.cpp): iteration `it` is released as generation it + 1, and SPEC_GEN_OVER says "this launch is over" — a
+    // workgroup that only becomes resident after workgroup 0 gave up on it leaves without touching the ticket.
 #if SPEC_ACCUMULATE_CHUNKS
 #define SPEC_LOOP_MANY 1
-    unsigned int gen0 = 0;
-    if (G > 1 && mode == SPEC_MODE_LOOP) gen0 = __hip_atomic_load(SPEC_A->ticket + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define SPEC_GEN_OVER 0x7fff0000u
+    const unsigned int gen0 = 0;
+    if (G > 1 && mode == SPEC_MODE_LOOP && blockIdx.x != 0 &&
+        __hip_atomic_load(SPEC_A->ticket + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= SPEC_GEN_OVER) return;
 #else
 #define SPEC_LOOP_MANY 0
 #endif
@@ -618,12 +621,18 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                     if (tid == 0) {
                         __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long t0 = wall_clock64();
-                        while ((int)(__hip_atomic_load(gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                            if (wall_clock64() - t0 > 400000000ull) break;          // 4 s of the 100 MHz clock
+                        unsigned int seen;
+                        bool over = false;
+                        while ((int)((seen = __hip_atomic_load(gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) - target) < 0) {
+                            if (wall_clock64() - t0 > 400000000ull) { over = true; break; }      // 4 s of the 100 MHz clock
                             __builtin_amdgcn_s_sleep(2);
                         }
+                        // (workgroup 0 gave up on a workgroup and ended the launch, or this one waited in vain: leave — going on
+                        //  would mean K more waits of four seconds)
+                        RED[3] = (over || seen >= SPEC_GEN_OVER) ? 1.0f : 0.0f;
                     }
                     __syncthreads();
+                    if (RED[3] != 0.0f) return;
                     if (it + 1u == n_it) return;
                     float* const params = SPEC_A->params;
                     for (uint32_t i = tid; i < SPEC_N_PARAMS; i += nthreads)
@@ -647,6 +656,28 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
                     RED[3] = late ? 1.0f : 0.0f;
                 }
                 __syncthreads();
+                if (RED[3] != 0.0f) {
+                    // A workgroup never arrived (not resident: a shared GPU, a CU mask, another stream's kernels).  The launch ends
+                    // HERE: this and every remaining iteration get a NaN loss and no step (the parameters in memory are those of
+                    // the last good iteration), the output block says so, and the generation number is set to "over" so that
+                    // every waiting workgroup — and any that starts later — leaves at once.  (Round 4 went on to the next
+                    // iteration and waited four seconds again: a K-iteration call took K x 4 s to fail.)
+                    SPEC_RELOAD_ARGS();
+                    float* const loss_slot = SPEC_A->loss_slot;
+                    float* const finite_slot = SPEC_A->finite_slot;
+                    float* const out = SPEC_A->out;
+                    const float nanv = __int_as_float(0x7fc00000);
+                    for (uint32_t k = it + tid; k < n_it; k += nthreads) {
+                        if (loss_slot) loss_slot[k] = nanv;
+                        if (finite_slot) finite_slot[k] = 0.0f;
+                    }
+                    if (tid == 0) {
+                        out[0] = nanv; out[1] = 1.0f; out[2] = nanv; out[3] = 0.0f;
+                        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(gen, SPEC_GEN_OVER, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return;
+                }
             } else
 #endif
             {
@@ -692,9 +723,6 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
             }
             if (tid == 0) {
                 __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if SPEC_LOOP_MANY
-                if (mode == SPEC_MODE_LOOP && RED[3] != 0.0f) RED[8] = __int_as_float(0x7fc00000);      // a workgroup never arrived: no step
-#endif
             }
             __syncthreads();
             rows = 1;

@@ -17,8 +17,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <link.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
@@ -601,6 +603,7 @@ struct Variant {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     bool failed = false;
+    int per_cu = 0;          // workgroups of this code object a CU holds (occupancy query, once)
 };
 
 // two launch geometries, each with its own compiled kernels (the transpose-tile size is part of the generated body):
@@ -870,6 +873,48 @@ static bool trusted(const std::string& dir) {
     return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
+// WHICH compiler will run.  hiprtc hands the translation unit to libamd_comgr (clang + lld inside), and which libamd_comgr a
+// process has is not a property of the hiprtc it calls: a Python host that imported torch first runs the ROCm libraries bundled
+// with the torch wheel (roc-7.0.2 here: clang 20), the same host under rocprofv3 — whose tool library brings the system's
+// libamd_comgr.so.3 in first — runs /opt/rocm's (roc-7.2.0: clang 22), and the two produce different code for the same source
+// and options (BASELINE config 1's loop kernel: 4 938 against 5 283 instructions, 40 against 62 spilled scalar registers;
+// profiles/r5/jit_cache_root_cause.txt).  Round 4's key hashed hiprtcVersion / hipRuntimeGetVersion only, so code objects stored
+// by profiled runs were served to unprofiled processes, which then compared them bit for bit with variants they compiled
+// themselves: the one-ulp failures of the suite after tools/r4/profile_r4.sh.  The key now carries the identity of every loaded
+// module that can take part in a compilation — path, size and modification time of each libamd_comgr / libhiprtc /
+// libLLVM / libclang in load order (the order decides which definition a symbol binds to).  When no libamd_comgr is loaded yet
+// (a host whose hiprtc opens it lazily), it is opened here by the name hiprtc uses, so that the identity is the one of the
+// library the first compilation will run.
+static int identity_cb(struct dl_phdr_info* info, size_t, void* data) {
+    const char* name = info->dlpi_name;
+    if (!name || !*name) return 0;
+    const char* base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    const char* const parts[] = {"libamd_comgr", "libhiprtc", "libLLVM", "libclang-cpp", "libclang.so"};
+    bool is_part = false;
+    for (const char* p : parts) is_part = is_part || strncmp(base, p, strlen(p)) == 0;
+    if (!is_part) return 0;
+    struct stat st;
+    std::string& id = *(std::string*)data;
+    id += name;
+    if (stat(name, &st) == 0) id += fmt(":%lld:%lld", (long long)st.st_size, (long long)st.st_mtime);
+    id += ";";
+    return 0;
+}
+std::string compiler_identity() {
+    static const std::string id = [] {
+        std::string s;
+        dl_iterate_phdr(identity_cb, &s);
+        if (s.find("amd_comgr") == std::string::npos) {
+            (void)dlopen("libamd_comgr.so.3", RTLD_LAZY | RTLD_GLOBAL);      // (kept: hiprtc finds it loaded)
+            s.clear();
+            dl_iterate_phdr(identity_cb, &s);
+        }
+        return s;
+    }();
+    return id;
+}
+
 static std::string key_of(const std::string& src) {
     static const Hash128 base = [] {        // everything but the generated source: the same for every program of a process
         Hash128 h;
@@ -879,6 +924,7 @@ static std::string key_of(const std::string& src) {
         (void)hiprtcVersion(&major, &minor);
         (void)hipRuntimeGetVersion(&runtime);
         feed(h, fmt("hiprtc %d.%d runtime %d abi %d", major, minor, runtime, BSVI_ABI_VERSION));
+        feed(h, compiler_identity());
         return h;
     }();
     Hash128 h = base;
@@ -966,6 +1012,7 @@ int obtain(const std::string& text, std::vector<char>& code, std::string& log, i
 
 int last_origin() { return t_last_source; }
 std::string cache_directory() { return disk_cache::enabled() ? disk_cache::directory() : std::string(); }
+std::string compiler_identity() { return disk_cache::compiler_identity(); }
 
 static int ensure_compiled(Spec* s, int v) {
     Variant& V = s->variant[v];
@@ -1089,6 +1136,26 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
     A.xchg = (const bsvi::SpecExchange*)L.xchg;
     A.n_iterations = L.n_iterations; A.pretraining_iterations = L.pretraining_iterations; A.n_params = s->n_params;
     if (L.cfg) A.cfg = *L.cfg;
+    if (g.blocks > 1) {
+        // every workgroup of the in-kernel loop over several workgroups must be resident (workgroup 0 waits for the others in every
+        // iteration): never more than the occupancy of THIS code object allows — fewer workgroups walk more chunks each
+        int per_cu = s->variant[v].per_cu;
+        if (!per_cu) {
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s->variant[v].fn, (int)g.threads, 0) != hipSuccess || per_cu <= 0) {
+                (void)hipGetLastError();
+                per_cu = -1;                 // (no answer: geo()'s register / LDS estimate stands)
+            }
+            s->variant[v].per_cu = per_cu;
+        }
+        if (per_cu > 0 && g.blocks > (uint32_t)per_cu * s->n_cus) g.blocks = (uint32_t)per_cu * s->n_cus;
+        if (L.mode == MODE_LOOP) {
+            // the launch's arrival ticket and generation number start from zero (spec_main.h): a launch that gave up on a workgroup
+            // leaves the generation at "over", and a straggler may have touched the ticket after workgroup 0 cleared it
+            hipError_t me = hipMemsetAsync(A.ticket, 0, 4, (hipStream_t)a->stream);
+            if (me == hipSuccess) me = hipMemsetAsync(A.ticket + 64, 0, 4, (hipStream_t)a->stream);
+            if (me != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("hipMemsetAsync (loop ticket): ") + hipGetErrorString(me));
+        }
+    }
     size_t size = sizeof A;
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     const hipError_t e = hipModuleLaunchKernel(s->variant[v].fn, g.blocks, 1, 1, g.threads, 1, 1, 0, (hipStream_t)a->stream, nullptr, config);

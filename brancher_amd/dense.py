@@ -326,7 +326,7 @@ class CompiledDense:
         args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, offset, noise_o, idx_o, fvals, logq_out=logq)
         native.check(self.lib.bsvi_dense_fwd_bwd(self.handle, C.byref(args)))
         engine.allreduce_sums(self.out)
-        engine.check_exchange(self.device)
+        engine.check_exchange(self.device, self.params)
         native.check(self.lib.bsvi_dense_finalize(self.handle, C.c_void_p(self.out.data_ptr()), number_samples, self._stream()))
         self.grads_valid = True
         res = dict(loss=self.out[2], finite=self.out[3], nonfinite_count=self.out[1],
@@ -356,7 +356,7 @@ class CompiledDense:
         args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, int(offset), f_weight=a, q_weight=b)
         native.check(self.lib.bsvi_dense_fwd_bwd(self.handle, C.byref(args)))
         engine.allreduce_sums(self.out)
-        engine.check_exchange(self.device)
+        engine.check_exchange(self.device, self.params)
         native.check(self.lib.bsvi_dense_finalize(self.handle, C.c_void_p(self.out.data_ptr()), 1, self._stream()))
         self.grads_valid = True
         return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
@@ -402,7 +402,7 @@ class CompiledDense:
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         if world > 1:
-            engine.check_exchange(self.device)         # (an abandoned exchange poisoned a step: say so, loudly)
+            engine.check_exchange(self.device, self.params)         # (an abandoned exchange poisoned a step: say so, loudly)
         return loss_curve[:K], finite[:K]
 
 

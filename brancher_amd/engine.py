@@ -56,6 +56,14 @@ def shard(n_global, rank, world):
 _exchanges = {}          # device index -> collective.Exchange, or False: decided (by all ranks together) that RCCL serves
 
 
+def collective_kind():
+    """BSVI_COLLECTIVE, default `torch`: torch.distributed's all-reduce (RCCL over xGMI under the "nccl" backend).  The library's
+    own one-shot exchange (`auto` / `exchange`) is OPT-IN: it has never run between two physical GPUs (every two-rank test
+    shares one GPU), its device-side wait is bounded, and an abandoned call is an error (`check_exchange`) where RCCL would
+    simply have waited for a rank that was writing a checkpoint or compiling a program."""
+    return os.environ.get("BSVI_COLLECTIVE", "torch")
+
+
 def _exchange_for(out):
     """The one-shot exchange of this device for a message of out.numel() floats, or None.  Decided ONCE per device and message
     capacity, by all ranks together and outside any stream capture: every rank creates its region and maps its peers'
@@ -99,7 +107,7 @@ def loop_exchange(out):
     `allreduce_sums` uses between launches — decided once, by all ranks together — or, for ONE rank walking the sharded path
     (`_force_sharded_path` with BSVI_LOOP_EXCHANGE=force: tests), an exchange of its own.  BSVI_LOOP_EXCHANGE=0 keeps the
     launch-per-step sequence."""
-    if os.environ.get("BSVI_LOOP_EXCHANGE", "1") == "0" or os.environ.get("BSVI_COLLECTIVE", "auto") not in ("auto", "exchange"):
+    if os.environ.get("BSVI_LOOP_EXCHANGE", "1") == "0" or collective_kind() not in ("auto", "exchange"):
         return None
     if not out.is_cuda or out.numel() > 16384:
         return None
@@ -124,16 +132,16 @@ def allreduce_sums(out):
     """The ONE collective of the multi-GPU path: sum the per-rank output blocks
     [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.
 
-    BSVI_COLLECTIVE=auto (the default): device messages of up to 16384 floats — every message of the scalar and dense paths,
-    188 bytes at BASELINE config 1 — go through the library's one-shot direct-write all-reduce over IPC-mapped peer regions
-    (`bsvi_exchange_*`: one one-workgroup kernel, no ring; DESIGN.md 6 puts the RCCL ring at 2-3 times its latency for these
-    sizes) when `_exchange_for` found it usable; everything else through torch.distributed's all-reduce (RCCL over xGMI when
-    the backend is "nccl"; gloo in the CPU tests).  BSVI_COLLECTIVE=torch forces that; BSVI_COLLECTIVE=rccl is the same RCCL
-    call through the C ABI (`bsvi_allreduce` on torch's communicator); BSVI_COLLECTIVE=exchange is `auto` spelled out."""
+    BSVI_COLLECTIVE=torch (the default): torch.distributed's all-reduce (RCCL over xGMI when the backend is "nccl"; gloo in the
+    CPU tests).  BSVI_COLLECTIVE=rccl is the same RCCL call through the C ABI (`bsvi_allreduce` on torch's communicator).
+    BSVI_COLLECTIVE=auto / exchange (opt-in, see `collective_kind`): device messages of up to 16384 floats — every message of
+    the scalar and dense paths, 188 bytes at BASELINE config 1 — go through the library's one-shot direct-write all-reduce over
+    IPC-mapped peer regions (`bsvi_exchange_*`: one one-workgroup kernel, no ring) when `_exchange_for` found it usable,
+    everything else through torch.distributed."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return out
-    kind = os.environ.get("BSVI_COLLECTIVE", "auto")
+    kind = collective_kind()
     if kind in ("auto", "exchange") and out.is_cuda and out.numel() <= 16384 and out.dtype == torch.float32:
         ex = _exchange_for(out)
         if ex is not None:
@@ -148,17 +156,30 @@ def allreduce_sums(out):
     return out
 
 
-def check_exchange(device):
+def check_exchange(device, params=None):
     """At the end of every public evaluation / training call of the three engines when ranks exchanged through the one-shot
-    exchange: did every call meet its peers?  An abandoned call poisons the sums (NaN loss, the optimizer step is skipped on
-    every rank — csrc/collective.hip), so nothing diverges silently; this turns it into the error it is."""
+    exchange: did every call meet its peers?  An abandoned call leaves NaN in the loss sum so that the optimizer step is
+    skipped — but not provably on EVERY rank: a peer that had already collected all flags when the abort word was raised
+    completes that call with valid totals and steps (csrc/collective.hip: one relaxed read of the abort word), so the
+    replicas can be one optimizer step apart afterwards.  Hence: the ranks agree on the outcome with one torch.distributed
+    all-reduce (every rank reaches this point: it is the end of a public call), and when any of them gave up, every rank
+    takes rank 0's parameters again before every rank raises."""
     ex = _exchanges.get(device.index if hasattr(device, "index") else device)
-    if ex:
-        gave_up = ex.status()
-        if gave_up:
-            raise native.NativeError("the one-shot exchange was abandoned at its call {} (a peer did not arrive within "
-                                     "BSVI_EXCHANGE_TIMEOUT_MS, or raised the abort word); that call's sums are NaN and its "
-                                     "optimizer step was skipped on every rank".format(gave_up))
+    if not ex:
+        return
+    gave_up = ex.status()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flag = torch.tensor([float(gave_up)], device=ex.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        gave_up = int(flag.item())
+        if gave_up and params is not None:
+            broadcast_from_rank0(params)
+    if gave_up:
+        raise native.NativeError("the one-shot exchange was abandoned at its call {} on some rank (a peer did not arrive within "
+                                 "BSVI_EXCHANGE_TIMEOUT_MS, or raised the abort word); that call's sums are NaN where it was "
+                                 "abandoned, the replicas may be one optimizer step apart — the parameters were taken from rank 0 "
+                                 "again".format(gave_up))
 
 
 def estimator_name(gradient_estimator):
@@ -471,7 +492,7 @@ class CompiledELBO:
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
-        check_exchange(self.device)
+        check_exchange(self.device, self.params)
         native.check(self.lib.bsvi_finalize(self.native.handle, C.c_void_p(self.out.data_ptr()), number_samples,
                                             self._stream()))
         self.grads_valid = True
@@ -504,7 +525,7 @@ class CompiledELBO:
         args.f_weight_dev, args.q_weight_dev = a.data_ptr(), b.data_ptr()
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
-        check_exchange(self.device)
+        check_exchange(self.device, self.params)
         native.check(self.lib.bsvi_finalize(self.native.handle, C.c_void_p(self.out.data_ptr()), 1, self._stream()))
         self.grads_valid = True
         return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
@@ -746,7 +767,7 @@ class CompiledELBO:
             if xplan and ex is not None:
                 native.check(xcall(K))
                 self.last_mode = "persistent+exchange"
-                check_exchange(dev)
+                check_exchange(dev, self.params)
                 return loss_curve, finite
         if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0" and not self._externals:
             # multi-GPU: the step sequence is captured once in a HIP graph and replayed — no Python between the launches
@@ -754,7 +775,7 @@ class CompiledELBO:
                 self._train_graph(K, n_local, number_samples, base, cfg, state, loss_curve, finite, seed, offset0,
                                   int(pretraining_iterations))
                 self.last_mode = "graph" if world == 1 else "graph+allreduce"
-                check_exchange(dev)
+                check_exchange(dev, self.params)
                 return loss_curve, finite
             except (RuntimeError, native.NativeError) as err:      # capture refused: launch by launch below
                 warnings.warn("HIP-graph capture of the sharded step failed ({}); stepping eagerly".format(err))
@@ -777,7 +798,7 @@ class CompiledELBO:
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
         self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
         if world > 1:
-            check_exchange(dev)
+            check_exchange(dev, self.params)
         return loss_curve, finite
 
 

@@ -133,6 +133,7 @@ EXPORTS = {
     "bsvi_jit_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "bsvi_jit_last_origin": (C.c_int, []),
     "bsvi_jit_cache_dir": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "bsvi_jit_compiler_identity": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "bsvi_program_engine": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32)]),
     "bsvi_max_lds_bytes": (C.c_int, [C.c_void_p]),
@@ -393,6 +394,15 @@ def jit_cache_dir():
     need = lib.bsvi_jit_cache_dir(None, 0)
     buf = C.create_string_buffer(need)
     lib.bsvi_jit_cache_dir(buf, need)
+    return buf.value.decode()
+
+
+def jit_compiler_identity():
+    """what the code-object cache's key holds about the compiler that will run (bsvi_jit_compiler_identity)"""
+    lib = load()
+    need = lib.bsvi_jit_compiler_identity(None, 0)
+    buf = C.create_string_buffer(need)
+    lib.bsvi_jit_compiler_identity(buf, need)
     return buf.value.decode()
 
 

@@ -403,6 +403,9 @@ int bsvi_svi_step(const bsvi_program* prog, const bsvi_elbo_args* args, const bs
  *   *origin: 1 hiprtc, 2 process cache, 3 disk cache.  Needs no device.
  * bsvi_jit_last_origin: the same code for the last specialised kernel this thread made ready (0: none yet).
  * bsvi_jit_cache_dir: the cache directory (byte count including the terminator; 1 = "", the disk cache is off).
+ * bsvi_jit_compiler_identity: what the key holds about WHICH compiler will run — path, size and modification time of every
+ *   loaded libamd_comgr / libhiprtc / libLLVM / libclang, in load order (a host that imported torch first compiles with the
+ *   ROCm libraries bundled with torch, the same host under rocprofv3 with the system's: different code for the same source).
  * bsvi_program_engine: 1 when a call in `mode` (0 bsvi_elbo_fwd_bwd, 1 bsvi_svi_step, 2 bsvi_train_persistent*) over
  *   n_local samples is served by the specialised kernel (and its launch geometry), 0 when by the interpreter. */
 size_t bsvi_program_source(const bsvi_program_desc* desc, int variant, char* buf, size_t capacity);
@@ -410,6 +413,7 @@ int bsvi_jit_compile(const char* source, size_t* code_bytes);
 int bsvi_jit_load(const char* source, size_t* code_bytes, int* origin);
 int bsvi_jit_last_origin(void);
 size_t bsvi_jit_cache_dir(char* buf, size_t capacity);
+size_t bsvi_jit_compiler_identity(char* buf, size_t capacity);
 int bsvi_program_engine(const bsvi_program* prog, uint32_t n_local, int mode, uint32_t* n_blocks, uint32_t* n_threads,
                         uint32_t* lds_bytes);
 

@@ -106,7 +106,7 @@ def test_two_ranks_walk_the_single_process_trajectory(workload, n_samples, optim
      "stepwise+allreduce"),
 ])
 def test_two_ranks_over_the_one_shot_exchange(workload, n_samples, optimizer, opt_kw, mode):
-    """the same trajectories with the DEFAULT collective (BSVI_COLLECTIVE=auto): the library's own exchange (bsvi_exchange_*:
+    """the same trajectories with the opt-in collective BSVI_COLLECTIVE=auto (the default is torch.distributed since round 5): the library's own exchange (bsvi_exchange_*:
     the ranks map each other's regions through HIP IPC, a self-test all-reduce and a vote decide once that it serves) in place
     of the host-staged all-reduce, on all three engines.  On the scalar path the whole loop is ONE launch per rank with the
     exchange inside the kernel's iteration (bsvi_train_persistent_exchange; "persistent+exchange"); with BSVI_LOOP_EXCHANGE=0
@@ -140,7 +140,7 @@ def test_two_ranks_over_the_one_shot_exchange(workload, n_samples, optimizer, op
 
 def _abandon_worker(rank, world, port, out_q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BSVI_EXCHANGE_TIMEOUT_MS="300")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BSVI_EXCHANGE_TIMEOUT_MS="300", BSVI_COLLECTIVE="auto")
     import time
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -198,24 +198,30 @@ def test_an_abandoned_exchange_poisons_the_sums_on_every_rank():
         assert np.isnan(again[0]) and np.isnan(again[1])
 
 
-def test_bench_with_two_ranks_dry_run():
+@pytest.mark.parametrize("extra, samples", [
+    ([], 300),                                                                  # BASELINE config 1 (the headline), scalar path
+    (["--workload", "cfg4", "--samples", "64", "--dataset-size", "4096", "--other-configs", "off"], 64),      # dense-link path
+    (["--workload", "cfg5", "--samples", "8", "--other-configs", "off"], 8),                                   # amortised path
+])
+def test_bench_with_two_ranks_dry_run(extra, samples):
     """`python bench.py --gpus 2` end to end — self-launch, rendezvous, sharded steps, barrier + max-over-ranks timing, ONE
     JSON line from rank 0 — with the two ranks sharing the box's GPU and gloo collectives (a dry run of the flow the driver
-    runs on an 8-GPU node with RCCL; not a measurement)."""
+    runs on an 8-GPU node with RCCL; not a measurement), for all three engines.  The line says which all-reduce the ranks took."""
     import json
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "BSVI_COLLECTIVE")}
     env.update(BSVI_BENCH_BACKEND="gloo", BSVI_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5",
-                          "--spinup-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
+                          "--spinup-ms", "0"] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     line = lines[0]
     assert line["n_gpus"] == 2 and line["steps"] == 40 and line["scaling"] == "weak" and line["all_finite"]
-    assert line["config"]["number_samples_global"] == 2 * line["config"]["number_samples_per_gpu"] == 600
-    # (the one-shot exchange serves here: the whole loop of a step call is one launch per rank with the exchange inside)
-    assert ("allreduce" in line["config"]["mode"] or line["config"]["mode"] == "persistent+exchange") and line["value"] > 0
+    assert line["config"]["number_samples_global"] == 2 * line["config"]["number_samples_per_gpu"] == 2 * samples
+    # (the default collective is torch.distributed's all-reduce — gloo here, RCCL on the driver's node — and the line says so)
+    assert "allreduce" in line["config"]["mode"] and line["value"] > 0
+    assert line["config"]["collective"].startswith("torch.distributed all_reduce")
     assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
 
 
@@ -226,7 +232,7 @@ def test_bench_falls_back_to_the_host_collective_when_the_exchange_fails_in_use(
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(BSVI_BENCH_BACKEND="gloo", BSVI_BENCH_SHARE_GPU="1", BSVI_BENCH_INJECT_EXCHANGE_FAILURE="1")
+    env.update(BSVI_BENCH_BACKEND="gloo", BSVI_BENCH_SHARE_GPU="1", BSVI_COLLECTIVE="auto", BSVI_TEST_HOOKS="1", BSVI_BENCH_INJECT_EXCHANGE_FAILURE="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
                           "--spinup-ms", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -242,6 +248,7 @@ def test_loop_exchange_on_one_rank_is_the_in_kernel_loop_bit_for_bit(monkeypatch
     sys.path.insert(0, ROOT)
     from brancher_amd import engine, workloads as W
     monkeypatch.setenv("BSVI_LOOP_EXCHANGE", "force")
+    monkeypatch.setenv("BSVI_COLLECTIVE", "exchange")       # (opt-in since round 5: the default collective is torch.distributed)
     for n_samples, T in ((300, 20), (128, 20), (200, 40)):      # (T = 40: 83 parameters, exchanged per thread instead of by the owners' wave)
         for optimizer, kw in (("SGD", dict(lr=1e-3)), ("Adam", dict(lr=2e-3))):
             ref = engine.compile_model(W.build_readme_ar(W.native_api(), T=T), None, "pathwise")

@@ -177,3 +177,66 @@ def test_code_object_cache_on_disk(tmp_path):
     # switched off: no directory, no file read
     off = run(BSVI_JIT_CACHE="0")
     assert off["origin"] == "hiprtc" and off["dir"] == ""
+
+
+def _jit_child(script_body, env):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import hashlib, json, os, sys\nsys.path.insert(0, %r)\n"
+              "from brancher_amd import lowering, native, workloads as W\napi = W.native_api()\n" % root) + script_body
+    out = subprocess.run([sys.executable, "-c", script], check=True, capture_output=True, text=True, env=dict(os.environ, **env)).stdout
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def test_a_code_object_is_a_function_of_what_the_cache_key_hashes(tmp_path):
+    """VERDICT r4 item 6.  The same generated translation unit compiled as the FIRST compilation of a process and after a dozen
+    other programs of the same process (one of them with the per-program -fno-slp-vectorize option) gives byte-identical code
+    objects: hiprtc keeps no state between compilations that reaches the code.  (tools/r5/jit_determinism.py runs the long form.)"""
+    body = (
+        "def srcs(b, e, **kw):\n"
+        "    m = getattr(W, b)(api, **kw)\n"
+        "    p = lowering.lower(m, m.posterior_model, e)\n"
+        "    return [native.specialised_source(p, v) for v in range(2)]\n"
+        "if os.environ['N_OTHER'] != '0':\n"
+        "    for b, e, kw in [('build_readme_ar', 'pathwise', dict(T=3)), ('build_readme_ar', 'blackbox', dict(T=4)),\n"
+        "                     ('build_beta_binomial', 'pathwise', {}), ('build_lognormal_normal', 'blackbox', {})]:\n"
+        "        for s in srcs(b, e, **kw):\n"
+        "            native.jit_compile(('// bsvi-jit-option: -fno-slp-vectorize\\n' if e == 'blackbox' else '') + s)\n"
+        "res = {}\n"
+        "for v, s in enumerate(srcs('build_readme_ar', 'pathwise', T=20)):\n"
+        "    os.environ['BSVI_JIT_DUMP'] = os.path.join(os.environ['OUT'], 'v%d.co' % v)\n"
+        "    native.jit_compile(s)\n"
+        "    res[str(v)] = hashlib.sha256(open(os.environ['BSVI_JIT_DUMP'], 'rb').read()).hexdigest()\n"
+        "print(json.dumps(res))\n")
+    first = _jit_child(body, dict(N_OTHER="0", OUT=str(tmp_path), BSVI_JIT_CACHE="0"))
+    late = _jit_child(body, dict(N_OTHER="8", OUT=str(tmp_path), BSVI_JIT_CACHE="0"))
+    assert first == late
+
+
+def test_the_cache_key_carries_the_identity_of_the_compiler(tmp_path):
+    """The root cause of round 4's one-ulp failures (profiles/r5/jit_cache_root_cause.txt): which libamd_comgr — i.e. which clang —
+    compiles a translation unit depends on what the process loaded first (the ROCm libraries bundled with torch, or the system's
+    when rocprofv3 or LD_PRELOAD brings them in), the two compilers produce different code for the same source, and the key did
+    not say which one had run.  Now a process with another compiler misses the entries of the first, stores its own, and each
+    context is served its own code afterwards."""
+    import os
+    system_comgr = "/opt/rocm/lib/libamd_comgr.so.3"
+    if not os.path.exists(system_comgr):
+        pytest.skip("no system libamd_comgr to bring in")
+    body = (
+        "m = W.build_readme_ar(api, T=5)\n"
+        "src = native.specialised_source(lowering.lower(m, m.posterior_model, 'pathwise'), 0)\n"
+        "n, origin = native.jit_load(src)\n"
+        "print(json.dumps(dict(origin=origin, n=n, identity=native.jit_compiler_identity())))\n")
+    env = dict(BSVI_CACHE_DIR=str(tmp_path))
+    preload = dict(env, LD_PRELOAD=":".join([system_comgr] + [p for p in os.environ.get("LD_PRELOAD", "").split(":") if p]))
+    a = _jit_child(body, env)
+    b = _jit_child(body, preload)
+    if a["identity"] == b["identity"]:
+        pytest.skip("the process already runs the system's compiler")
+    assert a["origin"] == "hiprtc" and b["origin"] == "hiprtc", (a, b)       # (round 4: the second would have been "disk cache")
+    assert len([f for f in os.listdir(str(tmp_path)) if f.endswith(".co")]) == 2
+    assert _jit_child(body, env)["origin"] == "disk cache" and _jit_child(body, preload)["origin"] == "disk cache"
