@@ -81,3 +81,30 @@ def vae_golden(request):
 def rel_err(a, b, floor=1e-7):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + floor))
+
+
+def yardstick_grad_check(named, exact, reference, tol=1e-5):
+    """The bound of every check that cannot hold the flat 1e-5 of BASELINE.json's north_star: the truth is the oracle in DOUBLE
+    precision on the same draws, and the kernel must be as close to it as the reference arithmetic — single precision — is
+    itself (x4), or within 1e-5 of the largest gradient:  err <= max(4 * |reference_fp32 - oracle_fp64|, 1e-5 * scale).
+    (BlackBox gradients multiply log q by f, two sums of opposite sign: the reference's own single-precision result is
+    1e-5 ... 1e-4 of the scale away from the double-precision one.  A flat 1e-4 said nothing about WHICH of the two is off.)"""
+    scale = max(np.abs(v).max() for v in exact.values() if v is not None)
+    for name, g64 in exact.items():
+        g64 = np.zeros(1) if g64 is None else g64
+        ref = np.zeros(1) if reference.get(name) is None else reference[name]
+        err, yard = np.abs(named[name] - g64).max(), np.abs(ref - g64).max()
+        assert err <= max(4 * yard, tol * scale), (name, err, yard, scale)
+
+
+def exact_oracle(g_or_model, n, estimator, noise, minibatch=None):
+    import torch as _t
+    from oracle.svi_oracle import Oracle
+    model = g_or_model.build() if isinstance(g_or_model, Golden) else g_or_model
+    return Oracle(model, dtype=_t.float64).loss_and_grads(n, estimator, noise, minibatch)
+
+
+def yardstick_loss_check(loss, exact_loss, reference_loss, tol=1e-5):
+    """the same bound for the value: err <= max(4 * |reference_fp32 - oracle_fp64|, 1e-5 * |oracle_fp64|)"""
+    err, yard = abs(loss - exact_loss), abs(reference_loss - exact_loss)
+    assert err <= max(4 * yard, tol * abs(exact_loss)), (loss, exact_loss, reference_loss)

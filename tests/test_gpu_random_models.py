@@ -64,6 +64,31 @@ def build_random_model(api, seed):
     return model
 
 
+def check_against_the_oracles(compiled, build, n, estimator, named, res):
+    """Both builds of the kernel (diagnostic: the launch that reported the draws; lean: the training build, fed the same draws)
+    against the oracle in DOUBLE precision on those draws.  Bound: as close to it as the reference arithmetic — the oracle in
+    single precision, torch's own kernels — is (x4), or within BASELINE.json's 1e-5 of the scale; never a flat relaxation
+    (BlackBox multiplies log q by f, two sums of opposite sign; Beta reparameterisation gradients carry the series error of
+    torch's dirichlet_grad in single precision: both show in the single-precision oracle as they show in the kernel)."""
+    ref = Oracle(build(), dtype=torch.float64).loss_and_grads(n, estimator, named)
+    if not np.isfinite(ref["loss"]):
+        pytest.skip("non-finite reference loss for this draw")
+    ref32 = Oracle(build()).loss_and_grads(n, estimator, named)
+    scale = max(1.0, max(np.abs(g).max() for g in ref["grads"].values() if g is not None))
+    for launch in ("diagnostic", "lean"):
+        if launch == "lean":
+            res = compiled.evaluate(n, noise=named)       # same noise through the training build of the kernel
+        loss = float(res["loss"].item())
+        assert abs(loss - ref["loss"]) <= max(4 * abs(ref32["loss"] - ref["loss"]), 1e-5 * max(1.0, abs(ref["loss"]))), \
+            (launch, estimator, loss, ref["loss"], ref32["loss"])
+        grads = compiled.named_grads()
+        for name, g in ref["grads"].items():
+            g = np.zeros_like(grads[name]) if g is None else np.asarray(g).reshape(grads[name].shape)
+            g32 = ref32["grads"].get(name)
+            g32 = np.zeros_like(grads[name]) if g32 is None else np.asarray(g32).reshape(grads[name].shape)
+            assert np.abs(grads[name] - g).max() <= max(4 * np.abs(g32 - g).max(), 1e-5 * scale), (launch, estimator, name)
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_model_matches_oracle(seed):
     api = W.native_api()
@@ -80,20 +105,7 @@ def test_random_model_matches_oracle(seed):
         noise = res["noise"].cpu().numpy()
         named = {name: noise[s.base:s.base + s.size].T.reshape((n,) + tuple(s.shape))
                  for name, s in compiled.program.slot_by_name.items()}
-        ref = Oracle(build_random_model(api, seed), dtype=torch.float64).loss_and_grads(n, estimator, named)
-        if not np.isfinite(ref["loss"]):
-            pytest.skip("non-finite reference loss for this draw")
-        tol = 2e-5 if estimator == "pathwise" else 2e-4
-        scale = max(1.0, max(np.abs(g).max() for g in ref["grads"].values() if g is not None))
-        for launch in ("diagnostic", "lean"):
-            if launch == "lean":
-                res = compiled.evaluate(n, noise=named)       # same noise through the training build of the kernel
-            loss = float(res["loss"].item())
-            assert abs(loss - ref["loss"]) <= tol * max(1.0, abs(ref["loss"])), (launch, estimator, loss, ref["loss"])
-            grads = compiled.named_grads()
-            for name, g in ref["grads"].items():
-                g = np.zeros_like(grads[name]) if g is None else g
-                assert np.abs(grads[name] - g).max() <= tol * scale, (launch, estimator, name)
+        check_against_the_oracles(compiled, lambda: build_random_model(api, seed), n, estimator, named, res)
 
 
 def build_random_generic_model(api, seed):
@@ -143,18 +155,7 @@ def test_random_generic_model_matches_oracle(seed):
     noise = res["noise"].cpu().numpy()
     named = {name: noise[s.base:s.base + s.size].T.reshape((n,) + tuple(s.shape))
              for name, s in compiled.program.slot_by_name.items()}
-    ref = Oracle(build_random_generic_model(api, seed), dtype=torch.float64).loss_and_grads(n, "pathwise", named)
-    scale = max(1.0, max(np.abs(g).max() for g in ref["grads"].values() if g is not None))
-    for launch in ("diagnostic", "lean"):
-        if launch == "lean":
-            res = compiled.evaluate(n, noise=named)
-        loss = float(res["loss"].item())
-        assert abs(loss - ref["loss"]) <= 3e-5 * max(1.0, abs(ref["loss"])), (launch, loss, ref["loss"])
-        grads = compiled.named_grads()
-        for name, g in ref["grads"].items():
-            g = np.zeros_like(grads[name]) if g is None else g
-            # Beta reparameterisation gradients (dirichlet_grad) carry fp32 series error of ~1e-4 of the largest entry
-            assert np.abs(grads[name] - g).max() <= 3e-4 * scale, (launch, name, grads[name], g)
+    check_against_the_oracles(compiled, lambda: build_random_generic_model(api, seed), n, "pathwise", named, res)
 
 
 def build_random_vector_model(api, seed):
@@ -193,18 +194,7 @@ def test_random_vector_model_matches_oracle(seed):
         noise = res["noise"].cpu().numpy()
         named = {name: noise[s.base:s.base + s.size].T.reshape((n,) + tuple(s.shape))
                  for name, s in compiled.program.slot_by_name.items()}
-        ref = Oracle(build_random_vector_model(api, seed), dtype=torch.float64).loss_and_grads(n, estimator, named)
-        tol = 2e-5 if estimator == "pathwise" else 3e-4
-        scale = max(1.0, max(np.abs(g).max() for g in ref["grads"].values() if g is not None))
-        for launch in ("diagnostic", "lean"):
-            if launch == "lean":
-                res = compiled.evaluate(n, noise=named)
-            loss = float(res["loss"].item())
-            assert abs(loss - ref["loss"]) <= tol * max(1.0, abs(ref["loss"])), (launch, estimator, loss, ref["loss"])
-            grads = compiled.named_grads()
-            for name, g in ref["grads"].items():
-                g = np.zeros_like(grads[name]) if g is None else g
-                assert np.abs(grads[name] - np.asarray(g).reshape(grads[name].shape)).max() <= tol * scale, (launch, estimator, name)
+        check_against_the_oracles(compiled, lambda: build_random_vector_model(api, seed), n, estimator, named, res)
 
 
 def build_random_view_model(api, seed):
@@ -262,18 +252,7 @@ def test_random_view_model_matches_oracle(seed):
         noise = res["noise"].cpu().numpy()
         named = {name: noise[s.base:s.base + s.size].T.reshape((n,) + tuple(s.shape))
                  for name, s in compiled.program.slot_by_name.items()}
-        ref = Oracle(build_random_view_model(api, seed), dtype=torch.float64).loss_and_grads(n, estimator, named)
-        tol = 2e-5 if estimator == "pathwise" else 3e-4
-        scale = max(1.0, max(np.abs(g).max() for g in ref["grads"].values() if g is not None))
-        for launch in ("diagnostic", "lean"):
-            if launch == "lean":
-                res = compiled.evaluate(n, noise=named)
-            loss = float(res["loss"].item())
-            assert abs(loss - ref["loss"]) <= tol * max(1.0, abs(ref["loss"])), (launch, estimator, loss, ref["loss"])
-            grads = compiled.named_grads()
-            for name, g in ref["grads"].items():
-                g = np.zeros_like(grads[name]) if g is None else g
-                assert np.abs(grads[name] - np.asarray(g).reshape(grads[name].shape)).max() <= tol * scale, (launch, estimator, name)
+        check_against_the_oracles(compiled, lambda: build_random_view_model(api, seed), n, estimator, named, res)
 
 
 @pytest.mark.parametrize("family,seed", [(f, s) for f in ("normal", "generic", "vector", "views") for s in range(6)])

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import Golden, golden_cases, rel_err
+from conftest import Golden, golden_cases, rel_err, yardstick_grad_check, yardstick_loss_check, exact_oracle
 from brancher_amd import engine, inference, workloads as W
 from brancher_amd.optimizers import ProbabilisticOptimizer
 
@@ -54,11 +54,16 @@ def test_interpreter_matches_reference_golden(case, estimator, interpreter):
     assert c.native.engine(g.N, 0)["engine"] == "interpreter"
     res = c.evaluate(g.N, noise=g.noise)
     ref = float(g.data["loss_" + estimator])
-    # (batched multivariate-normal terms: two single-precision Cholesky factorisations at a condition number of ~1e3 agree to
-    #  ~1e-4; tests/test_gpu_parity.py measures them against the double-precision oracle)
-    batched = case in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24")
-    assert abs(float(res["loss"].item()) - ref) <= (3e-4 if batched else TOL) * abs(ref)
-    grad_check(c.named_grads(), g.group("grad_%s/" % estimator), 1e-3 if batched else (TOL if estimator == "pathwise" else 1e-4))
+    if estimator == "pathwise" and case not in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24"):
+        assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
+        grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL)
+        return
+    # BlackBox (log q times f: two sums of opposite sign) and the batched multivariate-normal terms (two single-precision
+    # Cholesky factorisations at a condition number of ~1e3 agree to ~1e-4): the yardstick of tests/test_gpu_parity.py — as
+    # close to the double-precision oracle as the reference's own single-precision record is (x4), or 1e-5 of the scale
+    exact = exact_oracle(g, g.N, estimator, g.noise, g.minibatch)
+    yardstick_loss_check(float(res["loss"].item()), exact["loss"], ref)
+    yardstick_grad_check(c.named_grads(), exact["grads"], g.group("grad_%s/" % estimator))
 
 
 @pytest.mark.parametrize("builder,kwargs,n", [
@@ -255,4 +260,7 @@ def test_logit_normal_variable_matches_the_reference_fixture():
         res = c.evaluate(g.N, noise=g.noise)
         ref = float(g.data["loss_" + estimator])
         assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
-        grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL if estimator == "pathwise" else 1e-4)
+        if estimator == "pathwise":
+            grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL)
+        else:       # (the yardstick of tests/test_gpu_parity.py: the double-precision oracle on the fixture's draws)
+            yardstick_grad_check(c.named_grads(), exact_oracle(g, g.N, estimator, g.noise)["grads"], g.group("grad_%s/" % estimator))
