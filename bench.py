@@ -465,6 +465,11 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                          "launch latency per iteration on top" % us_iter)
     if issue is not None:
         roofline["issue"] = issue
+        # (flat copies: a record that keeps only scalars of `roofline` drops the nested object)
+        roofline["issue_frac"] = issue["frac"]
+        roofline["issue_us_per_iteration"] = issue["issue_us_per_iteration"]
+        roofline["valu_per_wave_iteration"] = issue["valu_per_wave_iteration"]
+        roofline["issue_waves_on_busiest_simd"] = issue["waves_on_busiest_simd"]
     if dense:
         # the whole iteration (6 launches) is timed; the two MFMA GEMMs are >80 % of it (profiles/)
         flops = dense_flops_per_iteration(program, n_per_gpu)

@@ -2384,6 +2384,15 @@ static int launch_gemm(int mode, GemmArgs G, hipStream_t stream) {
     return BSVI_OK;
 }
 
+// the f32-input MFMA products for the other kernel families of the library (the Bayesian-neural-network path on data that is not
+// exactly bf16, bnn_kernel.inc): no bias, no activation
+int bsvi_gemm_f32(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream) {
+    if ((mode != MODE_NT && mode != MODE_NN) || !A || !B || !C) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_gemm_f32: bad arguments");
+    GemmArgs G{};
+    G.A = A; G.B = B; G.C = C; G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
+    return launch_gemm(mode, G, (hipStream_t)stream);
+}
+
 extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev, float* c_dev, const int32_t* rows_dev,
                                uint32_t m, uint32_t n, uint32_t k, uint32_t lda, uint32_t ldb, uint32_t ldc,
                                const float* bias_or_y_dev, uint32_t ldy, uint32_t activation, float post_add,

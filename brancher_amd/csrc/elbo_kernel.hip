@@ -1457,6 +1457,9 @@ extern "C" size_t bsvi_sizeof(int kind) {
     case BSVI_SK_MVN_INSN: return sizeof(bsvi_mvn_insn);
     case BSVI_SK_MVN_DESC: return sizeof(bsvi_mvn_desc);
     case BSVI_SK_MVN_ARGS: return sizeof(bsvi_mvn_args);
+    case BSVI_SK_BNN_LAYER: return sizeof(bsvi_bnn_layer);
+    case BSVI_SK_BNN_DESC: return sizeof(bsvi_bnn_desc);
+    case BSVI_SK_BNN_ARGS: return sizeof(bsvi_bnn_args);
     default: return 0;
     }
 }
@@ -2348,3 +2351,4 @@ extern "C" int bsvi_debug_math(int fn, int dist, const float* x_dev, const float
 }
 
 #include "dense_kernel.inc"
+#include "bnn_kernel.inc"

@@ -778,7 +778,8 @@ const std::string& source(const Spec* s, int variant) { return s->variant[(varia
 // ---------------------------------------------------------------------------------------------------------------
 //  hiprtc
 // ---------------------------------------------------------------------------------------------------------------
-static const char* kJitOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+// (no packed-f32 VALU instructions: see the Makefile)
+static const char* kJitOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"};
 static const int kJitOptionCount = (int)(sizeof(kJitOptions) / sizeof(kJitOptions[0]));
 
 int compile(const std::string& src, std::vector<char>& code, std::string& log) {

@@ -574,6 +574,44 @@ def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=78
     return model
 
 
+def build_bayesian_neural_network(api, dataset_size=48, batch_size=30, n_features=784, n_hidden=20, n_classes=10, seed=0,
+                                  prior_scale=10., q_scale=0.2, q_scale1=None, q_loc_scale=0.0, pixels="uint8",
+                                  activation="tanh", hidden2=0):
+    """`tests/test_MNIST_bayesian_neural_network.py:20-60` of the reference: a one-hidden-layer network whose weight matrices AND
+    biases are latent — weights1 [H, P], b1 [H, 1], weights2 [C, H], b2 [C, 1], priors N(0, 10), a mean-field Normal posterior
+    over all four (scale 0.2) — `tanh(matmul(weights1, x) + b1)`, `matmul(weights2, hidden) + b2` as the logits of an observed
+    Categorical, a random minibatch per iteration.  (The reference's file spells the likelihood `softmax_p=`, which its
+    CategoricalVariable does not accept; `logits=` is what the sibling examples use.)  MNIST is not available offline: pixel
+    counts 0..255 as in `logreg_data`.  q_scale1: the posterior scale of weights1 alone (with raw pixel counts and 0.2 every
+    tanh saturates and every gradient of the first layer vanishes: the fixtures use a scale that keeps the units alive);
+    q_loc_scale: posterior means drawn at that many posterior scales from zero; hidden2 > 0: a second hidden layer."""
+    BF = api.BF
+    X, labels = logreg_data(dataset_size, n_features, n_classes, seed, pixels)
+    rng = np.random.RandomState(seed + 7)
+    act = getattr(BF, activation)
+    indices = api.RandomIndices(dataset_size=dataset_size, batch_size=batch_size, name="indices", is_observed=True)
+    x = api.EmpiricalVariable(X, indices=indices, name="x", is_observed=True)
+    y = api.EmpiricalVariable(labels, indices=indices, name="labels", is_observed=True)
+    widths = [n_features, n_hidden] + ([hidden2] if hidden2 else []) + [n_classes]
+    layer, q_vars = x, []
+    for l in range(1, len(widths)):
+        rows, cols = widths[l], widths[l - 1]
+        b = api.NormalVariable(np.zeros((rows, 1)), prior_scale * np.ones((rows, 1)), "b%d" % l)
+        w = api.NormalVariable(np.zeros((rows, cols)), prior_scale * np.ones((rows, cols)), "weights%d" % l)
+        pre = BF.matmul(w, layer) + b
+        layer = act(pre) if l + 1 < len(widths) else pre
+        sw = q_scale1 if (l == 1 and q_scale1 is not None) else q_scale
+        q_vars.append(api.NormalVariable(q_loc_scale * q_scale * rng.normal(0., 1., (rows, 1)), q_scale * np.ones((rows, 1)),
+                                         "b%d" % l, learnable=True))
+        q_vars.append(api.NormalVariable(q_loc_scale * sw * rng.normal(0., 1., (rows, cols)), sw * np.ones((rows, cols)),
+                                         "weights%d" % l, learnable=True))
+    k = api.CategoricalVariable(logits=layer, name="k")
+    model = api.ProbabilisticModel([k])
+    k.observe(y)
+    model.set_posterior_model(api.ProbabilisticModel(q_vars))
+    return model
+
+
 def vae_modules(n_features, latent_size, hidden1, hidden2, seed=0, decoder_sd_head=False):
     """Encoder / decoder networks with the layer plan of `examples/VAE_playground.py:27-62` (there: 784-256-512-(2,2)
     and 2-512-256-784): two ReLU layers, then a mean head and a softplus(+0.1) scale head; the decoder mirrors the

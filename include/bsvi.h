@@ -51,7 +51,8 @@ extern "C" {
 typedef enum bsvi_struct_kind {
     BSVI_SK_UNIFORM_ENTRY = 0, BSVI_SK_RECORD = 1, BSVI_SK_PROGRAM_DESC = 2, BSVI_SK_ELBO_ARGS = 3, BSVI_SK_OPT_CFG = 4,
     BSVI_SK_DENSE_DESC = 5, BSVI_SK_DENSE_ARGS = 6, BSVI_SK_MLP_LAYER = 7, BSVI_SK_AMORT_DESC = 8, BSVI_SK_AMORT_ARGS = 9,
-    BSVI_SK_MVN_INSN = 10, BSVI_SK_MVN_DESC = 11, BSVI_SK_MVN_ARGS = 12, BSVI_SK_COUNT = 13
+    BSVI_SK_MVN_INSN = 10, BSVI_SK_MVN_DESC = 11, BSVI_SK_MVN_ARGS = 12, BSVI_SK_BNN_LAYER = 13, BSVI_SK_BNN_DESC = 14,
+    BSVI_SK_BNN_ARGS = 15, BSVI_SK_COUNT = 16
 } bsvi_struct_kind;
 /* sizeof(struct) inside this build of the library; 0 for an unknown kind */
 size_t bsvi_sizeof(int kind);
@@ -504,6 +505,77 @@ int bsvi_dense_finalize(const bsvi_dense* d, float* out_dev, uint32_t n_samples_
 int bsvi_dense_step(const bsvi_dense* d, const bsvi_dense_args* args, const bsvi_opt_cfg* cfg,
                     float* params_dev, float* state_dev, const uint8_t* active_mask_dev,
                     float* loss_slot_dev, float* finite_slot_dev);
+
+/* =========================================================================================
+ *  Bayesian neural networks on the dense-link path (the reference's tests/test_MNIST_bayesian_neural_network.py:20-60):
+ *      logits = W_L act( ... act(W_1 x + b_1) ... ) + b_L        (`BF.tanh(BF.matmul(weights1, x) + b1)`, functions.py:28-41)
+ *  with EVERY weight matrix and bias a latent under a mean-field Normal posterior, an observed Categorical / Binomial(1)
+ *  likelihood and a random minibatch per iteration.  All latent scalars form one vector of n_rows rows — weights1 first
+ *  (H_1 x P, row r = h * P + p), the other tensors behind it — whose noise is the dense path's [n_rows][N] matrix (Philox
+ *  counters (sample, row >> 2)); every row reads its q loc / q scale / prior loc / prior scale from the uniform table through
+ *  row_uniform.  The two products with the minibatch (2 x 2 N H_1 P B flops) run on the matrix cores — on exact bf16 pieces when
+ *  the dataset is exactly bf16 (bsvi_bnn_exact_data), else on the f32-input MFMA kernels; the upper layers are per-sample
+ *  H_l x H_l-1 products evaluated per (sample, minibatch row).  Replaces the same reference lines as bsvi_dense_* for this graph.
+ * ========================================================================================= */
+typedef enum bsvi_bnn_activation {
+    BSVI_BNN_ACT_NONE = 0, BSVI_BNN_ACT_TANH = 1, BSVI_BNN_ACT_RELU = 2, BSVI_BNN_ACT_SIGMOID = 3, BSVI_BNN_ACT_SOFTPLUS = 4
+} bsvi_bnn_activation;
+
+typedef struct bsvi_bnn_layer {
+    uint32_t rows, cols;             /* W_l is [rows][cols]; cols = rows of the layer below (n_features for the first) */
+    uint32_t weight_row0;            /* first row of W_l in the latent vector, row-major (0 for the first layer)         */
+    uint32_t bias_row0;              /* first row of b_l, or 0xFFFFFFFF: no bias                                          */
+    uint32_t activation;             /* bsvi_bnn_activation of the layer's output; NONE for the last (the logits)         */
+    uint32_t reserved;
+} bsvi_bnn_layer;
+
+typedef struct bsvi_bnn_desc {
+    uint32_t struct_size;            /* sizeof(bsvi_bnn_desc) */
+    uint32_t abi_version;
+    uint32_t n_params, n_consts, n_uniform, n_uniform_grad;
+    uint32_t n_layers, n_rows, n_features, dataset_size, batch_size;
+    uint32_t likelihood;             /* bsvi_dense_likelihood */
+    uint32_t estimator;              /* bsvi_estimator: pathwise or BlackBox */
+    float lik_weight, prior_weight, entropy_weight;
+    const bsvi_bnn_layer* layers;    /* [n_layers], bottom up */
+    const uint32_t* row_uniform;     /* [4][n_rows]: uniform entry of q loc, q scale, prior loc, prior scale of every row */
+    const bsvi_uniform_entry* uniform;
+    const float* consts;
+    const uint32_t* param_uniform_ptr;
+    const uint32_t* param_uniform_idx;
+    const float* dataset;            /* [dataset_size][n_features] host copy */
+    const float* labels;             /* [dataset_size] host copy            */
+} bsvi_bnn_desc;
+
+typedef struct bsvi_bnn bsvi_bnn;
+
+typedef struct bsvi_bnn_args {
+    uint32_t struct_size;            /* sizeof(bsvi_bnn_args) */
+    uint32_t reserved0;
+    const float* params_dev;         /* [n_params]                                                   */
+    const float* noise_dev;          /* eps [n_rows][n_samples_local] or NULL -> Philox               */
+    const int32_t* indices_dev;      /* minibatch rows [batch_size] or NULL -> drawn on the device    */
+    uint64_t seed, offset;
+    uint32_t n_samples_local, n_samples_global, sample_base, reserved;
+    float* out_dev;                  /* [BSVI_OUT_HEADER + n_params], same layout as bsvi_elbo_fwd_bwd */
+    float* noise_out_dev;            /* eps used [n_rows][n_samples_local] or NULL                    */
+    int32_t* indices_out_dev;        /* minibatch used [batch_size] or NULL                           */
+    float* fvalue_out_dev;           /* per-sample f [n_samples_local] or NULL                        */
+    float* logq_out_dev;             /* per-sample log q [n_samples_local] or NULL (BlackBox)         */
+    void* workspace_dev;
+    void* stream;
+} bsvi_bnn_args;
+
+int bsvi_bnn_create(const bsvi_bnn_desc* desc, bsvi_bnn** out);
+void bsvi_bnn_destroy(bsvi_bnn* b);
+size_t bsvi_bnn_workspace_bytes(const bsvi_bnn* b, uint32_t n_samples_local);
+int bsvi_bnn_exact_data(const bsvi_bnn* b);
+/* ELBO forward + backward over this GPU's sample shard; sums in out_dev (then all-reduce / bsvi_bnn_finalize / bsvi_finalize_step) */
+int bsvi_bnn_fwd_bwd(const bsvi_bnn* b, const bsvi_bnn_args* args);
+int bsvi_bnn_finalize(const bsvi_bnn* b, float* out_dev, uint32_t n_samples_global, void* stream);
+/* single-GPU iteration: the same launches with finalize + optimizer step fused into the last one */
+int bsvi_bnn_step(const bsvi_bnn* b, const bsvi_bnn_args* args, const bsvi_opt_cfg* cfg, float* params_dev, float* state_dev,
+                  const uint8_t* active_mask_dev, float* loss_slot_dev, float* finite_slot_dev);
 
 /* =========================================================================================
  *  Amortised path (BASELINE config 5, examples/VAE_playground.py:18-88): the posterior of a latent

@@ -82,6 +82,17 @@ CASES = {
                                          6, 10, dict(iters=4, n=5, optimizer="SGD", lr=1e-7)),     # (SGD: Adam's first steps are the SIGN of gradients that cancel to rounding noise here)
     "logreg_C10_P784_DS24_B16_N4": ("build_logistic_regression",
                                     dict(dataset_size=24, batch_size=16, n_features=784, n_classes=10), 4, 8, None),
+    # the reference's Bayesian neural network (tests/test_MNIST_bayesian_neural_network.py:20-60): latent weight matrices AND biases of
+    # both layers, tanh hidden units, observed Categorical over a random minibatch — reduced sizes, one at the example's full width
+    "bnn_P48_H6_C4_DS30_B12_N5": ("build_bayesian_neural_network",
+                                  dict(dataset_size=30, batch_size=12, n_features=48, n_hidden=6, n_classes=4, q_scale1=2e-3, q_loc_scale=1.0),
+                                  5, 21, dict(iters=4, n=4, optimizer="Adam", lr=5e-3)),
+    "bnn_P784_H20_C10_DS40_B30_N3": ("build_bayesian_neural_network",
+                                     dict(dataset_size=40, batch_size=30, n_features=784, n_hidden=20, n_classes=10, q_scale1=4e-4, q_loc_scale=1.0),
+                                     3, 22, None),
+    "bnn_relu_P32_H8_H5_C3_DS24_B10_N6": ("build_bayesian_neural_network",
+                                          dict(dataset_size=24, batch_size=10, n_features=32, n_hidden=8, hidden2=5, n_classes=3, q_scale1=3e-3,
+                                               q_loc_scale=1.0, activation="relu"), 6, 23, dict(iters=3, n=4, optimizer="SGD", lr=1e-3)),
 }
 
 
