@@ -839,13 +839,18 @@ def compile_model(joint_model, posterior_model=None, gradient_estimator=None):
             try:
                 compiled = dense.CompiledDense(joint_model, posterior_model, est)
             except lowering.LoweringError as dense_error:
-                # encoder / decoder network links go to the amortised path (amortized.py)
-                from brancher_amd import amortized
+                # a chain of matmul links with latent matrices AND biases — a Bayesian neural network — goes to bnn.py
+                from brancher_amd import bnn
                 try:
-                    compiled = amortized.CompiledAmortized(joint_model, posterior_model, est)
-                except lowering.LoweringError as amort_error:
-                    raise lowering.LoweringError("{}; dense path: {}; amortised path: {}".format(
-                        scalar_error, dense_error, amort_error)) from None
+                    compiled = bnn.CompiledBnn(joint_model, posterior_model, est)
+                except lowering.LoweringError as bnn_error:
+                    # encoder / decoder network links go to the amortised path (amortized.py)
+                    from brancher_amd import amortized
+                    try:
+                        compiled = amortized.CompiledAmortized(joint_model, posterior_model, est)
+                    except lowering.LoweringError as amort_error:
+                        raise lowering.LoweringError("{}; dense path: {}; bnn path: {}; amortised path: {}".format(
+                            scalar_error, dense_error, bnn_error, amort_error)) from None
         if sibling is not None:
             if sibling.n_params != compiled.n_params:
                 raise RuntimeError("parameter layouts of two estimators of the same model differ")

@@ -150,6 +150,42 @@ EXPORTS = {
 EXPORTS.update(DENSE_EXPORTS)
 
 
+class BnnLayer(C.Structure):
+    _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("weight_row0", C.c_uint32), ("bias_row0", C.c_uint32),
+                ("activation", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BnnDesc(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("n_params", C.c_uint32), ("n_consts", C.c_uint32),
+                ("n_uniform", C.c_uint32), ("n_uniform_grad", C.c_uint32),
+                ("n_layers", C.c_uint32), ("n_rows", C.c_uint32), ("n_features", C.c_uint32), ("dataset_size", C.c_uint32),
+                ("batch_size", C.c_uint32), ("likelihood", C.c_uint32), ("estimator", C.c_uint32),
+                ("lik_weight", C.c_float), ("prior_weight", C.c_float), ("entropy_weight", C.c_float),
+                ("layers", C.c_void_p), ("row_uniform", C.c_void_p), ("uniform", C.c_void_p), ("consts", C.c_void_p),
+                ("param_uniform_ptr", C.c_void_p), ("param_uniform_idx", C.c_void_p), ("dataset", C.c_void_p), ("labels", C.c_void_p)]
+
+
+class BnnArgs(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("params_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("indices_dev", C.c_void_p),
+                ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32), ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
+                ("out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p), ("indices_out_dev", C.c_void_p),
+                ("fvalue_out_dev", C.c_void_p), ("logq_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p)]
+
+
+EXPORTS.update({
+    "bsvi_bnn_create": (C.c_int, [C.POINTER(BnnDesc), C.POINTER(C.c_void_p)]),
+    "bsvi_bnn_destroy": (None, [C.c_void_p]),
+    "bsvi_bnn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
+    "bsvi_bnn_exact_data": (C.c_int, [C.c_void_p]),
+    "bsvi_bnn_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(BnnArgs)]),
+    "bsvi_bnn_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bsvi_bnn_step": (C.c_int, [C.c_void_p, C.POINTER(BnnArgs), C.POINTER(OptCfg), C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+})
+
+
 class MlpLayer(C.Structure):
     _fields_ = [("in_value", C.c_uint32), ("out_value", C.c_uint32), ("n_in", C.c_uint32), ("n_out", C.c_uint32),
                 ("weight_off", C.c_uint32), ("bias_off", C.c_uint32), ("activation", C.c_uint32),
@@ -297,7 +333,7 @@ def mvn_source(node):
 
 # bsvi_struct_kind (include/bsvi.h) -> the ctypes mirror of the struct: load() checks every size against bsvi_sizeof()
 STRUCT_KINDS = {0: UniformEntry, 1: Record, 2: ProgramDesc, 3: ElboArgs, 4: OptCfg, 5: DenseDesc, 6: DenseArgs, 7: MlpLayer,
-                8: AmortDesc, 9: AmortArgs, 10: MvnInsn, 11: MvnDesc, 12: MvnArgs}
+                8: AmortDesc, 9: AmortArgs, 10: MvnInsn, 11: MvnDesc, 12: MvnArgs, 13: BnnLayer, 14: BnnDesc, 15: BnnArgs}
 
 _lib = None
 

@@ -48,7 +48,8 @@ C_NAMES = {native.UniformEntry: "bsvi_uniform_entry", native.Record: "bsvi_recor
            native.ElboArgs: "bsvi_elbo_args", native.OptCfg: "bsvi_opt_cfg", native.DenseDesc: "bsvi_dense_desc",
            native.DenseArgs: "bsvi_dense_args", native.MlpLayer: "bsvi_mlp_layer", native.AmortDesc: "bsvi_amort_desc",
            native.AmortArgs: "bsvi_amort_args", native.MvnInsn: "bsvi_mvn_insn", native.MvnDesc: "bsvi_mvn_desc",
-           native.MvnArgs: "bsvi_mvn_args"}
+           native.MvnArgs: "bsvi_mvn_args", native.BnnLayer: "bsvi_bnn_layer", native.BnnDesc: "bsvi_bnn_desc",
+           native.BnnArgs: "bsvi_bnn_args"}
 
 
 def test_struct_layouts(tmp_path):
@@ -120,12 +121,16 @@ def test_a_struct_of_another_size_is_refused():
     ad = native.AmortDesc(abi_version=native.ABI_VERSION)
     ad.struct_size = 0
     assert lib.bsvi_amort_create(ctypes.byref(ad), ctypes.byref(handle)) == -1 and b"bsvi_amort_desc" in lib.bsvi_last_error()
+    bd = native.BnnDesc(abi_version=native.ABI_VERSION, n_layers=1, n_rows=8, n_features=4, dataset_size=4, batch_size=2)
+    bd.struct_size -= 8
+    assert lib.bsvi_bnn_create(ctypes.byref(bd), ctypes.byref(handle)) == -1 and b"bsvi_bnn_desc" in lib.bsvi_last_error()
     md = native.MvnDesc(abi_version=native.ABI_VERSION, dim=4)
     md.struct_size = 88
     assert lib.bsvi_mvn_create(ctypes.byref(md), ctypes.byref(handle)) == -1 and b"bsvi_mvn_desc" in lib.bsvi_last_error()
     # argument structs: the check comes before the (null) object is looked at
     for fn, args in ((lib.bsvi_elbo_fwd_bwd, native.ElboArgs()), (lib.bsvi_dense_fwd_bwd, native.DenseArgs()),
-                     (lib.bsvi_amort_fwd_bwd, native.AmortArgs()), (lib.bsvi_mvn_eval, native.MvnArgs())):
+                     (lib.bsvi_amort_fwd_bwd, native.AmortArgs()), (lib.bsvi_mvn_eval, native.MvnArgs()),
+                     (lib.bsvi_bnn_fwd_bwd, native.BnnArgs())):
         args.struct_size += 8
         assert fn(None, ctypes.byref(args)) == -1
         assert b"struct_size" in lib.bsvi_last_error(), lib.bsvi_last_error()
@@ -414,3 +419,33 @@ def test_user_callables_are_traced_into_link_expressions():
     with pytest.raises((lowering.LoweringError, NotImplementedError)):
         lowering.lower(model, None, "pathwise")
 
+
+
+def test_bayesian_neural_network_lowers_to_the_bnn_family():
+    """the reference's tests/test_MNIST_bayesian_neural_network.py:20-60 (latent weight matrices AND biases of both layers, tanh):
+    `dense.lower_dense` declines it (one matrix, no bias), `bnn.lower_bnn` takes it — weights1 first in the latent vector, the
+    layers' rows chained, every row with its own four uniform entries; the prior's roots ARE the posterior's learnable
+    parameters by the reference's name-collision rule."""
+    from brancher_amd import bnn, dense
+    api = W.native_api()
+    kw = dict(dataset_size=30, batch_size=12, n_features=48, n_hidden=6, n_classes=4)
+    with pytest.raises(lowering.LoweringError):
+        m = W.build_bayesian_neural_network(api, **kw)
+        dense.lower_dense(m, m.posterior_model)
+    m = W.build_bayesian_neural_network(api, **kw)
+    p = bnn.lower_bnn(m, m.posterior_model, "blackbox")
+    assert [t["name"] for t in p.tensors] == ["weights1", "b1", "weights2", "b2"]
+    assert [(l["rows"], l["cols"], l["activation"]) for l in p.layers] == [(6, 48, 1), (4, 6, 0)]
+    assert p.n_rows == 6 * 48 + 6 + 4 * 6 + 4 == p.row_uniform.shape[1] and p.row_uniform.shape[0] == 4
+    assert p.layers[0]["weight_row0"] == 0 and p.layers[0]["bias_row0"] == 288 and p.layers[1]["weight_row0"] == 294
+    assert p.n_params == 2 * p.n_rows == p.n_uniform_grad             # loc and scale of every latent scalar, nothing else
+    assert (p.row_uniform[0] == p.row_uniform[2]).all() and (p.row_uniform[1] == p.row_uniform[3]).all()      # the collision rule
+    assert sorted(set(p.row_uniform.reshape(-1).tolist())) == list(range(p.n_uniform_grad))
+    # three layers, relu, and what is refused
+    m3 = W.build_bayesian_neural_network(api, dataset_size=24, batch_size=10, n_features=32, n_hidden=8, hidden2=5, n_classes=3, activation="relu")
+    assert [(l["rows"], l["cols"], l["activation"]) for l in bnn.lower_bnn(m3, m3.posterior_model).layers] == [(8, 32, 2), (5, 8, 2), (3, 5, 0)]
+    m_bad = W.build_bayesian_neural_network(api, dataset_size=24, batch_size=10, n_features=30, n_hidden=4, n_classes=3)
+    with pytest.raises(lowering.LoweringError, match="multiple of 4"):
+        bnn.lower_bnn(m_bad, m_bad.posterior_model)
+    with pytest.raises(lowering.LoweringError):
+        bnn.lower_bnn(m, m.posterior_model, "taylor1")
