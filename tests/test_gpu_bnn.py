@@ -123,4 +123,7 @@ def test_two_rank_step_sequence_equals_the_fused_step():
     a, b = compile_bnn("pathwise", **kw), compile_bnn("pathwise", **kw)
     la, _ = a.train(6, 40, "Adam", seed=2, lr=1e-2)
     lb, _ = b.train(6, 40, "Adam", seed=2, lr=1e-2, _force_sharded_path=True)
-    assert a.last_mode == "stepwise" and torch.equal(la, lb) and torch.equal(a.params, b.params)
+    # (the fused launch divides by N where bsvi_finalize_step multiplies by 1 / N: equal to rounding, as on the dense path)
+    assert a.last_mode == "stepwise" and b.last_mode == "stepwise"
+    np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(b.params.cpu().numpy(), a.params.cpu().numpy(), rtol=1e-6, atol=1e-7)
