@@ -968,6 +968,143 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {
         }
 }
 
+// The weight gradient of a wide layer, C[M][N] = sum_r A[r][m] B[r][n] (A = dY, B = the layer's input: BOTH f32 activations), as six
+// products of exact bf16 pieces (x6gemm_kernel's arithmetic) with the transposing split of both operands on the way into LDS — no
+// transposed copy in memory (its traffic would cost what the product saves).  Workgroup = one 128 x 128 output tile x one slice of
+// the rows (split k, a partial per slice, reduce_partials adds the slices in order); k step = 32 rows.  A thread owns ONE column
+// of the A tile and one of the B tile for 16 of the 32 rows: 16 coalesced 4-byte loads each (a wave reads 256 contiguous bytes of
+// a row), held one step ahead in registers; eight consecutive rows of a column are one 16-byte LDS store per piece, [column][k] —
+// the layout the MFMA fragments read.  The column sums of A (the bias gradient) ride along in the n = 0 tiles.
+struct X6TnArgs {
+    const float* A; int lda;            // [K][M]
+    const float* B; int ldb;            // [K][N]
+    float* C; long part_stride;         // partial slices [slice][M][N]
+    float* bias_grad;                   // [slice][M] or null
+    int M, N, K, chunk, tiles;          // rows per slice (a multiple of 32), output tiles
+};
+
+template <int DBG = 0>
+__global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
+    constexpr int APL = XPLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[6 * XPLANE];      // A hi | mid | lo | B hi | mid | lo, each [128][XLD]
+    __shared__ float colsum[2][128];
+    const int tiles_n = (G.N + 127) / 128;
+    int bid = blockIdx.x;
+    const int n_blocks = gridDim.x;
+    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // an XCD takes a contiguous range: the tiles of a slice share its rows
+    const int slice = bid / G.tiles, tile = bid - slice * G.tiles;
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    const int r_begin = slice * G.chunk, r_end = min(G.K, r_begin + G.chunk);
+    if (r_begin >= G.K) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
+    const int col = tid & 127, kg = tid >> 7;                                      // column of both tiles, rows 16 kg .. 16 kg + 15 of a step
+    const float* const pa = G.A + min(m0 + col, G.M - 1);
+    const float* const pb = G.B + min(n0 + col, G.N - 1);
+    const int n_steps = (r_end - r_begin + XBK - 1) / XBK;
+    float ra[16], rb[16];
+    auto fetch = [&](int step) {
+        const int r0 = r_begin + step * XBK + 16 * kg;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + i;
+            const bool ok = r < r_end;
+            const long rr = ok ? r : r_end - 1;
+            const float va = pa[rr * G.lda], vb = pb[rr * G.ldb];
+            ra[i] = ok ? va : 0.0f;
+            rb[i] = ok ? vb : 0.0f;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float asum = 0.0f;
+    fetch(0);
+    const unsigned char* at = lds + (wm + lm) * XLD + lk * 16;
+    const unsigned char* bt = lds + 3 * APL + (wn + lm) * XLD + lk * 16;
+    unsigned char* const sa = lds + col * XLD + kg * 32;                           // two 16-byte stores per piece: rows 16 kg .. +7, +8 .. +15
+    unsigned char* const sb = lds + 3 * APL + col * XLD + kg * 32;
+    for (int step = 0; step < n_steps; ++step) {
+        __syncthreads();                                   // the last step's reads of the stage are done
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x6_split2(ra[8 * h + 2 * q], ra[8 * h + 2 * q + 1], hi[q], mid[q], lo[q]);
+            *reinterpret_cast<xu4*>(sa + 16 * h) = xu4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<xu4*>(sa + APL + 16 * h) = xu4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<xu4*>(sa + 2 * APL + 16 * h) = xu4{lo[0], lo[1], lo[2], lo[3]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x6_split2(rb[8 * h + 2 * q], rb[8 * h + 2 * q + 1], hi[q], mid[q], lo[q]);
+            *reinterpret_cast<xu4*>(sb + 16 * h) = xu4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<xu4*>(sb + APL + 16 * h) = xu4{mid[0], mid[1], mid[2], mid[3]};
+            *reinterpret_cast<xu4*>(sb + 2 * APL + 16 * h) = xu4{lo[0], lo[1], lo[2], lo[3]};
+        }
+        if (G.bias_grad) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asum += ra[i];     // (rows in order; the two halves of a step are joined below)
+        }
+        __syncthreads();
+        if (step + 1 < n_steps) fetch(step + 1);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            bf16x8 a[3][2], b[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const bf16x8*>(at + p * APL + 32 * i * XLD + kc * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const bf16x8*>(bt + p * APL + 32 * j * XLD + kc * 32);
+            }
+            if (DBG == 3) continue;
+            // smallest products first: (lo hi), (hi lo), (mid mid), (mid hi), (hi mid), (hi hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // the slice's partial: acc[i][j][r] is C[m][n] with m = 32i + 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31)
+    float* const part = G.C + (long)slice * G.part_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + lm;
+            if (n >= G.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * lk + (r & 3);
+                if (m < G.M) part[(long)m * G.N + n] = acc[i][j][r];
+            }
+        }
+    if (G.bias_grad && n0 == 0) {
+        colsum[kg][col] = asum;
+        __syncthreads();
+        if (kg == 0 && m0 + col < G.M) G.bias_grad[(long)slice * G.M + m0 + col] = colsum[0][col] + colsum[1][col];
+    }
+}
+
+struct X6TnPlan { int tiles, splits, chunk, slices; };
+// 128 x 128 tiles, two workgroups per CU: as many slices of the rows as fill 512 slots in ONE round
+static X6TnPlan x6tn_plan(int M, int N, int K) {
+    X6TnPlan p{};
+    p.tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int splits = std::max(1, std::min((K + XBK - 1) / XBK, 512 / std::max(p.tiles, 1)));
+    p.chunk = ((K + splits - 1) / splits + XBK - 1) / XBK * XBK;
+    p.slices = (K + p.chunk - 1) / p.chunk;
+    p.splits = p.slices;
+    return p;
+}
+
 // dY [R][ld] f32 -> T [3][N][Rp] bf16 pieces, and the column sums of every 64-row block (the bias gradient's partials)
 __global__ __launch_bounds__(256) void dy_split_t_kernel(const float* dY, int ld, int R, int Rp, int N, uint16_t* T, float* colsum) {
     __shared__ float tile[64][65];
@@ -2197,7 +2334,9 @@ static TnPlan tn_plan(int M, int N, int K) {
 static size_t align4(size_t n) { return (n + 3) / 4 * 4; }      // partial regions start on 16-byte boundaries
 static size_t tn_partial_floats(int M, int N, int K, bool bias) {
     const TnPlan p = tn_plan(M, N, K);
-    return align4((size_t)p.slices * M * N) + (bias ? align4((size_t)p.slices * M) : 0);
+    // (the six-piece form of the same product, x6tn_kernel, cuts the rows into its own number of slices: room for either)
+    const size_t slices = p.skinny ? (size_t)p.slices : std::max<size_t>((size_t)p.slices, (size_t)x6tn_plan(M, N, K).slices);
+    return align4(slices * M * N) + (bias ? align4(slices * M) : 0);
 }
 
 // floats of the partial sums behind the per-row part of the workspace: one slice set per Linear layer (weights + bias)
@@ -2479,6 +2618,40 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
         X.act = (int)activation; X.post_add = post_add; X.accumulate = (int)accumulate;
         if (mode == 5) X.bias = bias_or_y_dev; else { X.Y = bias_or_y_dev; X.ldy = (int)ldy; }
         return launch_x6(mode == 6, X, st);
+    }
+    if (mode == 7) {
+        // mode 2 (C[m][n] = sum_k A[k][m] B[k][n], column sums of A into bias_or_y_dev) through x6tn_kernel: six products of exact pieces,
+        // both operands split and transposed on the way into LDS
+        if (!a_dev || !b_dev || !c_dev || rows_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
+        float* bias_acc = const_cast<float*>(bias_or_y_dev);
+        const X6TnPlan xp = x6tn_plan((int)m, (int)n, (int)k);
+        static float* part = nullptr;
+        static size_t part_floats = 0;
+        const size_t need = align4((size_t)xp.slices * m * n) + align4((size_t)xp.slices * m);
+        if (need > part_floats) {
+            (void)hipDeviceSynchronize();
+            if (part) (void)hipFree(part);
+            part = nullptr; part_floats = 0;
+            HIP_TRY(hipMalloc(&part, need * sizeof(float)));
+            part_floats = need;
+        }
+        X6TnArgs X{};
+        X.A = a_dev; X.lda = (int)lda; X.B = b_dev; X.ldb = (int)ldb; X.C = part; X.part_stride = (long)m * n;
+        X.bias_grad = bias_acc ? part + align4((size_t)xp.slices * m * n) : nullptr;
+        X.M = (int)m; X.N = (int)n; X.K = (int)k; X.chunk = xp.chunk; X.tiles = xp.tiles;
+        hipLaunchKernelGGL((x6tn_kernel<0>), dim3((unsigned)(xp.tiles * xp.slices)), dim3(256), 0, (hipStream_t)stream, X);
+        SegmentTable T{};
+        T.seg[0] = Segment{c_dev, part, m, n, ldc, (uint32_t)xp.slices, 0u, 0u, 0u, 0u};       // (C = the product: nothing kept)
+        T.n = 1;
+        uint32_t blocks = segment_blocks(T.seg[0]);
+        if (bias_acc) {
+            T.seg[1] = Segment{bias_acc, X.bias_grad, 1u, m, m, (uint32_t)xp.slices, blocks, 0u, 0u, 0u};
+            T.n = 2;
+            blocks += segment_blocks(T.seg[1]);
+        }
+        hipLaunchKernelGGL(reduce_partials, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T);
+        HIP_TRY(hipGetLastError());
+        return BSVI_OK;
     }
     if (mode < 0 || mode > 2 || !a_dev || !b_dev || !c_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
     GemmArgs G{};
@@ -2791,10 +2964,30 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 part += align4((size_t)plan.slices * G.M * G.N);
                 G.bias_grad = has_bias ? part : nullptr;
                 if (has_bias) part += align4((size_t)plan.slices * G.M);
+                // wide layers whose input is a network value: six products of exact pieces with the transposing split of both operands
+                // on the way into LDS (x6tn_kernel; round 5) — 6 / 16 of the f32-input MFMA's pipe time.  BSVI_X6_TN=0: the f32-input kernel
+                static const bool x6_tn = [] { const char* e = getenv("BSVI_X6_TN"); return !(e && e[0] == '0'); }();
+                if (x6_on && x6_tn && !from_data && !plan.skinny && G.M >= 64 && G.N >= 64) {
+                    const X6TnPlan xp = x6tn_plan(G.M, G.N, G.K);
+                    // (the partial regions were laid out for the larger of the two plans: tn_partial_floats)
+                    float* const cpart = G.C;
+                    float* bpart = nullptr;
+                    part = cpart + align4((size_t)std::max(plan.slices, xp.slices) * G.M * G.N);
+                    if (has_bias) { bpart = part; part += align4((size_t)std::max(plan.slices, xp.slices) * G.M); }
+                    X6TnArgs X{};
+                    X.A = G.A; X.lda = G.lda; X.B = G.B; X.ldb = G.ldb; X.C = cpart; X.part_stride = (long)G.M * G.N; X.bias_grad = bpart;
+                    X.M = G.M; X.N = G.N; X.K = G.K; X.chunk = xp.chunk; X.tiles = xp.tiles;
+                    hipLaunchKernelGGL((x6tn_kernel<0>), dim3((unsigned)(xp.tiles * xp.slices)), dim3(256), 0, wstream, X);
+                    HIP_TRY(hipGetLastError());
+                    int rc = add_segment(grads + l.weight_off, cpart, l.n_out, l.n_in, (uint32_t)xp.slices);
+                    if (!rc && has_bias) rc = add_segment(grads + l.bias_off, bpart, 1, l.n_out, (uint32_t)xp.slices);
+                    if (rc) return rc;
+                } else {
                 int rc = launch_gemm(MODE_TN, G, wstream);
                 if (!rc) rc = add_segment(grads + l.weight_off, G.C, l.n_out, l.n_in, (uint32_t)plan.slices);
                 if (!rc && has_bias) rc = add_segment(grads + l.bias_off, G.bias_grad, 1, l.n_out, (uint32_t)plan.slices);
                 if (rc) return rc;
+                }
             }
             if (l.in_value != 0 || input_grad) {   // dX = (dY W) * act'(x)
                 GemmArgs G{};

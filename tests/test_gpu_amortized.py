@@ -106,6 +106,43 @@ def test_six_piece_products_on_the_bf16_matrix_cores_match_f32_accuracy(mode, sh
     assert err <= max(2.0 * yard, 2e-6), (err, yard)
 
 
+@pytest.mark.parametrize("shape", [(784, 256, 25600), (512, 256, 25600), (256, 512, 25600), (200, 72, 17000), (300, 130, 4100), (128, 128, 33),
+                                   (64, 260, 1000)])
+def test_six_piece_weight_gradient_matches_f32_accuracy(shape):
+    """x6tn_kernel (round 5: the weight gradients of the amortised path's wide layers): C[m][n] = sum_k A[k][m] B[k][n] with BOTH
+    operands f32 activations — split into exact bf16 pieces and transposed on the way into LDS, six MFMAs per k chunk, one partial per
+    slice of the rows, the slices added in order; the column sums of A (the bias gradient) ride along.  Same bound as the forward
+    form: at most twice the error of torch's own f32 matmul against the product in double precision (or 2e-6 of the largest output);
+    cfg 5's three layer shapes at 25 600 rows, and shapes with tails in every dimension; bit-identical call to call."""
+    from brancher_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 7 * K)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    ldm = M + 4                                   # (dY lives in a wider value buffer)
+    Abuf, Bm = rnd(K, ldm), rnd(K, N)
+    A = Abuf[:, :M]
+    outs = []
+    for _ in range(2):
+        Cm, colsum = torch.full((M, N + 4), 7.0, device=dev), torch.zeros(M, device=dev)
+        native.check(lib.bsvi_debug_gemm(7, ptr(Abuf), ptr(Bm), ptr(Cm), None, M, N, K, ldm, N, N + 4, ptr(colsum), 0, 0, 0.0, 0, None))
+        torch.cuda.synchronize()
+        outs.append((Cm, colsum))
+    (Cm, colsum), (Cm2, colsum2) = outs
+    assert torch.equal(Cm, Cm2) and torch.equal(colsum, colsum2)
+    assert torch.all(Cm[:, N:] == 7.0)
+    ref = A.double().T @ Bm.double()
+    f32 = A.T @ Bm
+    scale = ref.abs().max().item()
+    err = (Cm[:, :N].double() - ref).abs().max().item() / scale
+    yard = (f32.double() - ref).abs().max().item() / scale
+    assert err <= max(2.0 * yard, 2e-6), (err, yard)
+    cs = A.double().sum(0)
+    assert ((colsum.double() - cs).abs().max() / cs.abs().max()).item() < 2e-6
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("shape", [(25600, 256, 784), (25600, 512, 256), (17000, 200, 72), (25600, 784, 256), (25000, 256, 512),
                                    (9000, 300, 48)])
