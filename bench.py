@@ -516,22 +516,24 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         x6_layers = [l for l in program.enc_layers if l.in_value != 0 and wide(l)] + [l for l in program.dec_layers if wide(l)]
         modes = os.environ.get("BSVI_X6_MODES")          # input gradients too: unset = those contracting >= 512 columns, 3 = all, 1 = none
         x6_back = lambda l: (modes == "3") or (modes is None and l.n_out >= 512)
+        x6_tn = os.environ.get("BSVI_X6_TN", "1") != "0"      # round 5: their weight gradients too (x6tn_kernel)
         x6_flops = (sum(2.0 * rows * l.n_in * l.n_out for l in x6_layers) +
-                    sum(2.0 * rows * l.n_in * l.n_out for l in x6_layers if x6_back(l))) if x6 else 0.0
+                    sum(2.0 * rows * l.n_in * l.n_out for l in x6_layers if x6_back(l)) +
+                    (sum(2.0 * rows * l.n_in * l.n_out for l in x6_layers) if x6_tn else 0.0)) if x6 else 0.0
         roof_s = (flops - x_flops - x6_flops) / (MFMA_F32_PEAK_TFLOPS * 1e12) + x_flops / (MFMA_EXACT_PEAK_TFLOPS * 1e12) \
             + x6_flops / (MFMA_EXACT_PEAK_TFLOPS / 2.0 * 1e12)
         peak = flops / roof_s / 1e12
         roofline = dict(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s",
                         frac=tf / peak, traffic=traffic,
-                        kernel="bsvi_amort_impl::gemm_kernel<1|2>" + (" + x6gemm_kernel (forward products of the wide layers, input gradients with K >= 512)" if x6_flops else "<0>") + (
+                        kernel="bsvi_amort_impl::gemm_kernel<1|2>" + (" + x6gemm_kernel (forward products of the wide layers, input gradients with K >= 512) + x6tn_kernel (their weight gradients)" if x6_flops else "<0>") + (
                             " + xgemm_nt_glds_kernel<128> (first encoder layer: forward%s)" % (" and weight gradient" if xdw else "") if exact else ""),
                         algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps,
                         rows_per_iteration=rows, data_path="bf16x3" if exact else "f32",
                         frac_of_f32_mfma_peak=tf / MFMA_F32_PEAK_TFLOPS,
                         x6_flops_per_iteration=x6_flops,
                         note="f32-input MFMA (v_mfma_f32_32x32x2_f32) for the products that are not named next" + (
-                             "; the forward products of the wide layers whose input is a network value (and their input gradients where 512 or more "
-                             "columns are contracted) run as SIX bf16 MFMAs on the exact pieces of both f32 operands (peak 2500 / 6 for their flops)" if x6_flops else "") + (
+                             "; the forward products of the wide layers whose input is a network value, their weight gradients (and their input gradients where 512 "
+                             "or more columns are contracted) run as SIX bf16 MFMAs on the exact pieces of both f32 operands (peak 2500 / 6 for their flops)" if x6_flops else "") + (
                              "; the forward product%s of the layer that reads the (exactly bf16) data rows run%s as three bf16 MFMAs on "
                              "the exact pieces of the f32 operand; peak = flops / (f32-input flops / 157.3 + those flops / (2500 / 3) + six-piece flops / (2500 / 6))"
                              % ((" and the weight gradient", "") if xdw else ("", "s")) if exact else "") +

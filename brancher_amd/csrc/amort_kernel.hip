@@ -1098,7 +1098,8 @@ struct X6TnPlan { int tiles, splits, chunk, slices; };
 static X6TnPlan x6tn_plan(int M, int N, int K) {
     X6TnPlan p{};
     p.tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    const int splits = std::max(1, std::min((K + XBK - 1) / XBK, 512 / std::max(p.tiles, 1)));
+    static const int slots = [] { const char* e = getenv("BSVI_X6TN_SLOTS"); return e ? atoi(e) : 512; }();
+    const int splits = std::max(1, std::min((K + XBK - 1) / XBK, slots / std::max(p.tiles, 1)));
     p.chunk = ((K + splits - 1) / splits + XBK - 1) / XBK * XBK;
     p.slices = (K + p.chunk - 1) / p.chunk;
     p.splits = p.slices;
