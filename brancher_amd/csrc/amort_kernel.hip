@@ -999,18 +999,23 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, lm = lane & 31, lk = lane >> 5;
     const int col = tid & 127, kg = tid >> 7;                                      // column of both tiles, rows 16 kg .. 16 kg + 15 of a step
-    const float* const pa = G.A + min(m0 + col, G.M - 1);
-    const float* const pb = G.B + min(n0 + col, G.N - 1);
+    // buffer loads: ONE 32-bit lane offset per operand (the thread's column), the row in the scalar offset — no vector arithmetic per
+    // load (with 64-bit lane addresses the 32 loads of a step cost ~100 vector instructions of address computation)
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.A), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.B), 0, -1, 0x00020000);
+    const uint32_t va_off = (uint32_t)min(m0 + col, G.M - 1) * 4u, vb_off = (uint32_t)min(n0 + col, G.N - 1) * 4u;
+    const int kgs = __builtin_amdgcn_readfirstlane(kg);                          // (a wave's threads share kg: rows as scalars)
     const int n_steps = (r_end - r_begin + XBK - 1) / XBK;
     float ra[16], rb[16];
     auto fetch = [&](int step) {
-        const int r0 = r_begin + step * XBK + 16 * kg;
+        const int r0 = r_begin + step * XBK + 16 * kgs;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int r = r0 + i;
             const bool ok = r < r_end;
-            const long rr = ok ? r : r_end - 1;
-            const float va = pa[rr * G.lda], vb = pb[rr * G.ldb];
+            const uint32_t rr = (uint32_t)(ok ? r : r_end - 1);
+            const float va = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_rsrc, va_off, rr * (uint32_t)G.lda * 4u, 0));
+            const float vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, vb_off, rr * (uint32_t)G.ldb * 4u, 0));
             ra[i] = ok ? va : 0.0f;
             rb[i] = ok ? vb : 0.0f;
         }

@@ -43,7 +43,8 @@ int main(int argc, char** argv) {
     /* the binding's view of every struct against the library's */
     const size_t mine[BSVI_SK_COUNT] = {sizeof(bsvi_uniform_entry), sizeof(bsvi_record), sizeof(bsvi_program_desc),
         sizeof(bsvi_elbo_args), sizeof(bsvi_opt_cfg), sizeof(bsvi_dense_desc), sizeof(bsvi_dense_args), sizeof(bsvi_mlp_layer),
-        sizeof(bsvi_amort_desc), sizeof(bsvi_amort_args), sizeof(bsvi_mvn_insn), sizeof(bsvi_mvn_desc), sizeof(bsvi_mvn_args)};
+        sizeof(bsvi_amort_desc), sizeof(bsvi_amort_args), sizeof(bsvi_mvn_insn), sizeof(bsvi_mvn_desc), sizeof(bsvi_mvn_args),
+        sizeof(bsvi_bnn_layer), sizeof(bsvi_bnn_desc), sizeof(bsvi_bnn_args)};
     for (int k = 0; k < BSVI_SK_COUNT; ++k)
         if (bsvi_sizeof(k) != mine[k]) { fprintf(stderr, "struct kind %d: header %zu bytes, library %zu\n", k, mine[k], bsvi_sizeof(k)); return 4; }
     if (bsvi_abi_version() != BSVI_ABI_VERSION) { fprintf(stderr, "ABI %d != %d\n", bsvi_abi_version(), BSVI_ABI_VERSION); return 4; }

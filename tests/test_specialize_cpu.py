@@ -9,7 +9,7 @@ import pytest
 from conftest import Golden, golden_cases
 from brancher_amd import lowering, native, workloads as W
 
-SCALAR = [c for c in golden_cases() if not c.startswith("logreg")]
+SCALAR = [c for c in golden_cases() if not c.startswith("logreg") and not c.startswith("bnn")]      # (dense-link and Bayesian-neural-network families: their own kernels)
 
 
 def lowered(case, estimator="pathwise"):
