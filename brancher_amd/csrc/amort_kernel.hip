@@ -981,9 +981,11 @@ struct X6TnArgs {
     float* C; long part_stride;         // partial slices [slice][M][N]
     float* bias_grad;                   // [slice][M] or null
     int M, N, K, chunk, tiles;          // rows per slice (a multiple of 32), output tiles
+    const int32_t* rows;                // gather of B's rows (the minibatch rows of the dataset), or null
 };
 
-template <int DBG = 0>
+// BX: B is exactly bf16 (the data rows): one piece, three products (a_lo b, a_mid b, a_hi b)
+template <int DBG = 0, bool BX = false>
 __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
     constexpr int APL = XPLANE;
     __shared__ __attribute__((aligned(16))) unsigned char lds[6 * XPLANE];      // A hi | mid | lo | B hi | mid | lo, each [128][XLD]
@@ -1014,8 +1016,9 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
             const int r = r0 + i;
             const bool ok = r < r_end;
             const uint32_t rr = (uint32_t)(ok ? r : r_end - 1);
+            const uint32_t rrb = G.rows ? (uint32_t)G.rows[rr] : rr;             // (a scalar load: the row is the wave's)
             const float va = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_rsrc, va_off, rr * (uint32_t)G.lda * 4u, 0));
-            const float vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, vb_off, rr * (uint32_t)G.ldb * 4u, 0));
+            const float vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, vb_off, rrb * (uint32_t)G.ldb * 4u, 0));
             ra[i] = ok ? va : 0.0f;
             rb[i] = ok ? vb : 0.0f;
         }
@@ -1043,11 +1046,17 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
             *reinterpret_cast<xu4*>(sa + 16 * h) = xu4{hi[0], hi[1], hi[2], hi[3]};
             *reinterpret_cast<xu4*>(sa + APL + 16 * h) = xu4{mid[0], mid[1], mid[2], mid[3]};
             *reinterpret_cast<xu4*>(sa + 2 * APL + 16 * h) = xu4{lo[0], lo[1], lo[2], lo[3]};
+            if (BX) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x6_split2(rb[8 * h + 2 * q], rb[8 * h + 2 * q + 1], hi[q], mid[q], lo[q]);
-            *reinterpret_cast<xu4*>(sb + 16 * h) = xu4{hi[0], hi[1], hi[2], hi[3]};
-            *reinterpret_cast<xu4*>(sb + APL + 16 * h) = xu4{mid[0], mid[1], mid[2], mid[3]};
-            *reinterpret_cast<xu4*>(sb + 2 * APL + 16 * h) = xu4{lo[0], lo[1], lo[2], lo[3]};
+                for (int q = 0; q < 4; ++q) hi[q] = x6_pack(rb[8 * h + 2 * q], rb[8 * h + 2 * q + 1]);
+                *reinterpret_cast<xu4*>(sb + 16 * h) = xu4{hi[0], hi[1], hi[2], hi[3]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x6_split2(rb[8 * h + 2 * q], rb[8 * h + 2 * q + 1], hi[q], mid[q], lo[q]);
+                *reinterpret_cast<xu4*>(sb + 16 * h) = xu4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<xu4*>(sb + APL + 16 * h) = xu4{mid[0], mid[1], mid[2], mid[3]};
+                *reinterpret_cast<xu4*>(sb + 2 * APL + 16 * h) = xu4{lo[0], lo[1], lo[2], lo[3]};
+            }
         }
         if (G.bias_grad) {
 #pragma unroll
@@ -1063,18 +1072,19 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const bf16x8*>(at + p * APL + 32 * i * XLD + kc * 32);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const bf16x8*>(bt + p * APL + 32 * j * XLD + kc * 32);
+                for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const bf16x8*>(bt + ((BX && p) ? 0 : p * APL) + 32 * j * XLD + kc * 32);
             }
             if (DBG == 3) continue;
-            // smallest products first: (lo hi), (hi lo), (mid mid), (mid hi), (hi mid), (hi hi)
+            // smallest products first: (lo hi), (hi lo), (mid mid), (mid hi), (hi mid), (hi hi); exact B: (lo b), (mid b), (hi b)
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PAX[3] = {2, 1, 0};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < (BX ? 3 : 6); ++q)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BX ? PAX[q] : PA[q]][i], b[BX ? 0 : PB[q]][j], acc[i][j], 0, 0, 0);
         }
     }
     // the slice's partial: acc[i][j][r] is C[m][n] with m = 32i + 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31)
@@ -2628,7 +2638,8 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
     if (mode == 7) {
         // mode 2 (C[m][n] = sum_k A[k][m] B[k][n], column sums of A into bias_or_y_dev) through x6tn_kernel: six products of exact pieces,
         // both operands split and transposed on the way into LDS
-        if (!a_dev || !b_dev || !c_dev || rows_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
+        // (with rows_dev: B's rows are gathered and B is taken as exactly bf16 — the data layer's form, one piece and three products)
+        if (!a_dev || !b_dev || !c_dev) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
         float* bias_acc = const_cast<float*>(bias_or_y_dev);
         const X6TnPlan xp = x6tn_plan((int)m, (int)n, (int)k);
         static float* part = nullptr;
@@ -2644,8 +2655,9 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
         X6TnArgs X{};
         X.A = a_dev; X.lda = (int)lda; X.B = b_dev; X.ldb = (int)ldb; X.C = part; X.part_stride = (long)m * n;
         X.bias_grad = bias_acc ? part + align4((size_t)xp.slices * m * n) : nullptr;
-        X.M = (int)m; X.N = (int)n; X.K = (int)k; X.chunk = xp.chunk; X.tiles = xp.tiles;
-        hipLaunchKernelGGL((x6tn_kernel<0>), dim3((unsigned)(xp.tiles * xp.slices)), dim3(256), 0, (hipStream_t)stream, X);
+        X.M = (int)m; X.N = (int)n; X.K = (int)k; X.chunk = xp.chunk; X.tiles = xp.tiles; X.rows = rows_dev;
+        if (rows_dev) hipLaunchKernelGGL((x6tn_kernel<0, true>), dim3((unsigned)(xp.tiles * xp.slices)), dim3(256), 0, (hipStream_t)stream, X);
+        else hipLaunchKernelGGL((x6tn_kernel<0>), dim3((unsigned)(xp.tiles * xp.slices)), dim3(256), 0, (hipStream_t)stream, X);
         SegmentTable T{};
         T.seg[0] = Segment{c_dev, part, m, n, ldc, (uint32_t)xp.slices, 0u, 0u, 0u, 0u};       // (C = the product: nothing kept)
         T.n = 1;
@@ -2903,7 +2915,11 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         return BSVI_OK;
     };
     size_t next_event = 0;
-    bool xt_pending = XT != nullptr, xt_on_side = false;
+    // (round 5) the data layer's weight gradient through x6tn_kernel<., true>: no transposed minibatch rows, no pieces of dY in memory.  BSVI_X6_TN_DATA=0: round 4's three launches
+    static const bool data_x6tn_env = [] { const char* e = getenv("BSVI_X6_TN_DATA"); return !(e && e[0] == '0'); }();
+    static const bool x6_tn_env = [] { const char* e = getenv("BSVI_X6_TN"); return !(e && e[0] == '0'); }();
+    const bool data_x6tn = x6_on && x6_tn_env && data_x6tn_env;
+    bool xt_pending = XT != nullptr && !data_x6tn, xt_on_side = false;
     auto launch_xt = [&](hipStream_t ts) {
         hipLaunchKernelGGL(xt_gather_kernel, dim3((unsigned)(Rp / 64), (unsigned)((P + 127) / 128)), dim3(256), 0, ts,
                            a->dataset_bf16_dev, idx, a->data_kp, P, (int)R, Rp, XT);
@@ -2934,6 +2950,25 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
             const float* dY = grad(net, l.out_value);
             const int ldy = net.ld[l.out_value];
             const bool from_data = gather && l.in_value == 0;
+            if (from_data && XT && xdw_layer(a, (size_t)i, R) && data_x6tn) {
+                // (round 5) the same product through x6tn_kernel: dY split and transposed on the way into LDS, the data rows gathered by
+                // the kernel and converted (they are exactly bf16: one piece, three products) — no transposed copies in memory, one launch
+                // in place of xt_gather + dy_split_t + the exact-piece product
+                const X6TnPlan xp = x6tn_plan((int)l.n_out, (int)l.n_in, (int)R);
+                const bool has_bias = l.bias_off != 0xFFFFFFFFu;
+                float* const cpart = part;
+                float* const bpart = cpart + align4((size_t)xp.slices * l.n_out * l.n_in);
+                part += xdw_floats(a, (size_t)i, R);
+                X6TnArgs X{};
+                X.A = dY; X.lda = ldy; X.B = a->dataset_dev; X.ldb = (int)P; X.rows = idx; X.C = cpart; X.part_stride = (long)l.n_out * l.n_in;
+                X.bias_grad = has_bias ? bpart : nullptr;
+                X.M = (int)l.n_out; X.N = (int)l.n_in; X.K = (int)R; X.chunk = xp.chunk; X.tiles = xp.tiles;
+                hipLaunchKernelGGL((x6tn_kernel<0, true>), dim3((unsigned)(xp.tiles * xp.slices)), dim3(256), 0, wstream, X);
+                HIP_TRY(hipGetLastError());
+                int rc = add_segment(grads + l.weight_off, cpart, l.n_out, l.n_in, (uint32_t)xp.slices);
+                if (!rc && has_bias) rc = add_segment(grads + l.bias_off, bpart, 1, l.n_out, (uint32_t)xp.slices);
+                if (rc) return rc;
+            } else
             if (from_data && XT && xdw_layer(a, (size_t)i, R)) {
                 // dW = dY^T x with x exact in bf16: the pieces of dY, transposed, times the transposed rows (split-k)
                 const XdwPlan plan = xdw_plan((int)l.n_in, (int)l.n_out, R);

@@ -141,6 +141,20 @@ def test_six_piece_weight_gradient_matches_f32_accuracy(shape):
     assert err <= max(2.0 * yard, 2e-6), (err, yard)
     cs = A.double().sum(0)
     assert ((colsum.double() - cs).abs().max() / cs.abs().max()).item() < 2e-6
+    # the data layer's form: B's rows gathered from a dataset of exactly-bf16 values (pixel counts) — one piece, three products
+    n_src = 3000
+    src = torch.randint(0, 256, (n_src, N), generator=g).float().to(dev)
+    rows = torch.randint(0, n_src, (K,), generator=g, dtype=torch.int32).to(dev)
+    Cx, colx = torch.zeros(M, N, device=dev), torch.zeros(M, device=dev)
+    native.check(lib.bsvi_debug_gemm(7, ptr(Abuf), ptr(src), ptr(Cx), ptr(rows), M, N, K, ldm, N, N, ptr(colx), 0, 0, 0.0, 0, None))
+    torch.cuda.synchronize()
+    Bg = src[rows.long()]
+    refx = A.double().T @ Bg.double()
+    sx = refx.abs().max().item()
+    errx = (Cx.double() - refx).abs().max().item() / sx
+    yardx = ((A.T @ Bg).double() - refx).abs().max().item() / sx
+    assert errx <= max(2.0 * yardx, 2e-6), (errx, yardx)
+    assert torch.equal(colx, colsum)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
