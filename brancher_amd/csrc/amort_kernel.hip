@@ -1004,11 +1004,24 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
     // buffer loads: ONE 32-bit lane offset per operand (the thread's column), the row in the scalar offset — no vector arithmetic per
     // load (with 64-bit lane addresses the 32 loads of a step cost ~100 vector instructions of address computation)
     const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.A), 0, -1, 0x00020000);
+    // (B from the dataset's f32 rows also when a bf16 copy exists: 2-byte buffer loads made the gather twice as slow — 208 against 100 us)
     const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.B), 0, -1, 0x00020000);
     const uint32_t va_off = (uint32_t)min(m0 + col, G.M - 1) * 4u, vb_off = (uint32_t)min(n0 + col, G.N - 1) * 4u;
+    const uint32_t b_row_bytes = (uint32_t)G.ldb * 4u;
     const int kgs = __builtin_amdgcn_readfirstlane(kg);                          // (a wave's threads share kg: rows as scalars)
     const int n_steps = (r_end - r_begin + XBK - 1) / XBK;
     float ra[16], rb[16];
+    // gathered rows (BX): the indices of a step are loaded a step ahead of the loads they address (a dependent pair of round trips
+    // — index, then a random dataset row from HBM — otherwise sits in front of every step), as VECTOR loads of one address (scalar
+    // loads share the LDS counter: every s_load in the product phase would turn its fine-grained LDS waits into lgkmcnt(0))
+    const __amdgpu_buffer_rsrc_t rows_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(G.rows ? G.rows : reinterpret_cast<const int32_t*>(G.A)), 0, -1, 0x00020000);
+    uint32_t ridx[16];
+    auto fetch_idx = [&](int step) {
+        if (!BX) return;
+        const int r0 = r_begin + step * XBK + 16 * kgs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ridx[i] = __builtin_amdgcn_raw_buffer_load_b32(rows_rsrc, 0u, (uint32_t)min(r0 + i, r_end - 1) * 4u, 0);
+    };
     auto fetch = [&](int step) {
         const int r0 = r_begin + step * XBK + 16 * kgs;
 #pragma unroll
@@ -1016,9 +1029,13 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
             const int r = r0 + i;
             const bool ok = r < r_end;
             const uint32_t rr = (uint32_t)(ok ? r : r_end - 1);
-            const uint32_t rrb = G.rows ? (uint32_t)G.rows[rr] : rr;             // (a scalar load: the row is the wave's)
             const float va = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_rsrc, va_off, rr * (uint32_t)G.lda * 4u, 0));
-            const float vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, vb_off, rrb * (uint32_t)G.ldb * 4u, 0));
+            float vb;
+            if (BX) {
+                vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, ridx[i] * b_row_bytes + vb_off, 0u, 0));
+            } else {
+                vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, vb_off, rr * b_row_bytes, 0));
+            }
             ra[i] = ok ? va : 0.0f;
             rb[i] = ok ? vb : 0.0f;
         }
@@ -1031,7 +1048,9 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     float asum = 0.0f;
+    fetch_idx(0);
     fetch(0);
+    if (n_steps > 1) fetch_idx(1);
     const unsigned char* at = lds + (wm + lm) * XLD + lk * 16;
     const unsigned char* bt = lds + 3 * APL + (wn + lm) * XLD + lk * 16;
     unsigned char* const sa = lds + col * XLD + kg * 32;                           // two 16-byte stores per piece: rows 16 kg .. +7, +8 .. +15
@@ -1063,7 +1082,10 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
             for (int i = 0; i < 16; ++i) asum += ra[i];     // (rows in order; the two halves of a step are joined below)
         }
         __syncthreads();
-        if (step + 1 < n_steps) fetch(step + 1);
+        if (step + 1 < n_steps) {
+            fetch(step + 1);                                 // (its indices arrived during the last step)
+            if (step + 2 < n_steps) fetch_idx(step + 2);
+        }
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             bf16x8 a[3][2], b[3][2];
