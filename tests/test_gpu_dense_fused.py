@@ -83,3 +83,24 @@ def test_fused_training_walks_the_trajectory_of_the_six_launch_sequence(monkeypa
     assert bool(fa.all()) and bool(fb.all())
     np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=2e-5)
     np.testing.assert_allclose(fused.params.cpu().numpy(), six.params.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[3]], ids=lambda s: "DS%d_B%d_P%d_C%d_N%d" % s)
+def test_sample_sums_inside_the_parameter_kernel_equal_the_epilogue_launch(shape, monkeypatch):
+    """dense_param_fold_kernel (every workgroup adds the value of the estimator itself) against dense_epilogue + dense_param_kernel
+    (BSVI_DENSE_FOLD=0): the same gradients bit for bit — they never pass through the folded sums — and the same value up to the
+    association of a 256- against a 1024-thread sum; the optimizer steps walk the same trajectory."""
+    api = W.native_api()
+    n = shape[4]
+    folded = engine.compile_model(build(api, shape), None, "pathwise")
+    monkeypatch.setenv("BSVI_DENSE_FOLD", "0")
+    two = engine.compile_model(build(api, shape), None, "pathwise")
+    ra, rb = folded.evaluate(n, seed=5, offset=1), two.evaluate(n, seed=5, offset=1)
+    torch.cuda.synchronize()
+    assert torch.equal(ra["grads"], rb["grads"])
+    assert abs(float(ra["loss"]) - float(rb["loss"])) <= 1e-6 * abs(float(rb["loss"]))
+    la, fa = folded.train(30, n, "Adam", lr=5e-3, seed=3)
+    lb, fb = two.train(30, n, "Adam", lr=5e-3, seed=3)
+    assert bool(fa.all()) and bool(fb.all())
+    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-6)
+    assert torch.equal(folded.params, two.params)
