@@ -470,6 +470,13 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         roofline["issue_us_per_iteration"] = issue["issue_us_per_iteration"]
         roofline["valu_per_wave_iteration"] = issue["valu_per_wave_iteration"]
         roofline["issue_waves_on_busiest_simd"] = issue["waves_on_busiest_simd"]
+        # round 5 (tools/r5/pk_rate.hip, profiles/r5/cfg1_wave_rate_notes.txt): ONE wave issues an independent VALU instruction every
+        # 3.14 ns (7.5 cycles at 2.4 GHz; 4.18 ns when it depends on the one before) whether or not a second wave shares its SIMD —
+        # the iteration is the instruction chain of one wave, and the figure above (two waves x 4 cycles) is the same number read
+        # the other way.  wave_chain_* prices the chain at the measured per-wave rate.
+        roofline["wave_ns_per_valu"] = 3.14
+        roofline["wave_chain_us_per_iteration"] = issue["valu_per_wave_iteration"] * 3.14e-3
+        roofline["wave_chain_frac"] = roofline["wave_chain_us_per_iteration"] / issue["measured_us_per_iteration"]
     if dense:
         # the whole iteration (6 launches) is timed; the two MFMA GEMMs are >80 % of it (profiles/)
         flops = dense_flops_per_iteration(program, n_per_gpu)
