@@ -866,12 +866,12 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {
         sb[i] = 3 * APL + plane * XPLANE + col * XLD + kq * 16;
     }
     const int n_steps = G.Kp / XBK;
-    // (the last step of a K that is not a multiple of 32 reads quads beyond the row: those come from a valid address and are zeroed)
+    // (the last step of a K that is not a multiple of 32 reads quads beyond the row: those come from a valid address and are zeroed
+    //  WHEN THEY ARE SPLIT.  Round 5: the select used to sit right behind the load — and the wave waited there, `s_waitcnt vmcnt`
+    //  in FRONT of the step's MFMAs, for the loads it had just requested: the whole L2 round trip exposed in every step.)
     auto lda4 = [&](int i, int step) {
         const bool ok = step * XBK + ka[i] < G.K;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ok ? pa[i] + step * XBK : pa[i]);
-        if (!ok) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        return v;
+        return *reinterpret_cast<const f32x4*>(ok ? pa[i] + step * XBK : pa[i]);
     };
     auto ldw = [&](uint32_t off, int step) { return *reinterpret_cast<const xu4*>(wbase + off + (size_t)step * (XBK * 2)); };
 
@@ -896,11 +896,12 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t h0, m0_, l0, h1, m1, l1;
+            const f32x4 v = (step * XBK + ka[i] < G.K) ? ra[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (DBG == 1) {
-                h0 = m0_ = l0 = __float_as_uint(ra[i][0]); h1 = m1 = l1 = __float_as_uint(ra[i][2]);
+                h0 = m0_ = l0 = __float_as_uint(v[0]); h1 = m1 = l1 = __float_as_uint(v[2]);
             } else {
-                x6_split2(ra[i][0], ra[i][1], h0, m0_, l0);
-                x6_split2(ra[i][2], ra[i][3], h1, m1, l1);
+                x6_split2(v[0], v[1], h0, m0_, l0);
+                x6_split2(v[2], v[3], h1, m1, l1);
             }
             *reinterpret_cast<x6_u2*>(lds + sa[i]) = x6_u2{h0, h1};
             *reinterpret_cast<x6_u2*>(lds + APL + sa[i]) = x6_u2{m0_, m1};
@@ -1036,8 +1037,19 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
             } else {
                 vb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_rsrc, vb_off, rr * b_row_bytes, 0));
             }
-            ra[i] = ok ? va : 0.0f;
-            rb[i] = ok ? vb : 0.0f;
+            // (rows beyond the slice are zeroed WHEN THEY ARE SPLIT, mask(): a select right behind the load is where the wave waits for
+            //  it — in front of the step's MFMAs, with the whole round trip exposed)
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+    auto mask = [&](int step) {
+        const int valid = r_end - (r_begin + step * XBK + 16 * kgs);      // (the same for a wave's threads)
+        if (valid >= 16) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ra[i] = i < valid ? ra[i] : 0.0f;
+            rb[i] = i < valid ? rb[i] : 0.0f;
         }
     };
     f32x16 acc[2][2];
@@ -1057,6 +1069,7 @@ __global__ __launch_bounds__(256, 2) void x6tn_kernel(const X6TnArgs G) {
     unsigned char* const sb = lds + 3 * APL + col * XLD + kg * 32;
     for (int step = 0; step < n_steps; ++step) {
         __syncthreads();                                   // the last step's reads of the stage are done
+        mask(step);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint32_t hi[4], mid[4], lo[4];
