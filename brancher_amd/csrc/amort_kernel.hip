@@ -2336,6 +2336,20 @@ int bsvi_xgemm_nt(const uint16_t* X, const int32_t* rows, const uint16_t* Wp, lo
     return BSVI_OK;
 }
 
+// the same product with the result TRANSPOSED: Ct[n][m] (leading dimension ldct >= M), the split-k form of the kernel with one split
+int bsvi_xgemm_nt_t(const uint16_t* X, const int32_t* rows, const uint16_t* Wp, long plane_stride, float* Ct, int ldct,
+                    int M, int N, int Kp, void* stream) {
+    if (Kp % bsvi_amort_impl::XBK != 0 || M <= 0 || N <= 0 || ldct < M) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_xgemm_nt_t: bad shape");
+    bsvi_amort_impl::XGemmArgs G{};
+    G.X = X; G.rows = rows; G.Wp = Wp; G.plane_stride = plane_stride; G.C = Ct; G.ldc = ldct; G.M = M; G.N = N; G.Kp = Kp;
+    G.steps_per_split = Kp / bsvi_amort_impl::XBK; G.part_stride = 0;
+    G.rows_fastest = 3L * N > (long)M ? 1 : 0;
+    const unsigned tiles = (unsigned)(((M + 127) / 128) * ((N + 127) / 128));
+    hipLaunchKernelGGL((bsvi_amort_impl::xgemm_nt_glds_kernel<128, true>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, G);
+    if (hipGetLastError() != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, "xgemm_nt_glds_kernel launch failed");
+    return BSVI_OK;
+}
+
 extern "C" int bsvi_amort_exact_data(const bsvi_amort* a) { return (a && a->data_exact) ? 1 : 0; }
 
 extern "C" void bsvi_amort_destroy(bsvi_amort* a) {

@@ -24,6 +24,8 @@ int bsvi_xgemm_nt(const uint16_t* X, const int32_t* rows, const uint16_t* Wp, lo
                   int M, int N, int Kp, void* stream);
 
 // amort_kernel.hip: C = A B^T (mode 0: B is [N][K]) or C = A B (mode 1: B is [K][N]) on the f32-input MFMA kernels, any shape
+int bsvi_xgemm_nt_t(const uint16_t* X, const int32_t* rows, const uint16_t* Wp, long plane_stride, float* Ct, int ldct,
+                    int M, int N, int Kp, void* stream);
 int bsvi_gemm_f32(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream);
 
 namespace bsvi_spec { struct Spec; }

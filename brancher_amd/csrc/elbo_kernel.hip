@@ -29,7 +29,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdarg.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 

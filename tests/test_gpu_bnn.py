@@ -127,3 +127,35 @@ def test_two_rank_step_sequence_equals_the_fused_step():
     assert a.last_mode == "stepwise" and b.last_mode == "stepwise"
     np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=1e-6)
     np.testing.assert_allclose(b.params.cpu().numpy(), a.params.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+@pytest.mark.parametrize("kw,n", [(EXAMPLE, 50),
+                                  (dict(dataset_size=40, batch_size=17, n_features=64, n_hidden=9, hidden2=6, n_classes=5, q_scale1=3e-3,
+                                        q_loc_scale=1.0, activation="relu"), 70)])
+def test_generated_middle_equals_the_separate_launches(kw, n, estimator, monkeypatch):
+    """Round 5: on exact data the upper layers, the likelihood, the reverse sweep, the pieces of d f / d a1 and the gradients of the small
+    tensors are ONE kernel generated for the network (bnn_mid_gen: a workgroup per sample, lanes along the minibatch rows), and the
+    per-(sample, row) kernel of the other data path is generated too (bnn_upper_gen).  Both against the generic kernels they replace
+    (BSVI_BNN_MID=0 / BSVI_BNN_JIT=0: bnn_upper + bnn_small + bnn_lik) on the same draws: the same arithmetic per (sample, row), sums
+    over the minibatch in another association — agreement to rounding; each form bit-reproducible."""
+    def outputs():
+        c = compile_bnn(estimator, **kw)
+        res = c.evaluate(n, seed=9, offset=2, want_fvalues=True)
+        torch.cuda.synchronize()
+        again = c.evaluate(n, seed=9, offset=2, want_fvalues=True)
+        torch.cuda.synchronize()
+        assert torch.equal(res["f"], again["f"]) and torch.equal(res["grads"], again["grads"])
+        return float(res["loss"]), res["f"].cpu().numpy().astype(np.float64), res["grads"].cpu().numpy().astype(np.float64)
+
+    gen = outputs()                                    # bnn_mid_gen
+    monkeypatch.setenv("BSVI_BNN_MID", "0")
+    upper_gen = outputs()                              # bnn_upper_gen + bnn_small + bnn_lik
+    monkeypatch.setenv("BSVI_BNN_JIT", "0")
+    generic = outputs()                                # bnn_upper + bnn_small + bnn_lik
+    fscale, gscale = np.abs(generic[1]).max(), max(np.abs(generic[2]).max(), 1e-6)
+    bb = estimator == "blackbox"
+    for other in (gen, upper_gen):
+        assert abs(other[0] - generic[0]) <= (2e-4 if bb else 2e-6) * abs(generic[0])
+        assert np.abs(other[1] - generic[1]).max() <= 2e-6 * fscale
+        assert np.abs(other[2] - generic[2]).max() <= (2e-4 if bb else 5e-6) * gscale
