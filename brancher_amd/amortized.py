@@ -19,6 +19,7 @@ live in the engine's flat parameter buffer in torch's layout; `sync_modules()` w
 """
 import ctypes as C
 import operator
+import os
 
 import numpy as np
 import torch
@@ -647,22 +648,62 @@ class CompiledAmortized:
         offset0 = self.iteration
         self.iteration += K
         self.grads_valid = True
-        for it in range(K):
-            nz = None if noise_seq is None else self._noise_tensor(noise_seq[it], base, n_local)
-            mb = None if minibatch_seq is None else self._indices_tensor(minibatch_seq[it], base, n_local)
-            args = self._args(n_local, number_samples, base, nz, mb, seed, offset0 + it)
-            mask = self.mask_all if it > pretraining_iterations else self.mask_first
-            native.check(self.lib.bsvi_amort_fwd_bwd(self.handle, C.byref(args)))
-            if world > 1 or _force_sharded_path:
-                engine.allreduce_sums(self.out)
-            native.check(self.lib.bsvi_finalize_step(
-                C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(mask), p.n_params,
-                number_samples * p.batch_size, C.c_void_p(loss_curve.data_ptr() + 4 * it),
-                C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
-        self.last_mode = "stepwise" if world == 1 else "stepwise+allreduce"
+        # Several ranks: the decoder's gradients are complete before the encoder's backward pass starts (bsvi_amort_bucket).  Their
+        # range of the output block is reduced by the library on a stream of its own and all-reduced THERE, beside the encoder's
+        # backward pass; the header and the other gradients follow at the end (BSVI_AMORT_BUCKETS=0: one all-reduce of the block).
+        pieces = self._bucket_pieces() if (world > 1 or _force_sharded_path) else None
+        if pieces is not None:
+            native.check(self.lib.bsvi_amort_set_bucket_stream(self.handle, C.c_void_p(self._bucket_stream.cuda_stream)))
+        try:
+            for it in range(K):
+                nz = None if noise_seq is None else self._noise_tensor(noise_seq[it], base, n_local)
+                mb = None if minibatch_seq is None else self._indices_tensor(minibatch_seq[it], base, n_local)
+                args = self._args(n_local, number_samples, base, nz, mb, seed, offset0 + it)
+                mask = self.mask_all if it > pretraining_iterations else self.mask_first
+                if pieces is not None:
+                    self._bucket_stream.wait_stream(torch.cuda.current_stream(dev))      # (the last step's finalize read the block)
+                native.check(self.lib.bsvi_amort_fwd_bwd(self.handle, C.byref(args)))
+                if pieces is not None:
+                    early, late = pieces
+                    with torch.cuda.stream(self._bucket_stream):
+                        engine.allreduce_sums(early)
+                    for piece in late:
+                        engine.allreduce_sums(piece)
+                    torch.cuda.current_stream(dev).wait_stream(self._bucket_stream)
+                elif world > 1 or _force_sharded_path:
+                    engine.allreduce_sums(self.out)
+                self._finalize_step(cfg, state, mask, number_samples * p.batch_size, loss_curve, finite, it)
+        finally:
+            if pieces is not None:
+                native.check(self.lib.bsvi_amort_set_bucket_stream(self.handle, None))
+        self.last_mode = ("stepwise" if world == 1 else "stepwise+allreduce") + ("+bucket" if pieces is not None else "")
         if world > 1:
             engine.check_exchange(self.device, self.params)         # (an abandoned exchange poisoned a step: say so, loudly)
         return loss_curve[:K], finite[:K]
+
+    def _bucket_pieces(self):
+        """(the decoder's range of the output block, [the rest as one or two views]) when the decoder's parameters are one range of
+        the parameter vector and the collective is torch.distributed's / RCCL's (the one-shot exchange takes whole blocks); else None"""
+        from brancher_amd import engine
+        if os.environ.get("BSVI_AMORT_BUCKETS", "1") == "0" or engine.collective_kind() not in ("torch", "rccl"):
+            return None
+        first, count = C.c_uint32(), C.c_uint32()
+        native.check(self.lib.bsvi_amort_bucket(self.handle, C.byref(first), C.byref(count)))
+        if not count.value:
+            return None
+        if getattr(self, "_bucket_stream", None) is None:
+            self._bucket_stream = torch.cuda.Stream(device=self.device)
+        lo, hi = native.OUT_HEADER + first.value, native.OUT_HEADER + first.value + count.value
+        late = [v for v in (self.out[:lo], self.out[hi:]) if v.numel()]
+        return self.out[lo:hi], late
+
+    def _finalize_step(self, cfg, state, mask, divisor, loss_curve, finite, it):
+        p = self.program
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        native.check(self.lib.bsvi_finalize_step(
+            C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(mask), p.n_params,
+            divisor, C.c_void_p(loss_curve.data_ptr() + 4 * it),
+            C.c_void_p(finite.data_ptr() + 4 * it), self._stream()))
 
 
 # every native call of a compiled program runs with its device current (engine._bound_to_device)

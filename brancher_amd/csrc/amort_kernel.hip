@@ -2119,6 +2119,14 @@ struct bsvi_amort {
     struct X6Layer { uint16_t* nt = nullptr; uint16_t* nn = nullptr; int kp_nt = 0, kp_nn = 0; };
     std::vector<X6Layer> x6[2];         // [0] encoder, [1] decoder
     bool x6_any = false;
+    // Several ranks (round 5): the backward pass finishes the DECODER's gradients first.  When the host names a bucket stream
+    // (bsvi_amort_set_bucket_stream) the reduction of the decoder's partial sums is launched THERE as soon as the decoder's weight
+    // gradients are in flight, and the host's all-reduce of that range of the output block — the decoder's parameters are one
+    // contiguous range [bucket_first, bucket_first + bucket_count) of the parameter vector when this is set — follows it on that
+    // stream, beside the encoder's backward pass; the rest of the block is reduced at the end as always.
+    hipStream_t bucket_stream = nullptr;
+    hipEvent_t bucket_ev[2] = {nullptr, nullptr};
+    uint32_t bucket_first = 0, bucket_count = 0;
 };
 
 static int pad4(int n) { return (n + 3) / 4 * 4; }
@@ -2314,6 +2322,23 @@ extern "C" int bsvi_amort_create(const bsvi_amort_desc* desc, bsvi_amort** out) 
         bool exact = true;
         for (const auto& sp : spans) { exact = exact && sp.first == at; at = sp.first + sp.second; }
         a->layers_cover_params = exact && at == (size_t)desc->n_params;
+        // the decoder's parameters (and the likelihood's scale, whose gradient is complete with them) as ONE range nothing else lies in
+        size_t lo = SIZE_MAX, hi = 0;
+        auto take = [&](size_t off, size_t n) { lo = std::min(lo, off); hi = std::max(hi, off + n); };
+        for (const auto& l : a->dec.layers) {
+            take(l.weight_off, (size_t)l.n_in * l.n_out);
+            if (l.bias_off != 0xFFFFFFFFu) take(l.bias_off, l.n_out);
+        }
+        if (desc->lik_scale_off != BSVI_AMORT_CONSTANT) take(desc->lik_scale_off, desc->lik_scale_size);
+        bool alone = lo < hi;
+        auto outside = [&](size_t off, size_t n) { if (off < hi && off + n > lo) alone = false; };
+        for (const auto& l : a->enc.layers) {
+            outside(l.weight_off, (size_t)l.n_in * l.n_out);
+            if (l.bias_off != 0xFFFFFFFFu) outside(l.bias_off, l.n_out);
+        }
+        for (uint32_t off : {desc->prior_loc_off, desc->prior_scale_off})
+            if (off != BSVI_AMORT_CONSTANT) outside(off, Dz);
+        if (alone) { a->bucket_first = (uint32_t)lo; a->bucket_count = (uint32_t)(hi - lo); }
     }
     a->d.enc_layers = a->enc.layers.data();
     a->d.dec_layers = a->dec.layers.data();
@@ -2369,6 +2394,8 @@ extern "C" void bsvi_amort_destroy(bsvi_amort* a) {
         if (e) (void)hipEventDestroy(e);
     if (a->joined) (void)hipEventDestroy(a->joined);
     if (a->side) (void)hipStreamDestroy(a->side);
+    for (auto e : a->bucket_ev)
+        if (e) (void)hipEventDestroy(e);
     delete a;
 }
 
@@ -3145,6 +3172,31 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     }
     rc = backward(a->dec, false, true);
     if (rc) return rc;
+    // several ranks: the decoder's partial sums are reduced NOW, on the host's bucket stream (behind the kernels that write them, on
+    // either stream), so that its all-reduce can run beside the encoder's backward pass
+    uint64_t early_mask = 0;                    // segments reduced on the bucket stream (those of the decoder's range that exist by now)
+    if (a->bucket_stream && a->bucket_count) {
+        SegmentTable early{};
+        uint32_t early_blocks = 0;
+        for (int k = 0; k < segments.n && k < 64; ++k) {
+            const float* const dst = segments.seg[k].dst;
+            if (dst < grads + a->bucket_first || dst >= grads + a->bucket_first + a->bucket_count) continue;
+            Segment& S = early.seg[early.n++];
+            S = segments.seg[k];
+            S.first_block = early_blocks;
+            early_blocks += segment_blocks(S);
+            early_mask |= 1ull << k;
+        }
+        if (early.n) {
+            HIP_TRY(hipEventRecord(a->bucket_ev[0], stream));
+            HIP_TRY(hipStreamWaitEvent(a->bucket_stream, a->bucket_ev[0], 0));
+            if (a->overlap) {
+                HIP_TRY(hipEventRecord(a->bucket_ev[1], a->side));
+                HIP_TRY(hipStreamWaitEvent(a->bucket_stream, a->bucket_ev[1], 0));
+            }
+            hipLaunchKernelGGL(reduce_partials, dim3(early_blocks), dim3(256), 0, a->bucket_stream, early);
+        }
+    }
     hipLaunchKernelGGL(amort_latent_bwd, row_grid, dim3(256), 0, stream, D);
     if (xt_pending) { launch_xt(stream); xt_pending = false; }       // (no side stream: BSVI_AMORT_OVERLAP=0)
     rc = backward(a->enc, true, false);
@@ -3153,8 +3205,38 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
         HIP_TRY(hipEventRecord(a->joined, a->side));
         HIP_TRY(hipStreamWaitEvent(stream, a->joined, 0));
     }
-    hipLaunchKernelGGL(reduce_partials, dim3(reduce_blocks), dim3(256), 0, stream, segments);
+    if (early_mask) {                           // (the decoder's segments went out on the bucket stream)
+        SegmentTable rest{};
+        uint32_t rest_blocks = 0;
+        for (int k = 0; k < segments.n; ++k) {
+            if (k < 64 && ((early_mask >> k) & 1ull)) continue;
+            Segment& S = rest.seg[rest.n++];
+            S = segments.seg[k];
+            S.first_block = rest_blocks;
+            rest_blocks += segment_blocks(S);
+        }
+        if (rest.n) hipLaunchKernelGGL(reduce_partials, dim3(rest_blocks), dim3(256), 0, stream, rest);
+    } else {
+        hipLaunchKernelGGL(reduce_partials, dim3(reduce_blocks), dim3(256), 0, stream, segments);
+    }
     HIP_TRY(hipGetLastError());
+    return BSVI_OK;
+}
+
+// the decoder's parameters as one range of the parameter vector (count 0: they are not one), and the stream on which their
+// gradients are to be complete early (NULL: everything is reduced by one launch at the end of bsvi_amort_fwd_bwd, the default)
+extern "C" int bsvi_amort_bucket(const bsvi_amort* a, uint32_t* first_param, uint32_t* n_params) {
+    if (!a || !first_param || !n_params) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    *first_param = a->bucket_first;
+    *n_params = a->bucket_count;
+    return BSVI_OK;
+}
+extern "C" int bsvi_amort_set_bucket_stream(bsvi_amort* a, void* stream) {
+    if (!a) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    if (stream && !a->bucket_count) return bsvi_fail(BSVI_ERR_UNSUPPORTED, "the decoder's parameters are not one range of the parameter vector");
+    for (auto& e : a->bucket_ev)
+        if (stream && !e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, "hipEventCreate");
+    a->bucket_stream = (hipStream_t)stream;
     return BSVI_OK;
 }
 

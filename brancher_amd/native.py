@@ -223,6 +223,8 @@ EXPORTS.update({
     "bsvi_amort_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32]),
     "bsvi_amort_exact_data": (C.c_int, [C.c_void_p]),
     "bsvi_amort_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(AmortArgs)]),
+    "bsvi_amort_bucket": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "bsvi_amort_set_bucket_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsvi_amort_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "bsvi_debug_gemm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,

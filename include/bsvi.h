@@ -692,6 +692,17 @@ int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* args);
 int bsvi_amort_apply(const bsvi_amort* a, int network, const float* params_dev, const float* input_dev, uint32_t n_rows,
                      uint32_t value, float* out_dev, void* workspace_dev, void* stream);
 
+/* Several ranks: the gradients of the DECODER complete early.  The backward pass of bsvi_amort_fwd_bwd finishes the decoder's
+ * weight gradients before it starts on the encoder's.  bsvi_amort_bucket reports the decoder's parameters (and the likelihood's
+ * scale) as one range [first_param, first_param + n_params) of the parameter vector (n_params = 0: they are not one range).  With a
+ * bucket stream set, bsvi_amort_fwd_bwd reduces that range's partial sums on THAT stream as soon as the kernels producing them are
+ * in flight (the stream waits for them through events), so that the host's all-reduce of out[4 + first_param ...] — enqueued on the
+ * bucket stream right after the call — runs beside the encoder's backward pass; everything else is reduced at the end of the call on
+ * args->stream as always.  The caller joins the two streams before bsvi_finalize_step.  NULL (the default): one reduction at the end.
+ * What torch.distributed's bucketed all-reduce does for the reference's PyTorch modules under DistributedDataParallel. */
+int bsvi_amort_bucket(const bsvi_amort* a, uint32_t* first_param, uint32_t* n_params);
+int bsvi_amort_set_bucket_stream(bsvi_amort* a, void* stream);
+
 /* Test hook: one launch of the f32 MFMA GEMM behind the amortised path.
  * mode 0: C[M][N] = A[M][K] B[N][K]^T   (+ bias[n], activation)        forward
  * mode 1: C[M][N] = A[M][K] B[K][N]     (* activation'(Y[m][n]))      backward-data

@@ -562,6 +562,27 @@ def test_vae_sharded_path_matches_single():
     assert np.abs(out[1][1] - out[0][1]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("kw,n", [(dict(dataset_size=60, batch_size=10, n_features=30, hidden1=20, hidden2=12, seed=4), 8),
+                                  (dict(dataset_size=400, batch_size=50, n_features=784, hidden1=512, hidden2=256, seed=3), 16)])
+def test_decoder_bucket_is_reduced_early_and_changes_nothing(kw, n, monkeypatch):
+    """on several ranks the decoder's range of the output block is reduced on a bucket stream as soon as the
+    decoder's weight gradients are in flight, and all-reduced there beside the encoder's backward pass (bsvi_amort_bucket /
+    bsvi_amort_set_bucket_stream).  The rank's sequence on one GPU (`_force_sharded_path`: the all-reduce of one rank is the
+    identity), with and without the bucket: the same sums from the same partials — bit-identical trajectories."""
+    from brancher_amd import engine, workloads as W
+    out = []
+    for buckets in ("1", "0"):
+        monkeypatch.setenv("BSVI_AMORT_BUCKETS", buckets)
+        model = W.build_vae(W.native_api(), **kw)
+        compiled = engine.compile_model(model, model.posterior_model, "pathwise")
+        losses, finite = compiled.train(6, n, "Adam", seed=7, lr=1e-3, _force_sharded_path=True)
+        torch.cuda.synchronize()
+        assert bool(finite.all())
+        assert ("+bucket" in compiled.last_mode) == (buckets == "1"), compiled.last_mode
+        out.append((losses.cpu().numpy(), compiled.params.cpu().numpy().copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_vae_decode_and_encode_match_the_torch_modules():
     """posterior-predictive step of examples/VAE_playground.py:90-103: the networks applied to caller-supplied rows"""
     from brancher_amd import engine, workloads as W
