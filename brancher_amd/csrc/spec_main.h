@@ -369,11 +369,25 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
 #if SPEC_TILE && SPEC_KEEP_NOISE && SPEC_KEEP_NOISE <= 68 && !SPEC_GENERIC_OWNERS && !SPEC_DIAG && !SPEC_ACCUMULATE_CHUNKS \
     && !defined(SPEC_DEBUG_NO_DRAW) && !defined(SPEC_NO_EARLY_DRAW) && !defined(SPEC_DEBUG_LATE_FREE) && defined(SPEC_WITH_DRAW_WAVE)
 #define SPEC_DRAW_WAVE 1
-    const bool has_draw_wave = mode == SPEC_MODE_LOOP && G == 1u && W >= 2u && (SPEC_A->n_local + 63u) / 64u < W;
+    const uint32_t WSN = (SPEC_A->n_local + 63u) / 64u;     // waves that carry samples
+    const bool has_draw_wave = mode == SPEC_MODE_LOOP && G == 1u && W >= 2u && WSN < W;
     const uint32_t fed_index = W == 2u ? 0u : 1u;         // the owners' wave, as without a draw wave (SPEC_OWNER_WAVE)
-    const bool draw_wave = __builtin_amdgcn_readfirstlane((has_draw_wave && wave == W - 1u) ? 1 : 0) != 0;
-    const bool fed_wave = __builtin_amdgcn_readfirstlane((has_draw_wave && wave == fed_index) ? 1 : 0) != 0;
-    float* const NZ = spec_lds + SPEC_OFF_TR + (W - 1u) * SPEC_TR_FLOATS + lane;
+    // The draw SERVICE (round 5): five sample waves and three draw waves.  One wave issues a vector instruction every ~3.1 ns whether
+    // or not a second wave shares its SIMD (profiles/r5/cfg1_wave_rate_notes.txt), so an iteration is the chain of one wave: body,
+    // flush, sums — barrier — the owners' epilogue; with five sample waves the owners' wave also had to draw its own next noise in
+    // front of that barrier (470 of its 1 650 instructions), and two late draws on one SIMD took longer than the epilogue they ran
+    // beside (the Philox multiplies and the transcendentals are quarter-rate: a draw is 1.5 us of a SIMD's pipe).  Here NO sample wave
+    // draws after the first iteration: the extra waves draw for all of them — draw wave k one set for sample wave k while the bodies
+    // run (kept in registers, stored behind the barrier: a sample wave reads its buffer at the top of its body), and, when there are
+    // more sample waves than draw waves, a second set beside the epilogue unless it sits on the owners' SIMD — into one buffer per
+    // sample wave in the draw waves' own, otherwise unused, transpose tiles.  (300 samples: waves 5, 6, 7 for 0 | 1, 3 | 2, 4.)
+    // The draws are functions of (seed, offset, sample, row): who computes them does not change a bit.
+    const bool draw_service = has_draw_wave && W - WSN >= 3u;      // (three or more extra waves: the host asked for the service)
+    const bool draw_wave = __builtin_amdgcn_readfirstlane((has_draw_wave && (draw_service ? wave >= WSN : wave == W - 1u)) ? 1 : 0) != 0;
+    const bool fed_wave = __builtin_amdgcn_readfirstlane((has_draw_wave && (draw_service ? wave < WSN : wave == fed_index)) ? 1 : 0) != 0;
+    // (one wave's set: SPEC_KEEP_NOISE rows of 64 lanes; the service's five buffers lie in the three draw waves' tiles)
+    float* const NZ = spec_lds + SPEC_OFF_TR + (draw_service ? WSN * SPEC_TR_FLOATS + wave * (SPEC_KEEP_NOISE * 64u) : (W - 1u) * SPEC_TR_FLOATS) + lane;
+    float* const NZB = spec_lds + SPEC_OFF_TR + WSN * SPEC_TR_FLOATS + lane;           // (service: buffer w at NZB + w * SPEC_KEEP_NOISE * 64)
     if (draw_wave) for (uint32_t k = lane; k < SPEC_WS_PAD; k += 64u) WSw[k] = 0.0f;     // its row of sums stays zero
 #else
 #define SPEC_DRAW_WAVE 0
@@ -480,6 +494,51 @@ extern "C" __global__ void __launch_bounds__(SPEC_BOUND_THREADS) SPEC_VGPR_ATTR 
     bool noise_ready = false;
 #else
 #define SPEC_EARLY_DRAW 0
+#endif
+#if SPEC_DRAW_WAVE
+    if (draw_service && draw_wave) {
+        // The service's draw waves run a loop of their OWN with the main loop's two barriers per iteration (a set drawn beside the
+        // bodies would otherwise be live across spec_body in the register allocation of EVERY wave: 15 spilled registers and
+        // 4.7 -> 6.5 us per iteration for every user of this kernel variant).  Their rows of the sums stay zero.
+        if (lane == 0u) { RED[8 + 2 * wave] = 0.0f; RED[9 + 2 * wave] = 0.0f; }
+        const uint32_t n_draw = W - WSN, k = wave - WSN;
+        const uint32_t first = k;                              // (k < WSN or nothing: `has_first`)
+        uint32_t before = 0;                                   // draw waves in front of this one that take a second set
+        for (uint32_t j = 0; j < k; ++j) before += (((WSN + j) & 3u) != 1u) ? 1u : 0u;
+        const uint32_t second = n_draw + before;
+        const bool has_first = first < WSN, has_second = (wave & 3u) != 1u && second < WSN;      // (wave & 3 == 1: the owners' SIMD)
+        auto draw_for = [&](uint32_t target, unsigned long long offn, SpecNoise& Zd) {
+            SpecLane Tn = T;
+            Tn.n = target * 64u + lane;
+            Tn.active = Tn.n < B0.n_local;
+            Tn.nc = Tn.active ? Tn.n : (B0.n_local - 1u);
+            Tn.nidx = sample_base + Tn.nc;
+            Tn.off_lo = (uint32_t)offn;
+            Tn.off_hi = (uint32_t)(offn >> 32);
+            Tn.vz = T.vz;
+            spec_draw(B0, Tn, Zd);
+        };
+        for (uint32_t it = 0; it < n_it; ++it) {
+            const bool more = it + 1u < n_it;
+            spec_lds_barrier();                                // (the main loop's first barrier: the sample waves read their buffers behind it)
+            SpecNoise Za;
+            if (more && has_first) draw_for(first, off0 + it + 1u, Za);     // beside the bodies, in registers
+            spec_lds_barrier();                                // (the second: the buffers are free)
+            if (more) {
+                if (has_first) {
+#pragma unroll
+                    for (uint32_t r = 0; r < SPEC_KEEP_NOISE; ++r) NZB[first * (SPEC_KEEP_NOISE * 64u) + 64u * r] = Za.z[r];
+                }
+                if (has_second) {
+                    SpecNoise Zb;
+                    draw_for(second, off0 + it + 1u, Zb);
+#pragma unroll
+                    for (uint32_t r = 0; r < SPEC_KEEP_NOISE; ++r) NZB[second * (SPEC_KEEP_NOISE * 64u) + 64u * r] = Zb.z[r];
+                }
+            }
+        }
+        return;
+    }
 #endif
     for (uint32_t it = 0; it < n_it; ++it) {
         SPEC_STAMP(0);

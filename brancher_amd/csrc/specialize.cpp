@@ -1039,11 +1039,15 @@ static int ensure_compiled(Spec* s, int v) {
 // ---------------------------------------------------------------------------------------------------------------
 //  launch
 // ---------------------------------------------------------------------------------------------------------------
-struct Geo { uint32_t blocks, threads; int geom; bool draw_wave = false; };
+struct Geo { uint32_t blocks, threads; int geom; bool draw_wave = false; uint32_t extra_waves = 0; };
 // The in-kernel loop is given one wave more than the samples need: it carries no samples and draws the next iteration's
 // normals of the owners' wave, whose chain — draw, body, sums, epilogue — is what an iteration takes (spec_main.h).
 static bool draw_wave() {
     const char* e = getenv("BSVI_SPEC_DRAW_WAVE");        // (read per call: the tests switch it within a process)
+    return !(e && e[0] == '0');
+}
+static bool draw_service() {
+    const char* e = getenv("BSVI_SPEC_DRAW_SERVICE");     // (read per call: the tests switch it within a process)
     return !(e && e[0] == '0');
 }
 static Geo geo(const Spec* s, uint32_t n_local, int mode = MODE_SUMS, bool exchange = false) {
@@ -1052,7 +1056,15 @@ static Geo geo(const Spec* s, uint32_t n_local, int mode = MODE_SUMS, bool excha
         // (up to four sample waves — one per SIMD: beyond that two of them share a SIMD and their draws set the pace, not the owners' chain)
         const bool extra = mode == MODE_LOOP && s->draw_wave_ok && draw_wave() && waves <= 4 && waves + 1 <= s->geom[GEOM_ONE].max_threads / 64
                            && !s->variant[exchange ? 5 : 4].failed;
-        return Geo{1, (waves + (extra ? 1u : 0u)) * 64, GEOM_ONE, extra};
+        // four or five sample waves: four / three draw waves draw for ALL of them (spec_main.h, the draw service; BSVI_SPEC_DRAW_SERVICE=0:
+        // the single draw wave up to four sample waves, none at five); the sets are handed over in the draw waves' transpose tiles.
+        // (Three sample waves: 3.89 us with the single draw wave, 3.94 with the service; one and two: the single draw wave.)
+        const uint32_t n_service = waves == 4 ? 4u : 3u;
+        const bool service = mode == MODE_LOOP && s->draw_wave_ok && draw_wave() && draw_service() && waves >= 4 && waves <= 5
+                             && waves + n_service <= s->geom[GEOM_ONE].max_threads / 64 && (size_t)s->n_noise * 64u * waves <= (size_t)n_service * 64u * 68u
+                             && !s->variant[exchange ? 5 : 4].failed;
+        const uint32_t more = service ? n_service : extra ? 1u : 0u;
+        return Geo{1, (waves + more) * 64, GEOM_ONE, more != 0u, more};
     }
     // many samples: 256-thread workgroups (one wave per SIMD), two per CU at most; beyond that every workgroup walks
     // several chunks of 256 samples
@@ -1110,7 +1122,7 @@ int launch(Spec* s, const bsvi_program* p, const Launch& L) {
             v = 5;
         }
         else if (g.draw_wave && v == 0 && ensure_compiled(s, 4) == BSVI_OK) v = 4;
-        else if (g.draw_wave) { g.threads -= 64; g.draw_wave = false; }        // (diagnostic kernel, or the variant did not compile)
+        else if (g.draw_wave) { g.threads -= 64 * g.extra_waves; g.draw_wave = false; }        // (diagnostic kernel, or the variant did not compile)
         const int rc = ensure_compiled(s, v);
         if (rc) return rc;
         seq = s->launch_seq++;

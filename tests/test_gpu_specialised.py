@@ -35,10 +35,12 @@ def test_default_engine_is_the_specialised_kernel():
     c = engine.compile_model(W.build_readme_ar(W.native_api(), T=20), None, "pathwise")
     for mode in (0, 1, 2):
         info = c.native.engine(300, mode)
-        assert info["engine"] == "specialised" and info["n_blocks"] == 1 and info["n_threads"] == 320
-    # up to four sample waves the in-kernel loop (mode 2) has one wave more than the samples need: it draws for the owners' wave
-    for n, waves in ((50, 1), (128, 2), (256, 4)):
-        assert c.native.engine(n, 1)["n_threads"] == 64 * waves and c.native.engine(n, 2)["n_threads"] == 64 * (waves + 1)
+        # (round 5: the in-kernel loop of five sample waves runs with three draw waves that draw for all five)
+        assert info["engine"] == "specialised" and info["n_blocks"] == 1 and info["n_threads"] == (512 if mode == 2 else 320)
+    # up to three sample waves the in-kernel loop (mode 2) has one wave more than the samples need: it draws for the owners' wave;
+    # four sample waves get four draw waves, five get three (the draw service: no sample wave draws after the first iteration)
+    for n, waves, extra in ((50, 1, 1), (128, 2, 1), (192, 3, 1), (256, 4, 4), (300, 5, 3)):
+        assert c.native.engine(n, 1)["n_threads"] == 64 * waves and c.native.engine(n, 2)["n_threads"] == 64 * (waves + extra)
     many = c.native.engine(262144, 1)
     assert many["engine"] == "specialised" and many["n_threads"] == 256 and many["n_blocks"] <= 512
     # (round 4: the in-kernel loop also runs over several workgroups — workgroup 0 owns the iteration)
@@ -104,11 +106,12 @@ def test_in_kernel_loop_equals_launch_per_iteration(optimizer, kw):
         assert np.abs(params[other] - params[0]).max() <= 2e-5
 
 
-@pytest.mark.parametrize("n", [50, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("n", [50, 64, 100, 128, 200, 256, 257, 300, 320])
 @pytest.mark.parametrize("optimizer,kw", [("SGD", dict(lr=1e-3)), ("Adam", dict(lr=1e-2))])
 def test_draw_wave_loop_equals_plain_loop(n, optimizer, kw, monkeypatch):
-    """the loop kernel with the extra wave that draws for the owners' wave (up to four sample waves) against the same loop
-    without it and against launch-per-iteration: the draws depend on (seed, offset, sample, row) only — bit-identical curves"""
+    """the loop kernel with the extra wave that draws for the owners' wave (up to four sample waves), or — five sample waves, BASELINE
+    config 1 — with the three draw waves that draw for all of them (the draw service), against the same loop without and against
+    launch-per-iteration: the draws depend on (seed, offset, sample, row) only — bit-identical curves"""
     curves = []
     for env, opts in (("1", dict()), ("0", dict()), ("1", dict(allow_persistent=False))):
         monkeypatch.setenv("BSVI_SPEC_DRAW_WAVE", env)
