@@ -136,13 +136,14 @@ def issue_roofline(rows, kernel_substrings, grid, n_samples, iterations, us_per_
     """roofline.issue of a latency-bound config: the vector instructions ONE wave issues per iteration (SQ_INSTS_VALU of
     the launch / its waves / its iterations, from this run's own counter pass) x 4 cycles of issue each
     (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') x the waves that share the busiest SIMD, at the 2.4 GHz peak
-    clock, against the measured iteration.  The sample shard runs as ceil(n / 64) waves on ONE CU's four SIMDs."""
+    clock, against the measured iteration.  The launch is ONE workgroup on one CU's four SIMDs: `grid` / 64 waves — the
+    sample waves and, in the in-kernel loop, the draw waves beside them (round 5: eight waves at 300 samples)."""
     sel = [r for r in (rows or []) if r["counter"] == "SQ_INSTS_VALU" and any(k in r["kernel"] for k in kernel_substrings)
            and (grid is None or r["grid"] == grid)]
     if not sel:
         return None
     insts = sel[-1]["value"] if last_only else sum(r["value"] for r in sel) / len(sel)
-    waves = (n_samples + 63) // 64
+    waves = max((n_samples + 63) // 64, int(grid) // 64 if grid else 0)
     per_wave_iter = insts / waves / max(iterations, 1)
     busiest = (waves + 3) // 4
     issue_us = per_wave_iter * 4.0 * busiest / 2400.0
@@ -473,7 +474,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         # round 5 (tools/r5/pk_rate.hip, profiles/r5/cfg1_wave_rate_notes.txt): ONE wave issues an independent VALU instruction every
         # 3.14 ns (7.5 cycles at 2.4 GHz; 4.18 ns when it depends on the one before) whether or not a second wave shares its SIMD —
         # the iteration is the instruction chain of one wave, and the figure above (two waves x 4 cycles) is the same number read
-        # the other way.  wave_chain_* prices the chain at the measured per-wave rate.
+        # the other way.  wave_chain_* prices the MEAN wave's instructions at the measured per-wave rate (with the draw service the
+        # launch's waves differ: sample waves ~830 + the owners' ~400 of epilogue, draw waves 470-940).
         roofline["wave_ns_per_valu"] = 3.14
         roofline["wave_chain_us_per_iteration"] = issue["valu_per_wave_iteration"] * 3.14e-3
         roofline["wave_chain_frac"] = roofline["wave_chain_us_per_iteration"] / issue["measured_us_per_iteration"]
