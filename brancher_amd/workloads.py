@@ -586,7 +586,9 @@ def build_bayesian_neural_network(api, dataset_size=48, batch_size=30, n_feature
     tanh saturates and every gradient of the first layer vanishes: the fixtures use a scale that keeps the units alive);
     q_loc_scale: posterior means drawn at that many posterior scales from zero; hidden2 > 0: a second hidden layer."""
     BF = api.BF
-    X, labels = logreg_data(dataset_size, n_features, n_classes, seed, pixels)
+    X, labels = logreg_data(dataset_size, n_features, max(n_classes, 2), seed, pixels)
+    if n_classes == 1:
+        labels = labels.astype(np.float32).reshape(-1, 1)          # (0 / 1, as minibatch_logistic_regression.py:20 stores them)
     rng = np.random.RandomState(seed + 7)
     act = getattr(BF, activation)
     indices = api.RandomIndices(dataset_size=dataset_size, batch_size=batch_size, name="indices", is_observed=True)
@@ -605,7 +607,9 @@ def build_bayesian_neural_network(api, dataset_size=48, batch_size=30, n_feature
                                          "b%d" % l, learnable=True))
         q_vars.append(api.NormalVariable(q_loc_scale * sw * rng.normal(0., 1., (rows, cols)), sw * np.ones((rows, cols)),
                                          "weights%d" % l, learnable=True))
-    k = api.CategoricalVariable(logits=layer, name="k")
+    # (n_classes = 1: a Bernoulli likelihood on one logit, `BinomialVariable(1, logits=...)` as in
+    #  examples/minibatch_logistic_regression.py:27 — the labels are then 0 / 1)
+    k = api.CategoricalVariable(logits=layer, name="k") if n_classes > 1 else api.BinomialVariable(1, logits=layer, name="k")
     model = api.ProbabilisticModel([k])
     k.observe(y)
     model.set_posterior_model(api.ProbabilisticModel(q_vars))

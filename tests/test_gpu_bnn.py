@@ -28,7 +28,9 @@ def compile_bnn(estimator="pathwise", **kw):
                                   (dict(dataset_size=40, batch_size=17, n_features=64, n_hidden=9, hidden2=6, n_classes=5, q_scale1=3e-3,
                                         q_loc_scale=1.0, activation="relu"), 70),                       # three layers, ragged sizes
                                   (dict(dataset_size=40, batch_size=33, n_features=36, n_hidden=5, n_classes=3, q_scale1=5e-3,
-                                        q_loc_scale=1.0, activation="sigmoid"), 130)])
+                                        q_loc_scale=1.0, activation="sigmoid"), 130),
+                                  (dict(dataset_size=64, batch_size=24, n_features=48, n_hidden=7, n_classes=1, q_scale1=2e-3,
+                                        q_loc_scale=1.0), 90)])                                          # one logit: Binomial(1, logits=...)
 def test_philox_path_matches_the_oracle_on_the_reported_draws(kw, n, estimator):
     """noise and minibatch drawn on the device, reported by the kernels and replayed by the oracle in double precision; the bound is
     the suite's yardstick — as close to it as the reference arithmetic (the oracle in single precision) is (x4), or 1e-5 of the scale"""
@@ -132,7 +134,9 @@ def test_two_rank_step_sequence_equals_the_fused_step():
 @pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
 @pytest.mark.parametrize("kw,n", [(EXAMPLE, 50),
                                   (dict(dataset_size=40, batch_size=17, n_features=64, n_hidden=9, hidden2=6, n_classes=5, q_scale1=3e-3,
-                                        q_loc_scale=1.0, activation="relu"), 70)])
+                                        q_loc_scale=1.0, activation="relu"), 70),
+                                  (dict(dataset_size=64, batch_size=24, n_features=48, n_hidden=7, n_classes=1, q_scale1=2e-3,
+                                        q_loc_scale=1.0), 90)])
 def test_generated_middle_equals_the_separate_launches(kw, n, estimator, monkeypatch):
     """Round 5: on exact data the upper layers, the likelihood, the reverse sweep, the pieces of d f / d a1 and the gradients of the small
     tensors are ONE kernel generated for the network (bnn_mid_gen: a workgroup per sample, lanes along the minibatch rows), and the
