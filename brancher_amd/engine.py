@@ -128,6 +128,31 @@ def loop_exchange(out):
     return ex or None
 
 
+def module_links_of(*models):
+    """every `torch.nn.Module` link (functions.ModuleLink) the models' link expressions call, once each"""
+    from brancher_amd import symbolic as sym
+    from brancher_amd.functions import ModuleLink
+    found = []
+
+    def walk(e):
+        if not isinstance(e, sym.Expr):
+            return
+        if e.op == "call" and isinstance(e.attr[0], ModuleLink) and e.attr[0] not in found:
+            found.append(e.attr[0])
+        for a in e.args:
+            walk(a)
+
+    for model in models:
+        if model is None:
+            continue
+        for v in model.flatten():
+            link = getattr(v, "link", None)
+            if link is not None and hasattr(link, "expressions"):
+                for l in link.expressions().values():
+                    walk(getattr(l, "expr", None))
+    return found
+
+
 def allreduce_sums(out):
     """The ONE collective of the multi-GPU path: sum the per-rank output blocks
     [loss sum, non-finite count, -, -, gradient sums...] over the sample shards.

@@ -37,7 +37,10 @@ class ModuleLink:
         self.module = module
         ModuleLink._count += 1
         self.name = "{}#{}".format(name, ModuleLink._count)
-        self.named = {pname: Parameter(p.detach().cpu().numpy(), name="{}.{}".format(self.name, pname))
+        # (the tensors are named after the function's name when it was given one — `BrancherFunction(net, name="net")` ->
+        #  "net.0.weight" — so that parameters and gradients can be addressed by name; anonymous functions keep the counter)
+        prefix = self.name if "?" in name else name
+        self.named = {pname: Parameter(p.detach().cpu().numpy(), name="{}.{}".format(prefix, pname))
                       for pname, p in module.named_parameters()}
 
     def parameters(self):

@@ -80,6 +80,10 @@ def perform_inference(joint_model, number_iterations, number_samples=1,
         warnings.warn("Numerical error, skipping sample")
     joint_model.diagnostics.update({"loss curve": np.array(losses)})
     inference_method.post_process(joint_model)
+    # torch modules used as links are trained IN PLACE by the reference (their nn.Parameters belong to the optimizers,
+    # `optimizers.py:36-49`); here their tensors live in the engine's parameter buffer: written back
+    for link in engine.module_links_of(joint_model, posterior_model):
+        link.sync_to_module()
 
 
 class InferenceMethod(ABC):

@@ -197,6 +197,18 @@ class Program:
                     estimator=self.estimator)
 
 
+class _ModuleTensor:
+    """One tensor of a ModuleLink seen by the program as a learnable root: what `uniform_entries` / `group_of` read of a
+    RootVariable.  Never sampled, never observed; belongs to the joint model's parameter group (`optimizers.py:36-49`)."""
+    learnable = True
+    value = None
+
+    def __init__(self, link, pname):
+        self.link, self.pname = link, pname
+        self.parameter = link.named[pname]
+        self.name = "%s.%s" % (link.name, pname)
+
+
 class _Lowering:
     def __init__(self, joint, posterior, estimator):
         if estimator not in EST:
@@ -218,6 +230,7 @@ class _Lowering:
         self.uni_param = []        # provisional uniform entries (param-sourced)
         self.uni_const = []
         self.uni_index = {}        # (kind, id/ key, transform, a, b) -> (is_param, local k0)
+        self.module_roots = {}     # (id(ModuleLink), tensor name) -> _ModuleTensor
         self.code = []             # list of instructions with symbolic operands
         self.records = []
         self.derived = {}          # IR key -> derived slot base
@@ -279,6 +292,9 @@ class _Lowering:
         if e.op == "call":
             fn, kwargs = e.attr
             if not isinstance(fn, str):
+                from brancher_amd.functions import ModuleLink
+                if isinstance(fn, ModuleLink) and len(e.args) == 1 and isinstance(e.args[0], sym.Expr) and not kwargs:
+                    return self.module_call(fn, self.from_expr(e.args[0], ctx))
                 raise LoweringError("user callables / nn.Modules inside links are not lowered to the fused "
                                     "kernel yet: %r" % (fn,))
             if fn in ("sum", "transpose") and e.args:
@@ -332,6 +348,60 @@ class _Lowering:
         if rank != 3:
             self.view_rank[node.key] = rank
         return node
+
+    def module_call(self, link, x):
+        """`BrancherFunction(nn.Module)(x)` on the scalar path (`brancher/functions.py:15-41`: the module is called on the value,
+        its tensors are optimised with the model's other parameters through the LinkConstructor, `optimizers.py:36-49`).  A small
+        MLP — `nn.Linear`, or an `nn.Sequential` of `nn.Linear` and Tanh / ReLU / Sigmoid / Softplus — acting on the LAST axis of
+        its input is unrolled into the per-sample program: every weight is a learnable uniform entry (its gradient one position
+        of the reduction), every unit a chain of multiply-adds.  The input is a scalar or a vector along the last axis, the
+        output one unit (a vector-valued result would need an array constructor the program does not have)."""
+        import torch.nn as nn
+        mod = link.module
+        stages = list(mod.children()) if isinstance(mod, nn.Sequential) else [mod]
+        prefixes = [str(i) + "." for i in range(len(stages))] if isinstance(mod, nn.Sequential) else [""]
+        if x.shape[0] != 1 or x.shape[1] != 1:
+            raise LoweringError("module link %s: the input must be a scalar or a vector along its last axis, got element shape %r"
+                                % (link.name, (x.shape,)))
+        units = [self.element_of(x, (0, 0, j)) for j in range(x.shape[2])]
+        acts = {nn.Tanh: "tanh", nn.ReLU: "relu", nn.Sigmoid: "sigmoid", nn.Softplus: "softplus"}
+        for stage, prefix in zip(stages, prefixes):
+            if isinstance(stage, nn.Linear):
+                if stage.in_features != len(units):
+                    raise LoweringError("module link %s: Linear(%d, %d) applied to %d values" % (link.name, stage.in_features,
+                                                                                              stage.out_features, len(units)))
+                w = self.module_root(link, prefix + "weight", (1, stage.out_features, stage.in_features))
+                b = self.module_root(link, prefix + "bias", (1, 1, stage.out_features)) if stage.bias is not None else None
+                out = []
+                for k in range(stage.out_features):
+                    acc = None
+                    for j, u in enumerate(units):
+                        t = self.mk("mul", (self.element_of(w, (0, k, j)), u))
+                        acc = t if acc is None else self.mk("add", (acc, t))      # (torch's addmm adds the products in this order)
+                    if b is not None:
+                        acc = self.mk("add", (acc, self.element_of(b, (0, 0, k))))
+                    out.append(acc)
+                units = out
+            elif type(stage) in acts:
+                if isinstance(stage, nn.Softplus) and (stage.beta != 1 or stage.threshold != 20):
+                    raise LoweringError("module link %s: Softplus with non-default beta / threshold" % link.name)
+                units = [self.mk("call:" + acts[type(stage)], (u,)) for u in units]
+            elif isinstance(stage, nn.Identity):
+                pass
+            else:
+                raise LoweringError("module link %s: %s is not lowered on the scalar path (Linear, Tanh, ReLU, Sigmoid, Softplus)"
+                                    % (link.name, type(stage).__name__))
+        if len(units) != 1:
+            raise LoweringError("module link %s: %d outputs — the scalar path takes modules with ONE output unit" % (link.name, len(units)))
+        return units[0]
+
+    def module_root(self, link, pname, shape):
+        """a tensor of a module link as a learnable root leaf of the program (its Parameter is a segment of the parameter buffer)"""
+        key = (id(link), pname)
+        hit = self.module_roots.get(key)
+        if hit is None:
+            hit = self.module_roots[key] = _ModuleTensor(link, pname)
+        return self.mk("root", (), hit, shape)
 
     def root_node(self, var):
         """a RootVariable leaf; its rank inside links is that of its stored value minus the sample axis"""

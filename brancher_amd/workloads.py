@@ -319,6 +319,41 @@ def build_mvn_forms(api, n=16, form="scale_tril", noise=0.3, seed=0):
     return model
 
 
+def build_module_link_regression(api, n_obs=6, hidden=4, seed=0, n_in=1, activation="Tanh", hidden2=0):
+    """A `torch.nn.Module` as a link on the scalar path (`brancher/functions.py:15-41`): the response is a small MLP of a
+    latent, `y_i ~ N(net(z) * x_i + c, 0.4)`, `net = Linear(1, H) -> Tanh -> Linear(H, 1)`, z ~ N(0, 1) with a learnable Normal
+    posterior.  The reference calls the module on the sample and steps its tensors with the joint model's optimizer
+    (`optimizers.py:36-49`, from iteration 1 on: `inference.py:102-104`); here they are learnable entries of the program."""
+    import torch
+    BF = api.BF
+    gen = torch.Generator().manual_seed(seed + 11)
+    act = getattr(torch.nn, activation)
+    stages = [torch.nn.Linear(n_in, hidden), act()]
+    if hidden2:
+        stages += [torch.nn.Linear(hidden, hidden2), act()]
+    stages.append(torch.nn.Linear(hidden2 or hidden, 1))
+    net = torch.nn.Sequential(*stages)                 # (n_in > 1: the module acts on a row vector of latents, [1, n_in])
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.7)
+    rng = np.random.RandomState(seed)
+    xs = rng.uniform(-1., 1., (n_obs, 1, 1)).astype(np.float32)
+    data = (0.8 * xs + 0.1 + 0.05 * rng.normal(0., 1., (n_obs, 1, 1))).astype(np.float32)
+    if n_in == 1:
+        z, qz = api.NormalVariable(0., 1., "z"), api.NormalVariable(0.3, 0.6, "z", learnable=True)
+    else:
+        z = api.NormalVariable(np.zeros((1, n_in)), np.ones((1, n_in)), "z")
+        qz = api.NormalVariable(0.3 * rng.normal(0., 1., (1, n_in)), 0.6 * np.ones((1, n_in)), "z", learnable=True)
+    f = BF.BrancherFunction(net, name="net")
+    x = api.DeterministicVariable(xs, "x", is_observed=True)              # [datapoints, 1, 1]
+    y = api.NormalVariable(f(z) * x + 0.1, 0.4, "y")
+    model = api.ProbabilisticModel([y])
+    y.observe(data)
+    model.set_posterior_model(api.ProbabilisticModel([qz]))
+    model._golden_modules = {"net": net}
+    return model
+
+
 def build_map_estimate(api, n_obs=12, seed=0):
     """Point estimates (MAP, `inference.py:251-275`; `examples/MAP_logistic_regression.py:46-56`): the "posterior" is a
     model of learnable RootVariables carrying the latents' names.  No sampling and no entropy: the loss is

@@ -47,6 +47,8 @@ CASES = {
                                          dict(iters=5, n=40, optimizer="Adam", lr=1e-3)),
     "dynamic_causal_model_T30_N20": ("build_dynamic_causal_model", dict(steps=30), 20, 16,
                                      dict(iters=4, n=5, optimizer="Adam", lr=0.01)),
+    # an nn.Module as a link on the scalar path (functions.py:15-41): its tensors are learnable parameters of the joint model
+    "module_link_mlp_N40": ("build_module_link_regression", dict(n_obs=6, hidden=4), 40, 41, dict(iters=5, n=24, optimizer="Adam", lr=1e-2)),
     "map_estimate_N3": ("build_map_estimate", dict(n_obs=12), 3, 15, dict(iters=6, n=2, optimizer="SGD", lr=0.01)),
     "vector_latent_d4_N70": ("build_vector_latent", dict(n_obs=9, dim=4), 70, 14, dict(iters=4, n=33, optimizer="SGD", lr=1e-3)),
     "linear_predictor_d4_N40": ("build_linear_predictor", dict(n_obs=5, dim=4), 40, 17, dict(iters=4, n=24, optimizer="Adam", lr=1e-2)),
@@ -207,12 +209,28 @@ def match_noise(q, z, draws):
     return noise
 
 
+class _ModuleTensor:
+    """A tensor of an nn.Module used as a link (functions.py:15-20), recorded like a learnable root: `.link.parameter` is the
+    nn.Parameter the reference's optimizer steps (optimizers.py:36-49), `.value` its current value."""
+
+    def __init__(self, tensor):
+        self.link = types.SimpleNamespace(parameter=tensor)
+
+    @property
+    def value(self):
+        return self.link.parameter
+
+
 def named_parameters(model, q):
     out = {}
     for m in (q, model):
         for v in m.flatten():
             if type(v).__name__ == "RootVariable" and v.learnable:
                 out.setdefault(v.name, v)
+    # (builders that use module links name them: {"net": module} -> "net.0.weight", ... as brancher_amd names the tensors)
+    for fname, module in getattr(model, "_golden_modules", {}).items():
+        for pname, tensor in module.named_parameters():
+            out.setdefault("%s.%s" % (fname, pname), _ModuleTensor(tensor))
     return out
 
 

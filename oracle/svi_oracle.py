@@ -138,12 +138,36 @@ class Oracle:
                     if id(par) not in self.params:
                         self.params[id(par)] = torch.tensor(par.numpy(), dtype=dtype, requires_grad=True)
                         self.param_objs[id(par)] = (v.name, par)
+        # tensors of nn.Modules used as links (functions.py:15-20): optimised with the model's parameters through the
+        # LinkConstructor (optimizers.py:36-49)
+        self.module_links = []
+        for model in (self.q, self.p):
+            for v in model.flatten():
+                link = getattr(v, "link", None)
+                if link is None or not hasattr(link, "expressions"):
+                    continue
+                for l in link.expressions().values():
+                    self._collect_module_links(getattr(l, "expr", None))
+        for ml in self.module_links:
+            for pname, par in ml.named.items():
+                if id(par) not in self.params:
+                    self.params[id(par)] = torch.tensor(par.numpy(), dtype=dtype, requires_grad=True)
+                    self.param_objs[id(par)] = (par.name, par)
         # q->p mapping by name, built once here (reference: rebuilt per call, utilities.py:282-293)
         table = {v.name: v for v in self.q._flatten()}
         self.mapping = {}
         for p_var in self.p._flatten():
             if p_var.name in table:
                 self.mapping[table[p_var.name]] = p_var
+
+    def _collect_module_links(self, e):
+        from brancher_amd.functions import ModuleLink
+        if not isinstance(e, sym.Expr):
+            return
+        if e.op == "call" and isinstance(e.attr[0], ModuleLink) and e.attr[0] not in self.module_links:
+            self.module_links.append(e.attr[0])
+        for a in e.args:
+            self._collect_module_links(a)
 
     # ------------------------------------------------------------------ parameters
     def named_parameters(self):
@@ -184,6 +208,12 @@ class Oracle:
         if e.op == "call":
             fn, kwargs = e.attr
             f = _call(fn) if isinstance(fn, str) else fn
+            if hasattr(fn, "named") and hasattr(fn, "module"):      # an nn.Module link: called on the value with THIS oracle's tensors
+                mod, tensors = fn.module, {pname: self.params[id(par)] for pname, par in fn.named.items()}
+                if self.dtype != torch.float32:
+                    import copy
+                    mod = copy.deepcopy(mod).to(self.dtype)
+                f = lambda x, _m=mod, _t=tensors: torch.func.functional_call(_m, _t, (x,))      # noqa: E731
             args = [self.eval_expr(a, values) if isinstance(a, sym.Expr) else a for a in e.args]
             kw = {k: (self.eval_expr(v, values) if isinstance(v, sym.Expr) else v) for k, v in kwargs.items()}
             return f(*args, **kw)                                   # functions.py:34-38

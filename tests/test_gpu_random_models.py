@@ -283,3 +283,41 @@ def test_random_model_training_loop_equals_launch_per_iteration(family, seed, op
     scale = max(1.0, np.abs(l1).max())
     assert np.abs(l0 - l1).max() <= 2e-5 * scale, (m0, l0, l1)
     assert np.abs(p0 - p1).max() <= 2e-5 * max(1.0, np.abs(p1).max()), m0
+
+
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+@pytest.mark.parametrize("kw,n", [(dict(n_obs=6, hidden=4), 300),
+                                  (dict(n_obs=5, hidden=4, n_in=3, activation="ReLU"), 70),
+                                  (dict(n_obs=7, hidden=3, n_in=2, activation="Sigmoid", hidden2=3), 129),
+                                  (dict(n_obs=4, hidden=5, n_in=4, activation="Softplus"), 64)])
+def test_module_links_on_the_scalar_path_match_the_oracles(kw, n, estimator):
+    """`BrancherFunction(nn.Module)` as a link of a scalar-path model (`brancher/functions.py:15-41`; the reference fixture
+    `module_link_mlp_N40` pins the 1-4-1 tanh network, its gradients and its training trajectory): scalar and row-vector inputs,
+    the four activations, two hidden layers — on device draws against the oracle, which calls the torch module itself."""
+    build = lambda: W.build_module_link_regression(W.native_api(), **kw)
+    compiled = engine.compile_model(build(), None, estimator)
+    names = {par.name for par, _, _, _ in compiled.program.parameters}
+    assert "net.0.weight" in names and "net.%d.bias" % (4 if kw.get("hidden2") else 2) in names      # the module's tensors are parameters
+    res = compiled.evaluate(n, seed=17, offset=3, want_noise=True)
+    noise = res["noise"].cpu().numpy()
+    named = {name: noise[s.base:s.base + s.size].T.reshape((n,) + tuple(s.shape)) for name, s in compiled.program.slot_by_name.items()}
+    check_against_the_oracles(compiled, build, n, estimator, named, res)
+    # ... and training moves the module's tensors (from the second iteration on: the joint model's optimizer, inference.py:102-104)
+    before = compiled.named_params()
+    losses, finite = compiled.train(5, n, "Adam", seed=3, lr=1e-2)
+    after = compiled.named_params()
+    assert bool(finite.all()) and not np.array_equal(before["net.0.weight"], after["net.0.weight"])
+
+
+def test_perform_inference_trains_a_module_link_in_place():
+    """the public API on a model whose link is an nn.Module: the loss falls and the user's torch module holds the trained tensors
+    afterwards (the reference steps the module's nn.Parameters themselves, `optimizers.py:36-49`)"""
+    from brancher_amd import inference
+    model = W.build_module_link_regression(W.native_api(), n_obs=8, hidden=4)
+    net = model._golden_modules["net"]
+    before = [p.detach().clone() for p in net.parameters()]
+    inference.perform_inference(model, number_iterations=300, number_samples=64, optimizer="Adam", lr=2e-2,
+                                inference_method=inference.ReverseKL())
+    curve = model.diagnostics["loss curve"]
+    assert np.isfinite(curve).all() and curve[-30:].mean() < curve[:30].mean()
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))

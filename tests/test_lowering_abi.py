@@ -449,3 +449,35 @@ def test_bayesian_neural_network_lowers_to_the_bnn_family():
         bnn.lower_bnn(m_bad, m_bad.posterior_model)
     with pytest.raises(lowering.LoweringError):
         bnn.lower_bnn(m, m.posterior_model, "taylor1")
+
+
+def test_module_links_lower_on_the_scalar_path_and_refuse_what_they_cannot_do():
+    """`BrancherFunction(nn.Module)` (brancher/functions.py:15-41) on the scalar path: Linear / Tanh / ReLU / Sigmoid / Softplus
+    chains with ONE output unit are unrolled into the program with their tensors as parameters; anything else is a LoweringError
+    that says what — not a wrong program."""
+    import torch
+    from brancher_amd import lowering, workloads as W
+    from brancher_amd.standard_variables import NormalVariable
+    from brancher_amd.variables import ProbabilisticModel
+    import brancher_amd.functions as BF
+
+    model = W.build_module_link_regression(W.native_api(), n_in=3, activation="ReLU", hidden2=2)
+    program = lowering.lower(model, model.posterior_model, "pathwise")
+    sizes = {par.name: size for par, _, size, _ in program.parameters}
+    assert sizes["net.0.weight"] == 12 and sizes["net.2.weight"] == 8 and sizes["net.4.weight"] == 2 and sizes["net.4.bias"] == 1
+    assert all(group == 1 for par, _, _, group in program.parameters if par.name.startswith("net."))      # the joint model's optimizer
+
+    def lower(net):
+        z = NormalVariable(0., 1., "z")
+        y = NormalVariable(BF.BrancherFunction(net, name="net")(z), 0.5, "y")
+        m = ProbabilisticModel([y])
+        y.observe(np.zeros((1, 1, 1), dtype=np.float32))
+        m.set_posterior_model(ProbabilisticModel([NormalVariable(0., 1., "z", learnable=True)]))
+        return lowering.lower(m, m.posterior_model, "pathwise")
+
+    with pytest.raises(lowering.LoweringError, match="ONE output unit"):
+        lower(torch.nn.Linear(1, 2))
+    with pytest.raises(lowering.LoweringError, match="not lowered on the scalar path"):
+        lower(torch.nn.Sequential(torch.nn.Linear(1, 2), torch.nn.GELU(), torch.nn.Linear(2, 1)))
+    with pytest.raises(lowering.LoweringError, match="applied to 1 values"):
+        lower(torch.nn.Linear(3, 1))
