@@ -43,6 +43,7 @@ struct MvnArgs {
     const bsvi_uniform_entry* loc_entries;    // [D] when the loc is learnable (MVN_LOC_PARAM), else null
     const bsvi_uniform_entry* value_entries;  // [D] when the value is learnable parameters (MVN_VALUE_PARAM: the taylor1 program), else null
     float* rows_out;                      // the surrogate's rows: [n_rows_out][n_local], row 0 = first input's coefficient
+    float* scratch;                       // MVN_SPILL: [n_local][DP * LD] — the matrix of a sample when it does not fit LDS, else null
     uint32_t n_local, value_row0;
     uint32_t input_rows[8];
     float weight;
@@ -54,6 +55,13 @@ struct MvnArgs {
 #endif
 #ifndef MVN_NIN_PAD
 #define MVN_NIN_PAD (MVN_NIN > 0 ? MVN_NIN : 1)
+#endif
+// MVN_SPILL (D > 192: DP x LD floats no longer fit the CU's 160 KiB): the matrix of a sample lives in its own DP x LD block of
+// device memory instead — the same steps on the same layout through the CU's vector cache and the L2.  A workgroup's waves share
+// one vector L1 and __syncthreads() waits for the stores, so what a step wrote is what the next step reads; the vectors and the
+// panel's 4 x 4 block stay in LDS.
+#ifndef MVN_SPILL
+#define MVN_SPILL 0
 #endif
 
 typedef float mvn_f4 __attribute__((ext_vector_type(4)));
@@ -155,7 +163,11 @@ extern "C" __global__ void __launch_bounds__(MVN_THREADS) bsvi_mvn_kernel(const 
     //   the diagonal         C_jj, L_jj, from step 3 on X_jj = 1 / L_jj
     // The diagonals of L live in diag / rdiag.  Readers of a row that mixes the two (the first block of a column of X, the
     // first block of a row in S = X^T X) mask the components that belong to the other triangle.
+#if MVN_SPILL
+    float* const A = G.scratch + (size_t)blockIdx.x * (size_t)(DP * LD);
+#else
     __shared__ __attribute__((aligned(16))) float A[DP * LD];
+#endif
     __shared__ __attribute__((aligned(16))) float Tblk[16];          // the panel's updated 4 x 4 diagonal block
     __shared__ __attribute__((aligned(16))) float sdiag[VP];
     __shared__ __attribute__((aligned(16))) float dvec[VP];

@@ -54,6 +54,7 @@ constexpr uint32_t kRescheduleAboveSlots = 40; // programs with more per-sample 
 constexpr uint32_t kFenceAboveCode = 100;     // programs longer than this get scheduling fences ...
 constexpr const char* kJitOptionMark = "// bsvi-jit-option: ";     // a per-program hiprtc option carried in the generated source
 constexpr uint32_t kFenceEvery = 4;           // ... every this many records
+constexpr uint32_t kBasicRegallocAboveCode = 700;   // programs longer than this are compiled with LLVM's basic register allocator
 constexpr uint32_t kAccumulateEntries = 1u << 30;   // up to this many gradient-carrying uniform entries accumulate in registers
 
 std::string fmt(const char* f, ...) {
@@ -709,6 +710,14 @@ Spec* create(const bsvi_program_desc& d, std::string& why) {
             const char* const slp = getenv("BSVI_JIT_SLP");
             if (slp ? slp[0] == '0' : (d.n_code > kFenceAboveCode && d.estimator == BSVI_EST_BLACKBOX))
                 src += std::string(kJitOptionMark) + "-fno-slp-vectorize\n";
+            // very long programs: the greedy allocator's time grows much faster than the unrolled stream once the register file is
+            // full (a Gaussian process over 100 inputs, 414 instructions: 15 s, of which 9 s are "Greedy Register Allocator"; over 200
+            // inputs, 814 instructions: 150 s and 690 spilled registers).  The basic allocator takes 16 s there (1 875 spills —
+            // beside the term's batched factorisation the program is a small part of such an iteration); same arithmetic.
+            // (BSVI_JIT_REGALLOC=greedy / basic forces one for every program)
+            const char* const ra = getenv("BSVI_JIT_REGALLOC");
+            if (ra ? ra[0] == 'b' : d.n_code > kBasicRegallocAboveCode)
+                src += std::string(kJitOptionMark) + "-mllvm\n" + kJitOptionMark + "-vgpr-regalloc=basic\n";
             src += fmt("#define SPEC_N_PARAMS %u\n#define SPEC_N_UNIFORM %u\n#define SPEC_N_UGRAD %u\n#define SPEC_N_OBS %u\n#define SPEC_N_NOISE %u\n",
                        d.n_params, d.n_uniform, d.n_uniform_grad, d.n_obs, d.n_noise);
             src += fmt("#define SPEC_N_POS %u\n", s->n_pos);

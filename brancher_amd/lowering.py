@@ -1095,7 +1095,7 @@ class _Lowering:
             terms.append((_Term(v, i), u, [mk("imm", (), 0.0), L[i][i]], (1, 1, 1)))
         return terms
 
-    kMaxExternalMvn = 192
+    kMaxExternalMvn = 1024        # (up to 192 the kernel keeps a sample's matrix in LDS, beyond it in a block of device memory)
 
     def mvn_external(self, v, mat, given="covariance_matrix"):
         """A MultivariateNormal term too large to unroll (D > kMaxSymbolicMvn) whose covariance is an ELEMENTWISE expression of
@@ -1114,8 +1114,8 @@ class _Lowering:
         links = v.link.expressions()
         _, dim, _ = mat.shape
         if dim > self.kMaxExternalMvn:
-            raise LoweringError("%r: a %dx%d covariance (the batched kernel keeps the matrix in LDS: limit %d)"
-                                % (v.name, dim, dim, self.kMaxExternalMvn))
+            raise LoweringError("%r: a %dx%d covariance (the batched kernel takes up to %dx%d)"
+                                % (v.name, dim, dim, self.kMaxExternalMvn, self.kMaxExternalMvn))
         host_g = dict(identity=lambda x: x, softplus=lambda x: np.logaddexp(0.0, x), sigmoid=lambda x: 1.0 / (1.0 + np.exp(-x)),
                       exp=np.exp, log=np.log, tanh=np.tanh, sqrt=np.sqrt, square=np.square)
         code, mats, memo = [], [], {}

@@ -291,6 +291,28 @@ def build_gp_hyperparameters(api, n=5, jitter=1e-2, noise=0.2, seed=0, learnable
     return model
 
 
+def build_gp_marginal_likelihood(api, n=200, noise=0.3, seed=0):
+    """Gaussian-process regression with the function values integrated out: y ~ MultivariateNormal(0, K(ell, amp) + noise^2 I)
+    OBSERVED, the squared-exponential covariance an elementwise link expression of a LogNormal latent length-scale (LogNormal
+    posterior) and a learnable amplitude (`distributions.py:314-331`, `standard_variables.py:317-347`,
+    `stochastic_processes.py:29-40`).  The per-sample program is a handful of records; all the work is the n x n factorisation
+    per Monte-Carlo sample — the batched kernel's, in LDS up to n = 192 and in device memory beyond."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    x = np.linspace(-3., 3., n)
+    sqdist = api.RootVariable(((x[:, None] - x[None, :]) ** 2).astype(np.float32), "sqdist")
+    eye = api.RootVariable((noise ** 2 * np.eye(n)).astype(np.float32), "noise")
+    ell = api.LogNormalVariable(-0.5, 0.3, "ell")
+    amp = api.RootVariable(1.3, "amplitude", learnable=True)
+    K = BF.exp(sqdist * (-0.5) / (ell * ell)) * amp + eye
+    y = api.MultivariateNormalVariable(loc=np.zeros((n,)), covariance_matrix=K, name="y")
+    model = api.ProbabilisticModel([y])
+    y.observe((np.sin(2 * np.pi * 0.25 * x) + noise * rng.normal(0., 1., (1, n))).astype(np.float32))
+    Qell = api.LogNormalVariable(-0.4, 0.2, "ell", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qell]))
+    return model
+
+
 def build_mvn_forms(api, n=16, form="scale_tril", noise=0.3, seed=0):
     """The other two parameterisations of `MultivariateNormalVariable` (`standard_variables.py:317-347`,
     `distributions.py:314-331`) with a matrix that depends on a sampled scalar, as an ELEMENTWISE link expression of constant

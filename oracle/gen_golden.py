@@ -58,6 +58,11 @@ CASES = {
     # the same model with 32 / 100 inputs: the covariance no longer fits the per-sample program (batched kernel, bsvi_mvn_*)
     "gp_hyperparameters_n32_N40": ("build_gp_hyperparameters", dict(n=32, jitter=5e-2), 40, 31, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
     "gp_hyperparameters_n100_N24": ("build_gp_hyperparameters", dict(n=100, jitter=5e-2), 24, 37, dict(iters=3, n=12, optimizer="Adam", lr=1e-2)),
+    # the function values integrated out (an OBSERVED MultivariateNormal): 40 inputs, and 200 / 260 — beyond what LDS holds, the
+    # batched kernel keeps the matrix of a sample in device memory (MVN_SPILL)
+    "gp_marginal_n40_N32": ("build_gp_marginal_likelihood", dict(n=40), 32, 53, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
+    "gp_marginal_n200_N16": ("build_gp_marginal_likelihood", dict(n=200), 16, 59, dict(iters=3, n=8, optimizer="Adam", lr=1e-2)),
+    "gp_marginal_n260_N12": ("build_gp_marginal_likelihood", dict(n=260), 12, 61, dict(iters=3, n=6, optimizer="Adam", lr=1e-2)),
     # the other two parameterisations of the MultivariateNormal node, with a matrix that depends on a sampled scale
     # (bsvi_mvn_form: the batched kernel skips the factorisation for a scale_tril and factorises the precision in its place)
     "mvn_scale_tril_n24_N40": ("build_mvn_forms", dict(n=24, form="scale_tril"), 40, 41, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
@@ -103,7 +108,7 @@ TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_l
                     "build_beta_binomial", "build_observed_ar", "build_lognormal_normal",
                     # (round 4: models with a MultivariateNormal term whose matrix depends on a latent — the taylor1 program reads it
                     #  at the posterior's means)
-                    "build_gp_hyperparameters", "build_mvn_forms")
+                    "build_gp_hyperparameters", "build_mvn_forms", "build_gp_marginal_likelihood")
 
 
 # ... and two user-defined estimators (workloads.custom_estimators) for these

@@ -56,7 +56,7 @@ def test_interpreter_matches_reference_golden(case, estimator, interpreter):
     assert c.native.engine(g.N, 0)["engine"] == "interpreter"
     res = c.evaluate(g.N, noise=g.noise)
     ref = float(g.data["loss_" + estimator])
-    if estimator == "pathwise" and case not in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24"):
+    if estimator == "pathwise" and case not in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24") and not case.startswith("gp_marginal"):
         assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
         grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL)
         return
@@ -86,6 +86,30 @@ def test_engines_agree_on_philox_draws(builder, kwargs, n, estimator, monkeypatc
     assert np.abs(sa - sb).max() <= 2e-6 * max(1.0, np.abs(sb).max())
     assert abs(la - lb) <= 2e-6 * abs(lb)
     assert np.abs(ga - gb).max() <= (2e-6 if estimator == "pathwise" else 2e-5) * np.abs(gb).max()
+
+
+def test_very_long_program_compiled_with_the_basic_allocator_agrees_with_the_interpreter(monkeypatch):
+    """A Gaussian process over 200 inputs with LATENT function values: 814 instructions, 604 noise rows, and a 200 x 200
+    covariance per sample that the batched kernel keeps in device memory.  Past 700 instructions the generated kernel is compiled
+    with LLVM's basic register allocator (specialize.cpp kBasicRegallocAboveCode: 14 s instead of 150 s) — the same arithmetic,
+    so it must agree with the interpreter on the same Philox draws; and the training loop must run on it."""
+    out = {}
+    for jit in ("1", "0"):
+        monkeypatch.setenv("BSVI_JIT", jit)
+        c = engine.compile_model(W.build_gp_hyperparameters(W.native_api(), n=200, jitter=5e-2), None, "pathwise")
+        assert c.native.engine(48, 0)["engine"] == ("specialised" if jit == "1" else "interpreter")
+        res = c.evaluate(48, seed=7, offset=3)
+        out[jit] = (float(res["loss"].item()), res["grads"].cpu().numpy().copy())
+    (la, ga), (lb, gb) = out["1"], out["0"]
+    assert np.isfinite(la) and np.isfinite(ga).all()
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    assert np.abs(ga - gb).max() <= 1e-5 * np.abs(gb).max()
+    monkeypatch.setenv("BSVI_JIT", "1")
+    model = W.build_gp_hyperparameters(W.native_api(), n=200, jitter=5e-2)
+    from brancher_amd import inference
+    inference.perform_inference(model, number_iterations=30, number_samples=32, optimizer="Adam", lr=0.02)
+    losses = np.asarray(model.diagnostics["loss curve"])
+    assert np.isfinite(losses).all() and losses[-10:].mean() < losses[:10].mean()
 
 
 @pytest.mark.parametrize("optimizer,kw", [("SGD", dict(lr=1e-3)), ("SGD", dict(lr=1e-3, momentum=0.9, nesterov=True)),

@@ -324,8 +324,14 @@ def test_multivariate_normal_with_a_sampled_covariance_is_unrolled():
     assert [(q.name, o, n) for q, o, n, _ in base.parameters] == [(q.name, o, n) for q, o, n, _ in full.parameters]
     source = native.mvn_source(ext)
     assert "#define MVN_D 12" in source and "mvn_cov" in source and native.jit_compile(source) > 0
-    with pytest.raises(lowering.LoweringError, match="limit"):
-        huge = W.build_gp_hyperparameters(api, n=200)
+    # 200 inputs: past what LDS holds, the kernel is generated in its device-memory form; past 1024 the lowering refuses
+    huge = W.build_gp_hyperparameters(api, n=200)
+    spilled = lowering.lower(huge, huge.posterior_model, "pathwise").externals[0]
+    source = native.mvn_source(spilled)
+    assert "#define MVN_D 200" in source and "#define MVN_SPILL 1" in source and native.jit_compile(source) > 0
+    assert "#define MVN_SPILL 0" in native.mvn_source(ext)
+    with pytest.raises(lowering.LoweringError, match="up to 1024x1024"):
+        huge = W.build_gp_hyperparameters(api, n=1030)
         lowering.lower(huge, huge.posterior_model, "pathwise")
     # (round 4) the taylor1 program reads the term at the posterior's MEANS: no slot inputs at all — the length-scale's mean is
     # an expression of two parameters, the value is the posterior's learnable loc (parameter entries where a latent value's rows stand)
