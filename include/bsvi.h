@@ -734,11 +734,13 @@ void bsvi_debug_set_stamps(unsigned long long* stamps_dev);
  *
  * log N(x | m, C) and its gradient for a covariance that is an ELEMENTWISE link expression of constant matrices and a
  * few scalars that differ per Monte-Carlo sample (latent kernel hyper-parameters) or are learnable — the case the
- * per-sample program cannot hold (D^2 values per sample).  One wave per sample factorises C in LDS (Cholesky,
+ * per-sample program cannot hold (D^2 values per sample).  One workgroup of four waves per sample factorises C (Cholesky,
  * triangular inverse, C^-1 = L^-T L^-1) and contracts d log p / d C = (alpha alpha^T - C^-1) / 2 with the expression's
  * derivatives.  The covariance expression arrives as three-address code (temp t = instruction t; the last instruction
  * is C_ij); the library generates HIP from it and compiles it with hiprtc at the first evaluation (same caches as the
- * program-specialised ELBO kernels).  dim <= 136 (two matrices in 160 KiB of LDS), at most 8 scalar inputs.
+ * program-specialised ELBO kernels).  dim <= 1024: up to 192 the one matrix of a sample (L, its inverse and C^-1 share it) is
+ * in LDS; beyond that it is a block of device memory the node allocates at its first evaluation (padded dim^2 floats per
+ * sample of the largest launch so far; freed by bsvi_mvn_destroy).  At most 8 scalar inputs.
  *
  * The node talks to the per-sample program through rows of per-sample values:
  *   in   samples_dev [rows][n_local]: the slot values of the draw (samples_out of a bsvi_elbo_fwd_bwd call);
