@@ -243,6 +243,7 @@ class _Lowering:
         self.slot_rank = {}
         self.mean_entropy = {}      # Taylor1: q variable -> its parameters rebuilt on the parents' means (entropy-only record)
         self.externals, self.pseudo_q, self.external_mode = [], [], "inject"
+        self.mean_q = []            # Taylor1: (pseudo variable, [mean expression, 0], shape) — a vector value's mean per sample, as rows of the draw
 
     # ---------------------------------------------------------------- IR construction
     def mk(self, op, args=(), attr=None, shape=None):
@@ -1240,9 +1241,32 @@ class _Lowering:
                 node.value_entries[i] = (src, tr, isp, 0, aa, bb)
             node.value, node.value_row0 = np.zeros(dim, dtype=np.float32), 0
             partners += [self.mk("elem", (value,), j, (1, 1, 1)) for j in range(dim)]
+        elif self.estimator == "taylor1" and value.has_z and int(np.prod(value.shape)) == dim:
+            # Taylor1 (`gradient_estimators.py:47-56`) with a posterior whose mean depends on SAMPLED parents (q(f) = Normal(g(z), s),
+            # z drawn): the value of the term is g(z) — an expression that differs per sample.  It reaches the batched kernel the
+            # way a latent value does, as rows of the draw: a pseudo posterior variable Normal(g(z), 0) behind the posterior's own
+            # variables (its draw IS its mean; no entropy, no log q), whose adjoint — the coefficient rows -alpha — runs back
+            # through g into z's reparameterised draw and the parameters of g in the program's ordinary reverse sweep.
+            if self.pseudo_q:
+                raise LoweringError("%r: a second batched multivariate-normal term whose value is a per-sample mean (its rows "
+                                    "would lie behind the first term's coefficient rows)" % v.name)
+
+            class _MeanValue:                              # a pseudo posterior variable: Normal(mean expression, 0)
+                _pseudo, _mean_value, is_observed = False, True, False
+
+                def __init__(self, name):
+                    self.name, self.distribution = name, D.NormalDistribution()
+
+            mean = _MeanValue("%s/mean" % v.name)
+            self.slots[mean] = SlotInfo(mean, self.n_slots, value.shape, D.DIST_NORMAL)
+            self.n_slots += dim
+            self.mean_q.append((mean, [value, self.mk("imm", (), 0.0)], value.shape))
+            zval = self.z_node(mean)
+            node.value, node.value_row0 = None, self.slots[mean].base
+            partners += [self.mk("elem", (zval,), j, (1, 1, 1)) for j in range(dim)]
         else:
-            raise LoweringError("%r: the batched kernel takes an observed value or the draw of ONE posterior variable of %d elements"
-                                % (v.name, dim))
+            raise LoweringError("%r: the batched kernel takes an observed value, the draw of ONE posterior variable of %d elements or "
+                                "(Taylor1) its mean as an expression of sampled parents" % (v.name, dim))
         partners += [n for n, _ in uniform_inputs]
         partners += loc_nodes
         node.loc_entries = loc_entries
@@ -1428,6 +1452,7 @@ class _Lowering:
             p_nodes.append((v, value, params, shape))
 
         # -- the coefficient rows of batched multivariate-normal terms: GIVEN pseudo-variables behind the posterior's own rows
+        q_nodes.extend(self.mean_q)                     # (Taylor1: per-sample means of vector values, rows of the draw like the q's own)
         n_real_q = len(q_nodes)
         for coeff in self.pseudo_q:
             q_nodes.append((coeff, [self.mk("imm", (), 0.0), self.mk("imm", (), 1.0)], (1, 1, 1)))
@@ -1476,6 +1501,11 @@ class _Lowering:
                 # its row of the noise tensor IS its value (a coefficient the batched kernel wrote); no term of its own
                 self.for_each_record(shape, params, False,
                                      lambda: self.emit_node(dist.kind, F_SAMPLE | F_GIVEN, params, slot=slot, w_lp=0.0, w_ent=0.0))
+                continue
+            if getattr(v, "_mean_value", False):
+                # Normal(mean expression, 0): the row of the draw carries the mean; no term of its own
+                self.for_each_record(shape, params, False,
+                                     lambda: self.emit_node(dist.kind, F_SAMPLE, params, slot=slot, w_lp=0.0, w_ent=0.0))
                 continue
             if self.estimator == "importance":
                 flags |= F_WF | F_GIVEN        # value supplied, log q accumulated, no entropy term
@@ -1721,7 +1751,8 @@ class _Lowering:
         prog.n_slots = self.temp_base + self.max_temps
         self.fill_parameter_tables(prog, uni, n_up)
         prog.slots = dict(self.slots)
-        prog.slot_by_name = {s.name: s for s in self.slots.values() if not getattr(s.var, "_pseudo", False)}
+        prog.slot_by_name = {s.name: s for s in self.slots.values()
+                             if not getattr(s.var, "_pseudo", False) and not getattr(s.var, "_mean_value", False)}
         # batched multivariate-normal terms (mvn_external): their descriptions, and how many noise rows are the posterior's own
         prog.externals = list(self.externals)
         prog.n_real_noise = self.n_latent - len(self.pseudo_q)

@@ -267,7 +267,7 @@ def build_gp_regression(api, n=8, length_scale=0.6, jitter=1e-3, noise=0.2, seed
     return model
 
 
-def build_gp_hyperparameters(api, n=5, jitter=1e-2, noise=0.2, seed=0, learnable_amplitude=True):
+def build_gp_hyperparameters(api, n=5, jitter=1e-2, noise=0.2, seed=0, learnable_amplitude=True, structured_mean=False):
     """A Gaussian process whose kernel hyper-parameters are inferred: f ~ MultivariateNormal(0, K(ell, amp)) with the
     squared-exponential covariance  K = amp * exp(-sqdist / (2 ell^2)) + jitter I  of fixed inputs, a LogNormal latent
     length-scale `ell` (inferred with a LogNormal posterior) and — type-II maximum likelihood — a learnable amplitude in the
@@ -282,10 +282,24 @@ def build_gp_hyperparameters(api, n=5, jitter=1e-2, noise=0.2, seed=0, learnable
     amp = api.RootVariable(1.3, "amplitude", learnable=True) if learnable_amplitude else 1.3
     K = BF.exp(sqdist * (-0.5) / (ell * ell)) * amp + eye
     f = api.MultivariateNormalVariable(loc=np.zeros((n,)), covariance_matrix=K, name="f")
-    y = api.NormalVariable(f, noise, name="y")
+    if structured_mean:
+        # an offset per observation, and a posterior whose mean of f FOLLOWS the sampled offsets: q(f | shift) =
+        # Normal(gain * shift + mean, s) — under the Taylor1 estimator the value of the multivariate-normal term is then an
+        # expression of a sampled parent (`gradient_estimators.py:47-56`), not a vector of parameters
+        shift = api.NormalVariable(np.zeros((n, 1)), 0.5, "shift")
+        y = api.NormalVariable(f + shift, noise, name="y")
+    else:
+        y = api.NormalVariable(f, noise, name="y")
     model = api.ProbabilisticModel([y])
     y.observe((np.sin(2 * np.pi * 0.3 * x) + noise * rng.normal(0., 1., (1, n))).astype(np.float32))
     Qell = api.LogNormalVariable(-0.4, 0.2, "ell", learnable=True)
+    if structured_mean:
+        Qshift = api.NormalVariable(np.full((n, 1), 0.1), 0.3, "shift", learnable=True)
+        gain = api.DeterministicVariable(np.full((n, 1), -0.5), "f_gain", learnable=True)
+        mean = api.DeterministicVariable(np.zeros((n, 1)), "f_mean", learnable=True)
+        Qf = api.NormalVariable(Qshift * gain + mean, 0.8, name="f", learnable=True)
+        model.set_posterior_model(api.ProbabilisticModel([Qell, Qshift, Qf]))
+        return model
     Qf = api.NormalVariable(loc=np.zeros((n,)), scale=0.8, name="f", learnable=True)
     model.set_posterior_model(api.ProbabilisticModel([Qell, Qf]))
     return model

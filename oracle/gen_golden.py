@@ -58,6 +58,10 @@ CASES = {
     # the same model with 32 / 100 inputs: the covariance no longer fits the per-sample program (batched kernel, bsvi_mvn_*)
     "gp_hyperparameters_n32_N40": ("build_gp_hyperparameters", dict(n=32, jitter=5e-2), 40, 31, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
     "gp_hyperparameters_n100_N24": ("build_gp_hyperparameters", dict(n=100, jitter=5e-2), 24, 37, dict(iters=3, n=12, optimizer="Adam", lr=1e-2)),
+    # a posterior whose mean of f follows a SAMPLED parent: under Taylor1 the value of the multivariate-normal term is an expression
+    # of that draw (a per-sample mean, rows of the draw behind the posterior's own)
+    "gp_structured_mean_n12_N40": ("build_gp_hyperparameters", dict(n=12, jitter=5e-2, structured_mean=True), 40, 67, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
+    "gp_structured_mean_n48_N24": ("build_gp_hyperparameters", dict(n=48, jitter=5e-2, structured_mean=True), 24, 71, dict(iters=3, n=12, optimizer="Adam", lr=1e-2)),
     # the function values integrated out (an OBSERVED MultivariateNormal): 40 inputs, and 200 / 260 — beyond what LDS holds, the
     # batched kernel keeps the matrix of a sample in device memory (MVN_SPILL)
     "gp_marginal_n40_N32": ("build_gp_marginal_likelihood", dict(n=40), 32, 53, dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),

@@ -37,6 +37,7 @@ def is_batched_mvn(case):
     to it as the reference's own single-precision result is (x4)."""
     return case in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24",
                     "gp_marginal_n40_N32", "gp_marginal_n200_N16", "gp_marginal_n260_N12",
+                    "gp_structured_mean_n12_N40", "gp_structured_mean_n48_N24",
                     # ... and the scale_tril / precision_matrix forms (bsvi_mvn_form), which the kernel family serves at any size
                     "mvn_scale_tril_n24_N40", "mvn_precision_n24_N40", "mvn_precision_n6_N60")
 
@@ -696,7 +697,8 @@ def test_dense_sharded_step_sequence_equals_the_fused_step():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["readme_ar_T5_N7", "readme_ar_T20_N300", "beta_binomial_N512", "heavy_tails_N64",
                                   "gp_hyperparameters_n5_N80", "gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24",
-                                  "gp_marginal_n40_N32", "gp_marginal_n200_N16", "gp_marginal_n260_N12", "mvn_scale_tril_n24_N40", "mvn_precision_n24_N40"])
+                                  "gp_marginal_n40_N32", "gp_marginal_n200_N16", "gp_marginal_n260_N12",
+                                  "gp_structured_mean_n12_N40", "gp_structured_mean_n48_N24", "mvn_scale_tril_n24_N40", "mvn_precision_n24_N40"])
 def test_importance_weights_match_reference_log_densities(case):
     """`ProbabilisticModel.get_importance_weights` (variables.py:821-841) on the posterior samples the reference
     drew: the fixtures hold log p(z, y) ("lp") and log q(z) ("lq") computed by the reference itself.  The Gaussian-process

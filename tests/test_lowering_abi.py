@@ -338,6 +338,16 @@ def test_multivariate_normal_with_a_sampled_covariance_is_unrolled():
     t1 = lowering.lower(W.build_gp_hyperparameters(api, n=12), None, "taylor1").externals[0]
     assert t1.slot_inputs == [] and len(t1.uniform_inputs) == 3 and t1.value_entries is not None and len(t1.value_entries) == 12
     assert t1.n_rows_out == 12 + 3 + 12 + 1 and "#define MVN_VALUE_PARAM 1" in native.mvn_source(t1)
+    # (round 5) a posterior whose mean of f is an expression of a SAMPLED parent: the taylor1 value is per sample — a pseudo posterior
+    # variable Normal(mean, 0) behind the posterior's own rows (in the base program too: it reports the rows), its draw the value's rows
+    sm = lambda: W.build_gp_hyperparameters(api, n=12, jitter=5e-2, structured_mean=True)
+    t1s = lowering.lower(sm(), None, "taylor1")
+    pw = lowering.lower(sm(), None, "pathwise")
+    e1, ep = t1s.externals[0], pw.externals[0]
+    assert pw.n_real_noise == 25 and ep.value_row0 == 13 and ep.value is None                  # ell, shift[12], f[12]: the draw of f
+    assert t1s.n_real_noise == 37 and e1.value_row0 == 25 and e1.value is None and e1.value_entries is None and e1.row0 == 37
+    assert sorted(t1s.slot_by_name) == ["ell", "f", "shift"]                                     # (no noise is asked for the mean's rows)
+    assert lowering.lower(sm(), None, "taylor1", external="omit").n_noise == 37
     # a constant covariance still takes the host-side factorisation (no derived slots for L)
     const = W.build_gp_regression(api, n=5)
     assert lowering.lower(const, const.posterior_model, "pathwise").summary()["n_derived"] < 5
