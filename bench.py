@@ -356,10 +356,11 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         cold = dict(ms_per_step=cold_dt * 1e3 / steps, device_ms_per_step=c0.elapsed_time(c1) / steps,
                     value=steps / cold_dt * (n_global / 300.0), unit="it/s",
                     note="the first %d-step call after the %d warm-up steps, before the untimed spin-up" % (steps, max(warmup, 1)))
-    # no garbage collection from here to the end of the timed region: a collection inside a 200 us region would be a
-    # tenth of it, and a pause between the spin-up and the region would let the clocks drop again
+    # one collection here, so that the collector's counters start from zero: a repeat of the same call frees what it allocates,
+    # the counters do not climb and no collection falls into the timed region.  (Until round 5 the collector was switched off
+    # for the region; with it off the library call of a 20-iteration launch took 13-14 us instead of 10-11 —
+    # tools/r5/one_shot_probe.py, profiles/r5/bench_host_overhead.txt.)
     gc.collect()
-    gc.disable()
     spun = 0
     if spinup_ms > 0:
         chunk = max(steps, 200) if not hasattr(program, "enc_layers") else steps
@@ -371,15 +372,28 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     barrier()
 
     # ---- timed region: exactly K steps
+    # (torch creates the HIP event at the FIRST record: one record of each ahead of the region, so that the closing record
+    #  inside it is a record and not a creation — a fresh pair cost the 20-iteration region 6-14 us of host time, same probe)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ev1.record()
+    if spinup_ms > 0:
+        # ... and the last of the untimed spin-up is the region's own sequence, twice: the first K-step call bracketed this way in
+        # a process takes ~12 us longer on the host than the second (cold code paths of the runtime behind a record)
+        for _ in range(2):
+            barrier()
+            ev0.record()
+            train(steps)
+            ev1.record()
+            spun += steps
     barrier()
     ev0.record()                    # (ahead of the host clock: the events bracket the wall region from outside)
     t0 = time.perf_counter()
     losses, finite = train(steps)
+    t_launched = time.perf_counter()
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0
-    gc.enable()
     dev_ms = ev0.elapsed_time(ev1)
     mode = compiled.last_mode
 
@@ -561,6 +575,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                             grid=geom, untimed_spinup_iterations=spun),
                 iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
                 device_ms_per_step=dev_ms / steps, all_finite=ok,
+                # the timed region taken apart on the host clock: the library call(s) that launch the K steps, then the wait
+                host_launch_us=(t_launched - t0) * 1e6, host_wait_us=(dt - (t_launched - t0)) * 1e6,
                 final_loss=float(losses[-1].item()), roofline=roofline)
     if cold is not None:
         part["cold_start"] = cold
