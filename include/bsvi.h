@@ -740,7 +740,8 @@ void bsvi_debug_set_stamps(unsigned long long* stamps_dev);
  * is C_ij); the library generates HIP from it and compiles it with hiprtc at the first evaluation (same caches as the
  * program-specialised ELBO kernels).  dim <= 1024: up to 192 the one matrix of a sample (L, its inverse and C^-1 share it) is
  * in LDS; beyond that it is a block of device memory the node allocates at its first evaluation (padded dim^2 floats per
- * sample of the largest launch so far; freed by bsvi_mvn_destroy).  At most 8 scalar inputs.
+ * sample of the largest launch so far; freed by bsvi_mvn_destroy — one block per node, so evaluations of ONE node with dim > 192
+ * must be ordered on a stream, not run on two streams at once).  At most 8 scalar inputs.
  *
  * The node talks to the per-sample program through rows of per-sample values:
  *   in   samples_dev [rows][n_local]: the slot values of the draw (samples_out of a bsvi_elbo_fwd_bwd call);
