@@ -365,7 +365,17 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     if spinup_ms > 0:
         chunk = max(steps, 200) if not hasattr(program, "enc_layers") else steps
         t_spin = time.perf_counter()
-        while (time.perf_counter() - t_spin) * 1e3 < spinup_ms:
+        go_on = torch.ones(1, device="cuda" if dist.get_backend() == "nccl" else "cpu") if world > 1 else None
+        while True:
+            more = (time.perf_counter() - t_spin) * 1e3 < spinup_ms
+            if world > 1:
+                # rank 0's clock decides for everybody: a rank that left the loop one call earlier than its peers would leave them
+                # waiting in that call's all-reduces
+                go_on[0] = 1.0 if more else 0.0
+                dist.broadcast(go_on, 0)
+                more = float(go_on[0]) != 0.0
+            if not more:
+                break
             train(chunk)
             torch.cuda.synchronize()
             spun += chunk
