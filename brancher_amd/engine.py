@@ -592,44 +592,63 @@ class CompiledELBO:
         """The sharded iteration — `bsvi_elbo_fwd_bwd` (this rank's samples), ONE all-reduce of the [4+P] sums over the
         ranks (RCCL), `bsvi_finalize_step_counted` (loss, finite flag, replicated optimizer step) — captured in a HIP
         graph, `BSVI_GRAPH_UNROLL` iterations per graph, and replayed.  The iteration number (Philox offset, loss slot,
-        pretraining mask) lives in device memory, so the replays are identical launches; the host only enqueues graphs."""
+        pretraining mask) lives in device memory, so the replays are identical launches; the host only enqueues graphs.
+
+        The graphs are KEPT for a repeat of the same call (round 5: every `train` captured anew — a warm-up launch, a
+        synchronize, the capture and the instantiation, milliseconds in front of a 20-iteration call of ~0.6 ms): they own their
+        loss / flag / optimizer-state buffers and counters; a repeat clears the state, sets the counters, replays and copies the
+        curve out.  Keyed by everything the captured launches hold by value or by address."""
         dev, p = self.device, self.program
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        counters = torch.tensor([int(offset0), 0], dtype=torch.int64, device=dev)
-        # hiprtc / module loading and RCCL's first-call set-up cannot happen inside a capture: one untimed launch of each
-        warm = self._elbo_args(n_local, n_global, base, None, seed, int(offset0))
-        native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(warm)))
-        allreduce_sums(torch.zeros_like(self.out))
-        torch.cuda.synchronize(dev)
+        key = (int(K), int(n_local), int(n_global), int(base), bytes(cfg), int(self._resolved(seed)), int(pretraining),
+               self.params.data_ptr(), self.out.data_ptr(), collective_kind(), os.environ.get("BSVI_JIT"), _graph_unroll())
+        cache = self.__dict__.setdefault("_graph_cache", {})
+        entry = cache.get(key)
+        if entry is None:
+            own_curve, own_finite, own_state = training_buffers(K, p.n_params, dev)
+            counters = torch.tensor([int(offset0), 0], dtype=torch.int64, device=dev)
+            # hiprtc / module loading and RCCL's first-call set-up cannot happen inside a capture: one untimed launch of each
+            warm = self._elbo_args(n_local, n_global, base, None, seed, int(offset0))
+            native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(warm)))
+            allreduce_sums(torch.zeros_like(self.out))
+            torch.cuda.synchronize(dev)
+            own_cfg = type(cfg).from_buffer_copy(cfg)          # (the captured launches read the block at capture time only; kept anyway)
 
-        def capture(n_steps):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                # a PRIVATE argument block (the cached one of the plain calls must not keep a pointer to `counters`),
-                # on the capturing stream
-                args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, n_global, base, None, seed, 0))
-                args.stream = self._stream()
-                args.offset_dev = counters.data_ptr()
-                for _ in range(n_steps):
-                    native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
-                    allreduce_sums(self.out)
-                    native.check(self.lib.bsvi_finalize_step_counted(
-                        C.byref(cfg), ptr(self.params), ptr(self.out), ptr(state), ptr(self.mask_all), ptr(self.mask_first),
-                        pretraining, p.n_params, n_global, ptr(loss_curve), ptr(finite), ptr(counters), self._stream()))
-            return graph
+            def capture(n_steps):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    # a PRIVATE argument block (the cached one of the plain calls must not keep a pointer to `counters`),
+                    # on the capturing stream
+                    args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, n_global, base, None, seed, 0))
+                    args.stream = self._stream()
+                    args.offset_dev = counters.data_ptr()
+                    for _ in range(n_steps):
+                        native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
+                        allreduce_sums(self.out)
+                        native.check(self.lib.bsvi_finalize_step_counted(
+                            C.byref(own_cfg), ptr(self.params), ptr(self.out), ptr(own_state), ptr(self.mask_all), ptr(self.mask_first),
+                            pretraining, p.n_params, n_global, ptr(own_curve), ptr(own_finite), ptr(counters), self._stream()))
+                return graph
 
-        unroll = min(K, _graph_unroll())
-        # the executables, their private pools and the counters they point at stay alive while the replays run
-        keep = [counters]
-        self._graphs = getattr(self, "_graphs", [])[-3:] + [keep]
-        main = capture(unroll)
-        keep.append(main)
-        for _ in range(K // unroll):
-            main.replay()
-        if K % unroll:
-            tail = capture(K % unroll)
-            keep.append(tail)
-            tail.replay()
+            unroll = min(K, _graph_unroll())
+            entry = dict(curve=own_curve, finite=own_finite, state=own_state, counters=counters, cfg=own_cfg, fresh=True,
+                         main=capture(unroll), n_main=K // unroll, tail=capture(K % unroll) if K % unroll else None)
+            while len(cache) >= 4:                              # (the executables, their pools and buffers live as long as the entry;
+                # an evicted one may still be replaying on the stream: it stays referenced until three more have gone)
+                self._graphs = getattr(self, "_graphs", [])[-3:] + [cache.pop(next(iter(cache)))]
+            cache[key] = entry
+        if not entry["fresh"]:
+            # a repeat: fresh optimizer state, the call's first Philox offset, iteration counter 0 — stream-ordered fills
+            entry["state"].zero_()
+            entry["counters"].zero_()
+            entry["counters"][0:1].fill_(int(offset0))
+        entry["fresh"] = False
+        for _ in range(entry["n_main"]):
+            entry["main"].replay()
+        if entry["tail"] is not None:
+            entry["tail"].replay()
+        loss_curve[:K].copy_(entry["curve"][:K])
+        finite[:K].copy_(entry["finite"][:K])
 
     def _prepare_fast_train(self, n_local, n_global, base, cfg, pretraining):
         """a repeat of one in-kernel training call (single rank, Philox noise, fresh optimizer inside the kernel) as a

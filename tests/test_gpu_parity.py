@@ -530,6 +530,39 @@ def test_graph_replayed_training_leaves_no_pointer_in_the_cached_argument_block(
 
 
 @pytest.mark.gpu
+def test_repeated_sharded_calls_replay_the_kept_graph_and_walk_the_same_trajectory():
+    """The graphs of the sharded step are kept for a repeat of the same call (engine._train_graph): the second and third call of the
+    same shape reuse the first one's executables and buffers — fresh optimizer state, the call's own Philox offset — and must give
+    what a call that captures anew gives: compared with the launch-per-iteration sequence (`BSVI_GRAPH=0`) call by call, Adam's state
+    included (a stale state would bend the second curve); the curves a caller holds are not overwritten by the next call."""
+    import os
+    api = W.native_api()
+    a = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    b = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    curves = []
+    for call in range(3):
+        la, fa = a.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+        assert a.last_mode == "graph"
+        curves.append((la, la.clone()))
+        os.environ["BSVI_GRAPH"] = "0"
+        try:
+            lb, fb = b.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+        finally:
+            del os.environ["BSVI_GRAPH"]
+        assert b.last_mode == "stepwise"
+        assert torch.equal(la, lb) and torch.equal(fa, fb) and torch.equal(a.params, b.params), call
+    assert len(a._graph_cache) == 1                                  # one capture served all three
+    assert all(torch.equal(held, copy) for held, copy in curves)
+    assert not torch.equal(curves[0][0], curves[1][0])               # (the calls continue the optimisation: different curves)
+    # another shape is another entry; the first one still replays
+    a.train(7, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+    b.train(7, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+    la, _ = a.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+    lb, _ = b.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+    assert len(a._graph_cache) == 2 and torch.equal(la, lb) and torch.equal(a.params, b.params)
+
+
+@pytest.mark.gpu
 def test_dense_path_at_baseline_config4_size():
     """BASELINE config 4 at FULL size (784 -> 10, dataset 60000, minibatch 512, number_samples 1024), where the oracle
     would take minutes: the size-independent properties instead -- (1) call-to-call bit equality of the whole output
