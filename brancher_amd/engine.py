@@ -308,6 +308,15 @@ def _bound_to_device(cls):
     return cls
 
 
+def _process_group_identity():
+    """what a captured all-reduce is tied to: (rank, world size, the default process group object) — a graph kept from an earlier
+    group must not be replayed in a later one"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return (0, 1, 0)
+    return (dist.get_rank(), dist.get_world_size(), id(dist.group.WORLD))
+
+
 def broadcast_from_rank0(tensor):
     """ranks must start from identical parameters (and draw with the same seed): every rank keeps its own copy and only
     sums are all-reduced, so nothing would ever re-synchronise them"""
@@ -601,7 +610,8 @@ class CompiledELBO:
         dev, p = self.device, self.program
         ptr = lambda t: C.c_void_p(t.data_ptr())
         key = (int(K), int(n_local), int(n_global), int(base), bytes(cfg), int(self._resolved(seed)), int(pretraining),
-               self.params.data_ptr(), self.out.data_ptr(), collective_kind(), os.environ.get("BSVI_JIT"), _graph_unroll())
+               self.params.data_ptr(), self.out.data_ptr(), collective_kind(), os.environ.get("BSVI_JIT"), _graph_unroll(),
+               _process_group_identity())
         cache = self.__dict__.setdefault("_graph_cache", {})
         entry = cache.get(key)
         if entry is None:
