@@ -310,7 +310,8 @@ class CompiledBnn:
     def _args(self, n_local, n_global, base, noise=None, indices=None, seed=None, offset=0, noise_out=None,
               indices_out=None, fvalue_out=None, logq_out=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        seed = _engine.shared_seed(seed, self.device)
+        if not isinstance(seed, int) or seed is True:      # (train() resolves the call's seed ONCE and hands the integer down)
+            seed = _engine.shared_seed(seed, self.device)
         return BnnArgs(params_dev=ptr(self.params), noise_dev=ptr(noise), indices_dev=ptr(indices), seed=seed, offset=int(offset),
                        n_samples_local=n_local, n_samples_global=n_global, sample_base=base, out_dev=ptr(self.out),
                        noise_out_dev=ptr(noise_out), indices_out_dev=ptr(indices_out), fvalue_out_dev=ptr(fvalue_out),
@@ -343,7 +344,12 @@ class CompiledBnn:
             return None
         if isinstance(minibatch, dict):
             minibatch = minibatch[self.program.indices_name]
-        return torch.as_tensor(np.asarray(minibatch, dtype=np.int32)).to(self.device)
+        idx = np.asarray(minibatch, dtype=np.int64).reshape(-1)
+        # the kernel reads labels[row] and dataset[row] (csrc/bnn_kernel.inc, bnn_gather): rows outside the dataset are refused here
+        if idx.size != self.program.batch_size or (idx.size and (idx.min() < 0 or idx.max() >= self.program.dataset_size)):
+            raise ValueError("minibatch indices must be {} rows in [0, {}): got {} rows in [{}, {}]".format(
+                self.program.batch_size, self.program.dataset_size, idx.size, idx.min() if idx.size else "-", idx.max() if idx.size else "-"))
+        return torch.as_tensor(idx.astype(np.int32)).to(self.device)
 
     def evaluate(self, number_samples, noise=None, minibatch=None, seed=None, offset=None, want_noise=False,
                  want_fvalues=False, want_indices=False, **_):
@@ -404,6 +410,8 @@ class CompiledBnn:
         offset0 = self.iteration
         self.iteration += K
         self.grads_valid = True
+        # (the call's Philox key once: with seed=None on several ranks `shared_seed` is a broadcast and a host sync — not per iteration)
+        seed = int(engine.shared_seed(seed, dev))
         for it in range(K):
             nz = None if noise_seq is None else self._noise_tensor(noise_seq[it], number_samples, base, n_local)
             mb = None if minibatch_seq is None else self._indices_tensor(minibatch_seq[it])

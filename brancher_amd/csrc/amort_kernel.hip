@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void x6_split_kernel(const X6SplitTable T) { x
 // loads TWO steps ahead in a second register set — 240 VGPRs, the same times to the microsecond on every cfg 5 shape: the
 // kernel does not wait for its loads.  profiles/r4/x6_notes.txt has what it does wait for.)
 template <bool NN, int DBG = 0>      // DBG (BSVI_X6_DEBUG, timing only, wrong results): 1 no split, 2 no stores, 3 no MFMAs, 4 no LDS fragment reads
-__global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {
+__global__ __launch_bounds__(256, 2) void x6gemm_r5_kernel(const X6Args G) {
     constexpr int TBM = 128, FA = 2, APL = TBM * XLD;
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * APL + 3 * XPLANE];      // A hi | mid | lo | B hi | mid | lo
     const int tiles_n = (G.N + 127) / 128;
@@ -967,6 +967,296 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {
                 }
             }
         }
+}
+
+// The tile epilogue of x6gemm_kernel: acc[j][r] is C[m][n] with m = 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31) of the wave's 32 x 128
+// tile.  Through LDS (the stages are dead by then), one 32 x 64 half at a time (row stride 64 words: the 32 lanes of a ds_write_b32 group write
+// one row, the 16 lanes of a ds_read_b128 group read 16 different bank quads of two rows), then 256 contiguous bytes of a row of C per
+// 16 lanes: 16 stores of 16 bytes per thread instead of 64 of 4, bias / activation / derivative applied on the way.
+template <bool NN, int DBG>
+__device__ __forceinline__ void x6_epilogue(const X6Args& G, unsigned char* lds, const f32x16 (&acc)[4], int m0, int n0, int wave, int lane) {
+    const int wm = wave * 32, lm = lane & 31, lk = lane >> 5;
+    __syncthreads();                                           // every wave is done with the stages
+    float* const tile = reinterpret_cast<float*>(lds) + wave * (32 * 64);
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(8 * (r >> 2) + 4 * lk + (r & 3)) * 64 + 32 * jj + lm] = acc[2 * half + jj][r];
+        const int n = n0 + 64 * half + ec;
+        f32x4 bias4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (!NN && G.bias && n < G.N) {                        // (N is a multiple of 4; a bias may start anywhere in the parameter vector: scalar loads)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias4[e] = G.bias[n + e];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = 4 * t + er, m = m0 + wm + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * 64 + ec);
+            if (m >= G.M || n >= G.N) continue;
+            float* c = G.C + (long)m * G.ldc + n;
+            if (DBG == 2) { if (v[0] == 1.2345f) *c = v[0]; continue; }
+            if (!NN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_forward(ACT_OF(G, n + e), v[e] + bias4[e], ADD_OF(G, n + e));
+            } else {
+                if (G.Y) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(G.Y + (long)m * G.ldy + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_derivative(ACT_OF(G, n + e), y[e], ADD_OF(G, n + e));
+                }
+                if (G.accumulate) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = c0[e] + v[e];
+                }
+            }
+            *reinterpret_cast<f32x4*>(c) = v;
+        }
+    }
+}
+// Round 6: the same product with NOTHING staged through registers.  What bounded the kernel above was never the matrix pipe (63 % of
+// its time remained with the MFMAs compiled out, profiles/r4/x6_notes.txt): per k step a workgroup pushed 48 KB through the CU's LDS
+// STORE path (ds_write_b64 / b128 at ~79 B/clk/CU, with 2-way bank conflicts on both operands: 3.1 M SQ_LDS_BANK_CONFLICT cycles per
+// launch, profiles/r5/cfg5_pmc_sq.csv) behind ~100 vector instructions of splitting, two barriers per step, and ended in 64 scalar
+// 4-byte stores per thread.  Now:
+//   * BOTH operands enter LDS by LDS-DMA (`global_load_lds_dwordx4`, the staging of xgemm_nt_glds_kernel): the weights' pieces as
+//     before, the activations AS F32 — 16 KB per step instead of 24 KB of pieces, no vector instruction, no ds_write, two stages,
+//     ONE barrier per step.  A wave's DMA writes 64 x 16 bytes linearly, so the conflict-free image is made on the SOURCE side: an
+//     A chunk is 8 rows x 128 bytes and slot s of row r holds the row's 16-byte piece s ^ ((r >> 1) & 7) (the 16 lanes of a
+//     ds_read_b128 group then read 16 different bank quads); the pieces' chunks keep xgemm_nt_glds_kernel's involution.
+//   * the split of the activations happens in REGISTERS, on the fragment a wave is about to multiply (two ds_read_b128 of f32 ->
+//     hi | mid | lo, 44 vector instructions per fragment) — in the shadow of the MFMAs (an MFMA holds the issue port for 8 of its
+//     32 cycles).  A wave's tile is 32 rows x 128 columns, so every row of A is split by exactly one wave (64 x 64 wave tiles
+//     would split it twice) and a wave's DMA fetches its own rows.
+//   * the epilogue goes through LDS (the stages are dead by then): a wave writes its 32 x 64 half tile as the accumulators hold
+//     it and reads rows back, 16 lanes x 16 bytes = 256 contiguous bytes of a row of C per quarter instruction — 16 stores of 16
+//     bytes per thread instead of 64 of 4, bias / activation / derivative applied on the way.
+// Same products in the same order as the kernel above: bit-identical results.  80 KB of LDS: two workgroups per CU.
+template <bool NN, int DBG = 0, int VAR = 0>      // DBG (BSVI_X6_DEBUG, timing only, wrong results): 2 no stores, 3 no MFMAs, 4 fragment reads from one address, 5 no DMA after the first
+__global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {      // VAR (BSVI_X6_VAR): 0 the compiler's order of the main loop, 1 the hand-ordered loop
+    constexpr int CHUNK = 1024, A_ST = 16 * CHUNK, B_PL = 8 * CHUNK, STAGE = A_ST + 3 * B_PL;      // f32 A (128 x 32) | hi | mid | lo (128 x 32 bf16 each)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    const int tiles_n = (G.N + 127) / 128;
+    int bid = blockIdx.x;
+    const int n_blocks = gridDim.x;
+    if ((n_blocks & 7) == 0) bid = (bid & 7) * (n_blocks >> 3) + (bid >> 3);      // an XCD takes a contiguous range of tiles
+    const int m0 = (bid / tiles_n) * 128, n0 = (bid % tiles_n) * 128;              // (neighbours share the rows of A)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave * 32, lm = lane & 31, lk = lane >> 5;
+    const int n_steps = G.Kp / XBK;
+    const bool k_tail = (G.K % XBK) != 0;
+
+    // DMA sources (`buffer_load_dwordx4 ... lds`: ONE 32-bit lane offset per piece, the k step in the SCALAR offset — no vector
+    // arithmetic per load; the descriptors end with the matrices, so the pieces of the last row beyond K — the k tail of a K that is
+    // not a multiple of 32 — are out of range: zeros, no access.  Other rows' tails read the next row's head; every fragment
+    // beyond K is zeroed when it is split).
+    // A: wave w fills chunks 4w .. 4w+3 = its own 32 rows; lane l of a chunk is slot (row l >> 3, piece l & 7).
+    // The pieces: chunks 6w .. 6w+5 of the 24 (plane, 16 columns); lane l is slot (column l >> 2, piece l & 3).
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G.A), 0, (int)(((size_t)(G.M - 1) * G.lda + G.K) * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.Bp), 0, (int)(3 * (size_t)G.plane_stride * 2), 0x00020000);
+    uint32_t srca[4], srcb[6], dstb[6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm + 8 * i + (lane >> 3);
+        const int gp = (lane & 7) ^ ((row >> 1) & 7);
+        srca[i] = (uint32_t)(((size_t)min(m0 + row, G.M - 1) * G.lda + gp * 4) * sizeof(float));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = 6 * wave + i, plane = c >> 3, chunk = c & 7, col = chunk * 16 + (lane >> 2);
+        const int gp = (lane & 3) ^ ((lane >> 4) & 3);
+        srcb[i] = (uint32_t)((plane * G.plane_stride + (long)min(n0 + col, G.N - 1) * G.Kp + gp * 8) * 2);
+        dstb[i] = A_ST + plane * B_PL + chunk * CHUNK;
+    }
+    auto issue = [&](int step, int stage) {
+        unsigned char* base = lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(base + (4 * wave + i) * CHUNK), 16, srca[i], step * (XBK * (int)sizeof(float)), 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr_t)(base + dstb[i]), 16, srcb[i], step * (XBK * 2), 0, 0);
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    // fragment addresses.  A: row R = wm + lm, the f32 k range [16 kc + 8 lk, + 8) = pieces q = 4 kc + 2 lk, q + 1 of the row:
+    //   (R >> 3) * 1 KB + (R & 7) * 128 + ((q ^ ((R >> 1) & 7)) * 16).  The pieces of B: as xgemm_nt_glds_kernel.
+    int offa[2][2], offb[4][2];
+    {
+        const int R = wm + lm, fa = (R >> 1) & 7;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) offa[kc][h] = (R >> 3) * CHUNK + (R & 7) * 128 + (((4 * kc + 2 * lk + h) ^ fa) * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = 32 * j + lm;
+                offb[j][kc] = A_ST + (rb >> 4) * CHUNK + (rb & 15) * 64 + (((2 * kc + lk) ^ ((rb >> 2) & 3)) * 16);
+            }
+        }
+    }
+    if constexpr (VAR == 1) {
+        // The hand-ordered loop.  hipcc leaves the 44 vector instructions of a fragment's split behind the chunk's last MFMA and waits
+        // for every fragment read right in front of the MFMA that needs it (neither sched_group_barrier nor a software-pipelined
+        // source changes that: the ISA is in profiles/r6/x6_notes.txt), so one wave never keeps the matrix pipe fed — measured: with
+        // NO DMA at all the kernel loses 10 % of its time, with no MFMAs 35 %.  Here the order is written out and pinned
+        // (`sched_barrier(0)` behind every MFMA): a chunk's twelve fragment reads of B and the two of the NEXT fragment of A go first,
+        // then 24 MFMAs with, behind each, either one of the step's ten DMAs or one piece of the next fragment's split (twelve pieces
+        // of 5 / 5 / 1 instructions per pair of values).  A wave fetches its OWN rows of A — the first four DMAs of a step — so it
+        // reads the next step's first fragment from the other stage behind its own `vmcnt(6)`, no barrier, half a chunk before the
+        // step ends.
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first
+        float x[8];
+        uint32_t ph[4], pm[4], pl[4];
+        auto take = [&](const f32x4& v0, const f32x4& v1, int k0, bool last) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = v0[e]; x[4 + e] = v1[e]; }
+            if (last) {                                        // (K is a multiple of 4: a quad lies inside or outside)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = k0 < G.K ? x[e] : 0.0f; x[4 + e] = k0 + 4 < G.K ? x[4 + e] : 0.0f; }
+            }
+        };
+        auto piece = [&](int c) {                              // piece c of the split of x[0..8): the arithmetic of x6_split2
+            const int p = c & 3;
+            float& u = x[2 * p];
+            float& v = x[2 * p + 1];
+            if (c < 4) { ph[p] = x6_pack(u, v); u -= __uint_as_float(ph[p] << 16); v -= __uint_as_float(ph[p] & 0xFFFF0000u); }
+            else if (c < 8) { pm[p] = x6_pack(u, v); u -= __uint_as_float(pm[p] << 16); v -= __uint_as_float(pm[p] & 0xFFFF0000u); }
+            else pl[p] = x6_pack(u, v);
+        };
+        auto pieces = [&](bf16x8 (&a)[3]) {
+            a[0] = __builtin_bit_cast(bf16x8, xu4{ph[0], ph[1], ph[2], ph[3]});
+            a[1] = __builtin_bit_cast(bf16x8, xu4{pm[0], pm[1], pm[2], pm[3]});
+            a[2] = __builtin_bit_cast(bf16x8, xu4{pl[0], pl[1], pl[2], pl[3]});
+        };
+        auto dma = [&](int i, int step, unsigned char* base) {
+            if (i < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)(base + (4 * wave + i) * CHUNK), 16, srca[i], step * (XBK * (int)sizeof(float)), 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr_t)(base + dstb[i - 4]), 16, srcb[i - 4], step * (XBK * 2), 0, 0);
+        };
+        bf16x8 a0[3], a1[3];
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // this wave's own rows of A (the first four DMAs) have landed
+        {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + offa[0][0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + offa[0][1]);
+            take(v0, v1, 8 * lk, k_tail && n_steps == 1);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) piece(c);
+            pieces(a0);
+        }
+        auto body = [&](int step, auto more_t, auto last_t) {
+            constexpr bool more = decltype(more_t)::value, last = decltype(last_t)::value;      // a step follows; this step holds the k tail
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of step `step` has landed
+            __syncthreads();                                   // everybody's has; everybody is done with the other stage
+            const unsigned char* base = lds + (step & 1) * STAGE;
+            unsigned char* nbase = lds + ((step + 1) & 1) * STAGE;
+            bf16x8 b[3][4];
+            // ---- chunk 0: a0 x the pieces of B; beside it the step's DMAs and the split of the chunk-1 fragment into a1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[0][j] = *reinterpret_cast<const bf16x8*>(base + offb[j][0]);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + offa[1][0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + offa[1][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[2][j] = *reinterpret_cast<const bf16x8*>(base + 2 * B_PL + offb[j][0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[1][j] = *reinterpret_cast<const bf16x8*>(base + B_PL + offb[j][0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[i >> 2]], b[PB[i >> 2]][i & 3], acc[i & 3], 0, 0, 0);
+                if (i == 0) take(v0, v1, step * XBK + 16 + 8 * lk, last);
+                if ((i & 1) == 0) { if (more && (i >> 1) < 10) dma(i >> 1, step + 1, nbase); }
+                else piece(i >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pieces(a1);
+            // ---- chunk 1: a1 x the pieces of B; in its second half the next step's first fragment (this wave's own rows: vmcnt(6)) into a0
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[0][j] = *reinterpret_cast<const bf16x8*>(base + offb[j][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[2][j] = *reinterpret_cast<const bf16x8*>(base + 2 * B_PL + offb[j][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[1][j] = *reinterpret_cast<const bf16x8*>(base + B_PL + offb[j][1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[i >> 2]], b[PB[i >> 2]][i & 3], acc[i & 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // (the four DMAs of A were issued first)
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(nbase + offa[0][0]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(nbase + offa[0][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                take(w0, w1, (step + 1) * XBK + 8 * lk, k_tail && step + 2 == n_steps);
+            }
+#pragma unroll
+            for (int i = 12; i < 24; ++i) {
+                acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA[i >> 2]], b[PB[i >> 2]][i & 3], acc[i & 3], 0, 0, 0);
+                if (more) piece(i - 12);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) pieces(a0);
+        };
+        for (int step = 0; step + 1 < n_steps; ++step) body(step, std::true_type{}, std::false_type{});
+        if (k_tail) body(n_steps - 1, std::false_type{}, std::true_type{});
+        else body(n_steps - 1, std::false_type{}, std::false_type{});
+    } else {
+        issue(0, 0);
+        for (int step = 0; step < n_steps; ++step) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA of step `step` has landed
+            __syncthreads();                                       // everybody's has; everybody is done with the other stage
+            if (step + 1 < n_steps && DBG != 5) issue(step + 1, (step + 1) & 1);
+            const unsigned char* base = lds + (step & 1) * STAGE;
+            const bool last = k_tail && step == n_steps - 1;
+    #pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (DBG == 4 ? 0 : offa[kc][0]));
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (DBG == 4 ? 0 : offa[kc][1]));
+                if (last) {                                        // (K is a multiple of 4: a quad lies inside or outside)
+                    const int k0 = step * XBK + 16 * kc + 8 * lk;
+                    if (k0 >= G.K) v0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (k0 + 4 >= G.K) v1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+                uint32_t h[4], m[4], l[4];
+                x6_split2(v0[0], v0[1], h[0], m[0], l[0]);
+                x6_split2(v0[2], v0[3], h[1], m[1], l[1]);
+                x6_split2(v1[0], v1[1], h[2], m[2], l[2]);
+                x6_split2(v1[2], v1[3], h[3], m[3], l[3]);
+                bf16x8 a[3];
+                a[0] = __builtin_bit_cast(bf16x8, xu4{h[0], h[1], h[2], h[3]});
+                a[1] = __builtin_bit_cast(bf16x8, xu4{m[0], m[1], m[2], m[3]});
+                a[2] = __builtin_bit_cast(bf16x8, xu4{l[0], l[1], l[2], l[3]});
+                bf16x8 b[3][4];
+    #pragma unroll
+                for (int p = 0; p < 3; ++p)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) b[p][j] = *reinterpret_cast<const bf16x8*>(base + (DBG == 4 ? 0 : p * B_PL + offb[j][kc]));
+                if (DBG == 3) {
+    #pragma unroll
+                    for (int p = 0; p < 3; ++p)
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][p] += (float)a[p][0] + (float)b[p][j][0];
+                    continue;
+                }
+                // smallest products first: (lo hi), (hi lo), (mid mid), (mid hi), (hi mid), (hi hi)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        #pragma unroll
+                for (int q = 0; q < 6; ++q)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b[PB[q]][j], acc[j], 0, 0, 0);
+                }
+        }
+    }
+    x6_epilogue<NN, DBG>(G, lds, acc, m0, n0, wave, lane);
 }
 
 // The weight gradient of a wide layer, C[M][N] = sum_r A[r][m] B[r][n] (A = dY, B = the layer's input: BOTH f32 activations), as six
@@ -2485,17 +2775,26 @@ constexpr int kX6MinRows = 256;
 static int launch_x6(bool nn, const X6Args& X, hipStream_t stream) {
     const int tiles = ((X.M + 127) / 128) * ((X.N + 127) / 128);
     static const int dbg = [] { const char* e = getenv("BSVI_X6_DEBUG"); return e ? atoi(e) : 0; }();
-    if (dbg && !nn && dbg != 12 && dbg != 13) {
-        switch (dbg) {
-        case 1: hipLaunchKernelGGL((x6gemm_kernel<false, 1>), dim3(tiles), dim3(256), 0, stream, X); break;
-        case 2: hipLaunchKernelGGL((x6gemm_kernel<false, 2>), dim3(tiles), dim3(256), 0, stream, X); break;
-        case 3: hipLaunchKernelGGL((x6gemm_kernel<false, 3>), dim3(tiles), dim3(256), 0, stream, X); break;
-        default: hipLaunchKernelGGL((x6gemm_kernel<false, 4>), dim3(tiles), dim3(256), 0, stream, X);
-        }
-    } else if (nn && dbg == 12) hipLaunchKernelGGL((x6gemm_kernel<true, 2>), dim3(tiles), dim3(256), 0, stream, X);
-    else if (nn && dbg == 13) hipLaunchKernelGGL((x6gemm_kernel<true, 3>), dim3(tiles), dim3(256), 0, stream, X);
-    else if (nn) hipLaunchKernelGGL((x6gemm_kernel<true>), dim3(tiles), dim3(256), 0, stream, X);
-    else hipLaunchKernelGGL((x6gemm_kernel<false>), dim3(tiles), dim3(256), 0, stream, X);
+    // round 6's kernel (LDS-DMA staging, 16-byte stores) wants 16-byte aligned rows of every matrix it touches with wide accesses;
+    // anything else — and BSVI_X6_V=5 — takes round 5's kernel, which stages through registers
+    static const bool v6 = [] { const char* e = getenv("BSVI_X6_V"); return !(e && e[0] == '5'); }();
+    auto al16 = [](const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; };
+    const bool wide_ok = v6 && (X.N & 3) == 0 && al16(X.A, X.lda) && al16(X.C, X.ldc) && (!X.Y || al16(X.Y, X.ldy)) && ((uintptr_t)X.Bp & 15) == 0;
+    static const int var = [] { const char* e = getenv("BSVI_X6_VAR"); return e ? atoi(e) : 0; }();
+    if (wide_ok && ((size_t)(X.M - 1) * X.lda + X.K) * sizeof(float) < 0x7fffffffull && 3 * (size_t)X.plane_stride * 2 < 0x7fffffffull) {
+#define BSVI_X6_LAUNCH(NNV, D, V) hipLaunchKernelGGL((x6gemm_kernel<NNV, D, V>), dim3(tiles), dim3(256), 0, stream, X)
+        if (!nn && dbg == 2) BSVI_X6_LAUNCH(false, 2, 0);
+        else if (!nn && dbg == 3) BSVI_X6_LAUNCH(false, 3, 0);
+        else if (!nn && dbg == 4) BSVI_X6_LAUNCH(false, 4, 0);
+        else if (!nn && dbg == 5) BSVI_X6_LAUNCH(false, 5, 0);
+        else if (nn && dbg == 12) BSVI_X6_LAUNCH(true, 2, 0);
+        else if (nn && dbg == 13) BSVI_X6_LAUNCH(true, 3, 0);
+        else if (var == 1) { if (nn) BSVI_X6_LAUNCH(true, 0, 1); else BSVI_X6_LAUNCH(false, 0, 1); }
+        else if (nn) BSVI_X6_LAUNCH(true, 0, 0);
+        else BSVI_X6_LAUNCH(false, 0, 0);
+#undef BSVI_X6_LAUNCH
+    } else if (nn) hipLaunchKernelGGL((x6gemm_r5_kernel<true>), dim3(tiles), dim3(256), 0, stream, X);
+    else hipLaunchKernelGGL((x6gemm_r5_kernel<false>), dim3(tiles), dim3(256), 0, stream, X);
     HIP_TRY(hipGetLastError());
     return BSVI_OK;
 }

@@ -26,6 +26,10 @@ from brancher_amd import native
 from brancher_amd.native import ElboArgs, OUT_HEADER
 
 
+class _CaptureRefused(Exception):
+    """the HIP-graph capture of a sharded step was refused on some rank: every rank steps eagerly (`CompiledELBO._train_graph`)"""
+
+
 class _Stale(Exception):
     """a prepared training call no longer matches the object's buffers"""
 
@@ -54,6 +58,12 @@ def shard(n_global, rank, world):
 
 
 _exchanges = {}          # device index -> collective.Exchange, or False: decided (by all ranks together) that RCCL serves
+_exchange_generation = [0]      # bumped whenever an Exchange is created, replaced or closed: a kept HIP graph holds the peers' IPC
+                                # region pointers of the exchange it was captured with BY VALUE (`_train_graph` keys on this)
+
+
+def _exchange_changed():
+    _exchange_generation[0] += 1
 
 
 def collective_kind():
@@ -82,6 +92,7 @@ def _exchange_for(out):
         return None                 # (cannot be decided inside a capture: the graph path makes an untimed call first)
     if ex is not None:
         ex.close()
+    _exchange_changed()
     capacity = max(out.numel(), 1024)
     ok = 1.0
     try:
@@ -125,6 +136,7 @@ def loop_exchange(out):
         except (native.NativeError, RuntimeError):
             ex = False
         _exchanges[key] = ex
+        _exchange_changed()
     return ex or None
 
 
@@ -308,13 +320,36 @@ def _bound_to_device(cls):
     return cls
 
 
+_group_seen = [None, 0]         # weak reference to the default process group last seen, and how many different ones there have been
+
+
 def _process_group_identity():
-    """what a captured all-reduce is tied to: (rank, world size, the default process group object) — a graph kept from an earlier
-    group must not be replayed in a later one"""
+    """what a captured all-reduce is tied to: (rank, world size, which default process group this is) — a graph kept from an
+    earlier group must not be replayed in a later one.  The group is told apart by a GENERATION counted here against a weak
+    reference (after destroy_process_group() / init_process_group() a new group object can get the old one's id())."""
+    import weakref
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return (0, 1, 0)
-    return (dist.get_rank(), dist.get_world_size(), id(dist.group.WORLD))
+    group = dist.group.WORLD
+    seen = _group_seen[0]() if _group_seen[0] is not None else None
+    if seen is not group:
+        try:
+            _group_seen[0] = weakref.ref(group)
+        except TypeError:                       # (not weak-referenceable: hold it — the comparison above stays exact)
+            _group_seen[0] = (lambda g: (lambda: g))(group)
+        _group_seen[1] += 1
+    return (dist.get_rank(), dist.get_world_size(), _group_seen[1])
+
+
+def _all_ranks_agree(ok, device):
+    """True when `ok` holds on EVERY rank: one MIN all-reduce of a flag (no process group: this rank's own answer)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    flag = torch.tensor([1.0 if ok else 0.0], device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return float(flag.item()) >= 1.0
 
 
 def broadcast_from_rank0(tensor):
@@ -609,18 +644,31 @@ class CompiledELBO:
         curve out.  Keyed by everything the captured launches hold by value or by address."""
         dev, p = self.device, self.program
         ptr = lambda t: C.c_void_p(t.data_ptr())
+        # (the exchange's generation: the captured exchange kernels hold the peers' IPC region pointers by value, and
+        #  `_exchange_for` closes and replaces the exchange when a larger message arrives — ADVICE r5)
         key = (int(K), int(n_local), int(n_global), int(base), bytes(cfg), int(self._resolved(seed)), int(pretraining),
-               self.params.data_ptr(), self.out.data_ptr(), collective_kind(), os.environ.get("BSVI_JIT"), _graph_unroll(),
-               _process_group_identity())
+               self.params.data_ptr(), self.out.data_ptr(), collective_kind(), _exchange_generation[0], os.environ.get("BSVI_JIT"),
+               _graph_unroll(), _process_group_identity())
+        keep = os.environ.get("BSVI_GRAPH_KEEP", "1") != "0"       # 0: capture per call, nothing kept (a first multi-GPU run's way back)
         cache = self.__dict__.setdefault("_graph_cache", {})
-        entry = cache.get(key)
+        entry = cache.get(key) if keep else None
+        if entry is False:
+            # some rank could not capture this call before: EVERY rank recorded that (the vote below) and steps eagerly
+            raise _CaptureRefused("capture of this call was refused on some rank before")
         if entry is None:
+            # A miss issues one more collective than a hit (the warm-up below) and the vote — so hit or miss must be the same on
+            # every rank: an entry is kept only when EVERY rank captured, otherwise every rank keeps a refusal (ADVICE r5: a rank
+            # whose capture alone failed would otherwise be one all-reduce ahead of its peers on the next identical call).
             own_curve, own_finite, own_state = training_buffers(K, p.n_params, dev)
             counters = torch.tensor([int(offset0), 0], dtype=torch.int64, device=dev)
+            failure = None
             # hiprtc / module loading and RCCL's first-call set-up cannot happen inside a capture: one untimed launch of each
-            warm = self._elbo_args(n_local, n_global, base, None, seed, int(offset0))
-            native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(warm)))
-            allreduce_sums(torch.zeros_like(self.out))
+            try:
+                warm = self._elbo_args(n_local, n_global, base, None, seed, int(offset0))
+                native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(warm)))
+            except (RuntimeError, native.NativeError) as err:
+                failure = err
+            allreduce_sums(torch.zeros_like(self.out))          # (every rank, whatever happened above: the collectives stay aligned)
             torch.cuda.synchronize(dev)
             own_cfg = type(cfg).from_buffer_copy(cfg)          # (the captured launches read the block at capture time only; kept anyway)
 
@@ -641,12 +689,26 @@ class CompiledELBO:
                 return graph
 
             unroll = min(K, _graph_unroll())
-            entry = dict(curve=own_curve, finite=own_finite, state=own_state, counters=counters, cfg=own_cfg, fresh=True,
-                         main=capture(unroll), n_main=K // unroll, tail=capture(K % unroll) if K % unroll else None)
-            while len(cache) >= 4:                              # (the executables, their pools and buffers live as long as the entry;
-                # an evicted one may still be replaying on the stream: it stays referenced until three more have gone)
-                self._graphs = getattr(self, "_graphs", [])[-3:] + [cache.pop(next(iter(cache)))]
-            cache[key] = entry
+            if failure is None:
+                try:
+                    entry = dict(curve=own_curve, finite=own_finite, state=own_state, counters=counters, cfg=own_cfg, fresh=True,
+                                 main=capture(unroll), n_main=K // unroll, tail=capture(K % unroll) if K % unroll else None)
+                except (RuntimeError, native.NativeError) as err:
+                    failure, entry = err, None
+            if not _all_ranks_agree(failure is None, dev):
+                entry = None
+                if keep:
+                    cache[key] = False
+                raise _CaptureRefused(str(failure) if failure is not None else "a peer rank could not capture the step")
+            if keep:
+                while len(cache) >= 4:                          # (the executables, their pools and buffers live as long as the entry;
+                    # an evicted one may still be replaying on the stream: it stays referenced until three more have gone)
+                    evicted = cache.pop(next(iter(cache)))
+                    if evicted:
+                        self._graphs = getattr(self, "_graphs", [])[-3:] + [evicted]
+                cache[key] = entry
+            else:
+                self._graphs = getattr(self, "_graphs", [])[-3:] + [entry]     # (alive until its replays have run)
         if not entry["fresh"]:
             # a repeat: fresh optimizer state, the call's first Philox offset, iteration counter 0 — stream-ordered fills
             entry["state"].zero_()
@@ -837,7 +899,7 @@ class CompiledELBO:
                 self.last_mode = "graph" if world == 1 else "graph+allreduce"
                 check_exchange(dev, self.params)
                 return loss_curve, finite
-            except (RuntimeError, native.NativeError) as err:      # capture refused: launch by launch below
+            except _CaptureRefused as err:      # capture refused on some rank (every rank is here then): launch by launch below
                 warnings.warn("HIP-graph capture of the sharded step failed ({}); stepping eagerly".format(err))
                 loss_curve.zero_()
         for it in range(K):
