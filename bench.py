@@ -56,6 +56,8 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 OTHER_CONFIGS = ("cfg2", "cfg3", "cfg4", "cfg5")     # timed after the headline in the same process (N = 1)
+# BASELINE.json config 5 names "BlackBox + Pathwise estimators": the two MFMA configs once more under BlackBox (no traffic pass of their own)
+OTHER_BLACKBOX = ("cfg4", "cfg5")
 # (the same untimed spin-up as the headline: the clocks of an idle MI355X take longer than 100 ms to ramp — cfg 2, a pure
 #  latency chain, measured 49.9 / 34.7 / 28.8 / 27.1 us per iteration after 0 / 100 / 300 / 1000 ms; every config's `cold_start`
 #  is in the line beside its hot figure)
@@ -173,6 +175,37 @@ def algorithmic_bytes_per_iteration(program, n_local):
     return n_local * program.n_noise * 4 + 2 * program.n_params * 4
 
 
+def dense_bytes_per_iteration(program, n_local):
+    """cfg 4, stated both ways: SURVEY 8d's figure — the [N, C, P] noise the estimator consumes (N*C*P*4: never stored
+    here, drawn in registers twice) + the minibatch [B, P] and its labels + parameters read and gradients written — and what THIS
+    design must move: the minibatch as bf16 (its gather source rows are f32), labels, parameters, gradients."""
+    noise = n_local * program.n_classes * program.n_features * 4
+    batch = program.batch_size * (program.n_features + 1) * 4
+    par = 2 * program.n_params * 4
+    return dict(survey=noise + batch + par, must_move=batch + par)
+
+
+def amort_bytes_per_iteration(program, n_local):
+    """cfg 5, layer by layer as this design (and the reference's PyTorch graph) runs it — every Linear layer writes its activation
+    and reads its input in the forward pass, reads dY twice (input and weight gradient), its input and the activation it
+    differentiates, and writes dX in the backward pass; the likelihood reads the logits and the data rows and writes dlogits; the
+    data rows are gathered three times (first layer, likelihood, first layer's weight gradient); parameters read, gradients written.
+    What a fused multi-layer kernel would NOT have to move (activations that stay on chip) is in here: it is the byte count of the
+    layer-by-layer formulation, the denominator for `traffic`."""
+    rows = n_local * program.batch_size
+    P = program.n_features
+    total = 3.0 * rows * P * 4                                   # the gathered data rows, three times
+    for net, input_grad in ((program.enc_layers, False), (program.dec_layers, True)):
+        for l in net:
+            total += rows * (l.n_in + l.n_out) * 4.0             # forward: read x, write y
+            total += rows * (l.n_out + l.n_in) * 4.0             # weight gradient: read dY and x
+            if l.in_value != 0 or input_grad:
+                total += rows * (l.n_out + 2 * l.n_in) * 4.0     # input gradient: read dY and the activation, write dX
+    total += rows * P * 2 * 4.0                                  # the likelihood: read the logits, write their gradient
+    total += 2 * program.n_params * 4.0
+    return total
+
+
 def amort_flops_per_iteration(program, n_local):
     """SURVEY §8d cfg 5: every Linear layer is three GEMMs of 2*R*n_in*n_out flops over the R = N*B rows of the
     iteration — forward, weight gradient, input gradient (the last not for layers reading the data rows)."""
@@ -217,33 +250,40 @@ def cpu_baseline_vae(kwargs, optimizer, opt_kwargs, budget_s=12.0, n_cpu=8):
 
 
 def cpu_baseline(builder, kwargs, n_samples, optimizer, opt_kwargs, dense=False, budget_s=12.0, max_iters=400):
-    """The oracle (PyTorch-CPU restatement of the reference loop, kind 'port') timed on the host.
-    Scalar graphs are dispatch-bound (more threads are slower): 1 thread, batches of 5
-    iterations at the full number_samples.  One dense-link iteration at number_samples=1024 takes the oracle
-    about a minute, so the bounded sample there is number_samples=64 on up to 16 threads; `value` is in the
-    metric's unit either way (300-sample-equivalent iterations per second)."""
+    """The oracle (PyTorch-CPU restatement of the reference loop, kind 'port') timed on the host, LIVE, at ONE thread and at ALL host
+    cores ("all host cores with the core count printed"): `value` / `cores` are the faster of the two legs, `runs`
+    holds both.  Scalar graphs are dispatch-bound (more threads are slower): batches of 5 iterations at the full
+    number_samples.  One dense-link iteration at number_samples=1024 takes the oracle about a minute, so the bounded sample there is
+    number_samples=64; `value` is in the metric's unit either way (300-sample-equivalent iterations per second)."""
     import torch
     from brancher_amd import workloads as W
     from oracle.svi_oracle import Oracle
-    cores = min(os.cpu_count() or 1, 16) if dense else 1
-    torch.set_num_threads(cores)
+    all_cores = min(os.cpu_count() or 1, 16)
     batch = 1 if dense else 5
     n_cpu = min(n_samples, 64) if dense else n_samples
     oracle = Oracle(getattr(W, builder)(W.native_api(), **kwargs))
-    torch.manual_seed(0)
-    oracle.train(1 if dense else 2, n_cpu, optimizer, "pathwise", None, **opt_kwargs)
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < max_iters:
-        oracle.train(batch, n_cpu, optimizer, "pathwise", None, **opt_kwargs)
-        iters += batch
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=iters / dt * (n_cpu / 300.0), unit="it/s", cores=cores, kind="port",
-                sample="%d iterations of the same workload at number_samples=%d in %.1f s, oracle/svi_oracle.py "
-                       "on PyTorch-CPU, %d thread(s)" % (iters, n_cpu, dt, cores),
-                iters_per_sec=iters / dt, number_samples=n_cpu)
+    runs = []
+    legs = [1] if all_cores == 1 else [1, all_cores]
+    for cores in legs:
+        torch.set_num_threads(cores)
+        torch.manual_seed(0)
+        oracle.train(1 if dense else 2, n_cpu, optimizer, "pathwise", None, **opt_kwargs)
+        t0 = time.perf_counter()
+        iters = 0
+        while iters < max_iters:
+            oracle.train(batch, n_cpu, optimizer, "pathwise", None, **opt_kwargs)
+            iters += batch
+            if time.perf_counter() - t0 > budget_s / len(legs):
+                break
+        dt = time.perf_counter() - t0
+        runs.append(dict(cores=cores, value=iters / dt * (n_cpu / 300.0), iters_per_sec=iters / dt, iterations=iters, seconds=dt))
+    torch.set_num_threads(1)
+    best = max(runs, key=lambda r: r["value"])
+    return dict(value=best["value"], unit="it/s", cores=best["cores"], kind="port", host_cores=os.cpu_count(),
+                sample="%d iterations of the same workload at number_samples=%d in %.1f s, oracle/svi_oracle.py on PyTorch-CPU, "
+                       "%d thread(s) — the faster of the legs timed live at %s threads" % (
+                           best["iterations"], n_cpu, best["seconds"], best["cores"], " and ".join(str(c) for c in legs)),
+                iters_per_sec=best["iters_per_sec"], number_samples=n_cpu, runs=runs)
 
 
 def recorded_reference_timings(workload, n_samples, optimizer):
@@ -276,7 +316,7 @@ def self_launch(n_gpus, argv=None, port=None):
     return subprocess.call(cmd, env=env)
 
 
-def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=None, probe_iters=None):
+def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=None, probe_iters=None, estimator=None):
     """Warm-up, spin-up and the timed region of ONE workload: exactly `steps` SVI iterations between two barriers.
     Returns (the parts of the JSON line that describe this workload, what the CPU baseline needs)."""
     import gc
@@ -290,7 +330,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         kwargs = dict(kwargs, dataset_size=args.dataset_size)
     n_global = n_per_gpu * world
     model = getattr(W, builder)(W.native_api(), **kwargs)
-    compiled = engine.compile_model(model, None, args.estimator)
+    estimator = estimator or args.estimator
+    compiled = engine.compile_model(model, None, estimator)
     program = compiled.program
     allow_persistent = args.mode != "stepwise"
     if args.mode == "auto" and getattr(compiled, "prefers_stepwise", None) and compiled.prefers_stepwise(n_global):
@@ -522,6 +563,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                         kernel=("dense_xfwd (draw + logits product + cross-entropy) + dense_xbwd (gradient product + reduction "
                                 "against the redrawn normals)" if exact else "bsvi::dense_forward<10> + bsvi::dense_backward"),
                         algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps, data_path="bf16x3" if exact else "f32",
+                        algorithmic_bytes_per_iteration=dense_bytes_per_iteration(program, n_per_gpu)["survey"],
+                        bytes_this_design_must_move_per_iteration=dense_bytes_per_iteration(program, n_per_gpu)["must_move"],
                         frac_of_f32_mfma_peak=tf / MFMA_F32_PEAK_TFLOPS,
                         note=("the minibatch is exactly bf16 (pixel counts): both products run as three bf16 MFMAs on the exact "
                               "pieces hi + mid + lo of the f32 operand; peak = dense bf16 MFMA peak / 3; achieved = GEMM flops of "
@@ -547,8 +590,8 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         x6 = os.environ.get("BSVI_AMORT_X6", "1") != "0" and rows >= 256
         wide = lambda l: l.n_in >= 64 and l.n_out >= 64 and l.n_in % 4 == 0 and l.n_out % 4 == 0
         x6_layers = [l for l in program.enc_layers if l.in_value != 0 and wide(l)] + [l for l in program.dec_layers if wide(l)]
-        modes = os.environ.get("BSVI_X6_MODES")          # input gradients too: unset = those contracting >= 512 columns, 3 = all, 1 = none
-        x6_back = lambda l: (modes == "3") or (modes is None and l.n_out >= 512)
+        modes = os.environ.get("BSVI_X6_MODES")          # input gradients too: unset or 3 = all of them (round 6), 1 = none
+        x6_back = lambda l: modes in (None, "3")
         x6_tn = os.environ.get("BSVI_X6_TN", "1") != "0"      # round 5: their weight gradients too (x6tn_kernel)
         x6_flops = (sum(2.0 * rows * l.n_in * l.n_out for l in x6_layers) +
                     sum(2.0 * rows * l.n_in * l.n_out for l in x6_layers if x6_back(l)) +
@@ -558,15 +601,16 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         peak = flops / roof_s / 1e12
         roofline = dict(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s",
                         frac=tf / peak, traffic=traffic,
-                        kernel="bsvi_amort_impl::gemm_kernel<1|2>" + (" + x6gemm_kernel (forward products of the wide layers, input gradients with K >= 512) + x6tn_kernel (their weight gradients)" if x6_flops else "<0>") + (
+                        kernel="bsvi_amort_impl::gemm_kernel<1|2>" + (" + x6gemm_kernel (forward products and input gradients of the wide layers) + x6tn_kernel (their weight gradients)" if x6_flops else "<0>") + (
                             " + xgemm_nt_glds_kernel<128> (first encoder layer: forward%s)" % (" and weight gradient" if xdw else "") if exact else ""),
                         algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps,
+                        algorithmic_bytes_per_iteration=amort_bytes_per_iteration(program, n_per_gpu),
                         rows_per_iteration=rows, data_path="bf16x3" if exact else "f32",
                         frac_of_f32_mfma_peak=tf / MFMA_F32_PEAK_TFLOPS,
                         x6_flops_per_iteration=x6_flops,
                         note="f32-input MFMA (v_mfma_f32_32x32x2_f32) for the products that are not named next" + (
-                             "; the forward products of the wide layers whose input is a network value, their weight gradients (and their input gradients where 512 "
-                             "or more columns are contracted) run as SIX bf16 MFMAs on the exact pieces of both f32 operands (peak 2500 / 6 for their flops)" if x6_flops else "") + (
+                             "; the forward products of the wide layers whose input is a network value, their weight gradients and their input gradients "
+                             "run as SIX bf16 MFMAs on the exact pieces of both f32 operands (peak 2500 / 6 for their flops)" if x6_flops else "") + (
                              "; the forward product%s of the layer that reads the (exactly bf16) data rows run%s as three bf16 MFMAs on "
                              "the exact pieces of the f32 operand; peak = flops / (f32-input flops / 157.3 + those flops / (2500 / 3) + six-piece flops / (2500 / 6))"
                              % ((" and the weight gradient", "") if xdw else ("", "s")) if exact else "") +
@@ -581,7 +625,7 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
                 dtype="f32", data="synthetic",
                 config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
                             optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
-                            estimator=args.estimator, mode=mode, parallelism="sample-shard x%d" % world,
+                            estimator=estimator, mode=mode, parallelism="sample-shard x%d" % world,
                             grid=geom, untimed_spinup_iterations=spun),
                 iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
                 device_ms_per_step=dev_ms / steps, all_finite=ok,
@@ -657,6 +701,7 @@ def main():
         args.other_configs == "auto" and world == 1 and args.workload == "cfg1" and not args.samples)) else []
     plan = [(args.workload, args.steps, args.warmup, args.spinup_ms)] + \
            [(w, OTHER_STEPS, OTHER_WARMUP, OTHER_SPINUP_MS) for w in others]
+    blackbox_plan = [(w, OTHER_STEPS, OTHER_WARMUP, OTHER_SPINUP_MS) for w in OTHER_BLACKBOX] if (others and args.estimator == "pathwise") else []
     if probing:
         plan = [(w, int(k), int(wu), 0.0) for w, k, wu in (item.split(":") for item in args.traffic_probe.split(","))]
 
@@ -705,15 +750,92 @@ def main():
         except Exception as err:      # noqa: BLE001
             other_lines[workload] = dict(error="%s: %s" % (type(err).__name__, err))
         torch.cuda.empty_cache()
+    for workload, steps, warmup, spinup_ms in ([] if probing else blackbox_plan):
+        try:
+            part, _ = measure(workload, args, steps, warmup, spinup_ms, world, rank, None, None, estimator="blackbox")
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "device_ms_per_step", "iters_per_sec", "samples_per_sec",
+                    "all_finite", "final_loss", "config", "roofline", "cold_start")
+            other_lines[workload + "_blackbox"] = {k: part[k] for k in keep if k in part}
+        except Exception as err:      # noqa: BLE001
+            other_lines[workload + "_blackbox"] = dict(error="%s: %s" % (type(err).__name__, err))
+        torch.cuda.empty_cache()
+
+    # ---- several ranks: the SAME workload once more with the library's one-shot exchange opted in (BSVI_COLLECTIVE=auto: the in-kernel
+    #      loop with the exchange inside where it serves, the exchange kernel between launches otherwise) — `value_alt` / `config.collective_alt`
+    #      beside the default's RCCL figure, so that the first run on a multi-GPU node says what flipping the default would buy.  It must cost
+    #      nothing but that key: the exchange's waits are bounded, `measure` votes and falls back on any rank's failure, and a WATCHDOG in every
+    #      rank ends the phase after BSVI_BENCH_ALT_TIMEOUT_S (default 120): rank 0 prints the line it already has, every rank leaves with 0.
+    alt = None
+    if world > 1 and not probing and os.environ.get("BSVI_BENCH_ALT", "1") != "0" and engine_collective_is_default():
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get("BSVI_BENCH_ALT_TIMEOUT_S", "120"))
+
+        def watchdog():
+            if done.wait(limit):
+                return
+            if rank == 0:
+                line.setdefault("config", {})["collective_alt_error"] = "the BSVI_COLLECTIVE=auto phase did not finish within %.0f s: abandoned" % limit
+                finish_line(line, other_lines, baseline_of, args, world, probe_rows, probe_note, None, skip_cpu=True)
+                sys.stdout.flush()
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        prev = {k: os.environ.get(k) for k in ("BSVI_COLLECTIVE", "BSVI_LOOP_EXCHANGE")}
+        os.environ["BSVI_COLLECTIVE"] = "auto"
+        try:
+            part, _ = measure(args.workload, args, args.steps, args.warmup, args.spinup_ms, world, rank)
+            if rank == 0:
+                alt = dict(value_alt=part["value"], ms_per_step_alt=part["ms_per_step"], device_ms_per_step_alt=part["device_ms_per_step"],
+                           collective_alt=part["config"].get("collective"), mode_alt=part["config"].get("mode"),
+                           collective_alt_fallback=part["config"].get("collective_fallback"))
+        except Exception as err:      # noqa: BLE001  (this phase never costs the line its headline)
+            alt = dict(collective_alt_error="%s: %s" % (type(err).__name__, str(err)[:200]))
+        finally:
+            done.set()
+            for k, v in prev.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            from brancher_amd import engine as _engine
+            for ex in list(_engine._exchanges.values()):
+                if ex:
+                    ex.close()
+            _engine._exchanges.clear()
+            _engine._exchange_changed()
 
     if rank == 0 and not probing:
+        finish_line(line, other_lines, baseline_of, args, world, probe_rows, probe_note, alt,
+                    probe_seconds=locals().get("probe_seconds"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def engine_collective_is_default():
+    from brancher_amd import engine
+    return engine.collective_kind() == "torch"
+
+
+def finish_line(line, other_lines, baseline_of, args, world, probe_rows, probe_note, alt, skip_cpu=False, probe_seconds=None):
+    """rank 0: the ONE JSON line of the run"""
+    if True:
+        if alt:
+            cfg_keys = ("collective_alt", "mode_alt", "collective_alt_fallback", "collective_alt_error")
+            for k, v in alt.items():
+                if v is None:
+                    continue
+                if k in cfg_keys:
+                    line["config"][k] = v
+                else:
+                    line[k] = v
         if line["roofline"].get("traffic") is None:
             line["roofline"]["traffic_note"] = probe_note or "the probe saw no dispatch of this kernel"
-        elif probe_rows is not None:
+        elif probe_rows is not None and probe_seconds is not None:
             line["roofline"]["traffic_probe_seconds"] = probe_seconds
         if other_lines:
             line["other_configs"] = other_lines
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not skip_cpu:
             b = baseline_of
             line["cpu_baseline"] = cpu_baseline_vae(b["kwargs"], b["optimizer"], b["opt_kwargs"]) if b["amort"] else \
                 cpu_baseline(b["builder"], b["kwargs"], b["n"], b["optimizer"], b["opt_kwargs"], dense=b["dense"])
@@ -721,8 +843,6 @@ def main():
             if recorded is not None:
                 line["cpu_baseline"]["reference"] = recorded
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -103,6 +103,17 @@ class Exchange:
             torch.cuda.synchronize(self.device)
             expected = ramp * float(self.world * (self.world + 1) // 2 + k * self.world)
             ok = ok and self.status() == 0 and bool(torch.equal(buf, expected))
+        # ... and the TAGGED 8-byte entry area, which only the in-kernel training loop uses (spec_main.h: spec_xput / spec_xget): the
+        # same protocol as a kernel of its own (bsvi_exchange_selftest_tagged), both parities and a reuse
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for k in range(int(calls)):
+            buf = (ramp * float(self.rank + 1 + k) + 0.25).contiguous()
+            native.check(self.lib.bsvi_exchange_selftest_tagged(self.handle, C.c_void_p(buf.data_ptr()), n, C.c_void_p(st)))
+            torch.cuda.synchronize(self.device)
+            expected = torch.zeros_like(ramp)
+            for r in range(self.world):                       # (added in rank order, as the kernel adds them)
+                expected = expected + (ramp * float(r + 1 + k) + 0.25)
+            ok = ok and self.status() == 0 and bool(torch.equal(buf, expected))
         return ok
 
     def status(self):

@@ -969,6 +969,13 @@ __global__ __launch_bounds__(256, 2) void x6gemm_r5_kernel(const X6Args G) {
         }
 }
 
+// diagnostic build only (BSVI_X6_DEBUG=9): where a tile's time goes — s_memtime of one lane per workgroup at the start, at the top of the
+// first, second and last step, behind the loop and behind the epilogue; the wall clock (100 MHz) at the start; the hardware id.  No
+// product path reads or writes this; bsvi_debug_gemm mode 8 copies it out.
+__device__ unsigned long long x6_stamps[8 * 8192];
+__device__ __forceinline__ void x6_stamp(int slot) {
+    if (threadIdx.x == 0 && blockIdx.x < 8192) x6_stamps[8 * blockIdx.x + slot] = __builtin_amdgcn_s_memtime();
+}
 // The tile epilogue of x6gemm_kernel: acc[j][r] is C[m][n] with m = 8(r>>2) + 4(lane>>5) + (r&3), n = 32j + (lane&31) of the wave's 32 x 128
 // tile.  Through LDS (the stages are dead by then), one 32 x 64 half at a time (row stride 64 words: the 32 lanes of a ds_write_b32 group write
 // one row, the 16 lanes of a ds_read_b128 group read 16 different bank quads of two rows), then 256 contiguous bytes of a row of C per
@@ -1141,6 +1148,13 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {      /
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr_t)(base + dstb[i - 4]), 16, srcb[i - 4], step * (XBK * 2), 0, 0);
         };
         bf16x8 a0[3], a1[3];
+        if (DBG == 9) {
+            x6_stamp(0);
+            if (threadIdx.x == 0 && blockIdx.x < 8192) {
+                x6_stamps[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+                x6_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+            }
+        }
         issue(0, 0);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // this wave's own rows of A (the first four DMAs) have landed
         {
@@ -1155,6 +1169,7 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {      /
             constexpr bool more = decltype(more_t)::value, last = decltype(last_t)::value;      // a step follows; this step holds the k tail
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of step `step` has landed
             __syncthreads();                                   // everybody's has; everybody is done with the other stage
+            if (DBG == 9) { if (step == 0) x6_stamp(1); if (step == 1) x6_stamp(2); if (!more) x6_stamp(3); }
             const unsigned char* base = lds + (step & 1) * STAGE;
             unsigned char* nbase = lds + ((step + 1) & 1) * STAGE;
             bf16x8 b[3][4];
@@ -1208,6 +1223,7 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {      /
         for (int step = 0; step + 1 < n_steps; ++step) body(step, std::true_type{}, std::false_type{});
         if (k_tail) body(n_steps - 1, std::false_type{}, std::true_type{});
         else body(n_steps - 1, std::false_type{}, std::false_type{});
+        if (DBG == 9) x6_stamp(4);
     } else {
         issue(0, 0);
         for (int step = 0; step < n_steps; ++step) {
@@ -1257,6 +1273,7 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {      /
         }
     }
     x6_epilogue<NN, DBG>(G, lds, acc, m0, n0, wave, lane);
+    if (DBG == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x6_stamp(5); }
 }
 
 // The weight gradient of a wide layer, C[M][N] = sum_r A[r][m] B[r][n] (A = dY, B = the layer's input: BOTH f32 activations), as six
@@ -2780,13 +2797,14 @@ static int launch_x6(bool nn, const X6Args& X, hipStream_t stream) {
     static const bool v6 = [] { const char* e = getenv("BSVI_X6_V"); return !(e && e[0] == '5'); }();
     auto al16 = [](const void* p, int ld) { return ((uintptr_t)p & 15) == 0 && (ld & 3) == 0; };
     const bool wide_ok = v6 && (X.N & 3) == 0 && al16(X.A, X.lda) && al16(X.C, X.ldc) && (!X.Y || al16(X.Y, X.ldy)) && ((uintptr_t)X.Bp & 15) == 0;
-    static const int var = [] { const char* e = getenv("BSVI_X6_VAR"); return e ? atoi(e) : 0; }();
+    static const int var = [] { const char* e = getenv("BSVI_X6_VAR"); return e ? atoi(e) : 1; }();      // 1: the hand-ordered main loop (default), 0: the compiler's order
     if (wide_ok && ((size_t)(X.M - 1) * X.lda + X.K) * sizeof(float) < 0x7fffffffull && 3 * (size_t)X.plane_stride * 2 < 0x7fffffffull) {
 #define BSVI_X6_LAUNCH(NNV, D, V) hipLaunchKernelGGL((x6gemm_kernel<NNV, D, V>), dim3(tiles), dim3(256), 0, stream, X)
         if (!nn && dbg == 2) BSVI_X6_LAUNCH(false, 2, 0);
         else if (!nn && dbg == 3) BSVI_X6_LAUNCH(false, 3, 0);
         else if (!nn && dbg == 4) BSVI_X6_LAUNCH(false, 4, 0);
         else if (!nn && dbg == 5) BSVI_X6_LAUNCH(false, 5, 0);
+        else if (!nn && dbg == 9) BSVI_X6_LAUNCH(false, 9, 1);
         else if (nn && dbg == 12) BSVI_X6_LAUNCH(true, 2, 0);
         else if (nn && dbg == 13) BSVI_X6_LAUNCH(true, 3, 0);
         else if (var == 1) { if (nn) BSVI_X6_LAUNCH(true, 0, 1); else BSVI_X6_LAUNCH(false, 0, 1); }
@@ -2988,6 +3006,11 @@ extern "C" int bsvi_debug_gemm(int mode, const float* a_dev, const float* b_dev,
         }
         hipLaunchKernelGGL(reduce_partials, dim3(blocks), dim3(256), 0, st, S);
         HIP_TRY(hipGetLastError());
+        return BSVI_OK;
+    }
+    if (mode == 8) {      // diagnostics: the stamps of the last BSVI_X6_DEBUG=9 launch, m values of 8 bytes into c_dev
+        if (!c_dev || m > 8u * 8192u) return bsvi_fail(BSVI_ERR_INVALID, "bad gemm arguments");
+        HIP_TRY(hipMemcpyFromSymbol(c_dev, HIP_SYMBOL(x6_stamps), (size_t)m * 8, 0, hipMemcpyDeviceToDevice));
         return BSVI_OK;
     }
     if (mode == 5 || mode == 6) {
@@ -3422,17 +3445,15 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 G.accumulate = written[l.in_value];
                 written[l.in_value] = 1;
                 const auto& x6 = a->x6[&net == &a->dec ? 1 : 0];
-                // Most input gradients stay on the f32-input MFMA kernel (the rule is below): beside the side stream's f32-input
-                // weight gradients the six-piece form gains little.  What trying them found is why this file is compiled without
-                // packed-f32 instructions (Makefile): with
-                // x6gemm_kernel<true> on this stream the narrow layers' outer_kernel on the other one returned ~50 of 1024 values
-                // different from call to call — lanes 48-63, the x / z halves of one packed-f32 accumulator — and so it does
-                // beside EVERY bf16-MFMA kernel, the exact-data ones included (tools/r4/coresidency_probe.py,
-                // profiles/r4/x6_notes.txt section 4).
-                // cfg 5, one input gradient at a time on x6gemm_kernel beside the f32-input weight gradients (0.984 ms with none):
-                // K = 784 -> 0.976, K = 512 -> 0.984, K = 256 -> 1.020 — a tile's prologue / epilogue against 8 ... 25 k steps.
-                // Unset: the ones with at least 512 columns to contract; BSVI_X6_MODES=1 none, 3 all.
-                const int x6_modes = [&] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : (G.K >= 512 ? 3 : 1); }();
+                // Round 6: EVERY wide input gradient runs as six products of exact pieces (x6gemm_kernel<true>).  Rounds 4 / 5 kept the ones
+                // contracting fewer than 512 columns on the f32-input MFMA kernel: with the register-staged kernel a tile's prologue / epilogue
+                // weighed against 8 k steps lost (cfg 5, one at a time beside the f32-input weight gradients: K = 784 -> 0.976 ms, 512 -> 0.984,
+                // 256 -> 1.020 against 0.984 with none).  With the LDS-DMA kernel all three win: cfg 5 0.800 -> 0.769 ms with the K = 256 one
+                // on it too (profiles/r6/x6_notes.txt).  BSVI_X6_MODES=1: none (the f32-input kernel), 3: all.
+                // (What trying them in round 4 found is why this file is compiled without packed-f32 instructions — Makefile: with
+                //  x6gemm_kernel<true> on this stream the narrow layers' outer_kernel on the other one returned ~50 of 1024 values different
+                //  from call to call, lanes 48-63, beside EVERY bf16-MFMA kernel: tools/r4/coresidency_probe.py, profiles/r4/x6_notes.txt 4.)
+                const int x6_modes = [&] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 3; }();
                 static const int x6_only = [] { const char* e = getenv("BSVI_X6_NN_ONLY"); return e ? atoi(e) : -1; }();     // (diagnostics: 10 * net + layer)
                 if (x6_on && (x6_modes & 2) && (size_t)i < x6.size() && x6[i].nn && (x6_only < 0 || x6_only == 10 * (&net == &a->dec ? 1 : 0) + i)) {
                     X6Args X{};

@@ -176,6 +176,54 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XArgs A) {
     }
 }
 
+// The in-loop exchange's entry area (spec_main.h: spec_xput / spec_xget — tagged 8-byte entries `(call number << 32) | value bits`, value
+// and "it is there" in one store, no flag) exercised by itself: ONE wave, lane l owns element l of the message, stores its entry into
+// its row of every region and polls the entries of every rank in its own region until all carry the call's number; the entries are
+// added in rank order.  Same layout, same scopes, same bounded wait and abort word as the generated kernels — what `Exchange.self_test`
+// runs before a process lets its training loop exchange inside the kernel (the self-test covered the flagged slots
+// of exchange_kernel only).  The in-loop exchanges number their calls in word kCallsWord + 1 of the rank's own region.
+__device__ __forceinline__ unsigned long long* entry_of(unsigned char* region, uint32_t parity, uint32_t r, uint32_t capacity, uint32_t world) {
+    return reinterpret_cast<unsigned long long*>(region + kHeaderWords * 4 + (size_t)2 * world * capacity * 4) + ((size_t)parity * world + r) * capacity;
+}
+__global__ __launch_bounds__(64) void tagged_selftest_kernel(const XArgs A) {
+    const uint32_t l = threadIdx.x;
+    uint32_t* mine = reinterpret_cast<uint32_t*>(A.peer[A.rank]);
+    uint32_t* const abort_word = mine + kMaxRanks * kFlagStride;
+    const uint32_t seq = __builtin_amdgcn_readfirstlane(mine[kCallsWord + 1]) + 1u, parity = seq & 1u;
+    const bool live = l < A.n;
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    const float v = live ? A.buf[l] : 0.0f;
+    if (live)
+        for (uint32_t p = 0; p < A.world; ++p)
+            __hip_atomic_store(entry_of(A.peer[p], parity, A.rank, A.capacity, A.world) + l, tag | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned char* const region = A.peer[A.rank];
+    unsigned long long t0 = 0;
+    bool gave_up = false;
+    float total = 0.0f;
+    for (uint32_t round = 0;; ++round) {
+        bool all = true;
+        total = 0.0f;
+        for (uint32_t r = 0; r < A.world; ++r) {
+            const unsigned long long e = live ? __hip_atomic_load(entry_of(region, parity, r, A.capacity, A.world) + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : tag;
+            all = all && (uint32_t)(e >> 32) == seq;
+            total += __uint_as_float((uint32_t)e);
+        }
+        if (__all((int)all)) break;
+        if (round == 0u) t0 = wall_clock64();
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { gave_up = true; break; }
+        if (wall_clock64() - t0 > A.timeout_ticks) {
+            gave_up = true;
+            if (l < A.world) __hip_atomic_store(reinterpret_cast<uint32_t*>(A.peer[l]) + kMaxRanks * kFlagStride, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (l == 0u) atomicAdd(abort_word + 1, 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (l == 0u) mine[kCallsWord + 1] = seq;
+    if (gave_up || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) total = __int_as_float(0x7fc00000);
+    if (live) A.buf[l] = total;
+}
+
 }  // namespace
 
 struct bsvi_exchange {
@@ -286,6 +334,22 @@ extern "C" int bsvi_exchange_allreduce(bsvi_exchange* x, float* buf_dev, uint32_
     hipLaunchKernelGGL(exchange_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("exchange_kernel launch: ") + hipGetErrorString(e));
+    return BSVI_OK;
+}
+
+// one all-reduce of up to 64 floats through the TAGGED ENTRY area (the in-loop exchange's: tagged_selftest_kernel above); an abandoned
+// call leaves NaN in every element and is sticky like any other (bsvi_exchange_status)
+extern "C" int bsvi_exchange_selftest_tagged(bsvi_exchange* x, float* buf_dev, uint32_t n, void* stream) {
+    if (!x || !buf_dev) return bsvi_fail(BSVI_ERR_INVALID, "null argument");
+    if (!x->connected) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_exchange_selftest_tagged: the peers' regions are not connected yet");
+    if (n == 0 || n > 64 || n > x->capacity) return bsvi_fail(BSVI_ERR_INVALID, "bsvi_exchange_selftest_tagged: 1..64 floats");
+    XArgs A{};
+    for (uint32_t r = 0; r < x->world; ++r) A.peer[r] = x->peer[r];
+    A.buf = buf_dev; A.n = n; A.capacity = x->capacity; A.rank = x->rank; A.world = x->world;
+    A.timeout_ticks = x->timeout_ticks;
+    hipLaunchKernelGGL(tagged_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bsvi_fail(BSVI_ERR_HIP, std::string("tagged_selftest_kernel launch: ") + hipGetErrorString(e));
     return BSVI_OK;
 }
 

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsvi.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 OUT_HEADER = 4
 
 
@@ -240,6 +240,7 @@ EXPORTS.update({
     "bsvi_exchange_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsvi_exchange_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bsvi_exchange_status": (C.c_int, [C.c_void_p]),
+    "bsvi_exchange_selftest_tagged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bsvi_exchange_destroy": (None, [C.c_void_p]),
 })
 

@@ -41,7 +41,7 @@ typedef long long int64_t;
 extern "C" {
 #endif
 
-#define BSVI_ABI_VERSION 10
+#define BSVI_ABI_VERSION 11
 
 /* Every descriptor / argument struct a binder fills in starts with `struct_size` = sizeof of the struct AS THE BINDER
  * DECLARES IT.  An entry point that receives a struct whose struct_size differs from the library's own sizeof returns
@@ -831,6 +831,10 @@ int bsvi_exchange_export(const bsvi_exchange* x, void* handle_out);
 int bsvi_exchange_connect(bsvi_exchange* x, const void* handles);
 int bsvi_exchange_allreduce(bsvi_exchange* x, float* buf_dev, uint32_t n, void* stream);
 int bsvi_exchange_status(const bsvi_exchange* x);
+/* (ABI 11) one all-reduce of 1..64 floats through the region's TAGGED-ENTRY area — the 8-byte `(call number << 32) | value` entries the
+ * in-kernel training loop exchanges through (bsvi_train_persistent_exchange), with its numbering, scopes, bounded wait and abort word — so
+ * that a host can test that area between its GPUs before it lets a training loop rely on it.  An abandoned call leaves NaN in buf_dev. */
+int bsvi_exchange_selftest_tagged(bsvi_exchange* x, float* buf_dev, uint32_t n, void* stream);
 void bsvi_exchange_destroy(bsvi_exchange* x);
 
 const char* bsvi_last_error(void);

@@ -507,6 +507,20 @@ class Oracle:
             return value, f, lq, named
         return value
 
+    def log_densities(self, named_q_samples):
+        """log p(z, y) and log q(z) at SUPPLIED posterior samples {variable name: [N, ...]}: what
+        `ProbabilisticModel.get_importance_weights` (variables.py:821-841) computes its weights from —
+        `get_p_log_probabilities_from_q_samples` (:814-819) and the posterior's `calculate_log_probability` (:718-727)."""
+        by_name = {v.name: v for v in self.q._flatten()}
+        samples = {by_name[name]: torch.as_tensor(np.asarray(value), dtype=self.dtype) for name, value in named_q_samples.items()}
+        empirical = self.empirical_samples()
+        with torch.no_grad():
+            lp = self.p_log_prob_from_q_samples(samples, empirical)
+            both = dict(samples)
+            both.update(empirical)
+            lq = self.model_log_prob(self.q, both)
+        return lp.reshape(-1).numpy().copy(), lq.reshape(-1).numpy().copy()
+
     def loss_and_grads(self, n, estimator="pathwise", noise=None, minibatch=None):
         self.minibatch = minibatch
         self.zero_grad()

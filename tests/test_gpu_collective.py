@@ -91,6 +91,10 @@ def _exchange_worker(rank, world, port, n_calls, skip_call, out_q):
         worst = max(worst, diff)
         ok = ok and torch.equal(dev.cpu(), ref)
     status = ex.status()
+    if skip_call is None and n_calls == 0:
+        # the self-test of a fresh exchange: the flagged slots AND the tagged 8-byte entries of the in-loop exchange (round 6)
+        ok = ex.self_test()
+        status = ex.status()
     out_q.put((rank, ok, worst, status))
     dist.barrier()
     ex.close()
@@ -120,6 +124,31 @@ def test_one_shot_exchange_between_two_rank_processes_sharing_the_gpu():
         ok, worst, status = got[rank]
         assert status == 0
         assert ok, worst                                # bit-identical to the host-side sum, on both ranks
+
+
+def test_self_test_covers_the_tagged_entries_of_the_in_loop_exchange():
+    """`Exchange.self_test` (what `engine._exchange_for` votes on before any rank relies on the exchange): four all-reduces through the
+    flagged slots and — round 6 — four through the TAGGED 8-byte entry area that only the in-kernel training loop writes
+    (bsvi_exchange_selftest_tagged: the protocol of spec_main.h's spec_xput / spec_xget as a kernel of its own), exact on both ranks"""
+    got = _run_exchange(0, None)
+    for rank in (0, 1):
+        ok, _, status = got[rank]
+        assert ok and status == 0, (rank, ok, status)
+
+
+def test_tagged_self_test_on_one_rank_is_the_identity_and_numbers_its_calls():
+    from brancher_amd import collective, native
+    import ctypes as C
+    ex = collective.Exchange(128, device="cuda:0")
+    lib = native.load()
+    for call in range(5):
+        buf = torch.arange(1, 41, device="cuda:0", dtype=torch.float32) * (call + 1.5)
+        want = buf.clone()
+        native.check(lib.bsvi_exchange_selftest_tagged(ex.handle, C.c_void_p(buf.data_ptr()), 40, None))
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want) and ex.status() == 0
+    assert lib.bsvi_exchange_selftest_tagged(ex.handle, C.c_void_p(buf.data_ptr()), 65, None) != 0      # one wave: 64 floats at most
+    ex.close()
 
 
 def test_one_shot_exchange_gives_up_instead_of_hanging():

@@ -563,6 +563,49 @@ def test_repeated_sharded_calls_replay_the_kept_graph_and_walk_the_same_trajecto
 
 
 @pytest.mark.gpu
+def test_a_refused_graph_capture_steps_eagerly_on_the_same_trajectory_and_is_remembered(monkeypatch):
+    """`engine.CompiledELBO._train_graph` when the capture is refused (ADVICE r5 / VERDICT r5 item 4d): the call falls back to the
+    launch-per-iteration sequence and walks the trajectory of a captured run bit for bit; the refusal is KEPT under the call's key —
+    every rank keeps it (the vote) — so the repeat neither attempts another capture nor issues the miss's extra warm-up collective;
+    BSVI_GRAPH_KEEP=0 captures per call and keeps nothing."""
+    import warnings
+    api = W.native_api()
+    a = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    b = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    attempts = []
+
+    class Refusing:
+        def __init__(self, *args, **kwargs):
+            attempts.append(1)
+            raise RuntimeError("capture refused (test)")
+
+    with monkeypatch.context() as m:
+        m.setattr(torch.cuda, "CUDAGraph", Refusing)
+        for call in range(2):
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                la, fa = a.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+            assert a.last_mode == "stepwise" and any("stepping eagerly" in str(w.message) for w in caught)
+            lb, fb = b.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+            assert b.last_mode == "graph"
+            assert torch.equal(la, lb) and torch.equal(fa, fb) and torch.equal(a.params, b.params), call
+        assert len(attempts) == 1                       # the second call found the kept refusal
+        assert list(a._graph_cache.values()) == [False]
+    # per-call capture, nothing kept
+    monkeypatch.setenv("BSVI_GRAPH_KEEP", "0")
+    c = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    d = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
+    monkeypatch.delenv("BSVI_GRAPH_KEEP")
+    for call in range(2):
+        monkeypatch.setenv("BSVI_GRAPH_KEEP", "0")
+        lc, _ = c.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+        monkeypatch.delenv("BSVI_GRAPH_KEEP")
+        ld, _ = d.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
+        assert c.last_mode == "graph" and torch.equal(lc, ld) and torch.equal(c.params, d.params)
+    assert not getattr(c, "_graph_cache", {}) and len(d._graph_cache) == 1
+
+
+@pytest.mark.gpu
 def test_dense_path_at_baseline_config4_size():
     """BASELINE config 4 at FULL size (784 -> 10, dataset 60000, minibatch 512, number_samples 1024), where the oracle
     would take minutes: the size-independent properties instead -- (1) call-to-call bit equality of the whole output
@@ -742,19 +785,38 @@ def test_importance_weights_match_reference_log_densities(case):
     q_samples = {name: g.data["z/" + name] for name in [k[2:] for k in g.data.files if k.startswith("z/")]}
     log_p, log_q = engine.importance_log_weights(model, model.posterior_model, q_samples)
     lp, lq = g.data["lp"].reshape(-1), g.data["lq"].reshape(-1)
-    scale = max(1.0, float(np.abs(lp).max()), float(np.abs(lq).max()))
-    assert np.abs(log_p.cpu().numpy() - lp).max() <= 2e-5 * scale
-    assert np.abs(log_q.cpu().numpy() - lq).max() <= 2e-5 * scale
+    # the bound of the suite (conftest.yardstick_*): the truth is the oracle in DOUBLE precision at the same samples, and the kernel must
+    # be as close to it as the reference's own record — single precision — is (x4), or within 1e-5 of the scale
+    from oracle.svi_oracle import Oracle
+    lp64, lq64 = Oracle(g.build(), dtype=torch.float64).log_densities(q_samples)
+
+    def close(got, exact, reference, what):
+        scale = max(1.0, float(np.abs(exact).max()))
+        err, yard = np.abs(np.asarray(got, dtype=np.float64).reshape(-1) - exact).max(), np.abs(reference - exact).max()
+        assert err <= max(4 * yard, 1e-5 * scale), (what, err, yard, scale)
+
+    close(log_p.cpu().numpy(), lp64, lp, "log p")
+    close(log_q.cpu().numpy(), lq64, lq, "log q")
     # the two public entry points that return these log-densities (variables.py:718-727)
     lp_api = model.calculate_log_probability(q_samples).cpu().numpy()
     lq_api = model.posterior_model.calculate_log_probability(q_samples).cpu().numpy()
-    assert lp_api.shape == (g.N, 1) and np.abs(lp_api.reshape(-1) - lp).max() <= 2e-5 * scale
-    assert np.abs(lq_api.reshape(-1) - lq).max() <= 2e-5 * scale
+    assert lp_api.shape == (g.N, 1)
+    close(lp_api, lp64, lp, "calculate_log_probability (model)")
+    close(lq_api, lq64, lq, "calculate_log_probability (posterior)")
+    # the weights: softmax of log p - log q.  d log w = d (log p - log q) up to the normaliser, so the bound on the log-densities is
+    # the bound on log w: each weight within (err of log p + err of log q), relative — the same yardstick, written for the ratio
     w = model.get_importance_weights(q_samples, model.posterior_model)
-    ref = np.exp((lp - lq) - (lp - lq).max())
-    ref /= ref.sum()
     assert w.shape == (g.N, 1)
-    np.testing.assert_allclose(w.reshape(-1), ref, rtol=5e-4, atol=1e-7)
+
+    def weights(a, b):
+        e = np.exp((a - b) - (a - b).max())
+        return e / e.sum()
+
+    w64, w32 = weights(lp64, lq64), weights(lp.astype(np.float64), lq.astype(np.float64))
+    live = w64 > 1e-7 * w64.max()
+    rel = lambda x: np.abs(np.log(np.maximum(np.asarray(x, dtype=np.float64).reshape(-1)[live], 1e-300)) - np.log(w64[live])).max()
+    log_scale = max(1.0, float(np.abs(lp64).max()), float(np.abs(lq64).max()))
+    assert rel(w) <= max(4 * rel(w32), 2 * 1e-5 * log_scale), (rel(w), rel(w32), log_scale)
 
 
 @pytest.mark.gpu
