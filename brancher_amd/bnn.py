@@ -74,8 +74,12 @@ def _chain(e):
 
 
 def lower_bnn(joint, posterior, estimator="pathwise"):
-    if estimator not in ("pathwise", "blackbox"):
-        raise LoweringError("the bnn path implements the Pathwise and BlackBox estimators")
+    # "taylor1" (gradient_estimators.py:47-56): f at the posterior's analytic means — every latent of the network is a mean-field Normal,
+    # whose mean is its loc (distributions.py:137 through torch), so the program is the Pathwise one evaluated on the draw eps = 0
+    # (CompiledBnn supplies it); the entropy of a Normal does not depend on the draw.  The reference tiles the means to number_samples
+    # identical rows and averages: kept (N identical samples), so that the value rounds as the reference's does.
+    if estimator not in ("pathwise", "blackbox", "taylor1"):
+        raise LoweringError("the bnn path implements the Pathwise, BlackBox and Taylor1 estimators")
     L = _Lowering(joint, posterior, estimator)
     q_flat = posterior._flatten()
     L.q_by_name = {v.name: v for v in q_flat}
@@ -308,14 +312,25 @@ class CompiledBnn:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _args(self, n_local, n_global, base, noise=None, indices=None, seed=None, offset=0, noise_out=None,
-              indices_out=None, fvalue_out=None, logq_out=None):
+              indices_out=None, fvalue_out=None, logq_out=None, f_weight=None, q_weight=None):
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        if getattr(self.program, "estimator", "pathwise") == "taylor1":
+            # f at the posterior's means: the draw eps = 0, whatever was drawn (the reference draws too and reads the means:
+            # gradient_estimators.py:50-55) — a caller's noise (parity tests replay the reference's) is not read
+            noise = self._zero_noise(n_local)
         if not isinstance(seed, int) or seed is True:      # (train() resolves the call's seed ONCE and hands the integer down)
             seed = _engine.shared_seed(seed, self.device)
         return BnnArgs(params_dev=ptr(self.params), noise_dev=ptr(noise), indices_dev=ptr(indices), seed=seed, offset=int(offset),
                        n_samples_local=n_local, n_samples_global=n_global, sample_base=base, out_dev=ptr(self.out),
                        noise_out_dev=ptr(noise_out), indices_out_dev=ptr(indices_out), fvalue_out_dev=ptr(fvalue_out),
-                       logq_out_dev=ptr(logq_out), workspace_dev=ptr(self.workspace(n_local)), stream=self._stream())
+                       logq_out_dev=ptr(logq_out), workspace_dev=ptr(self.workspace(n_local)), stream=self._stream(),
+                       f_weight_dev=ptr(f_weight), q_weight_dev=ptr(q_weight))
+
+    def _zero_noise(self, n_local):
+        z = self.__dict__.setdefault("_zeros", {}).get(n_local)
+        if z is None:
+            z = self._zeros[n_local] = torch.zeros((self.program.n_noise, n_local), device=self.device)
+        return z
 
     def noise_from_named(self, named, n):
         """{variable name: [N, 1, rows, cols]}  ->  [n_rows, N] (the latent vector's row order)"""
@@ -385,6 +400,28 @@ class CompiledBnn:
             if logq is not None:
                 res["lq"] = logq
         return res
+
+    def evaluate_weighted(self, number_samples, f_weight, q_weight, seed, offset, noise=None, minibatch=None):
+        """The second pass of a user-defined gradient estimator (`engine.custom_estimator_loss`), as `CompiledDense.evaluate_weighted`:
+        the draw and the minibatch of (seed, offset) again, and -(sum_n a_n grad f_n + b_n grad log q_n) in the output block
+        (bsvi_bnn_args::f_weight_dev / q_weight_dev; the model must have been created with the BlackBox estimator)."""
+        from brancher_amd import engine
+        rank, world = engine.dist_info()
+        base, n_local = engine.shard(number_samples, rank, world)
+        a = f_weight.reshape(-1)[base:base + n_local].contiguous().float()
+        b = q_weight.reshape(-1)[base:base + n_local].contiguous().float()
+        noise_t = self._noise_tensor(noise, number_samples, base, n_local)
+        idx_t = self._indices_tensor(minibatch)
+        args = self._args(n_local, number_samples, base, noise_t, idx_t, seed, int(offset), f_weight=a, q_weight=b)
+        native.check(self.lib.bsvi_bnn_fwd_bwd(self.handle, C.byref(args)))
+        engine.allreduce_sums(self.out)
+        engine.check_exchange(self.device, self.params)
+        native.check(self.lib.bsvi_bnn_finalize(self.handle, C.c_void_p(self.out.data_ptr()), 1, self._stream()))
+        self.grads_valid = True
+        return self.out[OUT_HEADER:OUT_HEADER + self.program.n_params]
+
+    def _seed(self, seed):
+        return _engine.shared_seed(seed, self.device)
 
     def named_grads(self):
         g = self.out[OUT_HEADER:].detach().cpu().numpy()

@@ -2354,3 +2354,37 @@ extern "C" int bsvi_debug_math(int fn, int dist, const float* x_dev, const float
 
 #include "dense_kernel.inc"
 #include "bnn_kernel.inc"
+
+// ---- the minibatch data path of the scalar engine (standard_variables.py:71-112, distributions.py:393-473) ------------
+// A variable observed through an EmpiricalVariable sees `batch` rows of a dataset, other rows in every evaluation.  To the per-sample
+// program they are ordinary observations; this launch refreshes that stretch of the observation buffer in front of the evaluation:
+// row i of the minibatch is dataset row `minibatch_index(i)` — the keyed bijection of [0, DS) the dense path's dense_head draws with
+// the same (seed, offset), sampling without replacement like np.random.choice(replace=False) — or the caller's.
+namespace bsvi {
+__global__ void __launch_bounds__(256) minibatch_gather_kernel(const float* dataset, uint32_t DS, uint32_t row, uint32_t B, const int32_t* indices_in,
+                                                                uint32_t seed_lo, uint32_t seed_hi, uint32_t off_lo, uint32_t off_hi, float* dst, int32_t* indices_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= B * row) return;
+    const uint32_t b = i / row, e = i - b * row;
+    DParams Dm;
+    Dm.indices_in = indices_in; Dm.DS = DS;
+    Dm.offset_lo = off_lo; Dm.offset_hi = off_hi; Dm.seed_lo = seed_lo; Dm.seed_hi = seed_hi;
+    const uint32_t r = minibatch_index(Dm, b);
+    dst[i] = dataset[(size_t)r * row + e];
+    if (indices_out && e == 0u) indices_out[b] = (int32_t)r;
+}
+}  // namespace bsvi
+
+extern "C" int bsvi_minibatch_gather(const float* dataset_dev, uint32_t dataset_size, uint32_t row_floats, uint32_t batch_size,
+                                     const int32_t* indices_dev, uint64_t seed, uint64_t offset, float* dst_dev, int32_t* indices_out_dev,
+                                     void* stream) {
+    if (!dataset_dev || !dst_dev || !dataset_size || !row_floats || !batch_size) return fail(BSVI_ERR_INVALID, "null argument");
+    if (batch_size > dataset_size) return fail(BSVI_ERR_INVALID, "bsvi_minibatch_gather: batch_size exceeds dataset_size");
+    if ((uint64_t)batch_size * row_floats >= (1ull << 31)) return fail(BSVI_ERR_RESOURCE, "bsvi_minibatch_gather: minibatch too large");
+    const uint32_t n = batch_size * row_floats;
+    hipLaunchKernelGGL(bsvi::minibatch_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dataset_dev, dataset_size,
+                       row_floats, batch_size, indices_dev, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
+                       dst_dev, indices_out_dev);
+    HIP_TRY(hipGetLastError());
+    return BSVI_OK;
+}

@@ -418,6 +418,14 @@ class CompiledELBO:
             self.base_out = torch.zeros(OUT_HEADER + max(bp.n_params, 1), device=dev, dtype=torch.float32)
             self._externals = [native.MvnNode(e) for e in p.externals]
             self._base_buffers = {}
+        # observations that are a MINIBATCH of a dataset (scalar-path f-1, lowering.MinibatchObs): the datasets resident on the device,
+        # the stretches of the observation buffer refreshed in front of every evaluation (`_refresh_minibatches`)
+        self._minibatches = []
+        for mb in getattr(p, "minibatches", None) or []:
+            if self._externals:
+                raise lowering.LoweringError("minibatch observations beside batched multivariate-normal terms are not lowered yet")
+            data = torch.from_numpy(np.ascontiguousarray(mb["dataset"], dtype=np.float32).reshape(mb["dataset_size"], -1)).to(dev)
+            self._minibatches.append(dict(mb, data=data))
         self._workspaces = {}
         self._train_plans = {}
         self._fast_train = {}
@@ -524,6 +532,35 @@ class CompiledELBO:
                       n_local, self._stream())
         return full
 
+    def _refresh_minibatches(self, seed, offset, minibatch=None, want_indices=False):
+        """The minibatch data path of the scalar engine (`standard_variables.py:71-112`, `distributions.py:393-473`): in front of an
+        evaluation every stretch of the observation buffer that is a minibatch takes its rows for this (seed, offset) —
+        `bsvi_minibatch_gather`: the keyed bijection of the dense path (sources that share a RandomIndices variable share the draw;
+        an EmpiricalVariable with its own batch_size draws with its own key), or the caller's rows (`minibatch`: {indices name:
+        rows}, parity tests replay the reference's).  Every rank draws the same rows: the key is (seed, offset)."""
+        if not self._minibatches:
+            return None
+        used = {}
+        for mb in self._minibatches:
+            given = None
+            if minibatch is not None:
+                rows = minibatch.get(mb["indices_name"]) if isinstance(minibatch, dict) else minibatch
+                if rows is not None:
+                    idx = np.asarray(rows, dtype=np.int64).reshape(-1)
+                    if idx.size != mb["batch"] or idx.min() < 0 or idx.max() >= mb["dataset_size"]:
+                        raise ValueError("minibatch rows of {!r} must be {} rows in [0, {})".format(mb["indices_name"], mb["batch"], mb["dataset_size"]))
+                    given = torch.from_numpy(idx.astype(np.int32)).to(self.device)
+            out_idx = torch.empty(mb["batch"], dtype=torch.int32, device=self.device) if want_indices else None
+            key = (int(seed) ^ (0x9E3779B97F4A7C15 * mb["group"])) & 0x7FFFFFFFFFFFFFFF       # (group 0: the dense path's key)
+            native.check(self.lib.bsvi_minibatch_gather(
+                C.c_void_p(mb["data"].data_ptr()), mb["dataset_size"], mb["row"], mb["batch"],
+                C.c_void_p(given.data_ptr()) if given is not None else None, key, int(offset),
+                C.c_void_p(self.obs.data_ptr() + 4 * mb["offset"]), C.c_void_p(out_idx.data_ptr()) if out_idx is not None else None,
+                self._stream()))
+            if want_indices:
+                used[mb["indices_name"]] = out_idx
+        return used
+
     def _noise_tensor(self, noise, n_global, base, n_local):
         """named dict / [n_noise, N] array / device tensor -> device [n_noise, n_local] (this rank's columns)"""
         if noise is None:
@@ -539,7 +576,7 @@ class CompiledELBO:
 
     # ---- one ELBO evaluation -------------------------------------------------------------------
     def evaluate(self, number_samples, noise=None, seed=None, offset=None, want_samples=False,
-                 want_noise=False, want_fvalues=False, minibatch=None):
+                 want_noise=False, want_fvalues=False, minibatch=None, want_indices=False):
         """Loss and gradients of one ELBO estimate (`variables.py:843-870` with
         for_gradient=True + `inference.py:100`).  Returns a dict of device tensors."""
         rank, world = dist_info()
@@ -558,6 +595,7 @@ class CompiledELBO:
         fvals = torch.empty((2, n_local), device=dev) if want_fvalues else None
         if self._externals:
             noise_t = self._external_rows(n_local, number_samples, base, noise_t, seed, offset)
+        used_rows = self._refresh_minibatches(seed, offset, minibatch, want_indices)
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
@@ -567,6 +605,8 @@ class CompiledELBO:
         self.grads_valid = True
         res = dict(loss=self.out[2], finite=self.out[3], nonfinite_count=self.out[1],
                    grads=self.out[OUT_HEADER:OUT_HEADER + p.n_params], n_local=n_local, sample_base=base)
+        if want_indices and used_rows is not None:
+            res["indices"] = used_rows
         if want_samples:
             res["samples"] = samples
         if want_noise:
@@ -575,7 +615,7 @@ class CompiledELBO:
             res["f"], res["lq"] = fvals[0], fvals[1]
         return res
 
-    def evaluate_weighted(self, number_samples, f_weight, q_weight, seed, offset, noise=None):
+    def evaluate_weighted(self, number_samples, f_weight, q_weight, seed, offset, noise=None, minibatch=None):
         """The second pass of a user-defined gradient estimator (`custom_estimator_loss`): with the draw of (seed, offset)
         again, leave  -(sum_n a_n grad f_n + b_n grad log q_n)  in the output block — the gradient of loss = -g(f, log q) for
         a_n = dg/df_n, b_n = dg/dlog q_n (bsvi_elbo_args::f_weight_dev / q_weight_dev; the program must be a BlackBox one)."""
@@ -588,6 +628,7 @@ class CompiledELBO:
             # batched multivariate-normal terms re-enter the program as linear surrogate records — model terms like any other,
             # so a_n weights them too; their rows come from the same three-launch sequence as in `evaluate`
             noise_t = self._external_rows(n_local, number_samples, base, noise_t, self._seed(seed), int(offset))
+        self._refresh_minibatches(self._seed(seed), int(offset), minibatch)
         args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, number_samples, base, None, self._seed(seed), int(offset)))
         args.stream = self._stream()
         args.noise_dev = noise_t.data_ptr() if noise_t is not None else None
@@ -815,8 +856,9 @@ class CompiledELBO:
             self.native.ensure_shares(n_local)          # (the share set attached to the program follows the last shard size)
             self._shares_for = n_local
         if plan is None:
+            # (observations that are a minibatch change in every iteration: the loop cannot stay in one launch)
             persistent = (allow_persistent and world == 1 and not _force_sharded_path and not self._externals
-                          and self.native.persistent_supported(n_local))
+                          and not self._minibatches and self.native.persistent_supported(n_local))
             shares = self.native.split_shares(n_local) if persistent else None
             # the specialised in-kernel loop starts a fresh optimizer itself and nobody reads its final state: no state
             # buffer, and with it no fill launch in front of the training launch
@@ -866,7 +908,7 @@ class CompiledELBO:
             return loss_curve, finite
 
         sharded = world > 1 or _force_sharded_path
-        if sharded and noise_t is None and not self._externals:
+        if sharded and noise_t is None and not self._externals and not self._minibatches:
             # several ranks, ONE launch each: the cross-rank sums are exchanged inside the in-kernel loop (spec_main.h,
             # spec_exchange).  Whether it serves — the shard on the specialised one-workgroup kernel, every parameter
             # owned by a thread of one wave, the exchange usable — is probed once per plan with an empty call (which
@@ -891,7 +933,7 @@ class CompiledELBO:
                 self.last_mode = "persistent+exchange"
                 check_exchange(dev, self.params)
                 return loss_curve, finite
-        if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0" and not self._externals:
+        if sharded and noise_t is None and os.environ.get("BSVI_GRAPH", "1") != "0" and not self._externals and not self._minibatches:
             # multi-GPU: the step sequence is captured once in a HIP graph and replayed — no Python between the launches
             try:
                 self._train_graph(K, n_local, number_samples, base, cfg, state, loss_curve, finite, seed, offset0,
@@ -906,6 +948,8 @@ class CompiledELBO:
             nz = None if noise_t is None else noise_t[it]
             if self._externals:
                 nz = self._external_rows(n_local, number_samples, base, nz, seed, offset0 + it)
+            if self._minibatches:
+                self._refresh_minibatches(seed, offset0 + it, None if minibatch_seq is None else minibatch_seq[it])
             args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
             mask = self.mask_all if it > pretraining_iterations else self.mask_first
             if world == 1 and not _force_sharded_path:
@@ -1017,9 +1061,9 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
         make = type(estimator_cls)
     compiled = compile_model(joint_model, posterior_model, "blackbox")
     kind = type(compiled).__name__
-    if kind not in ("CompiledELBO", "CompiledDense", "CompiledAmortized"):
+    if kind not in ("CompiledELBO", "CompiledDense", "CompiledBnn", "CompiledAmortized"):
         raise NotImplementedError("user-defined gradient estimators: unknown engine " + kind)
-    extra = dict(minibatch=minibatch) if kind != "CompiledELBO" else {}
+    extra = dict(minibatch=minibatch) if (kind != "CompiledELBO" or getattr(compiled, "_minibatches", None)) else {}
     N = int(number_samples)
     seed = compiled._seed(None)
     offset = compiled.iteration

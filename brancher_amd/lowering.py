@@ -147,6 +147,19 @@ def _split_axis(rec_shape, leaf_shapes):
     return 3
 
 
+class MinibatchObs:
+    """Observed data that is a MINIBATCH: `batch` rows of `dataset` [DS, ...] per evaluation (an observed EmpiricalVariable,
+    `standard_variables.py:71-96`).  Stands where an observed variable stands in the IR (`_observed_value`: the placeholder the
+    observation buffer is laid out from); `indices` is the RandomIndices variable it shares with others, or None (its own draw)."""
+
+    def __init__(self, source, dataset, batch, indices):
+        self.source, self.name, self.dataset, self.batch, self.indices = source, source.name, dataset, batch, indices
+        if batch > dataset.shape[0]:
+            raise LoweringError("batch_size %d of %r exceeds its dataset (%d rows)" % (batch, source.name, dataset.shape[0]))
+        self._observed_value = np.zeros((1, batch) + dataset.shape[1:], dtype=np.float32)      # [1, B, ...] like an observed value (utilities.py:226-232)
+        self.is_observed = True
+
+
 class SlotInfo:
     def __init__(self, var, base, shape, dist):
         self.var, self.base, self.shape, self.dist = var, base, shape, dist
@@ -227,6 +240,7 @@ class _Lowering:
         self.obs = []
         self.n_obs = 0
         self.obs_index = {}        # id(var) -> (offset, shape)
+        self.minibatch_obs = {}    # id(EmpiricalVariable) -> MinibatchObs: observations that are a minibatch of a dataset
         self.uni_param = []        # provisional uniform entries (param-sourced)
         self.uni_const = []
         self.uni_index = {}        # (kind, id/ key, transform, a, b) -> (is_param, local k0)
@@ -300,6 +314,18 @@ class _Lowering:
                                     "kernel yet: %r" % (fn,))
             if fn in ("sum", "transpose") and e.args:
                 return self.view_call(fn, self.from_expr(e.args[0], ctx), list(e.args[1:]), kwargs)
+            if fn == "matmul" and len(e.args) == 2 and not kwargs and all(isinstance(a, sym.Expr) for a in e.args):
+                # BF.matmul(A, x) (`functions.py:50-62` wraps torch.matmul) with x a COLUMN [c, 1] — a linear predictor over a handful of
+                # weights, the minibatched Bayesian linear regression next to `examples/minibatch_logistic_regression.py:13-51` —
+                # unrolled through the axis views: sum_c A[r][c] x[c] = BF.sum(A * BF.transpose(x, 1, 2), dim=2, keepdim=True).  (Real
+                # matrix products — a 10 x 784 weight matrix per sample — belong to the dense path: kMaxViewTerms refuses them here.)
+                a, b = self.from_expr(e.args[0], ctx), self.from_expr(e.args[1], ctx)
+                if b.shape[2] != 1 or a.shape[2] != b.shape[1]:
+                    raise LoweringError("BF.matmul on the scalar path takes a matrix [r, c] and a column [c, 1] (got %r and %r)"
+                                        % (a.shape[1:], b.shape[1:]))
+                bt = self.view_call("transpose", b, [1, 2], {})
+                prod = self.ranked(self.mk("mul", (a, bt)), self.check_ranks((a, bt), "BF.matmul"))
+                return self.view_call("sum", prod, [], dict(dim=2, keepdim=True))
             if kwargs:
                 raise LoweringError("keyword arguments of BF.%s are not supported by the fused kernel" % fn)
             args = [self.from_expr(a, ctx) if isinstance(a, sym.Expr) else self.mk("imm", (), float(a))
@@ -613,8 +639,16 @@ class _Lowering:
                 # (datapoint axis first), `standard_variables.py:37-68,115-130`
                 return self.from_expr(var.link.expressions()["value"].expr, self.p_value)
             if not var.has_observed_value:
-                raise LoweringError("variable %r is observed through a random dataset (minibatch data path, "
-                                    "SURVEY §8f-1): not lowered yet" % var.name)
+                # the minibatch data path on the scalar engine (`standard_variables.py:71-112`,
+                # `distributions.py:393-473`): the value is `batch_size` rows of a dataset, other rows in every evaluation — an
+                # observed EmpiricalVariable itself, or a variable observed THROUGH one (`variables.py:572-590`).  To the program these
+                # are ordinary observations [B, ...] in the observation buffer; the engine refreshes them in front of every launch
+                # (`bsvi_minibatch_gather`: the keyed bijection of the dense path's `dense_head`, or the caller's rows).
+                source = var if getattr(var, "_type", None) == "Empirical" else getattr(var, "dataset", None)
+                if source is None or getattr(source, "_type", None) != "Empirical":
+                    raise LoweringError("variable %r is observed without a value and not through an EmpiricalVariable" % var.name)
+                handle = self.minibatch_handle(source)
+                return self.mk("obs", (), handle, canonical_elem_shape(handle._observed_value.shape[1:]))
             return self.mk("obs", (), var, canonical_elem_shape(var._observed_value.shape[1:]))
         if var.name in self.q_by_name:
             qv = self.q_by_name[var.name]
@@ -647,6 +681,34 @@ class _Lowering:
             self.consts.append(flat)
             self.n_consts += flat.size
         return off
+
+    def minibatch_handle(self, source):
+        """the observation record behind an observed EmpiricalVariable: B rows of its dataset, refreshed per evaluation"""
+        hit = self.minibatch_obs.get(id(source))
+        if hit is not None:
+            return hit
+        from brancher_amd.standard_variables import RandomIndices
+        if not source.is_observed:
+            raise LoweringError("the EmpiricalVariable %r must be observed (is_observed=True) to feed the joint model" % source.name)
+        exprs = source.link.expressions()
+        ds = exprs["dataset"].expr
+        if ds.op != "var" or not isinstance(ds.attr, RootVariable) or "weights" in exprs:
+            raise LoweringError("the EmpiricalVariable %r must hold an array dataset (no weights)" % source.name)
+        data = np.asarray(ds.attr.value, dtype=np.float32)          # observed datasets are stored [1, DS, ...] (utilities.py:226-232)
+        if data.ndim < 2 or data.shape[0] != 1:
+            raise LoweringError("the dataset of %r has an unexpected layout %r" % (source.name, data.shape))
+        data = data[0]
+        indices = None
+        if "indices" in exprs:
+            ind = exprs["indices"].expr
+            if ind.op != "var" or not isinstance(ind.attr, RandomIndices):
+                raise LoweringError("the EmpiricalVariable %r must be indexed by a RandomIndices variable (or draw its own batch_size rows)" % source.name)
+            indices = ind.attr
+            if int(np.asarray(indices.link.expressions()["dataset"].expr.attr.value).size) != data.shape[0]:
+                raise LoweringError("the RandomIndices variable of %r ranges over another dataset size" % source.name)
+        handle = MinibatchObs(source, data, int(source.batch_size), indices)
+        self.minibatch_obs[id(source)] = handle
+        return handle
 
     def obs_offset(self, var):
         hit = self.obs_index.get(id(var))
@@ -1434,6 +1496,8 @@ class _Lowering:
         for v in p_flat:
             if not isinstance(v, RandomVariable) or getattr(v, "_type", None) == "Deterministic node":
                 continue
+            if v.distribution.kind == D.DIST_EMPIRICAL and v.is_observed:
+                continue        # an observed minibatch source: log-probability 0 (ImplicitDistribution, `distributions.py:226-227`)
             if v.distribution.kind == D.DIST_MVNORMAL:
                 p_nodes.extend(self.mvn_terms(v))
                 continue
@@ -1745,6 +1809,19 @@ class _Lowering:
         prog.uniform, prog.records, prog.code = uni, recs, code
         prog.consts = np.concatenate(self.consts) if self.consts else np.zeros(0, np.float32)
         prog.obs = np.concatenate(self.obs) if self.obs else np.zeros(0, np.float32)
+        # minibatch observations (scalar-path f-1): which stretches of the observation buffer are rows of which dataset.  Sources that share
+        # a RandomIndices variable share a draw (`group`); an EmpiricalVariable with its own batch_size draws for itself.
+        prog.minibatches = []
+        groups = {}
+        for handle in self.minibatch_obs.values():
+            if id(handle) not in self.obs_index:
+                continue                           # (lowered but never read: no stretch of the buffer)
+            key = id(handle.indices) if handle.indices is not None else id(handle)
+            group = groups.setdefault(key, len(groups))
+            prog.minibatches.append(dict(name=handle.name, offset=int(self.obs_index[id(handle)]), batch=handle.batch,
+                                         row=int(np.prod(handle.dataset.shape[1:], dtype=np.int64)), dataset=handle.dataset,
+                                         dataset_size=int(handle.dataset.shape[0]), group=group,
+                                         indices_name=handle.indices.name if handle.indices is not None else handle.name))
         prog.n_noise = self.n_latent
         prog.n_derived = self.temp_base - self.n_latent
         prog.n_temps = self.max_temps

@@ -171,7 +171,8 @@ class BnnArgs(Sized):
                 ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("n_samples_local", C.c_uint32), ("n_samples_global", C.c_uint32), ("sample_base", C.c_uint32), ("reserved", C.c_uint32),
                 ("out_dev", C.c_void_p), ("noise_out_dev", C.c_void_p), ("indices_out_dev", C.c_void_p),
-                ("fvalue_out_dev", C.c_void_p), ("logq_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p)]
+                ("fvalue_out_dev", C.c_void_p), ("logq_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("stream", C.c_void_p),
+                ("f_weight_dev", C.c_void_p), ("q_weight_dev", C.c_void_p)]
 
 
 EXPORTS.update({
@@ -241,6 +242,7 @@ EXPORTS.update({
     "bsvi_exchange_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bsvi_exchange_status": (C.c_int, [C.c_void_p]),
     "bsvi_exchange_selftest_tagged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bsvi_minibatch_gather": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsvi_exchange_destroy": (None, [C.c_void_p]),
 })
 

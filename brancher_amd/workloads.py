@@ -645,6 +645,61 @@ def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=78
     return model
 
 
+def build_minibatch_normal_mean(api, dataset_size=40, batch_size=8, seed=0, own_draw=False):
+    """The minibatch data path OUTSIDE the matmul patterns (`standard_variables.py:71-112`): a Normal mean whose
+    observations are `batch_size` rows of a dataset, other rows in every evaluation — `y.observe(EmpiricalVariable(...))`,
+    `variables.py:572-590`.  `own_draw`: the EmpiricalVariable draws its own rows (`batch_size=`, `distributions.py:436-441`)
+    instead of sharing a RandomIndices variable."""
+    rng = np.random.RandomState(seed)
+    data = rng.normal(1.5, 0.7, size=(dataset_size, 1)).astype(np.float32)
+    if own_draw:
+        ydata = api.EmpiricalVariable(data, batch_size=batch_size, name="ydata", is_observed=True)
+    else:
+        indices = api.RandomIndices(dataset_size=dataset_size, batch_size=batch_size, name="indices", is_observed=True)
+        ydata = api.EmpiricalVariable(data, indices=indices, name="ydata", is_observed=True)
+    mu = api.NormalVariable(0., 10., "mu")
+    nu = api.LogNormalVariable(0., 0.5, "nu")                     # the observation noise is latent too
+    y = api.NormalVariable(mu, nu, "y")
+    model = api.ProbabilisticModel([y])
+    y.observe(ydata)
+    Qmu = api.NormalVariable(0.3, 1.2, "mu", learnable=True)
+    Qnu = api.LogNormalVariable(-0.2, 0.3, "nu", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qmu, Qnu]))
+    return model
+
+
+def build_minibatch_linear_regression(api, dataset_size=40, batch_size=8, n_features=3, n_outputs=1, seed=0, prior="normal",
+                                      latent_scale=False):
+    """Minibatched Bayesian linear regression, the Normal-likelihood neighbour of `examples/minibatch_logistic_regression.py:13-51`:
+    `y ~ Normal(BF.matmul(weights, x), 0.3)` with x and the targets two EmpiricalVariables that share a RandomIndices variable.
+    `prior`: "normal" | "laplace" | "cauchy" — the weights' prior; `latent_scale`: the prior's scale is itself a latent
+    (`NormalVariable(0, tau, "weights")` with tau ~ LogNormal shared by every weight)."""
+    BF = api.BF
+    rng = np.random.RandomState(seed)
+    X = rng.normal(0., 1., size=(dataset_size, n_features, 1)).astype(np.float32)
+    true_w = rng.normal(0., 1.5, size=(n_outputs, n_features))
+    Y = (np.einsum("op,dpi->doi", true_w, X) + 0.3 * rng.normal(size=(dataset_size, n_outputs, 1))).astype(np.float32)
+    indices = api.RandomIndices(dataset_size=dataset_size, batch_size=batch_size, name="indices", is_observed=True)
+    x = api.EmpiricalVariable(X, indices=indices, name="x", is_observed=True)
+    targets = api.EmpiricalVariable(Y, indices=indices, name="targets", is_observed=True)
+    shape = (n_outputs, n_features)
+    q_vars = []
+    if latent_scale:
+        tau = api.LogNormalVariable(0., 0.5, "tau")
+        scale = tau
+        q_vars.append(api.LogNormalVariable(0.1, 0.25, "tau", learnable=True))
+    else:
+        scale = 2.0 * np.ones(shape)
+    make = {"normal": api.NormalVariable, "laplace": api.LaplaceVariable, "cauchy": api.CauchyVariable}[prior]
+    weights = make(np.zeros(shape), scale, "weights")
+    y = api.NormalVariable(BF.matmul(weights, x), 0.3, "y")
+    model = api.ProbabilisticModel([y])
+    y.observe(targets)
+    q_vars.append(api.NormalVariable(0.1 * np.ones(shape), 0.5 * np.ones(shape), "weights", learnable=True))
+    model.set_posterior_model(api.ProbabilisticModel(q_vars))
+    return model
+
+
 def build_bayesian_neural_network(api, dataset_size=48, batch_size=30, n_features=784, n_hidden=20, n_classes=10, seed=0,
                                   prior_scale=10., q_scale=0.2, q_scale1=None, q_loc_scale=0.0, pixels="uint8",
                                   activation="tanh", hidden2=0):

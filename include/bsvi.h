@@ -564,6 +564,12 @@ typedef struct bsvi_bnn_args {
     float* logq_out_dev;             /* per-sample log q [n_samples_local] or NULL (BlackBox)         */
     void* workspace_dev;
     void* stream;
+    /* ABI 11 — caller-weighted gradients, as bsvi_elbo_args / bsvi_dense_args::f_weight_dev, q_weight_dev (the two passes of a
+     * user-defined GradientEstimator, gradient_estimators.py:17-26): the call leaves sum_n a_n grad f_n + b_n grad log q_n in
+     * out_dev[4..].  NULL: the estimator's own weights (a_n = 1; BlackBox: b_n = f_n).  q_weight_dev needs a model created with the
+     * BlackBox estimator, which takes both or neither. */
+    const float* f_weight_dev;       /* [n_samples_local] or NULL */
+    const float* q_weight_dev;       /* [n_samples_local] or NULL */
 } bsvi_bnn_args;
 
 int bsvi_bnn_create(const bsvi_bnn_desc* desc, bsvi_bnn** out);
@@ -836,6 +842,16 @@ int bsvi_exchange_status(const bsvi_exchange* x);
  * that a host can test that area between its GPUs before it lets a training loop rely on it.  An abandoned call leaves NaN in buf_dev. */
 int bsvi_exchange_selftest_tagged(bsvi_exchange* x, float* buf_dev, uint32_t n, void* stream);
 void bsvi_exchange_destroy(bsvi_exchange* x);
+
+/* (ABI 11) The minibatch data path of the scalar engine (standard_variables.py:71-112, distributions.py:393-473: EmpiricalVariable /
+ * RandomIndices / EmpiricalDistribution._get_sample): writes batch_size rows of dataset_dev [dataset_size][row_floats] into dst_dev — a
+ * stretch of the observation buffer bsvi_elbo_args::obs_dev that the program reads as ordinary observations — in front of an evaluation.
+ * Row i is indices_dev[i] when given, else position i of a keyed bijection of [0, dataset_size) (distinct rows: sampling without
+ * replacement, np.random.choice(replace=False) at distributions.py:438) that depends on (seed, offset) only: the dense-link family
+ * draws the same rows for the same pair.  indices_out_dev (or NULL) receives the rows used. */
+int bsvi_minibatch_gather(const float* dataset_dev, uint32_t dataset_size, uint32_t row_floats, uint32_t batch_size,
+                          const int32_t* indices_dev, uint64_t seed, uint64_t offset, float* dst_dev, int32_t* indices_out_dev,
+                          void* stream);
 
 const char* bsvi_last_error(void);
 int bsvi_abi_version(void);

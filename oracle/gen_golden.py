@@ -93,6 +93,19 @@ CASES = {
                                          6, 10, dict(iters=4, n=5, optimizer="SGD", lr=1e-7)),     # (SGD: Adam's first steps are the SIGN of gradients that cancel to rounding noise here)
     "logreg_C10_P784_DS24_B16_N4": ("build_logistic_regression",
                                     dict(dataset_size=24, batch_size=16, n_features=784, n_classes=10), 4, 8, None),
+    # (round 6) the minibatch data path OUTSIDE the matmul patterns of the dense / BNN / amortised families: observations that are rows of
+    # a dataset on the scalar engine — a Normal mean with a latent noise scale, and minibatched Bayesian linear regressions (Normal
+    # likelihood over BF.matmul(weights, x)) with a Normal / Laplace prior and with a latent prior scale shared by the weights
+    "minibatch_normal_mean_DS40_B8_N30": ("build_minibatch_normal_mean", dict(dataset_size=40, batch_size=8), 30, 81,
+                                          dict(iters=5, n=12, optimizer="Adam", lr=0.02)),
+    "minibatch_linreg_P3_DS40_B8_N30": ("build_minibatch_linear_regression", dict(dataset_size=40, batch_size=8, n_features=3), 30, 83,
+                                        dict(iters=5, n=12, optimizer="Adam", lr=0.02)),
+    "minibatch_linreg_laplace_P4_O2_DS30_B6_N24": ("build_minibatch_linear_regression",
+                                                   dict(dataset_size=30, batch_size=6, n_features=4, n_outputs=2, prior="laplace"), 24, 85,
+                                                   dict(iters=4, n=10, optimizer="SGD", lr=1e-3)),
+    "minibatch_linreg_tau_P3_DS40_B8_N30": ("build_minibatch_linear_regression",
+                                            dict(dataset_size=40, batch_size=8, n_features=3, latent_scale=True), 30, 87,
+                                            dict(iters=5, n=12, optimizer="Adam", lr=0.02)),
     # the reference's Bayesian neural network (tests/test_MNIST_bayesian_neural_network.py:20-60): latent weight matrices AND biases of
     # both layers, tanh hidden units, observed Categorical over a random minibatch — reduced sizes, one at the example's full width
     "bnn_P48_H6_C4_DS30_B12_N5": ("build_bayesian_neural_network",
@@ -112,13 +125,19 @@ TAYLOR1_BUILDERS = ("build_readme_ar", "build_multivariate_regression", "build_l
                     "build_beta_binomial", "build_observed_ar", "build_lognormal_normal",
                     # (round 4: models with a MultivariateNormal term whose matrix depends on a latent — the taylor1 program reads it
                     #  at the posterior's means)
-                    "build_gp_hyperparameters", "build_mvn_forms", "build_gp_marginal_likelihood")
+                    "build_gp_hyperparameters", "build_mvn_forms", "build_gp_marginal_likelihood",
+                    # (round 6: the Bayesian neural network — every latent a mean-field Normal, its mean its loc)
+                    "build_bayesian_neural_network")
 
 
 # ... and two user-defined estimators (workloads.custom_estimators) for these
 CUSTOM_ESTIMATOR_BUILDERS = ("build_readme_ar", "build_vector_latent", "build_heavy_tails",
                              # ... and the dense-link path (BASELINE config 4 at reduced sizes)
-                             "build_logistic_regression", "build_binary_logistic_regression")
+                             "build_logistic_regression", "build_binary_logistic_regression",
+                             # ... and the Bayesian-neural-network path (round 6)
+                             "build_bayesian_neural_network",
+                             # ... and minibatch observations on the scalar path (round 6)
+                             "build_minibatch_normal_mean", "build_minibatch_linear_regression")
 
 
 def reference_api():

@@ -152,13 +152,15 @@ def test_user_defined_estimator_matches_reference_golden(case, which, jit, monke
     cls = W.custom_estimators(ge)[which]
     value = engine.custom_estimator_loss(model, model.posterior_model, cls, g.N, noise=g.noise, minibatch=g.minibatch)
     ref = float(g.data["loss_custom_" + which])             # the fixture holds the LOSS: -estimator value
-    if type(value.compiled).__name__ == "CompiledDense":
+    if type(value.compiled).__name__ in ("CompiledDense", "CompiledBnn"):
         # the dense-link path (round 4: per-sample weights through bsvi_dense_args::f_weight_dev / q_weight_dev); BSVI_JIT
         # does not apply to it — the exact-data (bf16x3) launches serve the pixel-count cases, the f32 ones the rest.
         # f is the difference of two sums of ~1e4 (test_loss_and_grads_match_reference_golden) and these estimators
         # exponentiate it or multiply it by log q, so the reference's own fp32 record is up to 3e-5 from the fp64 value:
         # the same yardstick as there — as close to the fp64 oracle as the fp32 reference is (x4), or 1e-5.
-        assert value.compiled.data_path() == ("bf16x3" if "pixels" in case else "f32")
+        # (round 6: the Bayesian-neural-network family takes the same weights — bsvi_bnn_args::f_weight_dev / q_weight_dev; its fixtures
+        #  hold pixel counts)
+        assert value.compiled.data_path() == ("bf16x3" if ("pixels" in case or case.startswith("bnn")) else "f32")
         import torch as _t
         from oracle.svi_oracle import Oracle
         fn = {"baseline": lambda f, lq: (lq * (f - f.mean()).detach() + f).mean(),
@@ -235,7 +237,9 @@ def test_training_trajectory_matches_reference_golden(case, persistent):
     model, c = compiled_for(g, "pathwise")
     losses, finite = c.train(tr["iters"], tr["n"], tr["optimizer"], noise_seq=g.trajectory_noise(),
                              minibatch_seq=g.trajectory_minibatch(), allow_persistent=persistent, **g.opt_kwargs())
-    assert c.last_mode == ("persistent" if persistent and not is_dense(case) and not is_batched_mvn(case) else "stepwise")
+    # (observations that are a minibatch — the scalar path's f-1, round 6 — change in every iteration: launch per iteration)
+    in_kernel_loop = persistent and not is_dense(case) and not is_batched_mvn(case) and not case.startswith("minibatch_")
+    assert c.last_mode == ("persistent" if in_kernel_loop else "stepwise")
     assert finite.cpu().numpy().all()
     after = g.group("traj/param_after/")
     if is_batched_mvn(case) or case.startswith("bnn"):
@@ -579,18 +583,18 @@ def test_a_refused_graph_capture_steps_eagerly_on_the_same_trajectory_and_is_rem
             attempts.append(1)
             raise RuntimeError("capture refused (test)")
 
-    with monkeypatch.context() as m:
-        m.setattr(torch.cuda, "CUDAGraph", Refusing)
-        for call in range(2):
+    for call in range(2):
+        lb, fb = b.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)       # (captures: the real CUDAGraph)
+        assert b.last_mode == "graph"
+        with monkeypatch.context() as m:
+            m.setattr(torch.cuda, "CUDAGraph", Refusing)
             with warnings.catch_warnings(record=True) as caught:
                 warnings.simplefilter("always")
                 la, fa = a.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
-            assert a.last_mode == "stepwise" and any("stepping eagerly" in str(w.message) for w in caught)
-            lb, fb = b.train(20, 300, "Adam", seed=3, lr=1e-2, _force_sharded_path=True)
-            assert b.last_mode == "graph"
-            assert torch.equal(la, lb) and torch.equal(fa, fb) and torch.equal(a.params, b.params), call
-        assert len(attempts) == 1                       # the second call found the kept refusal
-        assert list(a._graph_cache.values()) == [False]
+        assert a.last_mode == "stepwise" and any("stepping eagerly" in str(w.message) for w in caught)
+        assert torch.equal(la, lb) and torch.equal(fa, fb) and torch.equal(a.params, b.params), call
+    assert len(attempts) == 1                       # the second call found the kept refusal
+    assert list(a._graph_cache.values()) == [False]
     # per-call capture, nothing kept
     monkeypatch.setenv("BSVI_GRAPH_KEEP", "0")
     c = engine.compile_model(W.build_readme_ar(api, T=20), None, "pathwise")
@@ -936,3 +940,53 @@ def test_multi_workgroup_persistent_trainer_other_estimators(estimator):
     assert np.array_equal(f0, f1) and f0.all()
     assert rel_err(l1, l0) <= 1e-5
     assert np.abs(p1 - p0).max() <= 1e-4 * (1 + np.abs(p0).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("own_draw", [False, True])
+@pytest.mark.parametrize("estimator", ["pathwise", "blackbox"])
+def test_minibatch_observations_on_the_scalar_path_draw_on_the_device(own_draw, estimator):
+    """SURVEY 8f-1 outside the matmul patterns (round 6): a variable observed THROUGH an EmpiricalVariable on the scalar engine.  The rows
+    are drawn on the device (`bsvi_minibatch_gather`: the dense path's keyed bijection — distinct rows, a function of (seed, offset)
+    only), reported, and replayed by the oracle in double precision; an EmpiricalVariable with its own batch_size draws with a key of
+    its own; training refreshes the rows in every iteration and walks the trajectory of the same rows handed in."""
+    from oracle.svi_oracle import Oracle
+    kw = dict(dataset_size=40, batch_size=8, own_draw=own_draw)
+    build = lambda: W.build_minibatch_normal_mean(W.native_api(), **kw)
+    c = engine.compile_model(build(), None, estimator)
+    assert type(c).__name__ == "CompiledELBO" and len(c._minibatches) == 1
+    n = 200
+    rows_seen = []
+    for offset in (3, 4):
+        res = c.evaluate(n, seed=11, offset=offset, want_noise=True, want_indices=True)
+        (name, rows), = res["indices"].items()
+        assert name == ("ydata" if own_draw else "indices")
+        rows = rows.cpu().numpy()
+        assert len(set(rows.tolist())) == 8 and rows.min() >= 0 and rows.max() < 40
+        rows_seen.append(rows.tolist())
+        nz = res["noise"].cpu().numpy()
+        named = {k: nz[s.base:s.base + s.size].T.reshape((n,) + tuple(s.shape)) for k, s in c.program.slot_by_name.items()}
+        mb = {name: rows.tolist()}
+        exact = Oracle(build(), dtype=torch.float64).loss_and_grads(n, estimator, named, mb)
+        ref32 = Oracle(build()).loss_and_grads(n, estimator, named, mb)
+        yardstick_loss_check(float(res["loss"].item()), exact["loss"], ref32["loss"])
+        yardstick_grad_check(c.named_grads(), exact["grads"], ref32["grads"])
+        # the same rows handed in: the same launch, bit for bit
+        again = c.evaluate(n, seed=11, offset=offset, minibatch=mb)
+        assert torch.equal(again["loss"], res["loss"])
+    assert rows_seen[0] != rows_seen[1]                      # another offset, other rows
+    if estimator == "blackbox":
+        return
+    # training: launch per iteration (the rows change), the rows of (seed, offset0 + it); the same rows handed in give the same curve
+    a = engine.compile_model(build(), None, "pathwise")
+    b = engine.compile_model(build(), None, "pathwise")
+    la, fa = a.train(6, 64, "Adam", seed=5, lr=0.05)
+    assert a.last_mode == "stepwise" and bool(fa.all())
+    seq = []
+    for it in range(6):
+        probe = b.evaluate(1, seed=5, offset=it, want_indices=True)
+        seq.append({k: v.cpu().numpy().tolist() for k, v in probe["indices"].items()})
+    b.params.copy_(torch.from_numpy(b.program.initial_params()).to(b.params.device))
+    b.iteration = 0
+    lb, _ = b.train(6, 64, "Adam", seed=5, lr=0.05, minibatch_seq=seq)
+    assert torch.equal(la, lb) and torch.equal(a.params, b.params)

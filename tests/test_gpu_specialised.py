@@ -54,7 +54,7 @@ def test_interpreter_matches_reference_golden(case, estimator, interpreter):
     g = Golden(case)
     c = engine.compile_model(g.build(), None, estimator)
     assert c.native.engine(g.N, 0)["engine"] == "interpreter"
-    res = c.evaluate(g.N, noise=g.noise)
+    res = c.evaluate(g.N, noise=g.noise, minibatch=g.minibatch)
     ref = float(g.data["loss_" + estimator])
     if estimator == "pathwise" and case not in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24") and not case.startswith(("gp_marginal", "gp_structured")):
         assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
@@ -284,7 +284,7 @@ def test_logit_normal_variable_matches_the_reference_fixture():
     model = W.build_readme_ar(W.native_api(), logit_normal=True, **g.meta["kwargs"])
     for estimator in ("pathwise", "blackbox"):
         c = engine.compile_model(model, None, estimator)
-        res = c.evaluate(g.N, noise=g.noise)
+        res = c.evaluate(g.N, noise=g.noise, minibatch=g.minibatch)
         ref = float(g.data["loss_" + estimator])
         assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
         if estimator == "pathwise":

@@ -463,8 +463,11 @@ def test_bayesian_neural_network_lowers_to_the_bnn_family():
     m_bad = W.build_bayesian_neural_network(api, dataset_size=24, batch_size=10, n_features=30, n_hidden=4, n_classes=3)
     with pytest.raises(lowering.LoweringError, match="multiple of 4"):
         bnn.lower_bnn(m_bad, m_bad.posterior_model)
-    with pytest.raises(lowering.LoweringError):
-        bnn.lower_bnn(m, m.posterior_model, "taylor1")
+    # (round 6) Taylor1 lowers: the Pathwise program, which CompiledBnn evaluates on the draw eps = 0 — the means of mean-field Normals
+    t1 = bnn.lower_bnn(m, m.posterior_model, "taylor1")
+    assert t1.estimator == "taylor1" and t1.n_rows == p.n_rows and lowering.EST[t1.estimator] == lowering.EST["pathwise"]
+    with pytest.raises(lowering.LoweringError, match="Taylor1"):
+        bnn.lower_bnn(m, m.posterior_model, "importance")
 
 
 def test_module_links_lower_on_the_scalar_path_and_refuse_what_they_cannot_do():

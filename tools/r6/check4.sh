@@ -1,0 +1,6 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+OUT=$ROOT/gpurun_out/r6; mkdir -p $OUT; cd $ROOT
+timeout 1500 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "minibatch or bnn or refused" 2>&1 | tail -15 > $OUT/check4.txt
+timeout 1500 python3 -m pytest tests/test_gpu_specialised.py -x -q -m gpu -k "minibatch" 2>&1 | tail -8 >> $OUT/check4.txt
+cat $OUT/check4.txt
