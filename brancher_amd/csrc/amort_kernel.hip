@@ -791,6 +791,10 @@ struct X6Args {
     const float* Y; int ldy;
     int act; float post_add; int split; int act2; float post_add2;
     int accumulate;
+    // round 6 — the Bernoulli likelihood FUSED into the product that makes the logits (forward, the decoder's last layer): the tile's
+    // epilogue reads the data rows (their exact bf16 copy), stores d f / d logits where the logits would have gone and one partial
+    // log-likelihood per (row, column tile) — the logits never reach memory and amort_lik is not launched (x6_epilogue, LIK)
+    const uint16_t* lik_x; int lik_kp; const int32_t* lik_idx; float* lik_part;      // dataset_bf16 [DS][kp], row of every m, [tiles_n][M]
 };
 
 typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
@@ -980,19 +984,34 @@ __device__ __forceinline__ void x6_stamp(int slot) {
 // tile.  Through LDS (the stages are dead by then), one 32 x 64 half at a time (row stride 64 words: the 32 lanes of a ds_write_b32 group write
 // one row, the 16 lanes of a ds_read_b128 group read 16 different bank quads of two rows), then 256 contiguous bytes of a row of C per
 // 16 lanes: 16 stores of 16 bytes per thread instead of 64 of 4, bias / activation / derivative applied on the way.
-template <bool NN, int DBG>
+template <bool NN, int DBG, bool LIK = false>
 __device__ __forceinline__ void x6_epilogue(const X6Args& G, unsigned char* lds, const f32x16 (&acc)[4], int m0, int n0, int wave, int lane) {
     const int wm = wave * 32, lm = lane & 31, lk = lane >> 5;
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    // LIK: the data rows behind this lane's eight rows of the tile — requested before the barrier, and the data of a half before the
+    // accumulators go through LDS, so that the two dependent round trips (row index, then the row's 8 bytes) hide behind them
+    long lik_src[8];
+    if (LIK) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lik_src[t] = (long)G.lik_idx[min(m0 + wm + 4 * t + er, G.M - 1)] * G.lik_kp;
+    }
     __syncthreads();                                           // every wave is done with the stages
     float* const tile = reinterpret_cast<float*>(lds) + wave * (32 * 64);
-    const int er = lane >> 4, ec = (lane & 15) * 4;
+    float lik_row[8];                                         // LIK: the log-likelihood of rows 4t + er over this tile's columns
+#pragma unroll
+    for (int t = 0; t < 8; ++t) lik_row[t] = 0.0f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        const int n = n0 + 64 * half + ec;
+        uint2 lik_xv[8];
+        if (LIK) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) lik_xv[t] = *reinterpret_cast<const uint2*>(G.lik_x + lik_src[t] + min(n, G.N - 4));
+        }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tile[(8 * (r >> 2) + 4 * lk + (r & 3)) * 64 + 32 * jj + lm] = acc[2 * half + jj][r];
-        const int n = n0 + 64 * half + ec;
         f32x4 bias4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (!NN && G.bias && n < G.N) {                        // (N is a multiple of 4; a bias may start anywhere in the parameter vector: scalar loads)
 #pragma unroll
@@ -1002,6 +1021,29 @@ __device__ __forceinline__ void x6_epilogue(const X6Args& G, unsigned char* lds,
         for (int t = 0; t < 8; ++t) {
             const int row = 4 * t + er, m = m0 + wm + row;
             f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * 64 + ec);
+            if (LIK) {
+                // x ~ Bernoulli(logits): log p = x l - (max(l, 0) + log(1 + exp(-|l|))), d log p / d l = x - sigmoid(l) — amort_lik's
+                // arithmetic (the hardware exp2 / log2 / rcp forms), per element; the row's 64 columns of this half are summed over the
+                // 16 lanes that hold them (a fixed butterfly), the two halves in order
+                float lp = 0.0f;
+                if (m < G.M && n < G.N) {
+                    const uint2 xv = lik_xv[t];
+                    const float xs[4] = {__uint_as_float(xv.x << 16), __uint_as_float(xv.x & 0xFFFF0000u), __uint_as_float(xv.y << 16), __uint_as_float(xv.y & 0xFFFF0000u)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lj = v[e] + bias4[e];
+                        const float ex = __expf(-fabsf(lj)), one_e = 1.0f + ex, rc = __builtin_amdgcn_rcpf(one_e);
+                        lp += xs[e] * lj - (fmaxf(lj, 0.0f) + __logf(one_e));
+                        v[e] = xs[e] - (lj >= 0.0f ? rc : ex * rc);
+                    }
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) lp += __shfl_xor(lp, o, 64);
+                lik_row[t] += lp;
+                if (m >= G.M || n >= G.N) continue;
+                *reinterpret_cast<f32x4*>(G.C + (long)m * G.ldc + n) = v;
+                continue;
+            }
             if (m >= G.M || n >= G.N) continue;
             float* c = G.C + (long)m * G.ldc + n;
             if (DBG == 2) { if (v[0] == 1.2345f) *c = v[0]; continue; }
@@ -1023,6 +1065,14 @@ __device__ __forceinline__ void x6_epilogue(const X6Args& G, unsigned char* lds,
             *reinterpret_cast<f32x4*>(c) = v;
         }
     }
+    if (LIK && (lane & 15) == 0) {
+        float* const part = G.lik_part + (long)(n0 >> 7) * G.M;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int m = m0 + wm + 4 * t + er;
+            if (m < G.M) part[m] = lik_row[t];
+        }
+    }
 }
 // Round 6: the same product with NOTHING staged through registers.  What bounded the kernel above was never the matrix pipe (63 % of
 // its time remained with the MFMAs compiled out, profiles/r4/x6_notes.txt): per k step a workgroup pushed 48 KB through the CU's LDS
@@ -1042,7 +1092,7 @@ __device__ __forceinline__ void x6_epilogue(const X6Args& G, unsigned char* lds,
 //     it and reads rows back, 16 lanes x 16 bytes = 256 contiguous bytes of a row of C per quarter instruction — 16 stores of 16
 //     bytes per thread instead of 64 of 4, bias / activation / derivative applied on the way.
 // Same products in the same order as the kernel above: bit-identical results.  80 KB of LDS: two workgroups per CU.
-template <bool NN, int DBG = 0, int VAR = 0>      // DBG (BSVI_X6_DEBUG, timing only, wrong results): 2 no stores, 3 no MFMAs, 4 fragment reads from one address, 5 no DMA after the first
+template <bool NN, int DBG = 0, int VAR = 0, bool LIK = false>      // DBG (BSVI_X6_DEBUG, timing only, wrong results): 2 no stores, 3 no MFMAs, 4 fragment reads from one address, 5 no DMA after the first
 __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {      // VAR (BSVI_X6_VAR): 0 the compiler's order of the main loop, 1 the hand-ordered loop
     constexpr int CHUNK = 1024, A_ST = 16 * CHUNK, B_PL = 8 * CHUNK, STAGE = A_ST + 3 * B_PL;      // f32 A (128 x 32) | hi | mid | lo (128 x 32 bf16 each)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
@@ -1272,7 +1322,7 @@ __global__ __launch_bounds__(256, 2) void x6gemm_kernel(const X6Args G) {      /
                 }
         }
     }
-    x6_epilogue<NN, DBG>(G, lds, acc, m0, n0, wave, lane);
+    x6_epilogue<NN, DBG, LIK>(G, lds, acc, m0, n0, wave, lane);
     if (DBG == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x6_stamp(5); }
 }
 
@@ -2086,6 +2136,7 @@ struct RowParams {
     // ... or a decoder head: per row and feature (post-activation), its gradient buffer (pre-activation), the head's activation
     const float* lik_sd; float* dlik_sd; int ld_lik_sd, act_lik_sd; float add_lik_sd;
     float* rowf;             // [R] f per row
+    const float* lik_part; int lik_tiles;              // (round 6) [lik_tiles][R] partial log-likelihoods of the fused likelihood epilogue (x6_epilogue), or null
     float* rowlq;            // [R] log q per row
     float* logits; int ld_logits;
     float* out;
@@ -2300,7 +2351,13 @@ __global__ __launch_bounds__(256) void amort_latent_bwd(const RowParams D) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     float value = 0.0f, bad = 0.0f;
     if (r < D.R) {
-        const float f = D.rowf[r], lq = D.rowlq[r];
+        float f = D.rowf[r];
+        if (D.lik_part) {                                  // the column tiles' partial log-likelihoods, in tile order
+            float lp = 0.0f;
+            for (int t = 0; t < D.lik_tiles; ++t) lp += D.lik_part[(long)t * D.R + r];
+            f += lp;
+        }
+        const float lq = D.rowlq[r];
         value = D.estimator == 1 ? lq * f + f : f;
         if (!isfinite(value)) bad = 1.0f;
         if (D.fvalue_out) D.fvalue_out[r] = f;
@@ -2772,6 +2829,7 @@ static size_t partial_floats(const bsvi_amort* a, size_t R) {
         n += 2 * align4(((R + 255) / 256) * (size_t)a->d.latent_dim);                  // a learnable prior's gradient partials
     if (a->d.lik_scale_off != BSVI_AMORT_CONSTANT)
         n += align4((size_t)lik_scale_slices(R) * a->d.n_features);                    // a learnable likelihood scale's
+    n += align4((size_t)((a->d.n_features + 127) / 128) * R);                           // the fused likelihood epilogue's partial log-likelihoods [column tiles][R]
     return n + 16;
 }
 
@@ -2807,6 +2865,7 @@ static int launch_x6(bool nn, const X6Args& X, hipStream_t stream) {
         else if (!nn && dbg == 9) BSVI_X6_LAUNCH(false, 9, 1);
         else if (nn && dbg == 12) BSVI_X6_LAUNCH(true, 2, 0);
         else if (nn && dbg == 13) BSVI_X6_LAUNCH(true, 3, 0);
+        else if (!nn && X.lik_x) hipLaunchKernelGGL((x6gemm_kernel<false, 0, 1, true>), dim3(tiles), dim3(256), 0, stream, X);
         else if (var == 1) { if (nn) BSVI_X6_LAUNCH(true, 0, 1); else BSVI_X6_LAUNCH(false, 0, 1); }
         else if (nn) BSVI_X6_LAUNCH(true, 0, 0);
         else BSVI_X6_LAUNCH(false, 0, 0);
@@ -3260,6 +3319,27 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
             part += align4((size_t)P * Rp / 2);
         }
 
+    // (round 6) the Bernoulli likelihood fused into the epilogue of the product that makes the logits (x6_epilogue, LIK): when that product
+    // is a six-piece forward product without an activation, the data has its exact bf16 copy and no caller weights scale the seeds.
+    // BSVI_AMORT_FUSE_LIK=0: the separate amort_lik launch (80 MB of logits out, in, and their gradient out again at config 5)
+    const bool fuse_lik_env = [] { const char* e = getenv("BSVI_AMORT_FUSE_LIK"); return !(e && e[0] == '0'); }();      // (read per call: tests switch it)
+    bool fuse_lik = false, lik_fused = false;
+    float* lik_part = nullptr;
+    {
+        const int prod = a->dec.producer[d.dec_logits_value];
+        const int x6m = [] { const char* e = getenv("BSVI_X6_MODES"); return e ? atoi(e) : 1; }();
+        if (fuse_lik_env && prod >= 0 && d.likelihood == BSVI_AMORT_LIK_BINOMIAL1 && !args->f_weight_dev && a->data_exact && a->dataset_bf16_dev &&
+            x6_on && (x6m & 1) && (size_t)prod < a->x6[1].size() && a->x6[1][prod].nt && (P & 3) == 0 && (a->data_kp & 3) == 0) {
+            const auto& pl = a->dec.layers[prod];
+            const bool plain = pl.activation == BSVI_ACT_NONE && pl.post_add == 0.0f && !(pl.split_col > 0 && pl.split_col < pl.n_out) && (int)pl.n_out == P;
+            if (plain) {
+                fuse_lik = true;
+                lik_part = part;
+                part += align4((size_t)((P + 127) / 128) * R);
+                D.lik_part = lik_part; D.lik_tiles = (P + 127) / 128;
+            }
+        }
+    }
     auto forward = [&](const Net& net, bool gather) -> int {
         for (size_t li = 0; li < net.layers.size(); ++li) {
             const auto& l = net.layers[li];
@@ -3295,6 +3375,12 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
                 X.bias = l.bias_off != 0xFFFFFFFFu ? params + l.bias_off : nullptr;
                 X.act = (int)l.activation; X.post_add = l.post_add;
                 if (l.split_col > 0 && l.split_col < l.n_out) { X.split = (int)l.split_col; X.act2 = (int)l.activation2; X.post_add2 = l.post_add2; }
+                if (fuse_lik && &net == &a->dec && l.out_value == d.dec_logits_value) {
+                    // the Bernoulli likelihood in this product's epilogue: d f / d logits where the logits would have gone (the buffers are
+                    // one: the logits are overwritten by their own gradient), one partial log-likelihood per (row, column tile)
+                    X.lik_x = a->dataset_bf16_dev; X.lik_kp = a->data_kp; X.lik_idx = idx; X.lik_part = lik_part;
+                    lik_fused = true;
+                }
                 if (int rc = launch_x6(false, X, stream)) return rc;
                 continue;
             }
@@ -3477,7 +3563,10 @@ extern "C" int bsvi_amort_fwd_bwd(const bsvi_amort* a, const bsvi_amort_args* ar
     hipLaunchKernelGGL(amort_latent_fwd, row_grid, dim3(256), 0, stream, D);
     rc = forward(a->dec, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(amort_lik, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, D);
+    if (!lik_fused) {
+        D.lik_part = nullptr; D.lik_tiles = 0;                // (the product fell back to another kernel: the separate launch)
+        hipLaunchKernelGGL(amort_lik, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, D);
+    }
     if (d.lik_scale_off != BSVI_AMORT_CONSTANT) {
         // d log p / d (raw scale): column sums over the d log p / d mean that amort_lik left, per slice of the rows
         const uint32_t slices = lik_scale_slices(R);

@@ -645,6 +645,49 @@ def build_logistic_regression(api, dataset_size=64, batch_size=32, n_features=78
     return model
 
 
+def build_population_receptive_fields(api, field=40, n_data=15, seed=0):
+    """`examples/PopulationReceptiveFields.py:15-45`: the response of a Gaussian receptive field (centre mu_x, mu_y and width v latent)
+    to `n_data` stimulus images on a `field` x `field` mesh, `mean_response = BF.sum(BF.sum(receptive_field * input, dim=1), dim=2)` —
+    a reduction over field^2 elements per datapoint and Monte-Carlo sample.  The stimulus node `input` is observed BY FLAG only
+    (`is_observed=True`, never given a value): the reference draws it from its Normal once per evaluation (`variables.py:849`
+    takes `observed_submodel._get_sample(1, observed=True)`, `:553-565` draws what has no value) and all samples share the draw.
+    The example samples its data from the model; here the same generative process at the example's true values (mu = (1, 2),
+    v = 0.3, nu = 0.1) with numpy."""
+    BF = api.BF
+    S = 6.
+    x_range = np.linspace(-S / 2., S / 2., field)
+    x_mesh, y_mesh = np.meshgrid(x_range, x_range)
+    x = api.RootVariable(x_mesh, name="x")
+    y = api.RootVariable(y_mesh, name="y")
+    w1 = api.NormalVariable(0., 1., name="w1")
+    w2 = api.NormalVariable(0., 1., name="w2")
+    b = api.NormalVariable(0., 1., name="b")
+    experimental_input = api.NormalVariable(BF.exp(BF.sin(w1 * x + w2 * y + b)), 0.1, name="input", is_observed=True)
+    mu_x = api.NormalVariable(0., 1., name="mu_x")
+    mu_y = api.NormalVariable(0., 1., name="mu_y")
+    v = api.LogNormalVariable(0., 0.1, name="v")
+    nu = api.LogNormalVariable(-1, 0.01, name="nu")
+    receptive_field = BF.exp((-(x - mu_x) ** 2 - (y - mu_y) ** 2) / (2. * v ** 2)) / (2. * BF.sqrt(np.pi * v ** 2))
+    mean_response = BF.sum(BF.sum(receptive_field * experimental_input, dim=1, keepdim=True), dim=2, keepdim=True)
+    response = api.NormalVariable(mean_response, nu, name="response")
+    model = api.ProbabilisticModel([response, experimental_input])
+    rng = np.random.RandomState(seed)
+    w1v, w2v, bv = (rng.normal(0., 1., size=(n_data, 1)) for _ in range(3))
+    stim = np.exp(np.sin(w1v[:, :, None] * x_mesh + w2v[:, :, None] * y_mesh + bv[:, :, None])) + 0.1 * rng.normal(size=(n_data, field, field))
+    rf = np.exp((-(x_mesh - 1.) ** 2 - (y_mesh - 2.) ** 2) / (2. * 0.3 ** 2)) / (2. * np.sqrt(np.pi * 0.3 ** 2))
+    resp = (rf * stim).sum(axis=(1, 2)).reshape(n_data, 1, 1) + 0.1 * rng.normal(size=(n_data, 1, 1))
+    w1.observe(w1v.astype(np.float32))
+    w2.observe(w2v.astype(np.float32))
+    b.observe(bv.astype(np.float32))
+    response.observe(resp.astype(np.float32))
+    Qmu_x = api.NormalVariable(0., 1., name="mu_x", learnable=True)
+    Qmu_y = api.NormalVariable(0., 1., name="mu_y", learnable=True)
+    Qv = api.LogNormalVariable(0., 0.1, name="v", learnable=True)
+    Qnu = api.LogNormalVariable(-1, 0.01, name="nu", learnable=True)
+    model.set_posterior_model(api.ProbabilisticModel([Qmu_x, Qmu_y, Qv, Qnu]))
+    return model
+
+
 def build_minibatch_normal_mean(api, dataset_size=40, batch_size=8, seed=0, own_draw=False):
     """The minibatch data path OUTSIDE the matmul patterns (`standard_variables.py:71-112`): a Normal mean whose
     observations are `batch_size` rows of a dataset, other rows in every evaluation — `y.observe(EmpiricalVariable(...))`,

@@ -106,6 +106,10 @@ CASES = {
     "minibatch_linreg_tau_P3_DS40_B8_N30": ("build_minibatch_linear_regression",
                                             dict(dataset_size=40, batch_size=8, n_features=3, latent_scale=True), 30, 87,
                                             dict(iters=5, n=12, optimizer="Adam", lr=0.02)),
+    # (round 6) examples/PopulationReceptiveFields.py at the example's size: a double BF.sum over a 40 x 40 mesh per datapoint and sample, and
+    # an "observed" stimulus node the reference draws once per evaluation (recorded under drawn/)
+    "prf_F40_D15_N20": ("build_population_receptive_fields", dict(field=40, n_data=15), 20, 91,
+                        dict(iters=3, n=10, optimizer="Adam", lr=0.01)),
     # the reference's Bayesian neural network (tests/test_MNIST_bayesian_neural_network.py:20-60): latent weight matrices AND biases of
     # both layers, tanh hidden units, observed Categorical over a random minibatch — reduced sizes, one at the example's full width
     "bnn_P48_H6_C4_DS30_B12_N5": ("build_bayesian_neural_network",
@@ -300,6 +304,13 @@ def run_case(name, api):
         res = orig_obs(*a, **k)
         captured["minibatch"] = {var.name: np.array([int(i) for i in val], dtype=np.int64)
                                  for var, val in res.items() if type(var).__name__ == "RandomIndices"}
+        captured["emp"] = dict(res)
+        # variables observed by flag only (no value): drawn from their own distribution once per evaluation (variables.py:553-565)
+        captured["drawn"] = {var.name: val.detach().numpy().copy() for var, val in res.items()
+                             if getattr(var, "is_observed", False) and hasattr(var, "has_observed_value")
+                             and not getattr(var, "has_observed_value", False) and not getattr(var, "has_random_dataset", False)
+                             and torch.is_tensor(val)
+                             and type(var.distribution).__name__ not in ("EmpiricalDistribution", "DeterministicDistribution")}
         return res
 
     obs_model._get_sample = capture_obs
@@ -316,6 +327,10 @@ def run_case(name, api):
             if "minibatch/" + k in out:
                 assert np.array_equal(out["minibatch/" + k], v), "estimators drew different minibatches"
             out["minibatch/" + k] = v
+        for k, v in captured.get("drawn", {}).items():
+            if "drawn/" + k in out:
+                assert np.array_equal(out["drawn/" + k], v), "estimators drew different values of an observed-by-flag variable"
+            out["drawn/" + k] = v
         z = captured["z"]
         noise = match_noise(q, z, rec.draws)
         if est_name == "pathwise":
@@ -325,7 +340,12 @@ def run_case(name, api):
                 if type(var).__name__ != "RootVariable":
                     out["z/" + var.name] = s.detach().numpy().copy()
             np.random.seed(seed)
-            emp = model.observed_submodel._get_sample(1, observed=True, differentiable=False)
+            if captured.get("drawn"):
+                # (a variable observed by flag only is drawn from torch's generator: a second call would draw ANOTHER value — the
+                #  per-sample terms are recorded on the draw of the compute_loss call above)
+                emp = dict(captured["emp"])
+            else:
+                emp = model.observed_submodel._get_sample(1, observed=True, differentiable=False)
             zz = dict(z)
             zz.update(emp)
             lp = model.get_p_log_probabilities_from_q_samples(q_samples=zz, empirical_samples=emp,
@@ -397,7 +417,7 @@ def run_case(name, api):
                 opts.append(o)
         torch.manual_seed(seed + 1000)
         np.random.seed(seed + 1000)
-        losses, noise_seq, mb_seq = [], {}, {}
+        losses, noise_seq, mb_seq, drawn_seq = [], {}, {}, {}
         for it in range(traj["iters"]):
             with DrawRecorder() as rec:
                 loss = method.compute_loss(model, q, None, traj["n"])
@@ -406,6 +426,8 @@ def run_case(name, api):
                 noise_seq.setdefault(k, []).append(v)
             for k, v in captured.get("minibatch", {}).items():
                 mb_seq.setdefault(k, []).append(v)
+            for k, v in captured.get("drawn", {}).items():
+                drawn_seq.setdefault(k, []).append(v)
             if torch.isfinite(loss.detach()).all().item():
                 [o.zero_grad() for o in opts]
                 loss.backward()
@@ -418,6 +440,8 @@ def run_case(name, api):
             out["traj/noise/" + k] = np.stack(v)
         for k, v in mb_seq.items():
             out["traj/minibatch/" + k] = np.stack(v)
+        for k, v in drawn_seq.items():
+            out["traj/drawn/" + k] = np.stack(v)
         for pname, root in roots.items():
             out["traj/param_after/" + pname] = root.value.detach().numpy().copy()
 

@@ -340,6 +340,12 @@ class Oracle:
         params = self.apply_link(target, parents)
         if target.distribution.kind == D.DIST_EMPIRICAL:
             sample = self.empirical_draw(target, params)
+        elif self.minibatch is not None and target.name in self.minibatch:
+            # a variable observed BY FLAG only (examples/PopulationReceptiveFields.py:29): the reference draws it from its own
+            # distribution once per evaluation (variables.py:553-565); parity runs hand the drawn value in, like minibatch rows
+            sample = torch.as_tensor(np.asarray(self.minibatch[target.name]), dtype=self.dtype)
+            while sample.dim() < 2 or sample.shape[0] != 1:
+                sample = sample.unsqueeze(0)
         else:
             sample = self.dist_sample(target, params, None)
         memo[var] = sample

@@ -49,14 +49,23 @@ class Golden:
 
     @property
     def minibatch(self):
+        """what the reference drew for its OBSERVED variables in the recorded evaluation: the rows of every minibatch index variable
+        ("minibatch/<name>") and — round 6 — the value of every variable observed by flag only ("drawn/<name>": the reference draws it
+        from its own distribution once per evaluation, variables.py:553-565)"""
         mb = {k: [int(i) for i in v] for k, v in self.group("minibatch/").items()}
+        mb.update({k: np.asarray(v) for k, v in self.group("drawn/").items()})
         return mb or None
 
     def trajectory_minibatch(self):
-        seq = self.group("traj/minibatch/")
-        if not seq:
+        seq, drawn = self.group("traj/minibatch/"), self.group("traj/drawn/")
+        if not seq and not drawn:
             return None
-        return [{k: [int(i) for i in v[it]] for k, v in seq.items()} for it in range(self.meta["trajectory"]["iters"])]
+        out = []
+        for it in range(self.meta["trajectory"]["iters"]):
+            step = {k: [int(i) for i in v[it]] for k, v in seq.items()}
+            step.update({k: np.asarray(v[it]) for k, v in drawn.items()})
+            out.append(step)
+        return out
 
     def trajectory_noise(self):
         tr = self.meta["trajectory"]

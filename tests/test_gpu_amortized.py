@@ -843,3 +843,32 @@ def test_random_architectures_match_oracle(seed):
         grads = _module_view(c, c.named_grads())
         ref32 = VaeOracle(build(), dtype=torch.float32).loss_and_grads(rows, eps, estimator)
         yardstick_grad_check(grads, ref["grads"], ref32["grads"])      # (err <= max(4 |oracle_fp32 - oracle_fp64|, 1e-5 scale))
+
+
+def test_the_fused_likelihood_epilogue_equals_the_separate_launch():
+    """Round 6: the Bernoulli likelihood in the epilogue of the product that makes the logits (x6_epilogue, LIK: the logits never reach
+    memory, amort_lik is not launched) against the separate launch (BSVI_AMORT_FUSE_LIK=0) at cfg 5's layer widths and 512 rows: the same
+    per-row f, log q and gradients to rounding (the row sums of the log-likelihood are taken in another order), each bit-identical call
+    to call; both estimators."""
+    import os
+    from brancher_amd import engine, workloads as W
+    kw = dict(dataset_size=300, batch_size=64, n_features=784, latent_size=2, hidden1=512, hidden2=256, seed=3)
+    for estimator in ("pathwise", "blackbox"):
+        out = {}
+        for fused in ("1", "0"):
+            os.environ["BSVI_AMORT_FUSE_LIK"] = fused
+            try:
+                c = engine.compile_model(W.build_vae(W.native_api(), **kw), None, estimator)
+                assert c.data_path() == "bf16x3"
+                a = c.evaluate(8, seed=4, offset=2, want_fvalues=True)
+                first = c.out.clone()
+                fa = a["f"].clone()
+                b = c.evaluate(8, seed=4, offset=2, want_fvalues=True)
+                assert torch.equal(c.out, first) and torch.equal(b["f"], fa)
+                out[fused] = (first, fa)
+            finally:
+                del os.environ["BSVI_AMORT_FUSE_LIK"]
+        (g1, f1), (g0, f0) = out["1"], out["0"]
+        assert not torch.equal(f1, f0)                                  # (another launch sequence: another summation order)
+        assert float((f1 - f0).abs().max()) <= 2e-6 * float(f0.abs().max())
+        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())

@@ -1,0 +1,12 @@
+#!/bin/bash
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+OUT=$ROOT/gpurun_out/r6; mkdir -p $OUT; cd $ROOT
+timeout 1500 python3 -m pytest tests/test_gpu_amortized.py -x -q -m gpu 2>&1 | tail -8 > $OUT/check5.txt
+timeout 900 python3 -m pytest tests/test_gpu_two_ranks.py -x -q -m gpu -k "cfg5 or amort or vae" 2>&1 | tail -4 >> $OUT/check5.txt
+for e in "BSVI_AMORT_FUSE_LIK=0" "BSVI_AMORT_FUSE_LIK=1"; do
+  echo "== cfg5 $e" >> $OUT/check5.txt
+  env $e timeout 600 python3 bench.py --workload cfg5 --steps 100 --warmup 10 --no-cpu-baseline --other-configs off --traffic off 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['final_loss'])" >> $OUT/check5.txt 2>&1
+done
+echo "== cfg5 blackbox" >> $OUT/check5.txt
+timeout 600 python3 bench.py --workload cfg5 --estimator blackbox --steps 100 --warmup 10 --no-cpu-baseline --other-configs off --traffic off 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['final_loss'])" >> $OUT/check5.txt 2>&1
+cat $OUT/check5.txt
