@@ -1462,6 +1462,8 @@ extern "C" size_t bsvi_sizeof(int kind) {
     case BSVI_SK_BNN_LAYER: return sizeof(bsvi_bnn_layer);
     case BSVI_SK_BNN_DESC: return sizeof(bsvi_bnn_desc);
     case BSVI_SK_BNN_ARGS: return sizeof(bsvi_bnn_args);
+    case BSVI_SK_REDUCE_DESC: return sizeof(bsvi_reduce_desc);
+    case BSVI_SK_REDUCE_ARGS: return sizeof(bsvi_reduce_args);
     default: return 0;
     }
 }

@@ -416,7 +416,8 @@ class CompiledELBO:
             bp = self.base_program
             self.base_obs = torch.from_numpy(np.ascontiguousarray(bp.obs)).to(dev) if bp.obs.size else torch.zeros(1, device=dev)
             self.base_out = torch.zeros(OUT_HEADER + max(bp.n_params, 1), device=dev, dtype=torch.float32)
-            self._externals = [native.MvnNode(e) for e in p.externals]
+            # (round 6: a node is a batched multivariate-normal term or a REDUCE node — lowering.reduce_external)
+            self._externals = [native.ReduceNode(e) if getattr(e, "kind", "mvn") == "reduce" else native.MvnNode(e) for e in p.externals]
             self._base_buffers = {}
         # observations that are a MINIBATCH of a dataset (scalar-path f-1, lowering.MinibatchObs): the datasets resident on the device,
         # the stretches of the observation buffer refreshed in front of every evaluation (`_refresh_minibatches`)
@@ -501,7 +502,7 @@ class CompiledELBO:
                         fvalue_out_dev=ptr(fvalue_out), workspace_dev=ptr(self.workspace(n_local)),
                         stream=self._stream())
 
-    def _external_rows(self, n_local, n_global, base, noise_t, seed, offset):
+    def _external_rows(self, n_local, n_global, base, noise_t, seed, offset, minibatch=None):
         """Models with batched multivariate-normal terms, per evaluation: (1) the base program draws the posterior's sample
         (its noise and slot values land in buffers), (2) every bsvi_mvn node reads the draw and writes the rows of its linear
         surrogate — log p and d log p / d inputs of each sample — behind the real rows of the noise tensor, (3) the caller
@@ -528,8 +529,21 @@ class CompiledELBO:
                         workspace_dev=ptr(bufs["ws"]), stream=self._stream())
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.base_native.handle, C.byref(args)))
         for node in self._externals:
+            extra = {}
+            if getattr(node.node, "kind", "mvn") == "reduce":
+                # the reduce node's data — a variable observed by flag only — is drawn on the device from (seed, offset), the same on
+                # every rank, or handed in with the minibatch rows (`minibatch`: {variable name: value}; parity tests replay the reference's)
+                extra = dict(seed=self._resolved(seed), offset=int(offset))
+                given = minibatch.get(node.node.drawn_name) if isinstance(minibatch, dict) and node.node.drawn_name else None
+                if given is not None:
+                    data = torch.from_numpy(np.ascontiguousarray(np.asarray(given, dtype=np.float32).reshape(-1))).to(dev)
+                    if data.numel() != node.node.n_data * node.node.rows * node.node.cols:
+                        raise ValueError("the value of {!r} must have {} x {} x {} elements".format(
+                            node.node.drawn_name, node.node.n_data, node.node.rows, node.node.cols))
+                    bufs["given_data"] = data            # (alive until the launches that read it have run: one evaluation at a time)
+                    extra["data_ptr"] = ptr(data)
             node.eval(ptr(self.params), ptr(bufs["samples"]), C.c_void_p(full.data_ptr() + 4 * node.node.row0 * n_local),
-                      n_local, self._stream())
+                      n_local, self._stream(), **extra)
         return full
 
     def _refresh_minibatches(self, seed, offset, minibatch=None, want_indices=False):
@@ -594,7 +608,7 @@ class CompiledELBO:
         noise_o = torch.empty((p.n_noise, n_local), device=dev) if want_noise else None
         fvals = torch.empty((2, n_local), device=dev) if want_fvalues else None
         if self._externals:
-            noise_t = self._external_rows(n_local, number_samples, base, noise_t, seed, offset)
+            noise_t = self._external_rows(n_local, number_samples, base, noise_t, seed, offset, minibatch)
         used_rows = self._refresh_minibatches(seed, offset, minibatch, want_indices)
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
@@ -627,7 +641,7 @@ class CompiledELBO:
         if self._externals:
             # batched multivariate-normal terms re-enter the program as linear surrogate records — model terms like any other,
             # so a_n weights them too; their rows come from the same three-launch sequence as in `evaluate`
-            noise_t = self._external_rows(n_local, number_samples, base, noise_t, self._seed(seed), int(offset))
+            noise_t = self._external_rows(n_local, number_samples, base, noise_t, self._seed(seed), int(offset), minibatch)
         self._refresh_minibatches(self._seed(seed), int(offset), minibatch)
         args = ElboArgs.from_buffer_copy(self._elbo_args(n_local, number_samples, base, None, self._seed(seed), int(offset)))
         args.stream = self._stream()
@@ -947,7 +961,8 @@ class CompiledELBO:
         for it in range(K):
             nz = None if noise_t is None else noise_t[it]
             if self._externals:
-                nz = self._external_rows(n_local, number_samples, base, nz, seed, offset0 + it)
+                nz = self._external_rows(n_local, number_samples, base, nz, seed, offset0 + it,
+                                         None if minibatch_seq is None else minibatch_seq[it])
             if self._minibatches:
                 self._refresh_minibatches(seed, offset0 + it, None if minibatch_seq is None else minibatch_seq[it])
             args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
@@ -1063,7 +1078,8 @@ def custom_estimator_loss(joint_model, posterior_model, estimator_cls, number_sa
     kind = type(compiled).__name__
     if kind not in ("CompiledELBO", "CompiledDense", "CompiledBnn", "CompiledAmortized"):
         raise NotImplementedError("user-defined gradient estimators: unknown engine " + kind)
-    extra = dict(minibatch=minibatch) if (kind != "CompiledELBO" or getattr(compiled, "_minibatches", None)) else {}
+    extra = dict(minibatch=minibatch) if (kind != "CompiledELBO" or getattr(compiled, "_minibatches", None)
+                                          or any(getattr(n.node, "kind", "mvn") == "reduce" for n in getattr(compiled, "_externals", []))) else {}
     N = int(number_samples)
     seed = compiled._seed(None)
     offset = compiled.iteration

@@ -160,6 +160,35 @@ class MinibatchObs:
         self.is_observed = True
 
 
+class _SurrogateTerm:
+    """what the emission reads of a model term that is a LINEAR surrogate row (coefficient x partner): the reduce node's
+    log-probability of its drawn data"""
+    is_observed, b_axis = True, 1
+
+    def __init__(self, name):
+        self.name, self.distribution = name, D.LinearSurrogate()
+
+
+class DrawnObs:
+    """A variable that is observed BY FLAG only (`is_observed=True`, never given a value): the reference draws it from its own
+    distribution ONCE per evaluation and every Monte-Carlo sample shares the draw (`variables.py:849`, `:553-565`).  A Normal whose
+    mean / scale [B, D1, D2] are constants of the model; stands where an observed variable stands in the IR."""
+
+    def __init__(self, var, mean, scale):
+        self.var, self.name, self.mean, self.scale, self.consumed = var, var.name, mean, scale, False
+        self._observed_value = np.zeros((1,) + mean.shape, dtype=np.float32)
+        self.is_observed = True
+
+
+class ExternalReduce:
+    """A reduction evaluated by the reduce node of the library (lowering.reduce_external): what `native.reduce_desc` turns into a
+    bsvi_reduce_desc, and where its rows live in the program's noise tensor."""
+    kind = "reduce"
+    name = code = mats = uniform_inputs = slot_inputs = data_mean = data_scale = drawn_name = logp_node = None
+    rows = cols = n_data = row0 = n_rows_out = 0
+    drawn, weight = False, 0.0
+
+
 class SlotInfo:
     def __init__(self, var, base, shape, dist):
         self.var, self.base, self.shape, self.dist = var, base, shape, dist
@@ -241,6 +270,7 @@ class _Lowering:
         self.n_obs = 0
         self.obs_index = {}        # id(var) -> (offset, shape)
         self.minibatch_obs = {}    # id(EmpiricalVariable) -> MinibatchObs: observations that are a minibatch of a dataset
+        self.drawn_obs = {}        # id(variable observed by flag only) -> DrawnObs: drawn once per evaluation
         self.uni_param = []        # provisional uniform entries (param-sourced)
         self.uni_const = []
         self.uni_index = {}        # (kind, id/ key, transform, a, b) -> (is_param, local k0)
@@ -484,6 +514,11 @@ class _Lowering:
                 raise LoweringError("BF.sum needs an explicit dim (and only dim / keepdim): a full reduction would sum over "
                                     "Monte-Carlo samples")
             d, keep = axis_of(dim, "BF.sum dim"), bool(self.static_int(keep, "BF.sum keepdim"))
+            # both element axes reduced, and too many terms to unroll: the reduce node (reduce_external)
+            if keep and rank == 3 and arg.op == "vsum" and arg.attr[1] and arg.attr[0] != d:
+                inner = arg.args[0]
+                if self.rank_of(inner) == 3 and int(np.prod(inner.shape)) > self.kMaxViewTerms:
+                    return self.reduce_external(inner, "BF.sum(BF.sum(...)) over %d x %d elements" % inner.shape[1:])
             if d == 1:
                 shape = (B, 1, D2) if keep else (B, D2, 1)
             else:
@@ -645,6 +680,12 @@ class _Lowering:
                 # are ordinary observations [B, ...] in the observation buffer; the engine refreshes them in front of every launch
                 # (`bsvi_minibatch_gather`: the keyed bijection of the dense path's `dense_head`, or the caller's rows).
                 source = var if getattr(var, "_type", None) == "Empirical" else getattr(var, "dataset", None)
+                if source is None and getattr(var, "_type", None) != "Empirical":
+                    # observed BY FLAG only (`NormalVariable(..., is_observed=True)` never given a value — the stimulus node of
+                    # examples/PopulationReceptiveFields.py:29): the reference DRAWS it from its own distribution once per evaluation
+                    # (`variables.py:849` takes observed_submodel._get_sample(1, observed=True), `:553-565` draws what has no value)
+                    handle = self.drawn_handle(var)
+                    return self.mk("obs", (), handle, canonical_elem_shape(handle._observed_value.shape[1:]))
                 if source is None or getattr(source, "_type", None) != "Empirical":
                     raise LoweringError("variable %r is observed without a value and not through an EmpiricalVariable" % var.name)
                 handle = self.minibatch_handle(source)
@@ -681,6 +722,175 @@ class _Lowering:
             self.consts.append(flat)
             self.n_consts += flat.size
         return off
+
+    def host_value(self, node):
+        """numpy value [B, D1, D2] (broadcastable) of an IR node made of constants, non-learnable roots and OBSERVED values only
+        (else None): the parameters of a node that is drawn once per evaluation are constants of the model"""
+        if node.has_z:
+            return None
+        if node.op == "imm":
+            return np.full((1, 1, 1), float(node.attr))
+        if node.op == "carr":
+            return np.asarray(node.attr, dtype=np.float64).reshape(node.shape)
+        if node.op == "root":
+            if node.attr.learnable:
+                return None
+            return np.asarray(node.attr.value, dtype=np.float64).reshape(node.shape)
+        if node.op == "obs":
+            if isinstance(node.attr, (MinibatchObs, DrawnObs)):
+                return None
+            return np.asarray(node.attr._observed_value, dtype=np.float64).reshape(node.shape)
+        args = [self.host_value(a) for a in node.args]
+        if any(a is None for a in args):
+            return None
+        if node.op in ("add", "sub", "mul", "truediv", "pow"):
+            fn = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "truediv": np.divide, "pow": np.power}[node.op]
+            return fn(args[0], args[1])
+        if node.op.startswith("call:"):
+            g = node.op[5:]
+            table = dict(exp=np.exp, log=np.log, sqrt=np.sqrt, sin=np.sin, cos=np.cos, tanh=np.tanh, abs=np.abs, square=np.square,
+                         neg=np.negative, sigmoid=lambda x: 1.0 / (1.0 + np.exp(-x)), softplus=lambda x: np.logaddexp(0.0, x))
+            if g in table and len(args) == 1:
+                return table[g](args[0])
+        return None
+
+    def drawn_handle(self, var):
+        """the observation record behind a variable that is observed by flag only: a Normal whose parameters are constants of the model,
+        drawn once per evaluation and shared by all samples"""
+        hit = self.drawn_obs.get(id(var))
+        if hit is not None:
+            return hit
+        if var.distribution.kind != D.DIST_NORMAL:
+            raise LoweringError("variable %r is observed without a value: only a Normal node is drawn per evaluation here" % var.name)
+        loc, scale = self.node_params(var, self.p_value)
+        mean, sd = self.host_value(loc), self.host_value(scale)
+        if mean is None or sd is None:
+            raise LoweringError("variable %r is observed without a value and its parameters are not constants of the model" % var.name)
+        shape = broadcast_shapes3(loc.shape, scale.shape)
+        handle = DrawnObs(var, np.broadcast_to(mean, shape).astype(np.float32), np.broadcast_to(sd, shape).astype(np.float32))
+        self.drawn_obs[id(var)] = handle
+        return handle
+
+    def reduce_external(self, prod, what):
+        """A link reduces `prod` [B, D1, D2] over BOTH element axes and the product is too large to unroll (B x D1 x D2 terms beyond
+        kMaxViewTerms): `BF.sum(BF.sum(receptive_field * input, dim=1), dim=2)` of examples/PopulationReceptiveFields.py:29-31.  With
+        prod = A * X — A [1, D1, D2] an ELEMENTWISE expression of constant matrices and scalars that are sampled or learnable, X
+        [B, D1, D2] observed data (a value, or a node DRAWN once per evaluation: `drawn_handle`) — the reduction leaves the per-sample
+        program for the library's reduce node (`bsvi_reduce_*`, csrc/reduce_kernel.h): r_d = sum_e A(e; s) X[d][e] re-enters as
+        r_d = e_d + sum_k g_dk s_k, value and gradient exact at the sample, composed here from GIVEN rows the node fills (K + 1 pseudo
+        posterior variables of B elements each, behind the posterior's own rows — the mechanism of `mvn_external`)."""
+        if prod.op != "mul":
+            raise LoweringError("%s: a reduction over %d elements is lowered for a product  expression * data  only" % (what, int(np.prod(prod.shape))))
+        a, x = prod.args
+        if x.op != "obs":
+            a, x = x, a
+        B, D1, D2 = prod.shape
+        if x.op != "obs" or x.shape != (B, D1, D2) or a.shape != (1, D1, D2):
+            raise LoweringError("%s: the reduced product must be  expression [1, %d, %d] * observed data [%d, %d, %d]" % (what, D1, D2, B, D1, D2))
+        if isinstance(x.attr, MinibatchObs):
+            raise LoweringError("%s: a minibatch as the data of a large reduction is not lowered yet" % what)
+        if self.pseudo_q:
+            raise LoweringError("%s: a second external node (its rows would lie behind the first one's)" % what)
+        host_g = dict(identity=lambda v: v, softplus=lambda v: np.logaddexp(0.0, v), sigmoid=lambda v: 1.0 / (1.0 + np.exp(-v)),
+                      exp=np.exp, log=np.log, tanh=np.tanh, sqrt=np.sqrt, square=np.square)
+        code, mats, memo = [], [], {}
+        slot_inputs, uniform_inputs = [], []
+
+        def push(ins):
+            code.append(ins)
+            return len(code) - 1
+
+        def emit(node):
+            hit = memo.get(node.key)
+            if hit is not None:
+                return hit
+            if node.shape[0] != 1 or any(n not in (1, d) for n, d in zip(node.shape[1:], (D1, D2))):
+                raise LoweringError("%s: the expression under the reduction mixes shapes (%r over a %dx%d field)" % (what, node.shape, D1, D2))
+            arr = self.host_value(node)
+            if arr is not None:
+                arr = np.broadcast_to(arr, (1, D1, D2))[0]
+                if np.all(arr == arr.flat[0]):
+                    t = push(("IMM", 0, 0, 0, float(arr.flat[0])))
+                else:
+                    mats.append(np.ascontiguousarray(arr, dtype=np.float32))
+                    t = push(("MAT", 0, len(mats) - 1, 0, 0.0))
+            elif node.op == "z" or (node.op == "elem" and node.args[0].op == "z"):
+                if node.shape != (1, 1, 1):
+                    raise LoweringError("%s: a sampled VECTOR under the reduction (only scalars per sample are inputs of the reduce node)" % what)
+                child, j = (node, 0) if node.op == "z" else (node.args[0], int(node.attr))
+                slot_inputs.append((node, self.slots[child.attr].base + j))
+                t = push(("INPUT", 0, ("s", len(slot_inputs) - 1), 0, 0.0))
+            elif not node.has_z and self.match_uniform(node) is not None:
+                leaf, g, aa, bb = self.match_uniform(node)
+                if int(np.prod(leaf.shape)) != 1:
+                    raise LoweringError("%s: a learnable ARRAY under the reduction (only scalars are inputs of the reduce node)" % what)
+                is_param, k0 = self.uniform_entries(leaf, g, aa, bb)
+                uniform_inputs.append((node, self.uni_param[k0]))
+                t = push(("INPUT", 0, ("u", len(uniform_inputs) - 1), 0, 0.0))
+            elif node.op == "pow" and node.args[1].op == "imm":
+                t = push(("UN", UNOP["powi"], emit(node.args[0]), 0, float(node.args[1].attr)))
+            elif node.op in BINOP and node.op != "delta":
+                xx, yy = emit(node.args[0]), emit(node.args[1])
+                t = push(("BIN", BINOP[node.op], xx, yy, 0.0))
+            elif node.op.startswith("call:") and node.op[5:] in UNOP and node.op[5:] not in ("p2l", "relu", "log1p", "expm1"):
+                t = push(("UN", UNOP[node.op[5:]], emit(node.args[0]), 0, 0.0))
+            else:
+                raise LoweringError("%s: %s under the reduction is not served by the reduce node" % (what, node.op))
+            memo[node.key] = t
+            return t
+
+        emit(a)
+        K = len(slot_inputs) + len(uniform_inputs)
+        if K > 8:
+            raise LoweringError("%s: more than 8 sampled / learnable scalars under the reduction" % what)
+        n_s = len(slot_inputs)
+        code = [(k, f, (aa[1] if aa[0] == "s" else n_s + aa[1]) if isinstance(aa, tuple) else aa, bb, imm) for k, f, aa, bb, imm in code]
+        node = ExternalReduce()
+        node.name, node.rows, node.cols, node.n_data, node.code = what, D1, D2, B, code
+        node.mats = np.stack(mats) if mats else np.zeros((0, D1, D2), np.float32)
+        node.slot_inputs = [row for _, row in slot_inputs]
+        node.uniform_inputs = np.zeros(len(uniform_inputs), dtype=UNIFORM_DTYPE)
+        for k, (_, (src, tr, is_param, aa, bb)) in enumerate(uniform_inputs):
+            node.uniform_inputs[k] = (src, tr, is_param, 0, aa, bb)
+        handle = x.attr
+        node.drawn = isinstance(handle, DrawnObs)
+        if node.drawn:
+            node.data_mean, node.data_scale = handle.mean.reshape(B, D1 * D2), handle.scale.reshape(B, D1 * D2)
+            node.drawn_name, node.weight = handle.name, 1.0
+            handle.consumed = True
+        else:
+            node.data_mean, node.data_scale = np.asarray(handle._observed_value, dtype=np.float32).reshape(B, D1 * D2), None
+            node.drawn_name, node.weight = None, 0.0
+        node.n_rows_out = (K + 1) * B + 1
+        self.externals.append(node)
+        partners = [n for n, _ in slot_inputs] + [n for n, _ in uniform_inputs]
+        if self.external_mode == "omit":
+            # the base program makes the draw only: the reduction's value does not matter there (the model term that reads it is
+            # evaluated, its result unused) — a constant keeps the record well formed
+            return self.mk("carr", (), np.zeros((B, 1, 1), dtype=np.float32), (B, 1, 1))
+        node.row0 = self.n_slots
+
+        class _Rows:                                       # a pseudo posterior variable of B elements: its "noise" rows are GIVEN
+            _pseudo, is_observed = True, False
+
+            def __init__(self, name):
+                self.name, self.distribution = name, D.NormalDistribution()
+
+        def given(name, shape):
+            rows = _Rows(name)
+            self.slots[rows] = SlotInfo(rows, self.n_slots, shape, D.DIST_NORMAL)
+            self.n_slots += int(np.prod(shape))
+            self.pseudo_q.append(rows)
+            return self.mk("z", (), rows, shape)
+
+        out = None
+        for k in range(K):
+            term = self.mk("mul", (given("%s/gradient[%d]" % (what, k), (B, 1, 1)), partners[k]))
+            out = term if out is None else self.mk("add", (out, term))
+        e = given("%s/value" % what, (B, 1, 1))
+        out = e if out is None else self.mk("add", (e, out))
+        node.logp_node = given("%s/drawn log-probability" % what, (1, 1, 1))
+        return out
 
     def minibatch_handle(self, source):
         """the observation record behind an observed EmpiricalVariable: B rows of its dataset, refreshed per evaluation"""
@@ -1498,6 +1708,12 @@ class _Lowering:
                 continue
             if v.distribution.kind == D.DIST_EMPIRICAL and v.is_observed:
                 continue        # an observed minibatch source: log-probability 0 (ImplicitDistribution, `distributions.py:226-227`)
+            if (v.is_observed and not v.has_observed_value and not getattr(v, "has_random_dataset", False)
+                    and getattr(v, "_type", None) not in ("Empirical", "Deterministic node")):
+                # observed by flag only: drawn once per evaluation (drawn_handle).  Its log-probability at the draw — one number per
+                # evaluation, the same for every sample — comes from the reduce node that reads the draw (its last row), below
+                self.drawn_handle(v)
+                continue
             if v.distribution.kind == D.DIST_MVNORMAL:
                 p_nodes.extend(self.mvn_terms(v))
                 continue
@@ -1515,15 +1731,23 @@ class _Lowering:
                 continue
             p_nodes.append((v, value, params, shape))
 
+        for handle in self.drawn_obs.values():
+            nodes = [n for n in self.externals if getattr(n, "kind", "mvn") == "reduce" and n.drawn_name == handle.name]
+            if not nodes:
+                raise LoweringError("variable %r is observed without a value (drawn per evaluation) and read outside a large reduction: "
+                                    "not lowered" % handle.name)
+            if nodes[0].logp_node is not None:          # (None: the base program, which makes the draw only)
+                p_nodes.append((_SurrogateTerm("%s/log-probability of the draw" % handle.name), self.mk("imm", (), 1.0),
+                                [nodes[0].logp_node, self.mk("imm", (), 0.0)], (1, 1, 1)))
         # -- the coefficient rows of batched multivariate-normal terms: GIVEN pseudo-variables behind the posterior's own rows
         q_nodes.extend(self.mean_q)                     # (Taylor1: per-sample means of vector values, rows of the draw like the q's own)
         n_real_q = len(q_nodes)
         for coeff in self.pseudo_q:
-            q_nodes.append((coeff, [self.mk("imm", (), 0.0), self.mk("imm", (), 1.0)], (1, 1, 1)))
+            q_nodes.append((coeff, [self.mk("imm", (), 0.0), self.mk("imm", (), 1.0)], self.slots[coeff].shape))
 
         # -- weights from the [N, B] mean rule
         term_b = []
-        for v, params, shape in q_nodes:
+        for v, params, shape in q_nodes[:n_real_q]:      # (GIVEN rows have no term of their own: a vector of them — the reduce node's — does not count)
             term_b.append(shape[0])
         for v, value, params, shape in p_nodes:
             term_b.append(1 if v.is_observed else getattr(v, "b_axis", shape[0]))
@@ -1832,7 +2056,7 @@ class _Lowering:
                              if not getattr(s.var, "_pseudo", False) and not getattr(s.var, "_mean_value", False)}
         # batched multivariate-normal terms (mvn_external): their descriptions, and how many noise rows are the posterior's own
         prog.externals = list(self.externals)
-        prog.n_real_noise = self.n_latent - len(self.pseudo_q)
+        prog.n_real_noise = self.n_latent - sum(self.slots[c].size for c in self.pseudo_q)      # (a reduce node's GIVEN rows are vectors)
         prog.bmax = bmax
         prog.op_count = len(code)
         return prog

@@ -336,9 +336,76 @@ def mvn_source(node):
     return buf.value.decode()
 
 
+class ReduceDesc(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("abi_version", C.c_uint32), ("rows", C.c_uint32), ("cols", C.c_uint32),
+                ("n_code", C.c_uint32), ("n_mats", C.c_uint32), ("n_slot_inputs", C.c_uint32), ("n_uniform_inputs", C.c_uint32),
+                ("n_data", C.c_uint32), ("drawn", C.c_uint32), ("reserved1", C.c_uint32),
+                ("code", C.POINTER(MvnInsn)), ("mats", C.c_void_p), ("uniform_inputs", C.c_void_p), ("data_mean", C.c_void_p),
+                ("data_scale", C.c_void_p), ("weight", C.c_float), ("reserved2", C.c_uint32)]
+
+
+class ReduceArgs(Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32),
+                ("params_dev", C.c_void_p), ("samples_dev", C.c_void_p), ("rows_out_dev", C.c_void_p),
+                ("n_samples_local", C.c_uint32), ("reserved1", C.c_uint32), ("input_rows", C.c_uint32 * 8),
+                ("data_dev", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64), ("stream", C.c_void_p)]
+
+
+EXPORTS.update({
+    "bsvi_reduce_create": (C.c_int, [C.POINTER(ReduceDesc), C.POINTER(C.c_void_p)]),
+    "bsvi_reduce_destroy": (None, [C.c_void_p]),
+    "bsvi_reduce_rows_out": (C.c_uint32, [C.POINTER(ReduceDesc)]),
+    "bsvi_reduce_eval": (C.c_int, [C.c_void_p, C.POINTER(ReduceArgs)]),
+    "bsvi_reduce_source": (C.c_size_t, [C.POINTER(ReduceDesc), C.c_char_p, C.c_size_t]),
+})
+
+
+def reduce_desc(node):
+    """lowering.ExternalReduce -> (bsvi_reduce_desc, the arrays it points into)"""
+    code = (MvnInsn * len(node.code))(*[MvnInsn(kind=MVN_KIND[k], flag=f, a=a, b=b, imm=imm) for k, f, a, b, imm in node.code])
+    mats = np.ascontiguousarray(node.mats, dtype=np.float32)
+    uni = np.ascontiguousarray(node.uniform_inputs)
+    mean = np.ascontiguousarray(node.data_mean, dtype=np.float32)
+    scale = np.ascontiguousarray(node.data_scale, dtype=np.float32) if node.drawn else None
+    keep = dict(code=code, mats=mats, uni=uni, mean=mean, scale=scale)
+    d = ReduceDesc(abi_version=ABI_VERSION, rows=node.rows, cols=node.cols, n_code=len(node.code), n_mats=mats.shape[0] if mats.size else 0,
+                   n_slot_inputs=len(node.slot_inputs), n_uniform_inputs=len(uni), n_data=node.n_data, drawn=int(node.drawn),
+                   code=code, mats=_ptr(mats) if mats.size else None, uniform_inputs=_ptr(uni) if len(uni) else None,
+                   data_mean=_ptr(mean), data_scale=_ptr(scale) if scale is not None else None, weight=float(node.weight))
+    return d, keep
+
+
+class ReduceNode:
+    """Owns a ``bsvi_reduce*`` created from a lowering.ExternalReduce (links with a reduction the per-sample program does not unroll)."""
+
+    def __init__(self, node):
+        self.lib = load()
+        d, self._keep = reduce_desc(node)
+        handle = C.c_void_p()
+        check(self.lib.bsvi_reduce_create(C.byref(d), C.byref(handle)))
+        self.handle, self.node = handle, node
+        assert int(self.lib.bsvi_reduce_rows_out(C.byref(d))) == node.n_rows_out
+
+    def eval(self, params_ptr, samples_ptr, rows_out_ptr, n_local, stream, seed=0, offset=0, data_ptr=None):
+        args = ReduceArgs(params_dev=params_ptr, samples_dev=samples_ptr, rows_out_dev=rows_out_ptr, n_samples_local=n_local,
+                          data_dev=data_ptr, seed=int(seed) & 0x7FFFFFFFFFFFFFFF, offset=int(offset), stream=stream)
+        for k, row in enumerate(self.node.slot_inputs):
+            args.input_rows[k] = row
+        check(self.lib.bsvi_reduce_eval(self.handle, C.byref(args)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.bsvi_reduce_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 # bsvi_struct_kind (include/bsvi.h) -> the ctypes mirror of the struct: load() checks every size against bsvi_sizeof()
 STRUCT_KINDS = {0: UniformEntry, 1: Record, 2: ProgramDesc, 3: ElboArgs, 4: OptCfg, 5: DenseDesc, 6: DenseArgs, 7: MlpLayer,
-                8: AmortDesc, 9: AmortArgs, 10: MvnInsn, 11: MvnDesc, 12: MvnArgs, 13: BnnLayer, 14: BnnDesc, 15: BnnArgs}
+                8: AmortDesc, 9: AmortArgs, 10: MvnInsn, 11: MvnDesc, 12: MvnArgs, 13: BnnLayer, 14: BnnDesc, 15: BnnArgs,
+                16: ReduceDesc, 17: ReduceArgs}
 
 _lib = None
 

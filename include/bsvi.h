@@ -52,7 +52,7 @@ typedef enum bsvi_struct_kind {
     BSVI_SK_UNIFORM_ENTRY = 0, BSVI_SK_RECORD = 1, BSVI_SK_PROGRAM_DESC = 2, BSVI_SK_ELBO_ARGS = 3, BSVI_SK_OPT_CFG = 4,
     BSVI_SK_DENSE_DESC = 5, BSVI_SK_DENSE_ARGS = 6, BSVI_SK_MLP_LAYER = 7, BSVI_SK_AMORT_DESC = 8, BSVI_SK_AMORT_ARGS = 9,
     BSVI_SK_MVN_INSN = 10, BSVI_SK_MVN_DESC = 11, BSVI_SK_MVN_ARGS = 12, BSVI_SK_BNN_LAYER = 13, BSVI_SK_BNN_DESC = 14,
-    BSVI_SK_BNN_ARGS = 15, BSVI_SK_COUNT = 16
+    BSVI_SK_BNN_ARGS = 15, BSVI_SK_REDUCE_DESC = 16, BSVI_SK_REDUCE_ARGS = 17, BSVI_SK_COUNT = 18
 } bsvi_struct_kind;
 /* sizeof(struct) inside this build of the library; 0 for an unknown kind */
 size_t bsvi_sizeof(int kind);
@@ -806,6 +806,53 @@ uint32_t bsvi_mvn_rows_out(const bsvi_mvn_desc* desc);
 int bsvi_mvn_eval(bsvi_mvn* m, const bsvi_mvn_args* args);
 /* the generated translation unit (host only, like bsvi_program_source): byte count including the terminator, 0 on error */
 size_t bsvi_mvn_source(const bsvi_mvn_desc* desc, char* buf, size_t capacity);
+
+/* =========================================================================================
+ * The REDUCE node (ABI 11): links with a reduction over more elements than the per-sample program unrolls — the last of the
+ * reference's examples that did not lower, examples/PopulationReceptiveFields.py:29-31:
+ *     mean_response = BF.sum(BF.sum(receptive_field * input, dim=1, keepdim=True), dim=2, keepdim=True)
+ * i.e. r[n][d] = sum_e A(e; s_n) * X[d][e] with A an ELEMENTWISE link expression of constant matrices (rows x cols each) and at most
+ * 8 scalars that differ per Monte-Carlo sample or are learnable (three-address code, as the multivariate-normal node's), and X a data
+ * matrix [n_data][rows * cols]: a constant of the model (drawn == 0: data_mean IS X), or — drawn != 0 — the value of a Normal node that
+ * is observed BY FLAG only, which the reference draws from Normal(data_mean, data_scale) ONCE per evaluation for all samples
+ * (brancher/variables.py:849 takes observed_submodel._get_sample(1, observed=True); :553-565 draws what has no value): drawn on the
+ * device from (seed, offset), or handed in (bsvi_reduce_args::data_dev: parity tests replay the reference's draw).
+ *
+ * Rows out, [bsvi_reduce_rows_out][n_local]: for input k and datapoint d, row k * n_data + d = g_dk = d r_d / d input_k; then row
+ * n_inputs * n_data + d = e_d = r_d - sum_k g_dk input_k; then ONE row: weight * log N(X | data_mean, data_scale) (drawn; else 0).
+ * e_d + sum_k g_dk input_k has the value and the gradient of r_d at the sample: the per-sample program composes r_d from these GIVEN
+ * rows (lowering.reduce_external) wherever the link stood. */
+typedef struct bsvi_reduce_desc {
+    uint32_t struct_size, reserved0;           /* sizeof(bsvi_reduce_desc) */
+    uint32_t abi_version, rows, cols, n_code, n_mats;
+    uint32_t n_slot_inputs, n_uniform_inputs, n_data, drawn;
+    uint32_t reserved1;
+    const bsvi_mvn_insn* code;                 /* host: the expression A (the last instruction is its value); MAT: [n_mats][rows][cols] */
+    const float* mats;                         /* host [n_mats][rows][cols] */
+    const bsvi_uniform_entry* uniform_inputs;  /* host [n_uniform_inputs], parameter-sourced */
+    const float* data_mean;                    /* host [n_data][rows * cols] */
+    const float* data_scale;                   /* host [n_data][rows * cols] (drawn != 0) */
+    float weight;                              /* of the drawn node's log-probability in f */
+    uint32_t reserved2;
+} bsvi_reduce_desc;
+typedef struct bsvi_reduce_args {
+    uint32_t struct_size, reserved0;           /* sizeof(bsvi_reduce_args) */
+    const float* params_dev;
+    const float* samples_dev;                  /* [rows][n_local]: the slot values of the draw (samples_out of a bsvi_elbo_fwd_bwd call) */
+    float* rows_out_dev;
+    uint32_t n_samples_local, reserved1;
+    uint32_t input_rows[8];                    /* row of scalar input k < n_slot_inputs in samples_dev */
+    const float* data_dev;                     /* [n_data][rows * cols]: the caller's value of the drawn node, or NULL: drawn from (seed, offset) */
+    uint64_t seed, offset;
+    void* stream;
+} bsvi_reduce_args;
+typedef struct bsvi_reduce bsvi_reduce;
+int bsvi_reduce_create(const bsvi_reduce_desc* desc, bsvi_reduce** out);
+void bsvi_reduce_destroy(bsvi_reduce* r);
+uint32_t bsvi_reduce_rows_out(const bsvi_reduce_desc* desc);
+int bsvi_reduce_eval(bsvi_reduce* r, const bsvi_reduce_args* args);
+/* the generated translation unit (host only, like bsvi_mvn_source): byte count including the terminator, 0 on error */
+size_t bsvi_reduce_source(const bsvi_reduce_desc* desc, char* buf, size_t capacity);
 
 /* =========================================================================================
  * The exchange of the multi-GPU path (the reference is single-process and has none).

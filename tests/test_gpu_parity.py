@@ -39,7 +39,10 @@ def is_batched_mvn(case):
                     "gp_marginal_n40_N32", "gp_marginal_n200_N16", "gp_marginal_n260_N12",
                     "gp_structured_mean_n12_N40", "gp_structured_mean_n48_N24",
                     # ... and the scale_tril / precision_matrix forms (bsvi_mvn_form), which the kernel family serves at any size
-                    "mvn_scale_tril_n24_N40", "mvn_precision_n24_N40", "mvn_precision_n6_N60")
+                    "mvn_scale_tril_n24_N40", "mvn_precision_n24_N40", "mvn_precision_n6_N60",
+                    # ... and (round 6) the REDUCE node (bsvi_reduce_*): sums over 1 600 elements per datapoint and sample in single
+                    # precision, a likelihood of ~1e5 that is the difference of larger terms — the same yardstick
+                    "prf_F40_D15_N20")
 
 
 @pytest.mark.parametrize("case", golden_cases())

@@ -56,7 +56,7 @@ def test_interpreter_matches_reference_golden(case, estimator, interpreter):
     assert c.native.engine(g.N, 0)["engine"] == "interpreter"
     res = c.evaluate(g.N, noise=g.noise, minibatch=g.minibatch)
     ref = float(g.data["loss_" + estimator])
-    if estimator == "pathwise" and case not in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24") and not case.startswith(("gp_marginal", "gp_structured")):
+    if estimator == "pathwise" and case not in ("gp_hyperparameters_n32_N40", "gp_hyperparameters_n100_N24") and not case.startswith(("gp_marginal", "gp_structured", "prf_")):
         assert abs(float(res["loss"].item()) - ref) <= TOL * abs(ref)
         grad_check(c.named_grads(), g.group("grad_%s/" % estimator), TOL)
         return

@@ -49,7 +49,7 @@ C_NAMES = {native.UniformEntry: "bsvi_uniform_entry", native.Record: "bsvi_recor
            native.DenseArgs: "bsvi_dense_args", native.MlpLayer: "bsvi_mlp_layer", native.AmortDesc: "bsvi_amort_desc",
            native.AmortArgs: "bsvi_amort_args", native.MvnInsn: "bsvi_mvn_insn", native.MvnDesc: "bsvi_mvn_desc",
            native.MvnArgs: "bsvi_mvn_args", native.BnnLayer: "bsvi_bnn_layer", native.BnnDesc: "bsvi_bnn_desc",
-           native.BnnArgs: "bsvi_bnn_args"}
+           native.BnnArgs: "bsvi_bnn_args", native.ReduceDesc: "bsvi_reduce_desc", native.ReduceArgs: "bsvi_reduce_args"}
 
 
 def test_struct_layouts(tmp_path):
