@@ -51,11 +51,20 @@ WORKLOADS = {
              "VAE_playground.py MLP VAE 784-256-512-(2,2) / 2-512-256-784, Binomial(1, logits) likelihood, every sample "
              "draws its own minibatch of 100 of 60000 synthetic binary rows, number_samples=2048 sharded as 256 per GPU "
              "(25600 rows per GPU), Adam lr=1e-3 (BASELINE config 5)"),
+    "bnn": ("build_bayesian_neural_network", dict(dataset_size=60000, batch_size=30, n_features=784, n_hidden=20, n_classes=10,
+                                                  q_scale1=4e-4, q_loc_scale=1.0),
+            50, "Adam", dict(lr=5e-3),
+            "Bayesian neural network 784-20-10 (tanh), minibatch 30 of 60000 synthetic rows, number_samples=50, Adam lr=5e-3 "
+            "(tests/test_MNIST_bayesian_neural_network.py:20-60 of the reference: its example's size)"),
+    "bnn_cfg4scale": ("build_bayesian_neural_network", dict(dataset_size=60000, batch_size=512, n_features=784, n_hidden=20, n_classes=10,
+                                                            q_scale1=4e-4, q_loc_scale=1.0),
+                      1024, "Adam", dict(lr=5e-3),
+                      "the same Bayesian neural network at BASELINE config 4's scale: minibatch 512, number_samples=1024"),
     "cfg1_big": ("build_readme_ar", dict(T=20), 262144, "SGD", dict(lr=1e-3),
                  "README AR T=20 at number_samples=262144 (throughput regime of the same kernel)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-OTHER_CONFIGS = ("cfg2", "cfg3", "cfg4", "cfg5")     # timed after the headline in the same process (N = 1)
+OTHER_CONFIGS = ("cfg2", "cfg3", "cfg4", "cfg5", "bnn", "bnn_cfg4scale")     # timed after the headline in the same process (N = 1)
 # BASELINE.json config 5 names "BlackBox + Pathwise estimators": the two MFMA configs once more under BlackBox (no traffic pass of their own)
 OTHER_BLACKBOX = ("cfg4", "cfg5")
 # (the same untimed spin-up as the headline: the clocks of an idle MI355X take longer than 100 ms to ramp — cfg 2, a pure
@@ -458,6 +467,53 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
 
     iters_per_sec = steps / dt
     value = iters_per_sec * (n_global / 300.0)
+    bnn = hasattr(program, "tensors") and hasattr(program, "layers")
+
+    def make_part(roofline, geom):
+        part = dict(metric="ELBO iters/sec at num_samples=%d per GPU (300-sample-equivalent iterations, whole job)" % n_per_gpu,
+                    value=value, unit="it/s", n_gpus=world, steps=steps, warmup=warmup,
+                    ms_per_step=dt * 1e3 / steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="f32", data="synthetic",
+                    config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
+                                optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
+                                estimator=estimator, mode=mode, parallelism="sample-shard x%d" % world,
+                                grid=geom, untimed_spinup_iterations=spun),
+                    iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
+                    device_ms_per_step=dev_ms / steps, all_finite=ok,
+                    # the timed region taken apart on the host clock: the library call(s) that launch the K steps, then the wait
+                    host_launch_us=(t_launched - t0) * 1e6, host_wait_us=(dt - (t_launched - t0)) * 1e6,
+                    final_loss=float(losses[-1].item()), roofline=roofline)
+        if cold is not None:
+            part["cold_start"] = cold
+        if world > 1:
+            # which all-reduce every rank took (the first SCALE run says it): torch.distributed's (RCCL under the nccl backend) unless
+            # the one-shot exchange was opted in AND chosen by the self-test + vote
+            used = bool(engine._exchanges.get(torch.cuda.current_device()))
+            part["config"]["collective"] = ("one-shot exchange (bsvi_exchange_*)" if used else
+                                            "torch.distributed all_reduce, backend %s" % dist.get_backend())
+        if fallback:
+            part["config"]["collective_fallback"] = fallback
+        return part
+
+    if bnn:
+        # the two products of every (sample, layer-1 weight matrix): [H, P] x [P, B] forward and its weight gradient, bf16 x3 when the
+        # minibatch is exactly bf16; the [C, H] layer is 2 % of that and is priced at the same peak
+        L = program.layers
+        flops = sum(2.0 * 2.0 * n_per_gpu * l["rows"] * l["cols"] * program.batch_size for l in L)
+        tf = flops / (dev_ms * 1e-3 / steps) / 1e12
+        exact = compiled.data_path() == "bf16x3"
+        peak = MFMA_EXACT_PEAK_TFLOPS if exact else MFMA_F32_PEAK_TFLOPS
+        noise_bytes = n_per_gpu * sum(l["rows"] * l["cols"] + (l["rows"] if l.get("bias") is not None else 0) for l in L) * 4
+        roofline = dict(bound="mfma", achieved=tf, peak=peak, unit="TFLOP/s", frac=tf / peak, traffic=None,
+                        kernel="bnn_draw + bnn_lower (product 1) + bnn_upper + bnn_mid (product 2) + bnn_row_sums + bnn_epilogue",
+                        algorithmic_flops_per_iteration=flops, launch_ms=dev_ms / steps, data_path="bf16x3" if exact else "f32",
+                        algorithmic_bytes_per_iteration=noise_bytes + program.batch_size * L[0]["cols"] * 4 + 2 * program.n_params * 4,
+                        note="every sample has its OWN weight matrices (N x H x P normals per iteration: %.1f MB, drawn in registers, the "
+                             "sampled weights pass through HBM once as bf16 pieces); achieved = flops of the forward products and their "
+                             "weight gradients / duration of the whole iteration (6 launches); no traffic pass for this entry" % (noise_bytes / 1e6))
+        part = make_part(roofline, dict(kind="bnn", layers=[(l["rows"], l["cols"]) for l in L]))
+        del compiled, model
+        return part, dict(builder=builder, kwargs=kwargs, n=n_per_gpu, optimizer=optimizer, opt_kwargs=opt_kwargs, dense=False, amort=False, bnn=True)
     dense = hasattr(program, "n_classes")
     amort = hasattr(program, "enc_layers")
     geom = dict(kind="dense") if dense else dict(kind="amortized") if amort else compiled.native.geometry(n_per_gpu)
@@ -619,29 +675,7 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
     if traffic is not None:
         roofline["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py before its timed " \
                                      "regions (child processes, same workloads and step counts): " + traffic_how
-    part = dict(metric="ELBO iters/sec at num_samples=%d per GPU (300-sample-equivalent iterations, whole job)" % n_per_gpu,
-                value=value, unit="it/s", n_gpus=world, steps=steps, warmup=warmup,
-                ms_per_step=dt * 1e3 / steps, higher_is_better=True, scaling="weak", vs_baseline=None,
-                dtype="f32", data="synthetic",
-                config=dict(workload=desc, number_samples_per_gpu=n_per_gpu, number_samples_global=n_global,
-                            optimizer=optimizer, **{k: v for k, v in opt_kwargs.items()},
-                            estimator=estimator, mode=mode, parallelism="sample-shard x%d" % world,
-                            grid=geom, untimed_spinup_iterations=spun),
-                iters_per_sec=iters_per_sec, samples_per_sec=iters_per_sec * n_global,
-                device_ms_per_step=dev_ms / steps, all_finite=ok,
-                # the timed region taken apart on the host clock: the library call(s) that launch the K steps, then the wait
-                host_launch_us=(t_launched - t0) * 1e6, host_wait_us=(dt - (t_launched - t0)) * 1e6,
-                final_loss=float(losses[-1].item()), roofline=roofline)
-    if cold is not None:
-        part["cold_start"] = cold
-    if world > 1:
-        # which all-reduce every rank took (the first SCALE run says it): torch.distributed's (RCCL under the nccl backend) unless
-        # the one-shot exchange was opted in AND chosen by the self-test + vote
-        used = bool(engine._exchanges.get(torch.cuda.current_device()))
-        part["config"]["collective"] = ("one-shot exchange (bsvi_exchange_*)" if used else
-                                        "torch.distributed all_reduce, backend %s" % dist.get_backend())
-    if fallback:
-        part["config"]["collective_fallback"] = fallback
+    part = make_part(roofline, geom)
     del compiled, model
     return part, dict(builder=builder, kwargs=kwargs, n=n_per_gpu, optimizer=optimizer, opt_kwargs=opt_kwargs,
                       dense=dense, amort=amort)

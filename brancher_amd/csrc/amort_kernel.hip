@@ -41,7 +41,7 @@
 #include "philox.h"
 
 namespace bsvi_amort_impl {
-using bsvi::philox4x32_10;
+using bsvi::philox4x32;
 using bsvi::u01;
 using bsvi::u32x4;
 
@@ -2159,7 +2159,7 @@ __device__ __forceinline__ uint32_t minibatch_row(const RowParams& D, uint32_t s
     for (int walk = 0; walk < 64; ++walk) {
         uint32_t lft = (x >> half_bits) & mask, rgt = x & mask;
         for (uint32_t round = 0; round < 4; ++round) {
-            const u32x4 h = philox4x32_10(rgt, round | (s_global << 2), D.off_lo, D.off_hi, D.seed_lo ^ 0x7f4a7c15u, D.seed_hi);
+            const u32x4 h = philox4x32(rgt, round | (s_global << 2), D.off_lo, D.off_hi, D.seed_lo ^ 0x7f4a7c15u, D.seed_hi);
             const uint32_t t = lft ^ (h.x & mask);
             lft = rgt;
             rgt = t;
@@ -2213,7 +2213,7 @@ __global__ void amort_latent_fwd(const RowParams D) {
             e0 = D.noise_in[(long)r * D.Dz + d];
             if (d + 1 < D.Dz) e1 = D.noise_in[(long)r * D.Dz + d + 1];
         } else {
-            const u32x4 x = philox4x32_10(row_global, (uint32_t)(d >> 1), D.off_lo, D.off_hi, D.seed_lo, D.seed_hi);
+            const u32x4 x = philox4x32(row_global, (uint32_t)(d >> 1), D.off_lo, D.off_hi, D.seed_lo, D.seed_hi);
             bsvi::box_muller(x.x, x.y, e0, e1);
         }
         for (int j = 0; j < 2 && d + j < D.Dz; ++j) {

@@ -66,7 +66,7 @@ struct PhiloxKey { uint32_t nidx, seed_lo, seed_hi, off_lo, off_hi; };
 // offsets >= 2^62).  A noise row is a slot of the lane's row in LDS (<= 160 KB / 8 B = 20 480 of them): it fits 16 bits;
 // attempts are (stream << 12) + retry for the gamma sampler and total_count / 4 for a Binomial: 15 bits.
 __device__ __forceinline__ u32x4 philox_raw(const PhiloxKey& k, uint32_t row, uint32_t attempt) {
-    return philox4x32_10(k.nidx, (row & 0xFFFFu) | ((attempt & 0x7FFFu) << 16), k.off_lo, k.off_hi, k.seed_lo, k.seed_hi);
+    return philox4x32(k.nidx, (row & 0xFFFFu) | ((attempt & 0x7FFFu) << 16), k.off_lo, k.off_hi, k.seed_lo, k.seed_hi);
 }
 // Box-Muller on the hardware transcendental units: v_sin/v_cos take revolutions, so
 // sin(2*pi*u) is one instruction and needs no range reduction

@@ -125,7 +125,7 @@ struct Lane {
 __device__ __forceinline__ float philox_normal(const KParams& K, Lane& T, uint32_t row) {
     const uint32_t group = row >> 2;
     if (group != T.cached_group) {
-        const u32x4 x = philox4x32_10(T.nidx, group | 0x80000000u, K.offset_lo, K.offset_hi, K.seed_lo, K.seed_hi);
+        const u32x4 x = philox4x32(T.nidx, group | 0x80000000u, K.offset_lo, K.offset_hi, K.seed_lo, K.seed_hi);
         float z0, z1, z2, z3;
         box_muller_fast(x.x, x.y, z0, z1);
         box_muller_fast(x.z, x.w, z2, z3);

@@ -79,11 +79,11 @@ __device__ __forceinline__ void spec_naff_lp_bwd(float gw, float v, float loc, f
 }
 
 // ---- noise ---------------------------------------------------------------------------------------------------
-// four standard normals of noise-row group g (rows 4g..4g+3): ONE Philox4x32-10 call, Box-Muller on v_sin/v_cos —
+// four standard normals of noise-row group g (rows 4g..4g+3): ONE Philox4x32 call (kPhiloxRounds rounds, philox.h), Box-Muller on v_sin/v_cos —
 // the same stream as the interpreter's philox_normal (elbo_kernel.hip), so both engines draw the same samples
 __device__ __forceinline__ void spec_normals4(const SpecBody& A, const SpecLane& T, uint32_t g,
                                               float& z0, float& z1, float& z2, float& z3) {
-    const u32x4 x = philox4x32_10(T.nidx, g | 0x80000000u, T.off_lo, T.off_hi, A.seed_lo, A.seed_hi);
+    const u32x4 x = philox4x32(T.nidx, g | 0x80000000u, T.off_lo, T.off_hi, A.seed_lo, A.seed_hi);
     box_muller_fast(x.x, x.y, z0, z1);
     box_muller_fast(x.z, x.w, z2, z3);
 }
