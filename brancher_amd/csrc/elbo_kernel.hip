@@ -32,6 +32,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 

@@ -41,10 +41,11 @@ static void* to_device(const void* host, size_t bytes) {
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s <blob>\n", argv[0]); return 1; }
     /* the binding's view of every struct against the library's */
-    const size_t mine[BSVI_SK_COUNT] = {sizeof(bsvi_uniform_entry), sizeof(bsvi_record), sizeof(bsvi_program_desc),
+    const size_t mine[] = {sizeof(bsvi_uniform_entry), sizeof(bsvi_record), sizeof(bsvi_program_desc),
         sizeof(bsvi_elbo_args), sizeof(bsvi_opt_cfg), sizeof(bsvi_dense_desc), sizeof(bsvi_dense_args), sizeof(bsvi_mlp_layer),
         sizeof(bsvi_amort_desc), sizeof(bsvi_amort_args), sizeof(bsvi_mvn_insn), sizeof(bsvi_mvn_desc), sizeof(bsvi_mvn_args),
-        sizeof(bsvi_bnn_layer), sizeof(bsvi_bnn_desc), sizeof(bsvi_bnn_args)};
+        sizeof(bsvi_bnn_layer), sizeof(bsvi_bnn_desc), sizeof(bsvi_bnn_args), sizeof(bsvi_reduce_desc), sizeof(bsvi_reduce_args)};
+    _Static_assert(sizeof mine / sizeof mine[0] == BSVI_SK_COUNT, "a struct kind of bsvi.h is missing from this list");
     for (int k = 0; k < BSVI_SK_COUNT; ++k)
         if (bsvi_sizeof(k) != mine[k]) { fprintf(stderr, "struct kind %d: header %zu bytes, library %zu\n", k, mine[k], bsvi_sizeof(k)); return 4; }
     if (bsvi_abi_version() != BSVI_ABI_VERSION) { fprintf(stderr, "ABI %d != %d\n", bsvi_abi_version(), BSVI_ABI_VERSION); return 4; }
