@@ -1,5 +1,5 @@
 // round 6: what does a v_mfma_f32_32x32x16_bf16 cost inside a product loop?  One product wave per SIMD (256 threads), 8 accumulators,
-// 24 MFMAs per step as in dense_xfwd / x6gemm_kernel; variants: operands constant in registers | six fragment sets rotating in registers
+// 48 MFMAs per step as in dense_xfwd; variants: operands constant in registers | six fragment sets rotating in registers
 // (zeros / random data) | fragments read from LDS every step (14 ds_read_b128 per step) | the same beside four waves of vector work.
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_feed tools/r6/mfma_feed.hip
 #include <hip/hip_runtime.h>
@@ -89,7 +89,7 @@ int main() {
             }
             hipMemcpy(c, cyc, 32, hipMemcpyDeviceToHost);
             printf("data %d  %3d workgroups  accumulators in %s  mode %d: %.1f cycles per MFMA (wave 0's counter), %.2f ns per MFMA per wave (whole launch), %.0f TFLOP/s\n", data, blocks, agpr ? "AGPRs" : "VGPRs", mode,
-                   (double)c[0] / (n * 24.0), ms * 1e6 / (n * 24.0), 2.0 * 32 * 32 * 16 * n * 24.0 * 4 * blocks / (ms * 1e-3) / 1e12);
+                   (double)c[0] / (n * 48.0), ms * 1e6 / (n * 48.0), 2.0 * 32 * 32 * 16 * n * 48.0 * 4 * blocks / (ms * 1e-3) / 1e12);
         }
     }
     return 0;
