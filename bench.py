@@ -607,8 +607,9 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         if probe_rows:
             # (the probe runs every config in one process: the products of the six-launch form, `xgemm_nt_*`, are counted only
             #  between this config's first and last `dense_` dispatch — config 5 launches the same kernels for its first layer,
-            #  and the driver's line of round 3 carried them in config 4's figure: 510 MB against 304 MB measured alone)
-            own = [r["dispatch"] for r in probe_rows if "dense_" in r["kernel"]]
+            #  and the driver's line of round 3 carried them in config 4's figure: 510 MB against 304 MB measured alone.
+            #  The span is found from kernels only THIS config launches: the Bayesian-neural-network entries launch dense_param_kernel too.)
+            own = [r["dispatch"] for r in probe_rows if any(k in r["kernel"] for k in ("dense_head", "dense_xfwd", "dense_xbwd", "dense_forward", "dense_backward"))]
             span = [r for r in probe_rows if own and min(own) <= r["dispatch"] <= max(own)]
             traffic = traffic_of(span, ["dense_", "xgemm_nt"], per=iters_probed or 1, double_fetch=True)
             traffic_how = "all dense_* (and, six-launch form, xgemm_nt) launches of this config in the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
@@ -633,8 +634,13 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         flops = amort_flops_per_iteration(program, n_per_gpu)
         tf = flops / (dev_ms * 1e-3 / steps) / 1e12
         if probe_rows:
-            traffic = traffic_of(probe_rows, ["bsvi_amort_impl"], per=iters_probed or 1, double_fetch=True)
-            traffic_how = "all bsvi_amort_impl launches of the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
+            # (as for config 4: only from this config's first `amort_head` dispatch to the first launch of another config behind its last — the Bayesian neural
+            #  network's products are bsvi_amort_impl::xgemm_nt_glds_kernel launches too)
+            own = [r["dispatch"] for r in probe_rows if "amort_head" in r["kernel"] or "amort_latent" in r["kernel"]]
+            later = [r["dispatch"] for r in probe_rows if own and r["dispatch"] > max(own) and ("bnn_" in r["kernel"] or "dense_head" in r["kernel"] or "spec_kernel" in r["kernel"])]
+            span = [r for r in probe_rows if own and min(own) <= r["dispatch"] < (min(later) if later else float("inf"))]
+            traffic = traffic_of(span, ["bsvi_amort_impl"], per=iters_probed or 1, double_fetch=True)
+            traffic_how = "all bsvi_amort_impl launches of this config in the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
         exact = getattr(compiled, "data_path", lambda: "f32")() == "bf16x3"
         rows = n_per_gpu * program.batch_size
         # flops of the forward products that read the data rows (bf16 x3 when the data is exactly bf16), the rest on the f32-input MFMA

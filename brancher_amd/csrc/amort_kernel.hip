@@ -1062,7 +1062,7 @@ __device__ __forceinline__ void x6_epilogue(const X6Args& G, unsigned char* lds,
                     for (int e = 0; e < 4; ++e) v[e] = c0[e] + v[e];
                 }
             }
-            *reinterpret_cast<f32x4*>(c) = v;
+            *reinterpret_cast<f32x4*>(c) = v;      // (non-temporal stores: single products 0-3 % faster, cfg 5 unchanged — profiles/r6/x6_nt.txt)
         }
     }
     if (LIK && (lane & 15) == 0) {
