@@ -527,6 +527,7 @@ class CompiledELBO:
                         sample_base=base, out_dev=ptr(self.base_out), samples_out_dev=ptr(bufs["samples"]),
                         noise_out_dev=None if noise_t is not None else ptr(full), fvalue_out_dev=None,
                         workspace_dev=ptr(bufs["ws"]), stream=self._stream())
+        self.base_native.attach_shares()
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.base_native.handle, C.byref(args)))
         for node in self._externals:
             extra = {}
@@ -611,6 +612,7 @@ class CompiledELBO:
             noise_t = self._external_rows(n_local, number_samples, base, noise_t, seed, offset, minibatch)
         used_rows = self._refresh_minibatches(seed, offset, minibatch, want_indices)
         args = self._elbo_args(n_local, number_samples, base, noise_t, seed, offset, samples, noise_o, fvals)
+        self.native.attach_shares()
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
         check_exchange(self.device, self.params)
@@ -647,6 +649,7 @@ class CompiledELBO:
         args.stream = self._stream()
         args.noise_dev = noise_t.data_ptr() if noise_t is not None else None
         args.f_weight_dev, args.q_weight_dev = a.data_ptr(), b.data_ptr()
+        self.native.attach_shares()
         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
         allreduce_sums(self.out)
         check_exchange(self.device, self.params)
@@ -680,10 +683,11 @@ class CompiledELBO:
         every workgroup walks in full: 29.0 vs 32.3 us per iteration at BASELINE config 1."""
         rank, world = dist_info()
         base, n_local = shard(number_samples, rank, world)
-        self.native.ensure_shares(n_local)
-        self._shares_for = n_local
         if self.native.engine(n_local, 2)["engine"] == "specialised":
             return False        # the program-specialised kernel keeps the whole loop in one launch (DESIGN.md 4.7)
+        self.native.ensure_shares(n_local)
+        self.native.attach_shares()
+        self._shares_for = n_local
         return world == 1 and getattr(self.native, "_elbo_shares_set", 0) >= 4 \
             and os.environ.get("BSVI_ELBO_SHARES", "1") != "0"
 
@@ -720,6 +724,7 @@ class CompiledELBO:
             # hiprtc / module loading and RCCL's first-call set-up cannot happen inside a capture: one untimed launch of each
             try:
                 warm = self._elbo_args(n_local, n_global, base, None, seed, int(offset0))
+                self.native.attach_shares()
                 native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(warm)))
             except (RuntimeError, native.NativeError) as err:
                 failure = err
@@ -736,6 +741,7 @@ class CompiledELBO:
                     args.stream = self._stream()
                     args.offset_dev = counters.data_ptr()
                     for _ in range(n_steps):
+                        self.native.attach_shares()
                         native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
                         allreduce_sums(self.out)
                         native.check(self.lib.bsvi_finalize_step_counted(
@@ -968,10 +974,12 @@ class CompiledELBO:
             args = self._elbo_args(n_local, number_samples, base, nz, seed, offset0 + it)
             mask = self.mask_all if it > pretraining_iterations else self.mask_first
             if world == 1 and not _force_sharded_path:
+                self.native.attach_shares()
                 native.check(self.lib.bsvi_svi_step(
                     self.native.handle, C.byref(args), C.byref(cfg), ptr(self.params), ptr(state), ptr(mask),
                     C.c_void_p(loss_curve.data_ptr() + 4 * it), C.c_void_p(finite.data_ptr() + 4 * it)))
             else:
+                self.native.attach_shares()
                 native.check(self.lib.bsvi_elbo_fwd_bwd(self.native.handle, C.byref(args)))
                 allreduce_sums(self.out)
                 native.check(self.lib.bsvi_finalize_step(

@@ -30,6 +30,8 @@ import warnings
 
 import os
 
+import math
+
 import numpy as np
 
 from brancher_amd import distributions as D
@@ -192,7 +194,7 @@ class ExternalReduce:
 class SlotInfo:
     def __init__(self, var, base, shape, dist):
         self.var, self.base, self.shape, self.dist = var, base, shape, dist
-        self.size = int(np.prod(shape))
+        self.size = _nelem(shape)
         self.name = var.name
 
 
@@ -517,7 +519,7 @@ class _Lowering:
             # both element axes reduced, and too many terms to unroll: the reduce node (reduce_external)
             if keep and rank == 3 and arg.op == "vsum" and arg.attr[1] and arg.attr[0] != d:
                 inner = arg.args[0]
-                if self.rank_of(inner) == 3 and int(np.prod(inner.shape)) > self.kMaxViewTerms:
+                if self.rank_of(inner) == 3 and _nelem(inner.shape) > self.kMaxViewTerms:
                     return self.reduce_external(inner, "BF.sum(BF.sum(...)) over %d x %d elements" % inner.shape[1:])
             if d == 1:
                 shape = (B, 1, D2) if keep else (B, D2, 1)
@@ -780,7 +782,7 @@ class _Lowering:
         r_d = e_d + sum_k g_dk s_k, value and gradient exact at the sample, composed here from GIVEN rows the node fills (K + 1 pseudo
         posterior variables of B elements each, behind the posterior's own rows — the mechanism of `mvn_external`)."""
         if prod.op != "mul":
-            raise LoweringError("%s: a reduction over %d elements is lowered for a product  expression * data  only" % (what, int(np.prod(prod.shape))))
+            raise LoweringError("%s: a reduction over %d elements is lowered for a product  expression * data  only" % (what, _nelem(prod.shape)))
         a, x = prod.args
         if x.op != "obs":
             a, x = x, a
@@ -822,7 +824,7 @@ class _Lowering:
                 t = push(("INPUT", 0, ("s", len(slot_inputs) - 1), 0, 0.0))
             elif not node.has_z and self.match_uniform(node) is not None:
                 leaf, g, aa, bb = self.match_uniform(node)
-                if int(np.prod(leaf.shape)) != 1:
+                if _nelem(leaf.shape) != 1:
                     raise LoweringError("%s: a learnable ARRAY under the reduction (only scalars are inputs of the reduce node)" % what)
                 is_param, k0 = self.uniform_entries(leaf, g, aa, bb)
                 uniform_inputs.append((node, self.uni_param[k0]))
@@ -879,7 +881,7 @@ class _Lowering:
         def given(name, shape):
             rows = _Rows(name)
             self.slots[rows] = SlotInfo(rows, self.n_slots, shape, D.DIST_NORMAL)
-            self.n_slots += int(np.prod(shape))
+            self.n_slots += _nelem(shape)
             self.pseudo_q.append(rows)
             return self.mk("z", (), rows, shape)
 
@@ -936,7 +938,7 @@ class _Lowering:
         hit = self.uni_index.get(ukey)
         if hit is not None:
             return hit
-        size = int(np.prod(leaf.shape))
+        size = _nelem(leaf.shape)
         if leaf.op == "root" and leaf.attr.learnable:
             src0 = self.param_offset(leaf.attr.parameter, self.group_of(leaf.attr))
             table, is_param = self.uni_param, 1
@@ -1020,7 +1022,7 @@ class _Lowering:
         self.rec_sink = sink
         self.rec_shape = tuple(shape)
         self.rec_k, self.rec_outer = k, tuple(outer)
-        self.rec_elems = int(np.prod(self.rec_shape[k:]))
+        self.rec_elems = _nelem(self.rec_shape[k:])
         self.rec_begin = len(self.code)
         self.rec_operands = {}
         self.rec_ntemp = 0
@@ -1032,7 +1034,7 @@ class _Lowering:
     def place(self, leaf_shape):
         """(element offset inside the leaf, stride flag) of a leaf operand in the current record."""
         s = tuple(leaf_shape)
-        if int(np.prod(s)) == 1:
+        if _nelem(s) == 1:
             return 0, 0
         for i in range(3):
             if s[i] not in (1, self.rec_shape[i]):
@@ -1168,7 +1170,7 @@ class _Lowering:
             visit(r)
         for n in order:
             base = self.n_latent + self.n_derived
-            size = int(np.prod(n.shape))
+            size = _nelem(n.shape)
             self.n_derived += size
             def body(n=n, base=base):
                 off, stride = self.place(n.shape)
@@ -1282,11 +1284,11 @@ class _Lowering:
         value = self.p_value(v)
         loc = self.from_expr(links["loc"].expr, self.p_value)
         for what, node in (("value", value), ("loc", loc)):
-            if int(np.prod(node.shape)) not in (1, dim):
-                raise LoweringError("the %s of %r has %d elements, its covariance is %dx%d" % (what, v.name, int(np.prod(node.shape)), dim, dim))
+            if _nelem(node.shape) not in (1, dim):
+                raise LoweringError("the %s of %r has %d elements, its covariance is %dx%d" % (what, v.name, _nelem(node.shape), dim, dim))
 
         def element(node, j):
-            if int(np.prod(node.shape)) == 1:
+            if _nelem(node.shape) == 1:
                 return node
             return self.mk("elem", (node,), j, (1, 1, 1))
 
@@ -1330,12 +1332,12 @@ class _Lowering:
         value = self.p_value(v)
         loc = self.from_expr(links["loc"].expr, self.p_value)
         for what, node in (("value", value), ("loc", loc)):
-            if int(np.prod(node.shape)) not in (1, dim):
-                raise LoweringError("the %s of %r has %d elements, its covariance is %dx%d" % (what, v.name, int(np.prod(node.shape)), dim, dim))
+            if _nelem(node.shape) not in (1, dim):
+                raise LoweringError("the %s of %r has %d elements, its covariance is %dx%d" % (what, v.name, _nelem(node.shape), dim, dim))
         mk = self.mk
 
         def vec(node, j):                       # element j of a D-vector stored along whichever axis (or a scalar)
-            if int(np.prod(node.shape)) == 1:
+            if _nelem(node.shape) == 1:
                 return self.element_of(node, (0, 0, 0))
             idx = [0, 0, 0]
             idx[[a for a in range(3) if node.shape[a] == dim][0]] = j
@@ -1433,7 +1435,7 @@ class _Lowering:
                 t = push(("INPUT", 0, ("s", len(slot_inputs) - 1), 0, 0.0))
             elif not node.has_z and self.match_uniform(node) is not None:
                 leaf, g, a, b = self.match_uniform(node)                     # a learnable scalar behind its range transform
-                if int(np.prod(leaf.shape)) != 1:
+                if _nelem(leaf.shape) != 1:
                     raise LoweringError("%r: a learnable ARRAY inside a covariance expression (only scalars are inputs of the "
                                         "batched kernel)" % v.name)
                 is_param, k0 = self.uniform_entries(leaf, g, a, b)
@@ -1464,7 +1466,7 @@ class _Lowering:
             if m is None:
                 raise LoweringError("%r: the batched kernel takes a constant or a learnable loc (not one computed from samples)" % v.name)
             leaf, g, a, b = m
-            size = int(np.prod(leaf.shape))
+            size = _nelem(leaf.shape)
             if size not in (1, dim):
                 raise LoweringError("the loc of %r has %d elements, its covariance is %dx%d" % (v.name, size, dim, dim))
             if leaf.op == "root" and leaf.attr.learnable:
@@ -1494,7 +1496,7 @@ class _Lowering:
             if data.size != dim:
                 raise LoweringError("the value of %r has %d elements, its covariance is %dx%d" % (v.name, data.size, dim, dim))
             node.value, node.value_row0 = data, 0
-        elif value.op == "z" and int(np.prod(value.shape)) == dim:
+        elif value.op == "z" and _nelem(value.shape) == dim:
             node.value, node.value_row0 = None, self.slots[value.attr].base
             partners += [self.mk("elem", (value,), j, (1, 1, 1)) for j in range(dim)]
         elif self.match_uniform(value) is not None:
@@ -1502,7 +1504,7 @@ class _Lowering:
             # (gradient_estimators.py:47-56), and the mean of Normal(loc, scale) is its learnable loc: uniform entries like a
             # learnable loc's, with the coefficient rows -alpha where a latent value's stand
             leaf, g, a, b = self.match_uniform(value)
-            size = int(np.prod(leaf.shape))
+            size = _nelem(leaf.shape)
             if not (leaf.op == "root" and leaf.attr.learnable) or size != dim:
                 raise LoweringError("%r: the batched kernel takes an observed value, the draw of ONE posterior variable of %d elements "
                                     "or %d learnable values" % (v.name, dim, dim))
@@ -1513,7 +1515,7 @@ class _Lowering:
                 node.value_entries[i] = (src, tr, isp, 0, aa, bb)
             node.value, node.value_row0 = np.zeros(dim, dtype=np.float32), 0
             partners += [self.mk("elem", (value,), j, (1, 1, 1)) for j in range(dim)]
-        elif self.estimator == "taylor1" and value.has_z and int(np.prod(value.shape)) == dim:
+        elif self.estimator == "taylor1" and value.has_z and _nelem(value.shape) == dim:
             # Taylor1 (`gradient_estimators.py:47-56`) with a posterior whose mean depends on SAMPLED parents (q(f) = Normal(g(z), s),
             # z drawn): the value of the term is g(z) — an expression that differs per sample.  It reaches the batched kernel the
             # way a latent value does, as rows of the draw: a pseudo posterior variable Normal(g(z), 0) behind the posterior's own
@@ -1773,7 +1775,7 @@ class _Lowering:
         self.n_latent = self.n_slots
         n_derived_upper = 0
         for k in self.derived_nodes:
-            n_derived_upper += int(np.prod(self.ir_cache[k].shape))
+            n_derived_upper += _nelem(self.ir_cache[k].shape)
         self.temp_base = self.n_latent + n_derived_upper
 
         # -- emit q records
@@ -2005,31 +2007,34 @@ class _Lowering:
         # samples the posterior (all non-sink records) but evaluates only every V-th model log-prob record; the
         # estimator value and all adjoints are linear in those records, so the shares' partial sums add up to the
         # full program's.  Pathwise only: BlackBox multiplies per-sample totals.
-        prog.shares = {}
         sinks = [i for i, r in enumerate(self.records) if r[4]]
         # units of work: the elements of the sink records (a record over a datapoint / vector axis is split by elements:
         # share v takes a contiguous sub-range, operands shifted by that many strides)
         work = sum(self.records[i][2] for i in sinks)
-        if self.estimator == "pathwise" and work >= 6:
-            for V in (2, 3, 4, 6, 8):
-                if work < 2 * V:
-                    continue
-                parts = []
-                for v in range(V):
-                    records, single = [], 0
-                    for i, r in enumerate(self.records):
-                        if not r[4]:
+        all_records = list(self.records)
+
+        def parts_of(V):
+            parts = []
+            for v in range(V):
+                records, single = [], 0
+                for i, r in enumerate(all_records):
+                    if not r[4]:
+                        records.append(r)
+                    elif r[2] == 1:
+                        if single % V == v:
                             records.append(r)
-                        elif r[2] == 1:
-                            if single % V == v:
-                                records.append(r)
-                            single += 1
-                        else:
-                            lo, hi = (v * r[2]) // V, ((v + 1) * r[2]) // V
-                            if hi > lo:
-                                records.append((r[0], r[1], hi - lo, r[3], r[4], lo))
-                    parts.append(assemble(records, own_terms=(v == 0)))
-                prog.shares[V] = parts
+                        single += 1
+                    else:
+                        lo, hi = (v * r[2]) // V, ((v + 1) * r[2]) // V
+                        if hi > lo:
+                            records.append((r[0], r[1], hi - lo, r[3], r[4], lo))
+                parts.append(assemble(records, own_terms=(v == 0)))
+            return parts
+
+        # (assembled when first asked for: the 23 streams of V = 2, 3, 4, 6, 8 were 40 % of the lowering of the README model, and a
+        #  single-workgroup launch asks for none of them)
+        splits = [V for V in (2, 3, 4, 6, 8) if work >= 2 * V] if (self.estimator == "pathwise" and work >= 6) else []
+        prog.shares = _LazyShares(parts_of, splits)
         prog.uniform, prog.records, prog.code = uni, recs, code
         prog.consts = np.concatenate(self.consts) if self.consts else np.zeros(0, np.float32)
         prog.obs = np.concatenate(self.obs) if self.obs else np.zeros(0, np.float32)
@@ -2043,7 +2048,7 @@ class _Lowering:
             key = id(handle.indices) if handle.indices is not None else id(handle)
             group = groups.setdefault(key, len(groups))
             prog.minibatches.append(dict(name=handle.name, offset=int(self.obs_index[id(handle)]), batch=handle.batch,
-                                         row=int(np.prod(handle.dataset.shape[1:], dtype=np.int64)), dataset=handle.dataset,
+                                         row=int(math.prod(int(d) for d in handle.dataset.shape[1:])), dataset=handle.dataset,
                                          dataset_size=int(handle.dataset.shape[0]), group=group,
                                          indices_name=handle.indices.name if handle.indices is not None else handle.name))
         prog.n_noise = self.n_latent
@@ -2060,6 +2065,35 @@ class _Lowering:
         prog.bmax = bmax
         prog.op_count = len(code)
         return prog
+
+
+def _nelem(shape):
+    """number of elements of a shape (np.prod of a small tuple costs 5 us a call; the lowering makes hundreds)"""
+    return int(math.prod(int(d) for d in shape))
+
+
+class _LazyShares(dict):
+    """Program.shares: V -> [(code, records)] * V, every split assembled at its first use."""
+
+    def __init__(self, build, keys):
+        super().__init__((k, None) for k in keys)
+        self._build = build
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if v is None:
+            v = self._build(k)
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
 
 
 class ExternalMvn:

@@ -529,6 +529,7 @@ class NativeProgram:
         self.program = program
         self._elbo_share_sets = {}      # V -> [NativeProgram]: shares of the model's log-prob records
         self._elbo_shares_set = 0
+        self._shares_wanted = 0
         self.ensure_shares(1)
 
     def workspace_bytes(self, n_local):
@@ -554,15 +555,22 @@ class NativeProgram:
         return bool(self.lib.bsvi_persistent_supported(self.handle, n_local))
 
     def ensure_shares(self, n_local):
-        """attach the widest split of the model's log-prob records for which every (sample group, share) workgroup of a
-        launch over `n_local` samples still gets a CU of its own (bsvi_program_set_shares)"""
+        """choose the widest split of the model's log-prob records for which every (sample group, share) workgroup of a
+        launch over `n_local` samples still gets a CU of its own (bsvi_program_set_shares) ..."""
         available = getattr(self.program, "shares", {})
         if not available:
             return
         blocks = self.geometry(n_local)["n_blocks"] if n_local > 1 else 1
-        V = max([v for v in available if v * blocks <= 256] or [0])
+        self._shares_wanted = max([v for v in available if v * blocks <= 256] or [0])
+
+    def attach_shares(self):
+        """... and create / attach that split — in front of a launch that uses it (bsvi_elbo_fwd_bwd, bsvi_svi_step).  The in-kernel
+        training loop does not: a `perform_inference` call that only trains never creates the (up to eight) share programs, 5 of the
+        11 ms such a call took on a fresh model (profiles/r6/perform_inference_readme.txt)."""
+        V = self._shares_wanted
         if V == self._elbo_shares_set:
             return
+        available = self.program.shares
         if V >= 2 and V not in self._elbo_share_sets:
             self._elbo_share_sets[V] = [NativeProgram(self._share_program(code, records)) for code, records in available[V]]
         if V >= 2:
