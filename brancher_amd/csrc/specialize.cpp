@@ -893,8 +893,9 @@ static bool trusted(const std::string& dir) {
 // themselves: the one-ulp failures of the suite after tools/r4/profile_r4.sh.  The key now carries the identity of every loaded
 // module that can take part in a compilation — path, size and modification time of each libamd_comgr / libhiprtc /
 // libLLVM / libclang in load order (the order decides which definition a symbol binds to).  When no libamd_comgr is loaded yet
-// (a host whose hiprtc opens it lazily), it is opened here by the name hiprtc uses, so that the identity is the one of the
-// library the first compilation will run.
+// (a host whose hiprtc opens it lazily) the identity is UNRESOLVED: nothing is loaded to find out (round 5 opened it by soname, which
+// could itself decide which copy the process ends up with — ADVICE r5); such a process compiles its first kernel with hiprtc, has
+// its compiler loaded from then on, and stores and looks up under the resolved identity.  The identity is read again at every key.
 static int identity_cb(struct dl_phdr_info* info, size_t, void* data) {
     const char* name = info->dlpi_name;
     if (!name || !*name) return 0;
@@ -912,18 +913,11 @@ static int identity_cb(struct dl_phdr_info* info, size_t, void* data) {
     return 0;
 }
 std::string compiler_identity() {
-    static const std::string id = [] {
-        std::string s;
-        dl_iterate_phdr(identity_cb, &s);
-        if (s.find("amd_comgr") == std::string::npos) {
-            (void)dlopen("libamd_comgr.so.3", RTLD_LAZY | RTLD_GLOBAL);      // (kept: hiprtc finds it loaded)
-            s.clear();
-            dl_iterate_phdr(identity_cb, &s);
-        }
-        return s;
-    }();
-    return id;
+    std::string s;
+    dl_iterate_phdr(identity_cb, &s);
+    return s;
 }
+static bool identity_resolved(const std::string& id) { return id.find("amd_comgr") != std::string::npos; }
 
 static std::string key_of(const std::string& src) {
     static const Hash128 base = [] {        // everything but the generated source: the same for every program of a process
@@ -934,10 +928,10 @@ static std::string key_of(const std::string& src) {
         (void)hiprtcVersion(&major, &minor);
         (void)hipRuntimeGetVersion(&runtime);
         feed(h, fmt("hiprtc %d.%d runtime %d abi %d", major, minor, runtime, BSVI_ABI_VERSION));
-        feed(h, compiler_identity());
         return h;
     }();
     Hash128 h = base;
+    feed(h, compiler_identity());
     feed(h, src);
     return fmt("%016llx%016llx", (unsigned long long)h.a, (unsigned long long)h.b);
 }
@@ -1003,14 +997,15 @@ int obtain(const std::string& text, std::vector<char>& code, std::string& log, i
         const bool tuned = getenv("BSVI_SPEC_DEFINES") != nullptr;
         if (tuned) src = std::string(getenv("BSVI_SPEC_DEFINES")) + "\n" + src;     // tools: timing experiments
         const bool on_disk = disk_cache::enabled() && !getenv("BSVI_JIT_DUMP");
-        const std::string key = on_disk ? disk_cache::key_of(src) : std::string();
-        if (on_disk && disk_cache::load(key, code)) {
+        // (no compiler loaded yet: no lookup — the key would not say whose code it names; the store below is keyed after the compilation)
+        const bool lookup = on_disk && disk_cache::identity_resolved(disk_cache::compiler_identity());
+        if (lookup && disk_cache::load(disk_cache::key_of(src), code)) {
             from = 3;
         } else {
             const int rc = compile(src, code, log);
             if (rc) return rc;
             from = 1;
-            if (on_disk) disk_cache::store(key, code);
+            if (on_disk && disk_cache::identity_resolved(disk_cache::compiler_identity())) disk_cache::store(disk_cache::key_of(src), code);
         }
         std::lock_guard<std::mutex> g(g_cache_mu);
         if (!tuned) g_code_cache[text] = code;
