@@ -224,6 +224,12 @@ def test_bench_with_two_ranks_dry_run(extra, samples):
     assert "allreduce" in line["config"]["mode"] and line["value"] > 0
     assert line["config"]["collective"].startswith("torch.distributed all_reduce")
     assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
+    # ... and the second, guarded phase with BSVI_COLLECTIVE=auto (round 6): both values in the one line — or the reason why not
+    alt = {k: v for k, v in line.items() if k.endswith("_alt")}
+    alt.update({k: v for k, v in line["config"].items() if "_alt" in k})
+    sys.stdout.write("alt phase: %r\n" % (alt,))
+    assert ("value_alt" in line and line["value_alt"] > 0 and line["config"].get("collective_alt")) or "collective_alt_error" in line["config"], alt
+    assert "collective_alt_error" not in line["config"], alt          # (on this box the phase completes)
 
 
 def test_bench_falls_back_to_the_host_collective_when_the_exchange_fails_in_use():
