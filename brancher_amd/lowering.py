@@ -413,8 +413,8 @@ class _Lowering:
         its tensors are optimised with the model's other parameters through the LinkConstructor, `optimizers.py:36-49`).  A small
         MLP — `nn.Linear`, or an `nn.Sequential` of `nn.Linear` and Tanh / ReLU / Sigmoid / Softplus — acting on the LAST axis of
         its input is unrolled into the per-sample program: every weight is a learnable uniform entry (its gradient one position
-        of the reduction), every unit a chain of multiply-adds.  The input is a scalar or a vector along the last axis, the
-        output one unit (a vector-valued result would need an array constructor the program does not have)."""
+        of the reduction), every unit a chain of multiply-adds.  The input is a scalar or a vector along the last axis; several
+        output units come back as a `vstack` view along that axis."""
         import torch.nn as nn
         mod = link.module
         stages = list(mod.children()) if isinstance(mod, nn.Sequential) else [mod]
@@ -450,9 +450,11 @@ class _Lowering:
             else:
                 raise LoweringError("module link %s: %s is not lowered on the scalar path (Linear, Tanh, ReLU, Sigmoid, Softplus)"
                                     % (link.name, type(stage).__name__))
-        if len(units) != 1:
-            raise LoweringError("module link %s: %d outputs — the scalar path takes modules with ONE output unit" % (link.name, len(units)))
-        return units[0]
+        if len(units) == 1:
+            return units[0]
+        # several output units (round 6): a VIEW whose element j is unit j — consumers resolve it per element like BF.sum / x[...]
+        # (a model term over it becomes one scalar term per unit: split_elements)
+        return self.ranked(self.mk("vstack", tuple(units), None, (1, 1, len(units))), self.rank_of(x))
 
     def module_root(self, link, pname, shape):
         """a tensor of a module link as a learnable root leaf of the program (its Parameter is a segment of the parameter buffer)"""
@@ -565,7 +567,7 @@ class _Lowering:
     def has_view(self, node):
         hit = self.view_memo.get(node.key)
         if hit is None:
-            hit = node.op in ("vsum", "vperm", "vindex") or any(self.has_view(a) for a in node.args)
+            hit = node.op in ("vsum", "vperm", "vindex", "vstack") or any(self.has_view(a) for a in node.args)
             self.view_memo[node.key] = hit
         return hit
 
@@ -602,6 +604,8 @@ class _Lowering:
                 src.append(p[1] if p[0] == "int" else p[1] + free.pop(0))
             src += [0] * (2 - len(src))
             out = self.element_of(node.args[0], (b, src[0], src[1]))
+        elif node.op == "vstack":
+            out = node.args[j]
         elif node.op == "elem":
             out = node
         else:

@@ -355,7 +355,7 @@ def build_mvn_forms(api, n=16, form="scale_tril", noise=0.3, seed=0):
     return model
 
 
-def build_module_link_regression(api, n_obs=6, hidden=4, seed=0, n_in=1, activation="Tanh", hidden2=0):
+def build_module_link_regression(api, n_obs=6, hidden=4, seed=0, n_in=1, activation="Tanh", hidden2=0, n_out=1):
     """A `torch.nn.Module` as a link on the scalar path (`brancher/functions.py:15-41`): the response is a small MLP of a
     latent, `y_i ~ N(net(z) * x_i + c, 0.4)`, `net = Linear(1, H) -> Tanh -> Linear(H, 1)`, z ~ N(0, 1) with a learnable Normal
     posterior.  The reference calls the module on the sample and steps its tensors with the joint model's optimizer
@@ -367,7 +367,7 @@ def build_module_link_regression(api, n_obs=6, hidden=4, seed=0, n_in=1, activat
     stages = [torch.nn.Linear(n_in, hidden), act()]
     if hidden2:
         stages += [torch.nn.Linear(hidden, hidden2), act()]
-    stages.append(torch.nn.Linear(hidden2 or hidden, 1))
+    stages.append(torch.nn.Linear(hidden2 or hidden, n_out))
     net = torch.nn.Sequential(*stages)                 # (n_in > 1: the module acts on a row vector of latents, [1, n_in])
     with torch.no_grad():
         for p in net.parameters():
@@ -382,6 +382,9 @@ def build_module_link_regression(api, n_obs=6, hidden=4, seed=0, n_in=1, activat
         qz = api.NormalVariable(0.3 * rng.normal(0., 1., (1, n_in)), 0.6 * np.ones((1, n_in)), "z", learnable=True)
     f = BF.BrancherFunction(net, name="net")
     x = api.DeterministicVariable(xs, "x", is_observed=True)              # [datapoints, 1, 1]
+    if n_out > 1:
+        # (round 6) several output units: the response is a vector per datapoint, y_i ~ N(net(z) * x_i + c, 0.4) with net(z) in R^n_out
+        data = (data * np.linspace(0.5, 1.5, n_out).reshape(1, 1, n_out) + 0.05 * rng.normal(0., 1., (n_obs, 1, n_out))).astype(np.float32)
     y = api.NormalVariable(f(z) * x + 0.1, 0.4, "y")
     model = api.ProbabilisticModel([y])
     y.observe(data)

@@ -49,6 +49,9 @@ CASES = {
                                      dict(iters=4, n=5, optimizer="Adam", lr=0.01)),
     # an nn.Module as a link on the scalar path (functions.py:15-41): its tensors are learnable parameters of the joint model
     "module_link_mlp_N40": ("build_module_link_regression", dict(n_obs=6, hidden=4), 40, 41, dict(iters=5, n=24, optimizer="Adam", lr=1e-2)),
+    # ... with several output units (round 6: a vector-valued module output, one model term per unit)
+    "module_link_mlp_in2_out3_N30": ("build_module_link_regression", dict(n_obs=5, hidden=4, n_in=2, n_out=3), 30, 43,
+                                     dict(iters=4, n=16, optimizer="Adam", lr=1e-2)),
     "map_estimate_N3": ("build_map_estimate", dict(n_obs=12), 3, 15, dict(iters=6, n=2, optimizer="SGD", lr=0.01)),
     "vector_latent_d4_N70": ("build_vector_latent", dict(n_obs=9, dim=4), 70, 14, dict(iters=4, n=33, optimizer="SGD", lr=1e-3)),
     "linear_predictor_d4_N40": ("build_linear_predictor", dict(n_obs=5, dim=4), 40, 17, dict(iters=4, n=24, optimizer="Adam", lr=1e-2)),

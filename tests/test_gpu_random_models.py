@@ -289,7 +289,9 @@ def test_random_model_training_loop_equals_launch_per_iteration(family, seed, op
 @pytest.mark.parametrize("kw,n", [(dict(n_obs=6, hidden=4), 300),
                                   (dict(n_obs=5, hidden=4, n_in=3, activation="ReLU"), 70),
                                   (dict(n_obs=7, hidden=3, n_in=2, activation="Sigmoid", hidden2=3), 129),
-                                  (dict(n_obs=4, hidden=5, n_in=4, activation="Softplus"), 64)])
+                                  (dict(n_obs=4, hidden=5, n_in=4, activation="Softplus"), 64),
+                                  (dict(n_obs=5, hidden=4, n_in=2, n_out=3), 100),                       # (round 6) several output units
+                                  (dict(n_obs=3, hidden=3, n_in=1, n_out=2, activation="ReLU", hidden2=2), 65)])
 def test_module_links_on_the_scalar_path_match_the_oracles(kw, n, estimator):
     """`BrancherFunction(nn.Module)` as a link of a scalar-path model (`brancher/functions.py:15-41`; the reference fixture
     `module_link_mlp_N40` pins the 1-4-1 tanh network, its gradients and its training trajectory): scalar and row-vector inputs,

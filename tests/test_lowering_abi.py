@@ -472,7 +472,7 @@ def test_bayesian_neural_network_lowers_to_the_bnn_family():
 
 def test_module_links_lower_on_the_scalar_path_and_refuse_what_they_cannot_do():
     """`BrancherFunction(nn.Module)` (brancher/functions.py:15-41) on the scalar path: Linear / Tanh / ReLU / Sigmoid / Softplus
-    chains with ONE output unit are unrolled into the program with their tensors as parameters; anything else is a LoweringError
+    chains are unrolled into the program with their tensors as parameters (several output units: a view, one model term per unit); anything else is a LoweringError
     that says what — not a wrong program."""
     import torch
     from brancher_amd import lowering, workloads as W
@@ -494,8 +494,10 @@ def test_module_links_lower_on_the_scalar_path_and_refuse_what_they_cannot_do():
         m.set_posterior_model(ProbabilisticModel([NormalVariable(0., 1., "z", learnable=True)]))
         return lowering.lower(m, m.posterior_model, "pathwise")
 
-    with pytest.raises(lowering.LoweringError, match="ONE output unit"):
-        lower(torch.nn.Linear(1, 2))
+    # (round 6) several output units come back as a view along the last axis: one scalar model term per unit
+    two = lower(torch.nn.Linear(1, 2))
+    assert {par.name: size for par, _, size, _ in two.parameters}["net.weight"] == 2
+    assert sum(1 for r in two.records if r["flags"]) == 3          # (the model terms: z, y[0], y[1])
     with pytest.raises(lowering.LoweringError, match="not lowered on the scalar path"):
         lower(torch.nn.Sequential(torch.nn.Linear(1, 2), torch.nn.GELU(), torch.nn.Linear(2, 1)))
     with pytest.raises(lowering.LoweringError, match="applied to 1 values"):
