@@ -114,8 +114,8 @@ def run_traffic_probe(workloads, steps_of, warmup_of, estimator, mode, samples, 
         per = {}
         for f in files:
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] != counter or "bsvi" not in r["Kernel_Name"]:
-                    continue
+                if r["Counter_Name"] != counter or not ("bsvi" in r["Kernel_Name"] or "bnn_" in r["Kernel_Name"]):
+                    continue          # (the library's kernels; bnn_*: so that a config's span of the probe ends where the network's begins)
                 key = (int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Grid_Size"]))
                 per[key] = per.get(key, 0.0) + float(r["Counter_Value"])          # (one row per XCD / instance)
         for (dispatch, kernel, grid), kb in sorted(per.items()):
@@ -634,10 +634,10 @@ def measure(workload, args, steps, warmup, spinup_ms, world, rank, probe_rows=No
         flops = amort_flops_per_iteration(program, n_per_gpu)
         tf = flops / (dev_ms * 1e-3 / steps) / 1e12
         if probe_rows:
-            # (as for config 4: only from this config's first `amort_head` dispatch to the first launch of another config behind its last — the Bayesian neural
+            # (as for config 4: only from this config's first `amort_head` dispatch to the first launch of another config behind it — the Bayesian neural
             #  network's products are bsvi_amort_impl::xgemm_nt_glds_kernel launches too)
             own = [r["dispatch"] for r in probe_rows if "amort_head" in r["kernel"] or "amort_latent" in r["kernel"]]
-            later = [r["dispatch"] for r in probe_rows if own and r["dispatch"] > max(own) and ("bnn_" in r["kernel"] or "dense_head" in r["kernel"] or "spec_kernel" in r["kernel"])]
+            later = [r["dispatch"] for r in probe_rows if own and r["dispatch"] > min(own) and ("bnn_" in r["kernel"] or "dense_head" in r["kernel"] or "spec_kernel" in r["kernel"])]
             span = [r for r in probe_rows if own and min(own) <= r["dispatch"] < (min(later) if later else float("inf"))]
             traffic = traffic_of(span, ["bsvi_amort_impl"], per=iters_probed or 1, double_fetch=True)
             traffic_how = "all bsvi_amort_impl launches of this config in the probe / its %d iterations; FETCH_SIZE doubled (gfx950 rule)" % (iters_probed or 0)
