@@ -1916,8 +1916,14 @@ class _Lowering:
         self.temp_base = self.n_slots          # no derived slots in sampling programs
         self.derived_nodes = set()
         for v, params, shape, slot in self.outputs:
-            self.for_each_record(shape, params, False,
-                                 lambda: self.emit_node(v.distribution.kind, F_SAMPLE, params, slot=slot))
+            try:
+                self.for_each_record(shape, params, False,
+                                     lambda: self.emit_node(v.distribution.kind, F_SAMPLE, params, slot=slot))
+            except LoweringError as err:
+                if any(self.has_view(p) for p in params) and "vsum" in str(err):
+                    raise LoweringError("sampling %r: its parameters hold a reduction that only the ELBO programs evaluate (the reduce node, "
+                                        "DESIGN 4.1) — sample the posterior's own variables with model.posterior_model.get_sample(...)" % v.name) from err
+                raise
         prog = self.finish(1)
         prog.outputs = [(v, slot) for v, _, _, slot in self.outputs]
         return prog
