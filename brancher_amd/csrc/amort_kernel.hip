@@ -584,6 +584,9 @@ __global__ __launch_bounds__(256, 2) void xgemm_nt_kernel(const XGemmArgs G) {
 // global piece sp ^ ((r >> 2) & 3) of the row; the fragment reads apply the same involution (rows r, r+4, r+8, r+12 of a
 // 16-lane ds_read_b128 group then sit on four different bank quads).  Two LDS stages (64 KB per workgroup, two per CU), ONE
 // barrier per k step: wait for the DMA of step s, barrier, start the DMA of step s+1 into the other stage, multiply.
+// (Round 6, measured and dropped — tools/r6/experiments/xgemm_nt_three_stages.patch, profiles/r6/xgemm_stages_ab.txt: THREE stages, the DMA two
+//  steps ahead behind a bare s_barrier: 96 / 120 KB leave one workgroup per CU, and the Bayesian neural network's first product goes from
+//  83 to 125 us — the second workgroup of a CU covers more than the deeper prefetch.)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gmem_ptr_t;
 template <int TBM, bool SPLITK>
